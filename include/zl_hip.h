@@ -1,0 +1,155 @@
+/*
+ * zl_hip.h -- C-ABI of libzl_hip.so: the MI355X (gfx950) zstd one-shot compress/decompress
+ * path that sits where the reference package's R/C glue calls its bundled libzstd.
+ *
+ * Plain C, plain pointers and sizes; no torch/R types.  Every entry point below names the
+ * reference interface it replaces (paths relative to the reference repository; "zstd.h" is
+ * src/zstd/zstd.h, "zstd.c" is src/zstd/zstd.c).  INTEGRATION.md shows the two-line change
+ * in src/Makevars + src/raw-file.c / src/serialize.c / src/cctx.c / src/dctx.c that binds
+ * them.
+ *
+ * Conventions kept from libzstd so that the glue's error handling works unchanged
+ * (src/raw-file.c:81-83, :190-192):
+ *   - size_t results; an error is (size_t)-code with code from ZSTD_ErrorCode
+ *     (zstd.c:1463-1499), detected by zl_isError (zstd.c:1548), described by
+ *     zl_getErrorName with the same strings (zstd.c:3585-3628) -- the string
+ *     "Restored data doesn't match checksum" is asserted by the reference's
+ *     tests/testthat/test-checksums.R:24-27.
+ *   - the caller owns src and dst; nothing is retained after a call returns; no call
+ *     leaves device work in flight (the glue may longjmp via Rf_error right after).
+ *   - one caller thread per context.
+ *
+ * There is NO CPU fallback: every compress/decompress entry point runs HIP kernels and
+ * returns an error code (ZL_error_GPU_unavailable == memory_allocation, 64) when no gfx950
+ * device can be initialised.
+ */
+#ifndef ZL_HIP_H
+#define ZL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zl_cctx_s zl_cctx; /* replaces ZSTD_CCtx (zstd.h:266) */
+typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
+
+/* parameter ids: numerically identical to ZSTD_cParameter / ZSTD_dParameter so that
+ * src/cctx.c:265-284 and src/dctx.c:99,163 compile unchanged against the twins */
+#define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel */
+#define ZL_c_checksumFlag 201     /* zstd.h:440  ZSTD_c_checksumFlag     */
+#define ZL_c_nbWorkers 400        /* zstd.h:449  ZSTD_c_nbWorkers (accepted, ignored: the GPU path is always parallel) */
+#define ZL_c_stableInBuffer 1006  /* zstd.h:2083 ZSTD_c_stableInBuffer  (accepted, no-op) */
+#define ZL_c_stableOutBuffer 1007 /* zstd.h:2103 ZSTD_c_stableOutBuffer (accepted, no-op) */
+#define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
+#define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
+
+#define ZL_CONTENTSIZE_UNKNOWN_ (0ULL - 1) /* zstd.h:190 */
+#define ZL_CONTENTSIZE_ERROR_ (0ULL - 2)   /* zstd.h:191 */
+
+/* ---- error helpers: ZSTD_isError / ZSTD_getErrorName (zstd.c:15758,15762) -------------- */
+unsigned zl_isError(size_t code);
+const char *zl_getErrorName(size_t code);
+
+/* ---- sizes ------------------------------------------------------------------------------
+ * zl_compressBound replaces ZSTD_compressBound (zstd.h:232; call sites src/raw-file.c:52,
+ * src/serialize.c:73).  The GPU encoder emits one independent frame per 128 KiB chunk, so
+ * its bound is the sum of per-frame bounds; it is always >= ZSTD_compressBound(srcSize). */
+size_t zl_compressBound(size_t srcSize);
+
+/* First-frame helpers, exact twins of ZSTD_findFrameCompressedSize (zstd.h:210) and
+ * ZSTD_getFrameContentSize (zstd.h:192); call sites src/raw-file.c:150,155,
+ * src/serialize.c:171,177. */
+size_t zl_findFrameCompressedSize(const void *src, size_t srcSize);
+unsigned long long zl_getFrameContentSize(const void *src, size_t srcSize);
+
+/* Whole-buffer helpers for concatenated frames (what zl_compress2 produces for inputs
+ * larger than one chunk).  zl_findDecompressedSize is the twin of
+ * ZSTD_findDecompressedSize (zstd.h:1484): sum of the content sizes of all frames.
+ * zl_findAllFramesCompressedSize: total bytes covered by complete frames from src[0]. */
+unsigned long long zl_findDecompressedSize(const void *src, size_t srcSize);
+size_t zl_findAllFramesCompressedSize(const void *src, size_t srcSize);
+
+/* ---- compression context: ZSTD_createCCtx / ZSTD_freeCCtx / ZSTD_CCtx_setParameter /
+ * ZSTD_CCtx_getParameter / ZSTD_CCtx_loadDictionary (zstd.c:22610, 22693, 23223, 23531,
+ * 23826; call sites src/cctx.c:72-95,222,265-304,352-354) --------------------------------- */
+zl_cctx *zl_createCCtx(void);
+size_t zl_freeCCtx(zl_cctx *cctx);
+size_t zl_CCtx_setParameter(zl_cctx *cctx, int param, int value);
+size_t zl_CCtx_getParameter(const zl_cctx *cctx, int param, int *value);
+size_t zl_CCtx_loadDictionary(zl_cctx *cctx, const void *dict, size_t dictSize); /* copied, as zstd.c:23826-23830 */
+
+/* replaces ZSTD_compress2 (zstd.h:599; call sites src/raw-file.c:74, src/serialize.c:91):
+ * host src -> host dst, complete zstd frame(s) with content size recorded. */
+size_t zl_compress2(zl_cctx *cctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize);
+
+/* ---- decompression context: ZSTD_createDCtx / ZSTD_freeDCtx / ZSTD_DCtx_setParameter /
+ * ZSTD_DCtx_getParameter / ZSTD_DCtx_loadDictionary (zstd.c:40913, 40927, 42507, 42478,
+ * 42321; call sites src/dctx.c:54,99,119,163,181-186,234) --------------------------------- */
+zl_dctx *zl_createDCtx(void);
+size_t zl_freeDCtx(zl_dctx *dctx);
+size_t zl_DCtx_setParameter(zl_dctx *dctx, int param, int value);
+size_t zl_DCtx_getParameter(const zl_dctx *dctx, int param, int *value);
+size_t zl_DCtx_loadDictionary(zl_dctx *dctx, const void *dict, size_t dictSize);
+
+/* replaces ZSTD_decompressDCtx (zstd.h:290; call sites src/raw-file.c:189,
+ * src/serialize.c:197): decodes every frame in [src, src+srcSize) (concatenated frames
+ * are decoded in parallel, one workgroup per frame; skippable frames skipped), verifies
+ * content size and checksum, returns bytes regenerated. */
+size_t zl_decompressDCtx(zl_dctx *dctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize);
+
+/* dictionary id helpers: ZSTD_getDictID_fromDict / ZSTD_getDictID_fromFrame
+ * (src/dictionaries.c:23-58) */
+unsigned zl_getDictID_fromDict(const void *dict, size_t dictSize);
+unsigned zl_getDictID_fromFrame(const void *src, size_t srcSize);
+
+/* ---- batch entries (new; SURVEY.md section 7 H1: the reference API is one buffer per
+ * call, .Call()ed in an lapply loop -- vignettes/dictionaries.Rmd:129-138).  n independent
+ * inputs, one launch.  results[i] = bytes written for item i or an error code.  Return
+ * value: 0, or the first error met before any item ran (e.g. no GPU). ---------------------- */
+size_t zl_compress_batch(zl_cctx *cctx, size_t n, void *const *dsts, const size_t *dstCapacities,
+                         const void *const *srcs, const size_t *srcSizes, size_t *results);
+size_t zl_decompress_batch(zl_dctx *dctx, size_t n, void *const *dsts, const size_t *dstCapacities,
+                           const void *const *srcs, const size_t *srcSizes, size_t *results);
+
+/* ---- device-resident entries (new): data already in HBM, used by bench.py and by callers
+ * that keep buffers on the GPU.  Pointers are device addresses; `stream` is a hipStream_t
+ * (NULL = the context's own stream).  The *_async calls only enqueue work; *_finish waits
+ * for it and returns the total bytes or the first error. ----------------------------------- */
+typedef struct {
+    uint64_t src_off;  /* frame start inside d_src */
+    uint64_t src_size; /* compressed size of the frame */
+    uint64_t dst_off;  /* where its content goes inside d_dst */
+    uint64_t dst_cap;  /* bytes available there */
+} zl_frame_t;
+
+/* Decode nframes frames described by the host table `frames` from d_src into d_dst. */
+size_t zl_decompress_device_async(zl_dctx *dctx, void *d_dst, const void *d_src, const zl_frame_t *frames,
+                                  size_t nframes, void *stream);
+/* results (host, may be NULL) receives the per-frame regenerated sizes / error codes. */
+size_t zl_decompress_device_finish(zl_dctx *dctx, size_t *results);
+
+/* Compress d_src[0..srcSize) into d_dst as concatenated frames (one per 128 KiB chunk).
+ * d_dst must hold zl_compressBound(srcSize) bytes.  After _finish, frameSizes (host, may
+ * be NULL, capacity zl_compress_device_nframes(srcSize)) holds each frame's compressed
+ * size; the frames are contiguous in d_dst.  Returns total compressed bytes. */
+size_t zl_compress_device_nframes(size_t srcSize);
+size_t zl_compress_device_async(zl_cctx *cctx, void *d_dst, size_t dstCapacity, const void *d_src, size_t srcSize,
+                                void *stream);
+size_t zl_compress_device_finish(zl_cctx *cctx, size_t *frameSizes);
+
+/* Build a frame table for concatenated frames that live on the HOST (walks block headers as
+ * ZSTD_findFrameSizeInfo does, zstd.c:41335): fills up to cap entries, returns the number
+ * of data frames found or an error code.  dst offsets are assigned back to back. */
+size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size_t cap);
+
+/* library / device info */
+const char *zl_versionString(void); /* ZSTD_versionString twin for src/serialize.c:26 */
+int zl_deviceCount(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZL_HIP_H */

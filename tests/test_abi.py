@@ -1,0 +1,78 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/zl_hip.h
+declares, and its host-only entry points (frame-size helpers, parameters, error strings)
+behave like the reference's.  No compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import zstdlite_amd as z
+from zstdlite_amd import _lib
+from zl_testlib import GOLDEN, ROOT
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "zl_hip.h")).read()
+    declared = set(re.findall(r"\b(zl_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/zl_hip.h but not exported"
+    assert declared == {s[0] for s in _lib.SYMBOLS}
+
+
+def test_error_strings_match_reference_vocabulary():
+    L = _lib.lib()
+    assert L.zl_isError((1 << 64) - 22) == 1 and L.zl_isError(12345) == 0
+    assert _lib.error_name((1 << 64) - 22) == "Restored data doesn't match checksum"  # zstd.c:3600
+    assert _lib.error_name((1 << 64) - 20) == "Data corruption detected"
+    assert _lib.error_name((1 << 64) - 70) == "Destination buffer is too small"
+    assert _lib.error_name((1 << 64) - 10) == "Unknown frame descriptor"
+    assert _lib.error_name((1 << 64) - 72) == "Src size is incorrect"
+
+
+def test_frame_size_helpers_on_golden(golden, oracle):
+    L = _lib.lib()
+    cases, d = golden
+    for c in cases:
+        b = c["comp"]
+        assert L.zl_findFrameCompressedSize(b, len(b)) == c["csize"]
+        assert L.zl_getFrameContentSize(b, len(b)) == c["n"]
+        assert L.zl_findDecompressedSize(b, len(b)) == c["n"]
+    zj = open(os.path.join(GOLDEN, "data.json.zst"), "rb").read()
+    assert L.zl_findFrameCompressedSize(zj, len(zj)) == 126 and L.zl_getFrameContentSize(zj, len(zj)) == 172
+    two = cases[10]["comp"] + cases[20]["comp"]
+    assert L.zl_findDecompressedSize(two, len(two)) == cases[10]["n"] + cases[20]["n"]
+    assert L.zl_findAllFramesCompressedSize(two, len(two)) == len(two)
+    assert L.zl_findFrameCompressedSize(two, len(two)) == cases[10]["csize"]  # first frame only, as raw-file.c:150
+    assert L.zl_getDictID_fromDict(d, len(d)) == oracle.L.zlo_dict_id(d, len(d)) != 0
+    dc = next(c for c in cases if c["gen"] == "dict")
+    assert L.zl_getDictID_fromFrame(dc["comp"], len(dc["comp"])) == L.zl_getDictID_fromDict(d, len(d))
+    assert _lib.is_error(L.zl_findFrameCompressedSize(b"abcdefgh", 8))
+    assert L.zl_getFrameContentSize(b"abcdefgh", 8) == (1 << 64) - 2
+    table = (_lib.FrameT * 4)()
+    assert L.zl_index_frames(two, len(two), table, 4) == 2
+    assert table[1].src_off == cases[10]["csize"] and table[1].dst_off == cases[10]["n"]
+
+
+def test_bound_dominates_reference_bound(oracle):
+    L = _lib.lib()
+    for n in [0, 1, 100, 65536, 131072, 131073, 1 << 20, (1 << 30) + 5]:
+        assert L.zl_compressBound(n) >= oracle.L.zlo_compress_bound(n)
+
+
+def test_context_options_mirror_reference_glue():
+    with pytest.warns(UserWarning, match="init_cctx\\(\\): Unknown option 'bogus'"):  # src/cctx.c:288
+        z._init_cctx_with_opts({"bogus": 1})
+    with pytest.warns(UserWarning, match="init_dctx\\(\\): Unknown option 'bogus'"):
+        z._init_dctx_with_opts({"bogus": 1})
+    assert z.zstd_cctx_settings(z.zstd_cctx(level=99))["level"] == 22  # clamp, src/cctx.c:261-263
+    assert z.zstd_cctx_settings(z.zstd_cctx(level=-99))["level"] == -5
+    s = z.zstd_cctx_settings(z.zstd_cctx(level=7, include_checksum=True, num_threads=4))
+    assert s == {"level": 7, "num_threads": 4, "include_checksum": 1}
+    assert z.zstd_dctx_settings(z.zstd_dctx(validate_checksum=False))["validate_checksum"] == 1  # inverted, src/dctx.c:233
+    with pytest.raises(z.ZstdError, match="only accepts raw vectors or strings"):
+        z.zstd_compress(12345)
+    info = z.zstd_info(open(os.path.join(GOLDEN, "data.json.zst"), "rb").read())
+    assert info == {"compressed_size": 126, "uncompressed_size": 172, "dict_id": 0, "has_checksum": True}

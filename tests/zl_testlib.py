@@ -260,3 +260,22 @@ GENERATORS = {"rand": gen_rand, "iid10": gen_iid10, "text": gen_text, "int20": g
 
 def sha256(b):
     return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def load_golden():
+    """tests/golden/frames.npz (made by tests/golden/make_golden.py from the reference libzstd).
+    Returns (list of case dicts with 'comp' bytes and regenerated 'plain' bytes, dict bytes)."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "frames.npz"))
+    meta = json.loads(z["meta"].tobytes().decode())
+    cases = []
+    for m in meta:
+        m = dict(m)
+        m["comp"] = z[m["key"]].tobytes()
+        if m["gen"] == "dict":
+            m["plain"] = z[m["key"] + "_plain"].tobytes()
+        else:
+            m["plain"] = GENERATORS[m["gen"]](m["n"])
+        assert sha256(m["plain"]) == m["sha256"], "generator drifted from the committed golden hashes"
+        cases.append(m)
+    return cases, z["dict"].tobytes()

@@ -1,0 +1,331 @@
+"""zstdlite_amd -- host-side mirror of the reference package's R API for its one-shot
+compress/decompress path, on top of the C-ABI of libzl_hip.so (include/zl_hip.h).
+
+The reference's R wrappers are one-line .Call()s into hand-written C glue
+(R/serialize.R:56-156, R/cctx.R:38-114); R is not available in this image, so the glue's call
+order, option names, clamps, warnings and error messages are restated here in Python:
+
+    zstd_compress / zstd_decompress     src/raw-file.c:25-118, :125-210
+    zstd_serialize / zstd_unserialize   src/serialize.c:34-142, :149-240
+    zstd_cctx / zstd_dctx               src/cctx.c:213-343, src/dctx.c:110-228
+    zstd_info / zstd_dict_id            src/zstd-info.c:22-95, src/dictionaries.c:23-58
+
+Everything that touches bytes happens inside the HIP library; this module only marshals
+buffers.  `zstd_serialize` uses pickle where the reference uses R's native serialization
+(that step sits above the hot path and stays on the CPU in both).
+"""
+import ctypes as C
+import pickle
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import FrameT, ZstdError, is_error
+
+__all__ = [
+    "zstd_compress", "zstd_decompress", "zstd_serialize", "zstd_unserialize", "zstd_cctx", "zstd_dctx",
+    "zstd_cctx_settings", "zstd_dctx_settings", "zstd_info", "zstd_dict_id", "zstd_version",
+    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "ZstdError",
+]
+
+ZL_c_compressionLevel = 100
+ZL_c_checksumFlag = 201
+ZL_c_nbWorkers = 400
+ZL_d_forceIgnoreChecksum = 1002
+_UNKNOWN = (1 << 64) - 1
+_ERROR = (1 << 64) - 2
+
+
+def _as_buffer(x, what):
+    """bytes-like / numpy uint8 -> (ctypes pointer, length, keepalive)."""
+    if isinstance(x, str):
+        x = x.encode()
+    if isinstance(x, np.ndarray):
+        a = np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+        return a.ctypes.data_as(C.c_void_p), a.size, a
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(x, dtype=np.uint8)
+        return a.ctypes.data_as(C.c_void_p), a.size, a
+    raise TypeError(f"{what} only accepts raw vectors (bytes-like / uint8 arrays) or strings")
+
+
+class _Ctx:
+    _free = None
+
+    def __init__(self, ptr):
+        if not ptr:
+            raise ZstdError(f"init_{self._kind}(): Couldn't initialse memory for '{self._kind}'")
+        self._ptr = ptr
+
+    def __del__(self):  # the reference attaches a C finalizer to the external pointer (src/cctx.c:191)
+        ptr, self._ptr = getattr(self, "_ptr", None), None
+        if ptr:
+            getattr(_lib.lib(), self._free)(ptr)
+
+
+class ZSTD_CCtx(_Ctx):
+    _kind, _free = "cctx", "zl_freeCCtx"
+
+
+class ZSTD_DCtx(_Ctx):
+    _kind, _free = "dctx", "zl_freeDCtx"
+
+
+def _read_dict(d, who):
+    if isinstance(d, str):  # filename (src/cctx.c:300-305)
+        with open(d, "rb") as f:
+            return f.read()
+    if isinstance(d, (bytes, bytearray, memoryview, np.ndarray)):
+        return bytes(d)
+    raise ZstdError(f"{who}(): 'dict' must be a raw vector or a filename")
+
+
+def _init_cctx_with_opts(opts, quiet=False):
+    """src/cctx.c:213-315 init_cctx_with_opts."""
+    L = _lib.lib()
+    cctx = ZSTD_CCtx(L.zl_createCCtx())
+    dict_ = None
+    for name, val in opts.items():
+        if name == "level":
+            level = max(-5, min(22, int(val)))  # src/cctx.c:261-263
+            if is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_compressionLevel, level)):
+                raise ZstdError("init_cctx(): Bad compression level")
+        elif name == "num_threads":
+            if int(val) > 1:
+                L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))
+        elif name == "include_checksum":
+            if val:
+                if is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_checksumFlag, 1)):
+                    raise ZstdError("init_cctx(): Couldn't set checksum flag")
+        elif name == "dict":
+            dict_ = val
+        elif not quiet:
+            warnings.warn(f"init_cctx(): Unknown option '{name}'")
+    if dict_ is not None:
+        d = _read_dict(dict_, "init_cctx")
+        r = L.zl_CCtx_loadDictionary(cctx._ptr, d, len(d))
+        if is_error(r):
+            raise ZstdError(f"init_cctx(): Error initialising dict. {_lib.error_name(r)}")
+    return cctx
+
+
+def _init_dctx_with_opts(opts, quiet=False):
+    """src/dctx.c:110-197 init_dctx_with_opts."""
+    L = _lib.lib()
+    dctx = ZSTD_DCtx(L.zl_createDCtx())
+    dict_ = None
+    for name, val in opts.items():
+        if name == "validate_checksum":
+            if not int(val):
+                if is_error(L.zl_DCtx_setParameter(dctx._ptr, ZL_d_forceIgnoreChecksum, 1)):
+                    raise ZstdError("init_dctx(): Could not set 'ZSTD_d_forceIgnoreChecksum'")
+        elif name == "dict":
+            dict_ = val
+        elif not quiet:
+            warnings.warn(f"init_dctx(): Unknown option '{name}'")
+    if dict_ is not None:
+        d = _read_dict(dict_, "init_dctx")
+        r = L.zl_DCtx_loadDictionary(dctx._ptr, d, len(d))
+        if is_error(r):
+            raise ZstdError(f"init_dctx(): Error initialising dict. {_lib.error_name(r)}")
+    return dctx
+
+
+def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None):
+    """R/cctx.R:38-48 -> init_cctx_ (src/cctx.c:323)."""
+    return _init_cctx_with_opts({"level": level, "num_threads": num_threads, "include_checksum": include_checksum,
+                                 **({"dict": dict} if dict is not None else {})})
+
+
+def zstd_dctx(validate_checksum=True, dict=None):
+    """R/cctx.R:74-82 -> init_dctx_ (src/dctx.c:205)."""
+    return _init_dctx_with_opts({"validate_checksum": validate_checksum, **({"dict": dict} if dict is not None else {})})
+
+
+def zstd_cctx_settings(cctx):
+    """src/cctx.c:343-369 get_cctx_settings_."""
+    L = _lib.lib()
+    out = {}
+    for key, pid in (("level", ZL_c_compressionLevel), ("num_threads", ZL_c_nbWorkers), ("include_checksum", ZL_c_checksumFlag)):
+        v = C.c_int(0)
+        L.zl_CCtx_getParameter(cctx._ptr, pid, C.byref(v))
+        out[key] = v.value
+    return out
+
+
+def zstd_dctx_settings(dctx):
+    """src/dctx.c:228-245 get_dctx_settings_ -- like the reference it reports the raw
+    forceIgnoreChecksum flag under the name 'validate_checksum' (src/dctx.c:233-236)."""
+    v = C.c_int(0)
+    _lib.lib().zl_DCtx_getParameter(dctx._ptr, ZL_d_forceIgnoreChecksum, C.byref(v))
+    return {"validate_checksum": v.value}
+
+
+def zstd_version():
+    return _lib.lib().zl_versionString().decode()
+
+
+def zstd_compress_bound(n):
+    return _lib.lib().zl_compressBound(n)
+
+
+def _compress_bytes(src_ptr, src_size, cctx, opts, who):
+    """bound -> alloc -> ctx -> compress -> truncate (src/raw-file.c:52-111)."""
+    L = _lib.lib()
+    cap = L.zl_compressBound(src_size)
+    dst = np.empty(cap, dtype=np.uint8)
+    ctx = _init_cctx_with_opts(opts) if cctx is None else cctx  # opts only honoured without a cctx
+    r = L.zl_compress2(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, src_ptr, src_size)
+    if is_error(r):
+        raise ZstdError(f"{who}(): Compression error. {_lib.error_name(r)}")
+    return dst[:r].tobytes()
+
+
+def zstd_compress(x, *, dst=None, cctx=None, use_file_streaming=False, **opts):
+    """R/serialize.R:128-138 -> zstd_compress_ (src/raw-file.c:25-118)."""
+    if not isinstance(x, (bytes, bytearray, memoryview, np.ndarray, str)):
+        raise ZstdError("zstd_compress() only accepts raw vectors or strings")
+    ptr, n, _keep = _as_buffer(x, "zstd_compress()")
+    out = _compress_bytes(ptr, n, cctx, opts, "zstd_compress")
+    if dst is not None:
+        try:
+            with open(dst, "wb") as f:
+                f.write(out)
+        except OSError:
+            raise ZstdError(f"zstd_compress(): Couldn't open file for output '{dst}'")
+        return None
+    return out
+
+
+def _decompress_bytes(src, dctx, opts, who):
+    """first-frame size -> content size -> alloc -> ctx -> decompress (src/raw-file.c:150-192),
+    with the multi-frame size twins so that the chunked frames zl_compress2 emits for large
+    inputs come back whole (deviation H1)."""
+    L = _lib.lib()
+    ptr, n, _keep = _as_buffer(src, who)
+    csize = L.zl_findAllFramesCompressedSize(ptr, n)
+    if is_error(csize):
+        raise ZstdError(f"{who}(): De-compression error. {_lib.error_name(csize)}")
+    cap = L.zl_findDecompressedSize(ptr, csize)
+    if cap == _ERROR:
+        raise ZstdError(f"{who}(): De-compression error. {_lib.error_name((1 << 64) - 72)}")
+    if cap == _UNKNOWN:
+        raise ZstdError(f"{who}(): frame does not record its content size")
+    dst = np.empty(max(cap, 1), dtype=np.uint8)
+    ctx = _init_dctx_with_opts(opts) if dctx is None else dctx
+    r = L.zl_decompressDCtx(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, ptr, csize)
+    if is_error(r):
+        raise ZstdError(f"{who}(): De-compression error. {_lib.error_name(r)}")
+    return dst[:r].tobytes()
+
+
+def zstd_decompress(src, type="raw", *, dctx=None, use_file_streaming=False, **opts):
+    """R/serialize.R:146-156 -> zstd_decompress_ (src/raw-file.c:125-210)."""
+    if isinstance(src, str):  # filename (src/raw-file.c:133-138)
+        with open(src, "rb") as f:
+            src = f.read()
+    elif not isinstance(src, (bytes, bytearray, memoryview, np.ndarray)):
+        raise ZstdError("zstd_compress_() only accepts raw vectors or filenames")
+    out = _decompress_bytes(src, dctx, opts, "zstd_decompress_")
+    return out if type == "raw" else out.decode()
+
+
+def zstd_serialize(robj, *, dst=None, cctx=None, use_file_streaming=False, **opts):
+    """R/serialize.R:56-66 -> zstd_serialize_ (src/serialize.c:34-142)."""
+    payload = pickle.dumps(robj, protocol=pickle.HIGHEST_PROTOCOL)
+    ptr, n, _keep = _as_buffer(payload, "zstd_serialize()")
+    out = _compress_bytes(ptr, n, cctx, opts, "zstd_serialize")
+    if dst is not None:
+        with open(dst, "wb") as f:
+            f.write(out)
+        return None
+    return out
+
+
+def zstd_unserialize(src, *, dctx=None, use_file_streaming=False, **opts):
+    """R/serialize.R:74-84 -> zstd_unserialize_ (src/serialize.c:149-240)."""
+    if isinstance(src, str):
+        with open(src, "rb") as f:
+            src = f.read()
+    return pickle.loads(_decompress_bytes(src, dctx, opts, "zstd_unserialize"))
+
+
+def zstd_dict_id(dict):
+    """R/dictionaries.R:26 -> zstd_dict_id_ (src/dictionaries.c:23-58)."""
+    d = _read_dict(dict, "zstd_dict_id")
+    return _lib.lib().zl_getDictID_fromDict(d, len(d))
+
+
+def zstd_info(src):
+    """R/zstd-info.R:18 -> zstd_info_ (src/zstd-info.c:22-95): frame-header peek."""
+    L = _lib.lib()
+    ptr, n, _keep = _as_buffer(src, "zstd_info()")
+    csize = L.zl_findFrameCompressedSize(ptr, n)
+    usize = L.zl_getFrameContentSize(ptr, n)
+    b = bytes(src[:8]) if n >= 5 else b"\0" * 8
+    return {
+        "compressed_size": None if is_error(csize) else csize,
+        "uncompressed_size": None if usize >= _ERROR else usize,
+        "dict_id": L.zl_getDictID_fromFrame(ptr, n),
+        "has_checksum": bool(n >= 5 and (b[4] >> 2) & 1),
+    }
+
+
+def _ptr_array(bufs):
+    arr = (C.c_void_p * len(bufs))()
+    for i, (p, _, _) in enumerate(bufs):
+        arr[i] = p.value if isinstance(p, C.c_void_p) else p
+    return arr
+
+
+def zstd_compress_batch(xs, *, cctx=None, **opts):
+    """n independent inputs, one launch (new entry; the reference loops .Call() per object,
+    vignettes/dictionaries.Rmd:129-138)."""
+    L = _lib.lib()
+    n = len(xs)
+    if n == 0:
+        return []
+    ctx = _init_cctx_with_opts(opts) if cctx is None else cctx
+    srcs = [_as_buffer(x, "zstd_compress_batch()") for x in xs]
+    sizes = (C.c_size_t * n)(*[s[1] for s in srcs])
+    caps = [L.zl_compressBound(s[1]) for s in srcs]
+    outs = [np.empty(c, dtype=np.uint8) for c in caps]
+    dsts = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    res = (C.c_size_t * n)()
+    r = L.zl_compress_batch(ctx._ptr, n, dsts, (C.c_size_t * n)(*caps), _ptr_array(srcs), sizes, res)
+    if is_error(r):
+        raise ZstdError(f"zstd_compress_batch(): Compression error. {_lib.error_name(r)}")
+    out = []
+    for i in range(n):
+        if is_error(res[i]):
+            raise ZstdError(f"zstd_compress_batch(): Compression error in item {i}. {_lib.error_name(res[i])}")
+        out.append(outs[i][: res[i]].tobytes())
+    return out
+
+
+def zstd_decompress_batch(srcs, *, dctx=None, **opts):
+    """n independent single-frame inputs, one launch."""
+    L = _lib.lib()
+    n = len(srcs)
+    if n == 0:
+        return []
+    ctx = _init_dctx_with_opts(opts) if dctx is None else dctx
+    bufs = [_as_buffer(s, "zstd_decompress_batch()") for s in srcs]
+    sizes = (C.c_size_t * n)(*[b[1] for b in bufs])
+    caps = []
+    for p, sz, _ in bufs:
+        c = L.zl_getFrameContentSize(p, sz)
+        caps.append(0 if c >= _ERROR else c)
+    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in caps]
+    dsts = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    res = (C.c_size_t * n)()
+    r = L.zl_decompress_batch(ctx._ptr, n, dsts, (C.c_size_t * n)(*caps), _ptr_array(bufs), sizes, res)
+    if is_error(r):
+        raise ZstdError(f"zstd_decompress_batch(): De-compression error. {_lib.error_name(r)}")
+    out = []
+    for i in range(n):
+        if is_error(res[i]):
+            raise ZstdError(f"zstd_decompress_batch(): De-compression error in item {i}. {_lib.error_name(res[i])}")
+        out.append(outs[i][: res[i]].tobytes())
+    return out

@@ -1,0 +1,82 @@
+"""ctypes binding of libzl_hip.so (include/zl_hip.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback behind this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzl_hip.so")
+
+_ERR_FLOOR = (1 << 64) - 120
+
+
+class ZstdError(RuntimeError):
+    """Raised where the reference glue calls Rf_error() (src/raw-file.c:81-83,190-192)."""
+
+
+class FrameT(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("src_size", C.c_uint64), ("dst_off", C.c_uint64), ("dst_cap", C.c_uint64)]
+
+
+_lib = None
+
+# every symbol include/zl_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("zl_isError", C.c_uint, [C.c_size_t]),
+    ("zl_getErrorName", C.c_char_p, [C.c_size_t]),
+    ("zl_compressBound", C.c_size_t, [C.c_size_t]),
+    ("zl_findFrameCompressedSize", C.c_size_t, [C.c_void_p, C.c_size_t]),
+    ("zl_getFrameContentSize", C.c_ulonglong, [C.c_void_p, C.c_size_t]),
+    ("zl_findDecompressedSize", C.c_ulonglong, [C.c_void_p, C.c_size_t]),
+    ("zl_findAllFramesCompressedSize", C.c_size_t, [C.c_void_p, C.c_size_t]),
+    ("zl_createCCtx", C.c_void_p, []),
+    ("zl_freeCCtx", C.c_size_t, [C.c_void_p]),
+    ("zl_CCtx_setParameter", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    ("zl_CCtx_getParameter", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("zl_CCtx_loadDictionary", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("zl_compress2", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    ("zl_createDCtx", C.c_void_p, []),
+    ("zl_freeDCtx", C.c_size_t, [C.c_void_p]),
+    ("zl_DCtx_setParameter", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    ("zl_DCtx_getParameter", C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("zl_DCtx_loadDictionary", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("zl_decompressDCtx", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    ("zl_getDictID_fromDict", C.c_uint, [C.c_void_p, C.c_size_t]),
+    ("zl_getDictID_fromFrame", C.c_uint, [C.c_void_p, C.c_size_t]),
+    ("zl_compress_batch", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("zl_decompress_batch", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("zl_decompress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameT), C.c_size_t, C.c_void_p]),
+    ("zl_decompress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("zl_compress_device_nframes", C.c_size_t, [C.c_size_t]),
+    ("zl_compress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("zl_compress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("zl_index_frames", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(FrameT), C.c_size_t]),
+    ("zl_versionString", C.c_char_p, []),
+    ("zl_deviceCount", C.c_int, []),
+]
+
+
+def lib():
+    """Load libzl_hip.so (once).  Raises ImportError with build instructions if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -m zstdlite_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError == a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def is_error(code):
+    return code > _ERR_FLOOR
+
+
+def error_name(code):
+    return lib().zl_getErrorName(code).decode()

@@ -1,0 +1,589 @@
+// zl_api.hip -- the C-ABI of libzl_hip.so (include/zl_hip.h): contexts, host staging and
+// kernel launches.  This is the seam the reference's R/C glue crosses instead of calling its
+// bundled libzstd (src/raw-file.c:52-74,150-189; src/serialize.c:73-91,171-197;
+// src/cctx.c:213-315; src/dctx.c:110-197).  No CPU codec lives here: without a HIP device
+// every compress/decompress call returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/zl_hip.h"
+#include "zl_format.h"
+#include "zl_kernels.h"
+
+static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// host-side frame format helpers (own restatement of zstd.c:41050-41148, :41335-41398)
+// ---------------------------------------------------------------------------------------
+inline u32 rd_le(const u8* p, int n) {
+    u32 v = 0;
+    for (int i = 0; i < n; i++) v |= (u32)p[i] << (8 * i);
+    return v;
+}
+inline u64 rd_le64(const u8* p) { return (u64)rd_le(p, 4) | ((u64)rd_le(p + 4, 4) << 32); }
+
+struct FrameHeader {
+    u64 content_size = ZL_CONTENTSIZE_UNKNOWN;
+    u64 window_size = 0;
+    u32 dict_id = 0;
+    bool has_checksum = false;
+    bool skippable = false;
+    u32 skippable_size = 0;
+    size_t header_size = 0;
+};
+
+size_t parse_frame_header(FrameHeader& h, const u8* src, size_t n) {
+    if (n < 5) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    const u32 magic = rd_le(src, 4);
+    if ((magic & 0xFFFFFFF0u) == ZL_MAGIC_SKIPPABLE) {
+        if (n < 8) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        h.skippable = true;
+        h.skippable_size = rd_le(src + 4, 4);
+        h.header_size = 8;
+        return 0;
+    }
+    if (magic != ZL_MAGIC) return ZL_ERR(ZL_E_PREFIX_UNKNOWN);
+    const u32 fhd = src[4];
+    const u32 dflag = fhd & 3, single = (fhd >> 5) & 1, fflag = fhd >> 6;
+    if (fhd & 8) return ZL_ERR(ZL_E_FRAMEPARAM_UNSUPPORTED);
+    const u32 dbytes = dflag == 3 ? 4 : dflag;
+    const u32 fbytes = fflag == 0 ? (single ? 1 : 0) : (1u << fflag);
+    const size_t hs = 5 + (single ? 0 : 1) + dbytes + fbytes;
+    if (n < hs) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    size_t pos = 5;
+    u64 window = 0;
+    if (!single) {
+        const u32 wd = src[pos++];
+        const u32 wlog = (wd >> 3) + 10;
+        if (wlog > 31) return ZL_ERR(ZL_E_WINDOW_TOO_LARGE);
+        window = 1ULL << wlog;
+        window += (window >> 3) * (wd & 7);
+    }
+    h.dict_id = rd_le(src + pos, (int)dbytes);
+    pos += dbytes;
+    u64 fcs = ZL_CONTENTSIZE_UNKNOWN;
+    if (fflag == 0) { if (single) fcs = src[pos]; }
+    else if (fflag == 1) fcs = (u64)rd_le(src + pos, 2) + 256;
+    else if (fflag == 2) fcs = rd_le(src + pos, 4);
+    else fcs = rd_le64(src + pos);
+    if (single) window = fcs;
+    h.content_size = fcs;
+    h.window_size = window;
+    h.has_checksum = (fhd >> 2) & 1;
+    h.header_size = hs;
+    return 0;
+}
+
+size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
+    FrameHeader h;
+    size_t e = parse_frame_header(h, src, n);
+    if (ZL_IS_ERR(e)) return e;
+    if (out) *out = h;
+    if (h.skippable) {
+        const u64 total = 8ULL + h.skippable_size;
+        if (total > n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        return (size_t)total;
+    }
+    size_t pos = h.header_size;
+    for (;;) {
+        if (n - pos < 3) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        const u32 bh = rd_le(src + pos, 3);
+        const u32 type = (bh >> 1) & 3, bsize = bh >> 3;
+        if (type == 3) return ZL_ERR(ZL_E_CORRUPTION);
+        const size_t csize = (type == 1) ? 1 : bsize;
+        pos += 3;
+        if (n - pos < csize) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        pos += csize;
+        if (bh & 1) break;
+    }
+    if (h.has_checksum) {
+        if (n - pos < 4) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        pos += 4;
+    }
+    return pos;
+}
+
+// ---------------------------------------------------------------------------------------
+// device plumbing
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + (n >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + (n >> 3) + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
+int g_num_cu = 256;
+bool device_ok() {
+    if (g_device_state == 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            g_device_state = -1;
+        } else {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+            g_device_state = 1;
+        }
+    }
+    return g_device_state == 1;
+}
+
+const size_t kGpuUnavailable = ZL_ERR(ZL_E_MEMORY);
+
+}  // namespace
+
+// =========================================================================================
+// contexts
+// =========================================================================================
+struct zl_dctx_s {
+    int ignore_checksum = 0;
+    std::vector<u8> dict;
+    u32 dict_id = 0;
+    bool dict_formatted = false;
+    bool dict_uploaded = false;
+    u32 dict_content_off = 0;
+    hipStream_t own_stream = nullptr;
+    DevBuf d_src, d_dst, d_frames, d_results, d_counter, d_lit, d_seq, d_dict, d_dict_tables;
+    PinBuf h_frames, h_results, h_stage_in, h_stage_out;
+    // pending device-resident call
+    hipStream_t pending_stream = nullptr;
+    size_t pending_n = 0;
+    bool pending = false;
+    u32 slots = 0;
+};
+
+extern "C" {
+
+unsigned zl_isError(size_t code) { return ZL_IS_ERR(code); }
+
+// zstd.c:3585-3628 ERR_getErrorString: identical user-visible strings
+const char* zl_getErrorName(size_t code) {
+    if (!ZL_IS_ERR(code)) return "No error detected";
+    switch ((int)(0 - code)) {
+    case ZL_E_GENERIC: return "Error (generic)";
+    case ZL_E_PREFIX_UNKNOWN: return "Unknown frame descriptor";
+    case ZL_E_VERSION_UNSUPPORTED: return "Version not supported";
+    case ZL_E_FRAMEPARAM_UNSUPPORTED: return "Unsupported frame parameter";
+    case ZL_E_WINDOW_TOO_LARGE: return "Frame requires too much memory for decoding";
+    case ZL_E_CORRUPTION: return "Data corruption detected";
+    case ZL_E_CHECKSUM_WRONG: return "Restored data doesn't match checksum";
+    case ZL_E_LITERALS_HEADER: return "Header of Literals' block doesn't respect format specification";
+    case ZL_E_PARAM_UNSUPPORTED: return "Unsupported parameter";
+    case ZL_E_PARAM_OUTOFBOUND: return "Parameter is out of bound";
+    case ZL_E_INIT_MISSING: return "Context should be init first";
+    case ZL_E_MEMORY: return "Allocation error : not enough memory";
+    case ZL_E_WORKSPACE_TOO_SMALL: return "workSpace buffer is not large enough";
+    case ZL_E_STAGE_WRONG: return "Operation not authorized at current processing stage";
+    case ZL_E_TABLELOG_TOO_LARGE: return "tableLog requires too much memory : unsupported";
+    case ZL_E_MAXSYMBOL_TOO_LARGE: return "Unsupported max Symbol Value : too large";
+    case ZL_E_MAXSYMBOL_TOO_SMALL: return "Specified maxSymbolValue is too small";
+    case ZL_E_DICT_CORRUPTED: return "Dictionary is corrupted";
+    case ZL_E_DICT_WRONG: return "Dictionary mismatch";
+    case ZL_E_DSTSIZE_TOO_SMALL: return "Destination buffer is too small";
+    case ZL_E_SRCSIZE_WRONG: return "Src size is incorrect";
+    case ZL_E_DSTBUFFER_NULL: return "Operation on NULL destination buffer";
+    default: return "Unspecified error code";
+    }
+}
+
+const char* zl_versionString(void) { return "zl-hip 0.1 (zstd format 1.5.6-compatible)"; }
+
+int zl_deviceCount(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t zl_findFrameCompressedSize(const void* src, size_t n) { return find_frame_size((const u8*)src, n); }
+
+unsigned long long zl_getFrameContentSize(const void* src, size_t n) {
+    FrameHeader h;
+    if (ZL_IS_ERR(parse_frame_header(h, (const u8*)src, n))) return ZL_CONTENTSIZE_ERROR;
+    if (h.skippable) return 0;
+    return h.content_size;
+}
+
+unsigned zl_getDictID_fromDict(const void* dict, size_t n) {
+    if (n < 8 || rd_le((const u8*)dict, 4) != ZL_MAGIC_DICT) return 0;
+    return rd_le((const u8*)dict + 4, 4);
+}
+
+unsigned zl_getDictID_fromFrame(const void* src, size_t n) {
+    FrameHeader h;
+    if (ZL_IS_ERR(parse_frame_header(h, (const u8*)src, n)) || h.skippable) return 0;
+    return h.dict_id;
+}
+
+// zstd.c:41232-41270 ZSTD_findDecompressedSize
+unsigned long long zl_findDecompressedSize(const void* src_, size_t n) {
+    const u8* src = (const u8*)src_;
+    unsigned long long total = 0;
+    while (n >= 5) {
+        FrameHeader h;
+        size_t fs = find_frame_size(src, n, &h);
+        if (ZL_IS_ERR(fs)) return ZL_CONTENTSIZE_ERROR;
+        if (!h.skippable) {
+            if (h.content_size == ZL_CONTENTSIZE_UNKNOWN) return ZL_CONTENTSIZE_UNKNOWN;
+            if (total + h.content_size < total) return ZL_CONTENTSIZE_ERROR;
+            total += h.content_size;
+        }
+        src += fs;
+        n -= fs;
+    }
+    if (n) return ZL_CONTENTSIZE_ERROR;
+    return total;
+}
+
+size_t zl_findAllFramesCompressedSize(const void* src_, size_t n) {
+    const u8* src = (const u8*)src_;
+    size_t total = 0;
+    while (n >= 5) {
+        size_t fs = find_frame_size(src, n);
+        if (ZL_IS_ERR(fs)) return total ? total : fs;
+        src += fs;
+        n -= fs;
+        total += fs;
+    }
+    return total;
+}
+
+size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t cap) {
+    const u8* src = (const u8*)src_;
+    size_t pos = 0, count = 0;
+    u64 dst_off = 0;
+    while (n - pos >= 5) {
+        FrameHeader h;
+        size_t fs = find_frame_size(src + pos, n - pos, &h);
+        if (ZL_IS_ERR(fs)) return fs;
+        if (!h.skippable) {
+            if (h.content_size == ZL_CONTENTSIZE_UNKNOWN) return ZL_ERR(ZL_E_FRAMEPARAM_UNSUPPORTED);
+            if (count < cap) {
+                frames[count].src_off = pos;
+                frames[count].src_size = fs;
+                frames[count].dst_off = dst_off;
+                frames[count].dst_cap = h.content_size;
+            }
+            dst_off += h.content_size;
+            count++;
+        }
+        pos += fs;
+    }
+    if (pos != n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    return count;
+}
+
+// =========================================================================================
+// decompression
+// =========================================================================================
+zl_dctx* zl_createDCtx(void) { return new (std::nothrow) zl_dctx_s(); }
+
+size_t zl_freeDCtx(zl_dctx* d) {
+    if (!d) return 0;
+    if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
+    DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables};
+    for (DevBuf* b : bufs) b->release();
+    PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out};
+    for (PinBuf* b : pins) b->release();
+    if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+    delete d;
+    return 0;
+}
+
+size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    switch (param) {
+    case ZL_d_forceIgnoreChecksum: d->ignore_checksum = value ? 1 : 0; return 0;
+    case ZL_d_stableOutBuffer: return 0;
+    default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
+    }
+}
+
+size_t zl_DCtx_getParameter(const zl_dctx* d, int param, int* value) {
+    if (!d || !value) return ZL_ERR(ZL_E_GENERIC);
+    switch (param) {
+    case ZL_d_forceIgnoreChecksum: *value = d->ignore_checksum; return 0;
+    case ZL_d_stableOutBuffer: *value = 1; return 0;
+    default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
+    }
+}
+
+// zstd.c:42321 ZSTD_DCtx_loadDictionary: the dictionary is copied (the R vector may be
+// collected afterwards); it is digested on the device at first use.
+size_t zl_DCtx_loadDictionary(zl_dctx* d, const void* dict, size_t n) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    d->dict.clear();
+    d->dict_uploaded = false;
+    d->dict_id = 0;
+    d->dict_formatted = false;
+    if (dict && n) {
+        d->dict.assign((const u8*)dict, (const u8*)dict + n);
+        if (n >= 8 && rd_le((const u8*)dict, 4) == ZL_MAGIC_DICT) {
+            d->dict_formatted = true;
+            d->dict_id = rd_le((const u8*)dict + 4, 4);
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+hipStream_t dctx_stream(zl_dctx* d, void* user) {
+    if (user) return (hipStream_t)user;
+    if (!d->own_stream) (void)hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
+    return d->own_stream;
+}
+
+// upload + digest the dictionary once per context
+size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
+    if (d->dict.empty() || d->dict_uploaded) return 0;
+    if (!d->d_dict.ensure(d->dict.size() + 16)) return kGpuUnavailable;
+    if (hipMemcpyAsync(d->d_dict.p, d->dict.data(), d->dict.size(), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    d->dict_content_off = 0;
+    if (d->dict_formatted) {
+        if (!d->d_dict_tables.ensure(sizeof(zl_dict_tables))) return kGpuUnavailable;
+        if (zl_launch_digest_dict((const u8*)d->d_dict.p, (u32)d->dict.size(), d->d_dict_tables.p, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        zl_dict_tables hdr;
+        if (hipMemcpyAsync(&hdr, d->d_dict_tables.p, sizeof(hdr), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hdr.status) return ZL_ERR(hdr.status);
+        d->dict_content_off = hdr.content_off;
+    } else {
+        if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    d->dict_uploaded = true;
+    return 0;
+}
+
+// enqueue one decode launch over `n` frames whose table sits in d->h_frames (pinned)
+size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_t st) {
+    size_t e = dctx_prepare_dict(d, st);
+    if (ZL_IS_ERR(e)) return e;
+    const u32 max_slots = (u32)g_num_cu * 6;
+    const u32 slots = (u32)std::min<size_t>(n, max_slots);
+    if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) ||
+        !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)))
+        return kGpuUnavailable;
+    if (hipMemcpyAsync(d->d_frames.p, d->h_frames.p, n * sizeof(zl_frame_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemsetAsync(d->d_counter.p, 0, 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    zl_decode_args a;
+    a.frames = (const zl_frame_desc*)d->d_frames.p;
+    a.nframes = (u32)n;
+    a.src = d_src;
+    a.dst = d_dst;
+    a.results = (u64*)d->d_results.p;
+    a.counter = (u32*)d->d_counter.p;
+    a.lit_scratch = (u8*)d->d_lit.p;
+    a.seq_scratch = (u32*)d->d_seq.p;
+    a.dict_content = nullptr;
+    a.dict_len = 0;
+    a.dict_id = d->dict_id;
+    a.dict_tables = nullptr;
+    if (!d->dict.empty()) {
+        a.dict_content = (const u8*)d->d_dict.p + d->dict_content_off;
+        a.dict_len = (u32)(d->dict.size() - d->dict_content_off);
+        if (d->dict_formatted) a.dict_tables = d->d_dict_tables.p;
+    }
+    a.ignore_checksum = (u32)d->ignore_checksum;
+    if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t zl_decompress_device_async(zl_dctx* d, void* d_dst, const void* d_src, const zl_frame_t* frames, size_t n, void* stream) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (n == 0) { d->pending = true; d->pending_n = 0; d->pending_stream = dctx_stream(d, stream); return 0; }
+    if (n > 0xFFFFFFF0u) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+    hipStream_t st = dctx_stream(d, stream);
+    if (!d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64))) return kGpuUnavailable;
+    memcpy(d->h_frames.p, frames, n * sizeof(zl_frame_desc));
+    size_t e = dctx_enqueue(d, (u8*)d_dst, (const u8*)d_src, n, st);
+    if (ZL_IS_ERR(e)) return e;
+    if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    d->pending = true;
+    d->pending_n = n;
+    d->pending_stream = st;
+    return 0;
+}
+
+size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
+    if (!d || !d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    d->pending = false;
+    if (hipStreamSynchronize(d->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const u64* r = (const u64*)d->h_results.p;
+    size_t total = 0, first_err = 0;
+    for (size_t i = 0; i < d->pending_n; i++) {
+        if (results) results[i] = (size_t)r[i];
+        if (ZL_IS_ERR(r[i])) { if (!first_err) first_err = (size_t)r[i]; }
+        else total += (size_t)r[i];
+    }
+    return first_err ? first_err : total;
+}
+
+// zstd.c:41798 ZSTD_decompressDCtx -> :41671 ZSTD_decompressMultiFrame, frames decoded in
+// parallel.  A frame without a recorded content size ends a launch group: its size is only
+// known once decoded, so later frames are placed after reading it back.
+size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    const u8* src = (const u8*)src_;
+    // ---- index frames on the host (serial header walk, zstd.c:41335)
+    std::vector<zl_frame_desc> table;
+    std::vector<u8> known;
+    size_t pos = 0;
+    bool any = false;
+    while (n - pos >= 5) {
+        FrameHeader h;
+        size_t fs = find_frame_size(src + pos, n - pos, &h);
+        if (ZL_IS_ERR(fs)) {
+            if (any && fs == ZL_ERR(ZL_E_PREFIX_UNKNOWN)) fs = ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:41752
+            return fs;
+        }
+        if (!h.skippable) {
+            zl_frame_desc fd;
+            fd.src_off = pos;
+            fd.src_size = fs;
+            fd.dst_off = 0;
+            fd.dst_cap = h.content_size;
+            table.push_back(fd);
+            known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
+        }
+        any = true;
+        pos += fs;
+    }
+    if (pos != n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    if (table.empty()) return 0;
+    if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+    hipStream_t st = dctx_stream(d, nullptr);
+    if (!d->d_src.ensure(n + 16) || !d->d_dst.ensure(cap + 16)) return kGpuUnavailable;
+    if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    size_t total = 0, i = 0;
+    while (i < table.size()) {
+        size_t j = i;
+        u64 off = total;
+        while (j < table.size()) {
+            table[j].dst_off = off;
+            if (!known[j]) { table[j].dst_cap = cap - std::min<u64>(off, cap); j++; break; }
+            if (table[j].dst_cap > cap - std::min<u64>(off, cap)) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+            off += table[j].dst_cap;
+            j++;
+        }
+        const size_t cnt = j - i;
+        if (!d->h_frames.ensure(cnt * sizeof(zl_frame_desc)) || !d->h_results.ensure(cnt * sizeof(u64))) return kGpuUnavailable;
+        memcpy(d->h_frames.p, &table[i], cnt * sizeof(zl_frame_desc));
+        size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
+        if (ZL_IS_ERR(e)) return e;
+        if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        const u64* r = (const u64*)d->h_results.p;
+        for (size_t k = 0; k < cnt; k++) {
+            if (ZL_IS_ERR(r[k])) return (size_t)r[k];
+            total += (size_t)r[k];
+        }
+        i = j;
+    }
+    if (total) {
+        if (hipMemcpyAsync(dst, d->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    return total;
+}
+
+size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t* caps, const void* const* srcs,
+                           const size_t* sizes, size_t* results) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (n == 0) return 0;
+    // Each item must be exactly one data frame with a recorded content size (what
+    // zl_compress_batch / ZSTD_compress2 produce); pack inputs into one pinned staging buffer.
+    std::vector<zl_frame_desc> table(n);
+    std::vector<size_t> pre(n, 0);
+    size_t in_total = 0, out_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        FrameHeader h;
+        const u8* s = (const u8*)srcs[i];
+        size_t fs = find_frame_size(s, sizes[i], &h);
+        if (ZL_IS_ERR(fs)) { pre[i] = fs; fs = 0; }
+        else if (h.skippable || fs != sizes[i]) { pre[i] = ZL_ERR(ZL_E_SRCSIZE_WRONG); }
+        else if (h.content_size == ZL_CONTENTSIZE_UNKNOWN) { pre[i] = ZL_ERR(ZL_E_FRAMEPARAM_UNSUPPORTED); }
+        else if (h.content_size > caps[i]) { pre[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL); }
+        table[i].src_off = in_total;
+        table[i].src_size = pre[i] ? 0 : sizes[i];
+        table[i].dst_off = out_total;
+        table[i].dst_cap = pre[i] ? 0 : h.content_size;
+        in_total += (table[i].src_size + 15) & ~(size_t)15;
+        out_total += (table[i].dst_cap + 15) & ~(size_t)15;
+    }
+    hipStream_t st = dctx_stream(d, nullptr);
+    if (!d->h_stage_in.ensure(in_total + 16) || !d->h_stage_out.ensure(out_total + 16) || !d->d_src.ensure(in_total + 16) ||
+        !d->d_dst.ensure(out_total + 16) || !d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64)))
+        return kGpuUnavailable;
+    for (size_t i = 0; i < n; i++)
+        if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, srcs[i], table[i].src_size);
+    if (hipMemcpyAsync(d->d_src.p, d->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    memcpy(d->h_frames.p, table.data(), n * sizeof(zl_frame_desc));
+    size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, n, st);
+    if (ZL_IS_ERR(e)) return e;
+    if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (out_total && hipMemcpyAsync(d->h_stage_out.p, d->d_dst.p, out_total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const u64* r = (const u64*)d->h_results.p;
+    for (size_t i = 0; i < n; i++) {
+        if (pre[i]) { results[i] = pre[i]; continue; }
+        results[i] = (size_t)r[i];
+        if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
+    }
+    return 0;
+}
+
+}  // extern "C"
