@@ -1,0 +1,112 @@
+"""Parity tests for the HIP encoder, through the C-ABI.  The bar (BASELINE.json north_star):
+output is valid zstd that the REFERENCE decoder (oracle/_ref) and the oracle restatement
+round-trip bit-exact, it is deterministic, and the level-3 ratio stays within 5 % of the
+reference libzstd on the SURVEY 8(d) inputs.  Mirrors tests/testthat/test-compress-raw.R,
+test-round-trip.R, test-cctx.R, test-checksums.R."""
+import numpy as np
+import pytest
+
+import zstdlite_amd as z
+from zl_testlib import GENERATORS, have_ref
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [0, 1, 2, 7, 8, 9, 63, 64, 65, 255, 256, 257, 1000, 4096, 65535, 65536, 131071, 131072, 131073, 300000, 1 << 20]
+
+
+def _decoders(oracle):
+    decs = [("oracle", lambda c, n: oracle.decompress(c, cap=n))]
+    if have_ref():
+        from zl_testlib import Ref
+        r = Ref()
+        decs.append(("reference", lambda c, n: r.decompress(c, n)))
+    return decs
+
+
+@pytest.mark.parametrize("gen", ["text", "iid10", "int20", "rand"])
+def test_roundtrip_through_reference_decoder(gen, oracle):
+    decs = _decoders(oracle)
+    cctx = z.zstd_cctx()
+    for n in SIZES:
+        data = GENERATORS[gen](n, seed=n + 17)
+        comp = z.zstd_compress(data, cctx=cctx)
+        assert len(comp) <= z.zstd_compress_bound(n)
+        for name, dec in decs:
+            assert dec(comp, n) == data, (gen, n, name)
+        assert z.zstd_decompress(comp) == data, (gen, n, "hip")  # identical(dat, zstd_decompress(zstd_compress(dat)))
+
+
+def test_special_inputs(oracle):
+    decs = _decoders(oracle)
+    rng = np.random.default_rng(1)
+    cases = {
+        "zeros": bytes(300000),
+        "one_byte_runs": b"".join(bytes([i % 251]) * (i % 97 + 1) for i in range(4000)),
+        "period3": b"abc" * 70000,
+        "period257": bytes(range(256)) * 3 + b"x" + (bytes(range(256)) + b"y") * 500,
+        "ramp_u16": np.arange(100000, dtype="<u2").tobytes(),
+        "sparse": bytes(np.where(rng.random(250000) < 0.02, rng.integers(0, 256, 250000), 0).astype(np.uint8)),
+        "text_then_rand": GENERATORS["text"](200000) + GENERATORS["rand"](200000),
+        "two_symbols": bytes(rng.integers(0, 2, 150000, dtype=np.uint8) * 255),
+        "all_256_symbols_skewed": bytes((rng.zipf(1.3, 200000) % 256).astype(np.uint8)),
+    }
+    for name, data in cases.items():
+        comp = z.zstd_compress(data)
+        for dn, dec in decs:
+            assert dec(comp, len(data)) == data, (name, dn)
+        assert z.zstd_decompress(comp) == data, name
+
+
+def test_deterministic_and_cctx_reuse():
+    """tests/testthat/test-cctx.R:5-37: on-the-fly context == reused zstd_cctx(), twice."""
+    data = GENERATORS["text"](500000)
+    cctx = z.zstd_cctx()
+    a = z.zstd_compress(data)
+    assert a == z.zstd_compress(data, cctx=cctx)
+    assert a == z.zstd_compress(data, cctx=cctx)
+    assert z.zstd_serialize({"a": list(range(1000))}) == z.zstd_serialize({"a": list(range(1000))}, cctx=cctx)
+
+
+def test_checksum_adds_four_bytes_per_frame():
+    """tests/testthat/test-checksums.R:2-35."""
+    dat = list(range(1, 11))
+    v1 = z.zstd_serialize(dat)
+    cctx = z.zstd_cctx(include_checksum=True)
+    v2 = z.zstd_serialize(dat, cctx=cctx)
+    assert len(v1) + 4 == len(v2)
+    assert z.zstd_unserialize(v2) == dat
+    bad = bytearray(v2)
+    bad[-1] = (bad[-1] + 1) & 0xFF
+    with pytest.raises(z.ZstdError, match="doesn't match checksum"):
+        z.zstd_unserialize(bytes(bad))
+    assert z.zstd_unserialize(bytes(bad), dctx=z.zstd_dctx(validate_checksum=False)) == dat
+    big = GENERATORS["text"](400000)
+    assert len(z.zstd_compress(big, include_checksum=True)) == len(z.zstd_compress(big)) + 4 * 4
+
+
+def test_serialize_roundtrip():
+    """tests/testthat/test-round-trip.R:3-44 (pickle stands in for R's serialize)."""
+    obj = {"mtcars": [[21.0, 6, 160.0], [22.8, 4, 108.0]], "s": "x" * 1000, "v": np.arange(100000).tolist()}
+    assert z.zstd_unserialize(z.zstd_serialize(obj)) == obj
+    assert z.zstd_unserialize(z.zstd_serialize(obj, level=7, num_threads=2)) == obj
+
+
+def test_batch_compress(oracle):
+    items = [GENERATORS[g](n, seed=i) for i, (g, n) in enumerate(
+        [("text", 0), ("text", 300), ("iid10", 5000), ("rand", 777), ("int20", 70000), ("text", 200000), ("text", 131072)])]
+    comps = z.zstd_compress_batch(items)
+    singles = [z.zstd_compress(x) for x in items]
+    assert comps == singles
+    for x, c in zip(items, comps):
+        assert oracle.decompress(c, cap=len(x)) == x
+    assert z.zstd_decompress_batch([c for x, c in zip(items, comps) if len(x) <= 131072]) == [x for x in items if len(x) <= 131072]
+
+
+@pytest.mark.parametrize("gen,slack", [("text", 1.05), ("iid10", 1.05), ("int20", 1.05), ("rand", 1.001)])
+def test_ratio_within_five_percent_of_reference(gen, slack, ref):
+    """north_star: zstd_compress() level-3 ratio within 5 % of CPU libzstd (SURVEY 8d inputs)."""
+    n = 8 << 20
+    data = GENERATORS[gen](n)
+    ours = len(z.zstd_compress(data))
+    theirs = len(ref.compress(data, level=3))
+    assert ours <= theirs * slack, (gen, ours, theirs, ours / theirs)

@@ -13,6 +13,7 @@
 
 #include "../../include/zl_hip.h"
 #include "zl_format.h"
+#include "zl_host.h"
 #include "zl_kernels.h"
 
 static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
@@ -109,68 +110,6 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
     }
     return pos;
 }
-
-// ---------------------------------------------------------------------------------------
-// device plumbing
-// ---------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    bool ensure(size_t n) {
-        if (n <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + (n >> 3) + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
-        cap = want;
-        return true;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-struct PinBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    bool ensure(size_t n) {
-        if (n <= cap) return true;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + (n >> 3) + 256;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
-        cap = want;
-        return true;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
-int g_num_cu = 256;
-bool device_ok() {
-    if (g_device_state == 0) {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-            g_device_state = -1;
-        } else {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
-            g_device_state = 1;
-        }
-    }
-    return g_device_state == 1;
-}
-
-const size_t kGpuUnavailable = ZL_ERR(ZL_E_MEMORY);
 
 }  // namespace
 

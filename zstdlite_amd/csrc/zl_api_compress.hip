@@ -1,41 +1,159 @@
-// zl_api_compress.hip -- compression half of the C-ABI (include/zl_hip.h).
+// zl_api_compress.hip -- compression half of the C-ABI (include/zl_hip.h): the context the
+// reference builds in init_cctx_with_opts (src/cctx.c:213-315) and the one-shot call it
+// makes at src/raw-file.c:74 / src/serialize.c:91, on HIP kernels (zl_encode.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "../../include/zl_hip.h"
+#include "zl_encode.h"
 #include "zl_format.h"
+#include "zl_host.h"
+
+#define ZL_GROUP_CHUNKS 8192u  // chunks encoded per launch group (1 GiB of input); bounds the scratch
 
 struct zl_cctx_s {
     int level = 3;
     int checksum = 0;
     int nb_workers = 0;
     std::vector<u8> dict;
+    hipStream_t own_stream = nullptr;
+    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_meta, d_staged, d_fsize, d_foff, d_totals;
+    PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
+    // pending device-resident call
+    bool pending = false;
+    hipStream_t pending_stream = nullptr;
+    size_t pending_chunks = 0, pending_groups = 0;
 };
+
+namespace {
+
+hipStream_t cctx_stream(zl_cctx* c, void* user) {
+    if (user) return (hipStream_t)user;
+    if (!c->own_stream) (void)hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    return c->own_stream;
+}
+
+inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_CHUNK; }
+
+// Enqueue the whole encoder over a chunk table already written to c->h_chunks (nchunks entries):
+// E1 -> E2 -> size scan -> gather, in groups that reuse the scratch.  Frames end up back to
+// back in d_dst; per-chunk sizes in d_fsize, per-group running totals in d_totals[g+1].
+size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st) {
+    const size_t group = std::min<size_t>(nchunks, ZL_GROUP_CHUNKS);
+    const size_t ngroups = (nchunks + ZL_GROUP_CHUNKS - 1) / ZL_GROUP_CHUNKS;
+    if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
+        !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) ||
+        !c->d_meta.ensure(group * sizeof(zl_chunk_meta)) || !c->d_lits.ensure(group * (size_t)ZL_LIT_STRIDE_ENC) ||
+        !c->d_seqs.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(zl_seq)) || !c->d_staged.ensure(group * (size_t)ZL_OUT_STRIDE))
+        return kGpuUnavailable;
+    if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    for (size_t g = 0; g < ngroups; g++) {
+        const size_t first = g * ZL_GROUP_CHUNKS;
+        const u32 cnt = (u32)std::min<size_t>(ZL_GROUP_CHUNKS, nchunks - first);
+        zl_match_args m;
+        m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
+        m.src = d_src;
+        m.lits = (u8*)c->d_lits.p;
+        m.seqs = (zl_seq*)c->d_seqs.p;
+        m.meta = (zl_chunk_meta*)c->d_meta.p;
+        m.lit_stride = ZL_LIT_STRIDE_ENC;
+        m.seq_stride = ZL_SEQ_STRIDE;
+        if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        zl_entropy_args e;
+        e.chunks = m.chunks;
+        e.src = d_src;
+        e.lits = m.lits;
+        e.seqs = m.seqs;
+        e.meta = m.meta;
+        e.out = (u8*)c->d_staged.p;
+        e.frame_size = (u32*)c->d_fsize.p + first;
+        e.lit_stride = ZL_LIT_STRIDE_ENC;
+        e.seq_stride = ZL_SEQ_STRIDE;
+        e.out_stride = ZL_OUT_STRIDE;
+        e.checksum = (u32)c->checksum;
+        e.dict_id = 0;
+        if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        u64* totals = (u64*)c->d_totals.p;
+        if (zl_launch_scan_sizes(e.frame_size, (u64*)c->d_foff.p + first, totals + g, totals + g + 1, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        zl_gather_args ga;
+        ga.staged = e.out;
+        ga.frame_size = e.frame_size;
+        ga.frame_off = (const u64*)c->d_foff.p + first;
+        ga.dst = d_dst;
+        ga.out_stride = ZL_OUT_STRIDE;
+        if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64))) return kGpuUnavailable;
+    if (hipMemcpyAsync(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemcpyAsync(c->h_totals.p, c->d_totals.p, (ngroups + 1) * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    c->pending_chunks = nchunks;
+    c->pending_groups = ngroups;
+    return 0;
+}
+
+size_t fill_chunk_table(zl_cctx* c, size_t n) {
+    const size_t nchunks = chunks_of(n);
+    if (!c->h_chunks.ensure(nchunks * sizeof(zl_chunk_desc))) return kGpuUnavailable;
+    zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
+    for (size_t i = 0; i < nchunks; i++) {
+        t[i].src_off = (u64)i * ZL_CHUNK;
+        t[i].src_size = (u32)std::min<size_t>(ZL_CHUNK, n - i * (size_t)ZL_CHUNK);
+        t[i].flags = 0;
+    }
+    return nchunks;
+}
+
+}  // namespace
 
 extern "C" {
 
+// One frame per chunk: header <= 13 bytes, block header 3, checksum 4; a chunk that does not
+// compress is stored raw.  Always >= ZSTD_COMPRESSBOUND(n) (zstd.h:231) so a buffer sized by
+// this bound is also large enough for what the reference would have produced.
 size_t zl_compressBound(size_t n) {
-    // per-chunk frame: <= 13 header + 3 block header + chunk + 4 checksum; keep >= ZSTD_COMPRESSBOUND
-    const size_t chunks = n / ZL_BLOCK_MAX + 1;
     const size_t zb = n + (n >> 8) + (n < ZL_BLOCK_MAX ? ((ZL_BLOCK_MAX - n) >> 11) : 0);
-    return zb + chunks * 24;
+    return zb + chunks_of(n) * ZL_FRAME_OVERHEAD;
 }
 
+size_t zl_compress_device_nframes(size_t n) { return chunks_of(n); }
+
 zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
-size_t zl_freeCCtx(zl_cctx* c) { delete c; return 0; }
+
+size_t zl_freeCCtx(zl_cctx* c) {
+    if (!c) return 0;
+    if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals};
+    for (DevBuf* b : bufs) b->release();
+    PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
+    for (PinBuf* b : pins) b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+// zstd.c:23223 ZSTD_CCtx_setParameter for the parameters the glue uses (src/cctx.c:72-95,265-284).
+// The encoder implements the level-3 strategy (double-hash greedy, zstd.c:29529); the level is
+// recorded and reported back but does not select another strategy yet.
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     switch (param) {
-    case ZL_c_compressionLevel: c->level = value; return 0;
+    case ZL_c_compressionLevel:
+        if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        c->level = value;
+        return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
-    case ZL_c_stableInBuffer: case ZL_c_stableOutBuffer: return 0;
+    case ZL_c_stableInBuffer:
+    case ZL_c_stableOutBuffer: return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
+
 size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     if (!c || !value) return ZL_ERR(ZL_E_GENERIC);
     switch (param) {
@@ -45,16 +163,114 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
+
+// zstd.c:23826 ZSTD_CCtx_loadDictionary: copied.  The encoder does not use dictionaries yet:
+// frames are produced without a dictionary id and decode with or without one loaded.
 size_t zl_CCtx_loadDictionary(zl_cctx* c, const void* dict, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     c->dict.clear();
     if (dict && n) c->dict.assign((const u8*)dict, (const u8*)dict + n);
     return 0;
 }
-size_t zl_compress2(zl_cctx*, void*, size_t, const void*, size_t) { return ZL_ERR(ZL_E_GENERIC); }
-size_t zl_compress_batch(zl_cctx*, size_t, void* const*, const size_t*, const void* const*, const size_t*, size_t*) { return ZL_ERR(ZL_E_GENERIC); }
-size_t zl_compress_device_nframes(size_t n) { return n / ZL_BLOCK_MAX + ((n % ZL_BLOCK_MAX) || n == 0 ? 1 : 0); }
-size_t zl_compress_device_async(zl_cctx*, void*, size_t, const void*, size_t, void*) { return ZL_ERR(ZL_E_GENERIC); }
-size_t zl_compress_device_finish(zl_cctx*, size_t*) { return ZL_ERR(ZL_E_GENERIC); }
+
+size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void* d_src, size_t n, void* stream) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (cap < zl_compressBound(n)) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    hipStream_t st = cctx_stream(c, stream);
+    const size_t nchunks = fill_chunk_table(c, n);
+    if (ZL_IS_ERR(nchunks)) return nchunks;
+    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st);
+    if (ZL_IS_ERR(e)) return e;
+    c->pending = true;
+    c->pending_stream = st;
+    return 0;
+}
+
+size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
+    if (!c || !c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    c->pending = false;
+    if (hipStreamSynchronize(c->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (frame_sizes) {
+        const u32* fs = (const u32*)c->h_fsize.p;
+        for (size_t i = 0; i < c->pending_chunks; i++) frame_sizes[i] = fs[i];
+    }
+    return (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+}
+
+// replaces ZSTD_compress2 (zstd.h:599): host buffers in and out.
+size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+    hipStream_t st = cctx_stream(c, nullptr);
+    const size_t bound = zl_compressBound(n);
+    if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16)) return kGpuUnavailable;
+    if (n && hipMemcpyAsync(c->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t nchunks = fill_chunk_table(c, n);
+    if (ZL_IS_ERR(nchunks)) return nchunks;
+    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
+    if (ZL_IS_ERR(e)) return e;
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    if (total > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    if (hipMemcpyAsync(dst, c->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    return total;
+}
+
+// n independent inputs in one launch: every input becomes its own frame (inputs above one
+// chunk become several concatenated frames, exactly as zl_compress2 would emit them).
+size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* caps, const void* const* srcs,
+                         const size_t* sizes, size_t* results) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (n == 0) return 0;
+    hipStream_t st = cctx_stream(c, nullptr);
+    size_t nchunks = 0, in_total = 0, bound_total = 0;
+    std::vector<size_t> first_chunk(n + 1), in_off(n);
+    for (size_t i = 0; i < n; i++) {
+        first_chunk[i] = nchunks;
+        in_off[i] = in_total;
+        nchunks += chunks_of(sizes[i]);
+        in_total += (sizes[i] + 15) & ~(size_t)15;
+        bound_total += zl_compressBound(sizes[i]);
+    }
+    first_chunk[n] = nchunks;
+    if (!c->h_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->h_stage_in.ensure(in_total + 16) || !c->h_stage_out.ensure(bound_total + 16) ||
+        !c->d_src.ensure(in_total + 16) || !c->d_dst.ensure(bound_total + 16))
+        return kGpuUnavailable;
+    zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
+    for (size_t i = 0; i < n; i++) {
+        if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
+        const size_t k = chunks_of(sizes[i]);
+        for (size_t j = 0; j < k; j++) {
+            zl_chunk_desc& d = t[first_chunk[i] + j];
+            d.src_off = in_off[i] + j * (size_t)ZL_CHUNK;
+            d.src_size = (u32)std::min<size_t>(ZL_CHUNK, sizes[i] - j * (size_t)ZL_CHUNK);
+            d.flags = 0;
+        }
+    }
+    if (in_total && hipMemcpyAsync(c->d_src.p, c->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
+    if (ZL_IS_ERR(e)) return e;
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    if (hipMemcpyAsync(c->h_stage_out.p, c->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const u32* fs = (const u32*)c->h_fsize.p;
+    size_t off = 0;
+    for (size_t i = 0; i < n; i++) {
+        size_t sz = 0;
+        for (size_t j = first_chunk[i]; j < first_chunk[i + 1]; j++) sz += fs[j];
+        if (sz > caps[i]) results[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+        else { memcpy(dsts[i], (const u8*)c->h_stage_out.p + off, sz); results[i] = sz; }
+        off += sz;
+    }
+    return 0;
+}
 
 }  // extern "C"

@@ -460,83 +460,6 @@ __device__ __forceinline__ u8 resolve_byte(const DecShared& S, u32 nb, u32 p, u3
     }
 }
 
-__device__ __forceinline__ u64 xxh_round(u64 acc, u64 in) {
-    acc += in * 0xC2B2AE3D27D4EB4FULL;
-    acc = (acc << 31) | (acc >> 33);
-    return acc * 0x9E3779B185EBCA87ULL;
-}
-
-// XXH64 of the regenerated frame (zstd.c:11708-11800), low 32 bits go in the frame footer.
-// The 4 accumulator lanes are inherently serial; the workgroup stages 8 KiB tiles into LDS
-// with coalesced loads and lanes 0..3 of wave 0 run the rounds out of LDS.
-__device__ u32 frame_xxh64_low32(DecShared& S, const u8* data, u64 len) {
-    const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
-              P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
-    u8* tile = (u8*)S.huf;  // 8 KiB
-    const u32 t = threadIdx.x;
-    if (t == 0) { S.xxh_acc[0] = P1 + P2; S.xxh_acc[1] = P2; S.xxh_acc[2] = 0; S.xxh_acc[3] = 0 - P1; }
-    __syncthreads();
-    const u64 stripes = len / 32;
-    for (u64 s0 = 0; s0 < stripes; s0 += 256) {
-        const u32 ns = (u32)((stripes - s0 < 256) ? (stripes - s0) : 256);
-        const u8* base = data + s0 * 32;
-        for (u32 i = t; i < ns * 32; i += DEC_THREADS) tile[i] = base[i];
-        __syncthreads();
-        if (t < 4) {
-            u64 acc = S.xxh_acc[t];
-            for (u32 r = 0; r < ns; r++) {
-                u64 v;
-                __builtin_memcpy(&v, tile + r * 32 + t * 8, 8);
-                acc = xxh_round(acc, v);
-            }
-            S.xxh_acc[t] = acc;
-        }
-        __syncthreads();
-    }
-    u32 out = 0;
-    if (t == 0) {
-        u64 h;
-        if (len >= 32) {
-            u64 v1 = S.xxh_acc[0], v2 = S.xxh_acc[1], v3 = S.xxh_acc[2], v4 = S.xxh_acc[3];
-            h = ((v1 << 1) | (v1 >> 63)) + ((v2 << 7) | (v2 >> 57)) + ((v3 << 12) | (v3 >> 52)) + ((v4 << 18) | (v4 >> 46));
-            h = (h ^ xxh_round(0, v1)) * P1 + P4;
-            h = (h ^ xxh_round(0, v2)) * P1 + P4;
-            h = (h ^ xxh_round(0, v3)) * P1 + P4;
-            h = (h ^ xxh_round(0, v4)) * P1 + P4;
-        } else {
-            h = P5;
-        }
-        h += len;
-        const u8* p = data + stripes * 32;
-        const u8* end = data + len;
-        while (end - p >= 8) {
-            u64 v = 0;
-            for (int i = 0; i < 8; i++) v |= (u64)p[i] << (8 * i);
-            h ^= xxh_round(0, v);
-            h = ((h << 27) | (h >> 37)) * P1 + P4;
-            p += 8;
-        }
-        if (end - p >= 4) {
-            u64 v = 0;
-            for (int i = 0; i < 4; i++) v |= (u64)p[i] << (8 * i);
-            h ^= v * P1;
-            h = ((h << 23) | (h >> 41)) * P2 + P3;
-            p += 4;
-        }
-        while (p < end) {
-            h ^= (u64)(*p++) * P5;
-            h = ((h << 11) | (h >> 53)) * P1;
-        }
-        h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
-        out = (u32)h;
-        S.scan_a[0] = out;
-    }
-    __syncthreads();
-    out = S.scan_a[0];
-    __syncthreads();
-    return out;
-}
-
 // ---------------------------------------------------------------------------------------
 // thread-0 header parsers
 // ---------------------------------------------------------------------------------------
@@ -864,7 +787,7 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a
             }
             __syncthreads();
             if (!S.err && S.has_checksum && !a.ignore_checksum) {
-                const u32 got = frame_xxh64_low32(S, out, op);
+                const u32 got = zl_xxh64_low32((u8*)S.huf, S.xxh_acc, S.scan_a, out, op);
                 if (t == 0 && got != zl_rd_le(src + pos, 4)) S.err = ZL_E_CHECKSUM_WRONG;  // zstd.c:41655
             }
             __syncthreads();

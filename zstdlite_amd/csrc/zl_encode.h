@@ -1,0 +1,68 @@
+// zl_encode.h -- launch-argument structs for the encoder kernels (zl_encode.hip) shared with the
+// C-ABI host code (zl_api_compress.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "zl_format.h"
+
+#define ZL_CHUNK ZL_BLOCK_MAX                    // one frame (one block) per 128 KiB of input
+#define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
+#define ZL_LIT_STRIDE_ENC (ZL_CHUNK + 64)
+#define ZL_FRAME_OVERHEAD 24                     // magic 4 + FHD 1 + dictID 4 + FCS 4 + block header 3 + checksum 4 (+ slack)
+#define ZL_OUT_STRIDE (ZL_CHUNK + ZL_FRAME_OVERHEAD + 8)
+
+struct zl_chunk_desc {
+    u64 src_off;   // first byte of the chunk inside the source buffer
+    u32 src_size;  // <= ZL_CHUNK
+    u32 flags;     // reserved
+};
+
+struct zl_seq {
+    u32 lit_cum;    // literals emitted before this sequence (cumulative within the chunk)
+    u32 match_len;
+    u32 offset;
+    u32 pos;        // position of the match inside the chunk
+};
+
+struct zl_chunk_meta {
+    u32 nseq;
+    u32 nlit;
+};
+
+struct zl_match_args {
+    const zl_chunk_desc* chunks;
+    const u8* src;
+    u8* lits;         // per chunk lit_stride bytes
+    zl_seq* seqs;     // per chunk seq_stride records
+    zl_chunk_meta* meta;
+    u32 lit_stride;
+    u32 seq_stride;
+};
+
+struct zl_entropy_args {
+    const zl_chunk_desc* chunks;
+    const u8* src;
+    const u8* lits;
+    const zl_seq* seqs;
+    const zl_chunk_meta* meta;
+    u8* out;           // per chunk out_stride bytes: the finished frame
+    u32* frame_size;   // per chunk: bytes of the frame
+    u32 lit_stride;
+    u32 seq_stride;
+    u32 out_stride;
+    u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
+    u32 dict_id;       // 0 = none
+};
+
+struct zl_gather_args {
+    const u8* staged;      // frames at out_stride
+    const u32* frame_size;
+    const u64* frame_off;  // exclusive scan of frame_size
+    u8* dst;
+    u32 out_stride;
+};
+
+extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hipStream_t stream);

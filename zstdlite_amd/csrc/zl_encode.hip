@@ -1,0 +1,1006 @@
+// zl_encode.hip -- chunk-parallel zstd encoder for gfx950 (MI355X).
+//
+// The input is cut into independent 128 KiB chunks; each chunk becomes one single-segment
+// zstd frame holding one block (the reference's ZSTD_compress_frameChunk, zstd.c:27007, walks
+// the same 128 KiB blocks serially inside one frame).  Three kernels:
+//
+//   zl_match_kernel    E1: LZ77 parse, one 256-thread workgroup per chunk.  Restates the
+//                      double-hash greedy parse of ZSTD_compressBlock_doubleFast
+//                      (zstd.c:29909-30116) for a wide machine: each iteration looks at 256
+//                      consecutive positions at once -- every lane hashes its position with an
+//                      8-byte and a 5-byte multiplicative hash, probes two LDS tables holding
+//                      the most recent earlier position per bucket, verifies and extends its
+//                      best candidate (plus the running repeat offset); the greedy parse over
+//                      those 256 (position -> position + matchLength | +1) links is then
+//                      resolved by pointer jumping in LDS instead of a serial walk, on-path
+//                      matches become sequences, on-path non-matches become literals (both
+//                      compacted with block-wide scans), and all 256 positions are inserted
+//                      with LDS atomicMax, which makes the table content -- and therefore the
+//                      output -- independent of wave scheduling (determinism).
+//   zl_entropy_kernel  E2: per chunk, Huffman-code the literals (4 streams, one wave each)
+//                      and FSE-code the sequences (zstd.c:20692 ZSTD_compressLiterals,
+//                      zstd.c:25265 ZSTD_buildSequencesStatistics, zstd.c:21146
+//                      ZSTD_encodeSequences): histograms in LDS, table construction on one
+//                      lane per table, the three FSE state chains on three lanes, and all bit
+//                      placement by prefix scan + LDS atomicOr so that stores are whole words.
+//                      Raw / RLE fallbacks as ZSTD_compressBlock_internal (zstd.c:26833).
+//   zl_gather_kernel   frames are produced at a fixed stride, then packed back to back after
+//                      an exclusive scan of their sizes.
+#include <hip/hip_runtime.h>
+
+#include "zl_device.h"
+#include "zl_encode.h"
+#include "zl_format.h"
+
+#define ENC_THREADS 256
+#define WIN 256            // positions examined per iteration
+#define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
+#define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
+#define LANE_MATCH_CAP 40  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
+#define MIN_MATCH 4
+
+__device__ __forceinline__ u64 ld64(const u8* p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ u32 hash8(u64 v) { return (u32)((v * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
+__device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << 24) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
+__device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
+    const u64 x = a ^ b;
+    return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
+}
+
+struct MatchShared {
+    u32 tbl_long[1 << LONG_LOG];
+    u32 tbl_short[1 << SHORT_LOG];
+    u16 jump[2][WIN];
+    u8 mark[WIN];
+    u32 scan_a[4], scan_b[4];
+    u32 carry;    // where the parse enters the next window (0 = its first position)
+    u32 rep;      // offset of the most recent sequence (repeat-offset candidate)
+};
+
+__device__ __forceinline__ void block_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if ((int)lane >= d) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
+    __syncthreads();
+    u32 pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (u32 w = 0; w < 4; w++) {
+        const u32 xa = sa[w], xb = sb[w];
+        if (w < wave) { pa += xa; pb += xb; }
+        ta += xa; tb += xb;
+    }
+    ex_a = pa + ia - a;
+    ex_b = pb + ib - b;
+    tot_a = ta;
+    tot_b = tb;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// E1: match finding.  chunk c covers src[c*chunk_size, +len); output per chunk:
+//   lits[c*lit_stride ...]   literal bytes in order
+//   seqs[c*seq_stride ...]   {lit_cum, match_len, offset} per sequence
+//   meta[c]                  {nseq, nlit}
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) {
+    __shared__ MatchShared S;
+    const u32 t = threadIdx.x;
+    const u32 c = blockIdx.x;
+    const zl_chunk_desc cd = a.chunks[c];
+    const u8* src = a.src + cd.src_off;
+    const u32 n = cd.src_size;
+    u8* lits = a.lits + (size_t)c * a.lit_stride;
+    zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
+
+    for (u32 i = t; i < (1u << LONG_LOG); i += ENC_THREADS) S.tbl_long[i] = 0;
+    for (u32 i = t; i < (1u << SHORT_LOG); i += ENC_THREADS) S.tbl_short[i] = 0;
+    if (t == 0) { S.carry = 0; S.rep = 0; }
+    __syncthreads();
+
+    u32 nseq = 0, nlit = 0;  // uniform running totals
+    for (u32 ip = 0; ip < n; ip += WIN) {
+        const u32 p = ip + t;
+        const bool in_range = p < n;
+        const bool can_match = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
+        u64 v = 0;
+        if (can_match) v = ld64(src + p);
+        else if (in_range) v = src[p];
+        u32 hl = 0, hs = 0, best_len = 0, best_off = 0;
+        const u32 carry = S.carry, rep = S.rep;
+        if (can_match) {
+            hl = hash8(v);
+            hs = hash5(v);
+            const u32 cl = S.tbl_long[hl], cs = S.tbl_short[hs];
+            if (carry < WIN) {  // otherwise the whole window lies inside an earlier match
+                u32 q_best = 0;
+                if (rep && p >= rep) {
+                    const u32 l = common_bytes(v, ld64(src + p - rep));
+                    if (l >= MIN_MATCH) { best_len = l; best_off = rep; q_best = p - rep; }
+                }
+                if (cl) {
+                    const u32 q = cl - 1;
+                    const u32 l = common_bytes(v, ld64(src + q));
+                    if (l == 8 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
+                }
+                if (cs && best_len < 8) {
+                    const u32 q = cs - 1;
+                    const u32 l = common_bytes(v, ld64(src + q));
+                    if (l >= MIN_MATCH + 1 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
+                }
+                // extend while whole 8-byte words keep matching
+                while (best_len >= 8 && (best_len & 7) == 0 && best_len < LANE_MATCH_CAP && p + best_len + 8 <= n) {
+                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + q_best + best_len));
+                    best_len += l;
+                    if (l < 8) break;
+                }
+            }
+        }
+        const bool has_match = best_len >= MIN_MATCH;
+        // ---- greedy parse over the window by pointer jumping
+        const u32 nxt = t + (has_match ? best_len : 1u);
+        S.jump[0][t] = (u16)nxt;
+        S.mark[t] = (t == carry) ? 1 : 0;
+        __syncthreads();
+        int cur = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const u32 j = S.jump[cur][t];
+            if (j < WIN) {
+                if (S.mark[t]) S.mark[j] = 1;
+                S.jump[cur ^ 1][t] = S.jump[cur][j];
+            } else {
+                S.jump[cur ^ 1][t] = (u16)j;
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+        const bool on_path = S.mark[t] != 0;
+        const bool is_seq = on_path && has_match;
+        const bool is_lit = on_path && !has_match && in_range;
+        u32 ex_s, ex_l, tot_s, tot_l;
+        block_scan2(S.scan_a, S.scan_b, is_seq ? 1u : 0u, is_lit ? 1u : 0u, ex_s, ex_l, tot_s, tot_l);
+        if (is_lit) lits[nlit + ex_l] = (u8)v;
+        if (is_seq) {
+            zl_seq s;
+            s.lit_cum = nlit + ex_l;
+            s.match_len = best_len;
+            s.offset = best_off;
+            s.pos = p;
+            seqs[nseq + ex_s] = s;
+            if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
+        }
+        if (on_path && nxt >= WIN) S.carry = nxt - WIN;  // exactly one path node leaves the window
+        if (carry >= WIN && t == 0) S.carry = carry - WIN;
+        // ---- insert every position of the window (most recent position wins: atomicMax)
+        if (can_match) {
+            atomicMax(&S.tbl_long[hl], p + 1);
+            atomicMax(&S.tbl_short[hs], p + 1);
+        }
+        nseq += tot_s;
+        nlit += tot_l;
+        __syncthreads();
+    }
+    if (t == 0) {
+        a.meta[c].nseq = nseq;
+        a.meta[c].nlit = nlit;
+    }
+}
+
+extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_match_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
+    return hipGetLastError();
+}
+
+// =======================================================================================
+// E2: entropy stage
+// =======================================================================================
+#define HUF_MAX_BITS 11  // zstd.c:15452 LitHufLog
+#define SEQ_TILE 256
+
+__constant__ u32 e_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                  20, 22, 24, 28, 32, 40, 48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000,
+                                  0x2000, 0x4000, 0x8000, 0x10000};
+__constant__ u8 e_LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ u32 e_ML_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                  21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                  43, 47, 51, 59, 67, 83, 99, 0x83, 0x103, 0x203, 0x403, 0x803, 0x1003, 0x2003,
+                                  0x4003, 0x8003, 0x10003};
+__constant__ u8 e_ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ short e_LL_default[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                       2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ short e_ML_default[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ short e_OF_default[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+__device__ __forceinline__ u32 hb32(u32 v) { return 31 - __clz(v); }  // v > 0
+
+// inverse of the literal-length / match-length baseline tables (zstd.c:19533 ZSTD_LLcode,
+// :19550 ZSTD_MLcode compute the same mapping from lookup tables)
+__device__ __forceinline__ u32 ll_code(u32 ll) {
+    if (ll < 16) return ll;
+    if (ll >= 64) return hb32(ll) + 19;
+    if (ll < 24) return 16 + ((ll - 16) >> 1);
+    if (ll < 32) return 20 + ((ll - 24) >> 2);
+    if (ll < 48) return 22 + ((ll - 32) >> 3);
+    return 24;
+}
+__device__ __forceinline__ u32 ml_code(u32 ml) {  // ml >= 3
+    const u32 mb = ml - 3;
+    if (mb < 32) return mb;
+    if (mb >= 128) return hb32(mb) + 36;
+    if (mb < 40) return 32 + ((mb - 32) >> 1);
+    if (mb < 48) return 36 + ((mb - 40) >> 2);
+    if (mb < 64) return 38 + ((mb - 48) >> 3);
+    if (mb < 96) return 40 + ((mb - 64) >> 4);
+    return 42;
+}
+
+struct FseCTable {   // encoding side of one FSE table (zstd.c:15917 FSE_buildCTable_wksp)
+    u16 state[512];  // next-state table, values in [size, 2*size)
+    i32 dnb[56];     // deltaNbBits per symbol
+    i32 dfs[56];     // deltaFindState per symbol
+    u32 log;         // 0 for RLE mode
+    int max_sym;     // last symbol described by the table header
+};
+
+struct EntShared {
+    u32 hist[4][256];
+    u8 hlen[256];
+    u16 hcode[256];
+    u16 sorted[256];
+    u32 node_w[512];
+    u16 node_parent[512];
+    u8 node_depth[512];
+    u8 weights[256];
+    short norm[64];
+    u8 tsym[512];
+    short tnorm[3][64];  // per-table normalised counts (kept for the header writer)
+    u8 ttsym[3][512];    // per-table spread scratch
+    FseCTable ct[3];  // K_LL, K_OF, K_ML order below
+    u16 wstate[64];   // Huffman-weight FSE
+    i32 wdnb[16], wdfs[16];
+    u32 seq_hist[3][64];
+    u8 code[3][SEQ_TILE];
+    u32 stbits[3][SEQ_TILE];  // [15:0] value, [23:16] nbits
+    u32 stage[1024];          // bit staging: sequences use [0,640), Huffman wave w uses [256w, 256w+256)
+    u32 scan_a[4], scan_b[4];
+    u64 xxh_acc[4];
+    u32 stream_bits[4];
+    u32 chain_state[3];
+    // control
+    u32 lit_mode;  // 0 raw, 1 rle, 2 huffman
+    u32 huf_log, huf_present, huf_maxsym, tree_size;
+    u32 lit_sec_size;
+    u32 seq_mode[3];
+    u32 seq_hdr_size;
+    u32 wpos;  // write cursor inside the frame
+    u32 fail;
+};
+enum { T_LL = 0, T_OF = 1, T_ML = 2 };
+static_assert(offsetof(EntShared, node_depth) >= 8192, "XXH64 tile aliases the literal-stage arrays");
+
+// serial LSB-first bit writer used by the table-description writers (one thread)
+struct BitW {
+    u8* p;
+    u32 pos;   // bytes written
+    u64 acc;
+    u32 nb;
+};
+__device__ __forceinline__ void bw_init(BitW& w, u8* p) { w.p = p; w.pos = 0; w.acc = 0; w.nb = 0; }
+__device__ __forceinline__ void bw_add(BitW& w, u32 v, u32 n) {
+    w.acc |= (u64)(v & ((n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1))) << w.nb;
+    w.nb += n;
+    while (w.nb >= 8) { w.p[w.pos++] = (u8)w.acc; w.acc >>= 8; w.nb -= 8; }
+}
+__device__ __forceinline__ u32 bw_finish(BitW& w) {
+    if (w.nb) { w.p[w.pos++] = (u8)w.acc; w.acc = 0; w.nb = 0; }
+    return w.pos;
+}
+
+// Normalise counts to sum 2^log (own rounding scheme; any distribution that sums to the
+// table size is valid -- cf. zstd.c:16314 FSE_normalizeCount).  Symbols rarer than one slot
+// get the "less than one" marker -1.  Requires >= 2 present symbols.  One thread.
+__device__ void fse_normalize(short* norm, const u32* count, u32 total, int max_sym, int log) {
+    const u32 size = 1u << log;
+    int largest = 0;
+    u32 largest_c = 0, used = 0;
+    for (int s = 0; s <= max_sym; s++) {
+        const u32 c = count[s];
+        if (c == 0) { norm[s] = 0; continue; }
+        u64 scaled = ((u64)c << log);
+        u32 n = (u32)(scaled / total);
+        const u32 rem = (u32)(scaled - (u64)n * total);
+        if (n == 0) { norm[s] = -1; used += 1; }
+        else {
+            if (rem * 2 >= total && n < 8) n++;  // round small probabilities to nearest
+            norm[s] = (short)n;
+            used += n;
+        }
+        if (c > largest_c) { largest_c = c; largest = s; }
+    }
+    if (used <= size) {
+        if (used < size) norm[largest] = (short)(norm[largest] < 0 ? 1 + (size - used) : norm[largest] + (size - used));
+    } else {
+        u32 excess = used - size;
+        while (excess) {  // take from the biggest cells first, never below one slot
+            int big = -1;
+            for (int s = 0; s <= max_sym; s++)
+                if (norm[s] > 1 && (big < 0 || norm[s] > norm[big])) big = s;
+            u32 take = (u32)(norm[big] - 1);
+            if (take > excess) take = excess;
+            const u32 soft = (u32)norm[big] / 4 + 1;  // spread the correction over several symbols
+            if (take > soft) take = soft;
+            norm[big] = (short)(norm[big] - take);
+            excess -= take;
+        }
+    }
+}
+
+// zstd.c:16179 FSE_writeNCount: exact inverse of read_ncount in zl_decode.hip.  One thread.
+__device__ u32 fse_write_ncount(u8* dst, const short* norm, int max_sym, int log) {
+    BitW w;
+    bw_init(w, dst);
+    bw_add(w, (u32)(log - 5), 4);
+    int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1;
+    int sym = 0;
+    bool prev_zero = false;
+    while (sym <= max_sym && remaining > 1) {
+        if (prev_zero) {
+            int start = sym;
+            while (sym <= max_sym && norm[sym] == 0) sym++;
+            int run = sym - start;
+            while (run >= 3) { bw_add(w, 3, 2); run -= 3; }
+            bw_add(w, (u32)run, 2);
+            if (sym > max_sym) break;
+        }
+        int count = norm[sym++];
+        const int max = (2 * threshold - 1) - remaining;
+        remaining -= count < 0 ? -count : count;
+        count++;
+        if (count >= threshold) count += max;
+        bw_add(w, (u32)count, (u32)(nbits - (count < max ? 1 : 0)));
+        prev_zero = (count == 1);
+        while (remaining < threshold && threshold > 1) { nbits--; threshold >>= 1; }
+    }
+    return bw_finish(w);
+}
+
+// zstd.c:15917 FSE_buildCTable_wksp: same spread as the decoder, then rank the cells of each
+// symbol.  One thread.  tsym: LDS scratch of table size.
+__device__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8* tsym, const short* norm, int max_sym, int log) {
+    const int size = 1 << log;
+    u16 cumul[64];
+    int high = size - 1;
+    cumul[0] = 0;
+    for (int s = 0; s <= max_sym; s++) {
+        const int n = norm[s];
+        cumul[s + 1] = (u16)(cumul[s] + (n == -1 ? 1 : n));
+        if (n == -1) tsym[high--] = (u8)s;
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s <= max_sym; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+            tsym[pos] = (u8)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    for (int u = 0; u < size; u++) {
+        const int s = tsym[u];
+        state[cumul[s]++] = (u16)(size + u);
+    }
+    int total = 0;
+    for (int s = 0; s <= max_sym; s++) {
+        const int n = norm[s];
+        if (n == 0) { dnb[s] = ((log + 1) << 16) - size; dfs[s] = 0; }
+        else if (n == -1 || n == 1) { dnb[s] = (log << 16) - size; dfs[s] = total - 1; total++; }
+        else {
+            const int max_bits_out = log - (int)hb32((u32)(n - 1));
+            const int min_state_plus = n << max_bits_out;
+            dnb[s] = (max_bits_out << 16) - min_state_plus;
+            dfs[s] = total - n;
+            total += n;
+        }
+    }
+}
+
+// FSE encoder primitives (zstd.c:2060-2110 FSE_initCState2 / FSE_encodeSymbol)
+__device__ __forceinline__ u32 fse_init_state(const u16* state, i32 dnb, i32 dfs) {
+    const u32 nb = (u32)(dnb + (1 << 15)) >> 16;
+    const i32 value = (i32)(nb << 16) - dnb;
+    return state[(value >> nb) + dfs];
+}
+__device__ __forceinline__ u32 fse_encode(const u16* state, i32 dnb, i32 dfs, u32& st) {
+    const u32 nb = (u32)((i32)st + dnb) >> 16;
+    const u32 out = (st & ((1u << nb) - 1)) | (nb << 16);
+    st = state[(i32)(st >> nb) + dfs];
+    return out;  // [15:0] bits, [23:16] count
+}
+
+// OR `n` (<= 64) bits into a zeroed LDS word array at bit position `pos`.
+__device__ __forceinline__ void stage_or(u32* stage, u32 pos, u64 v, u32 n) {
+    if (n == 0) return;
+    const u32 w = pos >> 5, sh = pos & 31;
+    atomicOr(&stage[w], (u32)(v << sh));
+    if (sh + n > 32) {
+        const u64 hi = v >> (32 - sh);
+        atomicOr(&stage[w + 1], (u32)hi);
+        if (sh + n > 64) atomicOr(&stage[w + 2], (u32)(hi >> 32));
+    }
+}
+
+// ---- Huffman code construction (one thread; counts in S.hist[0], symbols pre-sorted) -----
+// Optimal tree by the two-queue method, depths limited to HUF_MAX_BITS by moving leaves down
+// until the Kraft sum is exactly one (cf. zstd.c:17200 HUF_buildCTable_wksp / HUF_setMaxHeight
+// which reach the same goal differently).  Returns table log (max length used).
+__device__ u32 huf_build_lengths(EntShared& S, u32 m) {
+    for (u32 i = 0; i < m; i++) S.node_w[i] = S.hist[0][S.sorted[i]];
+    u32 q1 = 0, q2 = m, next = m;
+    for (u32 k = 0; k + 1 < m; k++) {
+        u32 a, b;
+        if (q1 < m && (q2 >= next || S.node_w[q1] <= S.node_w[q2])) a = q1++; else a = q2++;
+        if (q1 < m && (q2 >= next || S.node_w[q1] <= S.node_w[q2])) b = q1++; else b = q2++;
+        S.node_w[next] = S.node_w[a] + S.node_w[b];
+        S.node_parent[a] = (u16)next;
+        S.node_parent[b] = (u16)next;
+        next++;
+    }
+    const u32 root = next - 1;
+    S.node_depth[root] = 0;
+    u32 bl[HUF_MAX_BITS + 2];
+    for (u32 i = 0; i <= HUF_MAX_BITS + 1; i++) bl[i] = 0;
+    u32 kraft = 0;  // in units of 2^-HUF_MAX_BITS
+    for (int i = (int)root - 1; i >= 0; i--) {
+        u32 d = S.node_depth[S.node_parent[i]] + 1u;
+        if (d > HUF_MAX_BITS) d = HUF_MAX_BITS;
+        S.node_depth[i] = (u8)d;
+        if ((u32)i < m) { bl[d]++; kraft += 1u << (HUF_MAX_BITS - d); }
+    }
+    while (kraft > (1u << HUF_MAX_BITS)) {
+        u32 bits = HUF_MAX_BITS - 1;
+        while (bl[bits] == 0) bits--;
+        bl[bits]--;
+        bl[bits + 1] += 2;
+        bl[HUF_MAX_BITS]--;
+        kraft--;
+    }
+    // least frequent symbols take the longest codes
+    u32 i = 0, maxlen = 0;
+    for (u32 bits = HUF_MAX_BITS; bits >= 1; bits--) {
+        for (u32 k = 0; k < bl[bits]; k++) S.hlen[S.sorted[i++]] = (u8)bits;
+        if (bl[bits] && bits > maxlen) maxlen = bits;
+    }
+    return maxlen;
+}
+
+// Huffman tree description (zstd.c:16907 HUF_writeCTable_wksp): weights of symbols
+// 0..maxsym-1, FSE-compressed when that is smaller (zstd.c:16840 HUF_compressWeights),
+// else 4 bits each.  One thread.  Returns bytes written, 0 if the table cannot be described.
+__device__ u32 huf_write_tree(EntShared& S, u8* dst) {
+    const u32 maxsym = S.huf_maxsym, log = S.huf_log;
+    for (u32 s = 0; s < maxsym; s++) S.weights[s] = S.hlen[s] ? (u8)(log + 1 - S.hlen[s]) : 0;
+    // ---- try FSE
+    u32 wc[16];
+    for (u32 w = 0; w < 16; w++) wc[w] = 0;
+    u32 maxw = 0, maxcount = 0;
+    for (u32 s = 0; s < maxsym; s++) { const u32 w = S.weights[s]; wc[w]++; if (w > maxw) maxw = w; }
+    for (u32 w = 0; w <= maxw; w++) if (wc[w] > maxcount) maxcount = wc[w];
+    u32 fse_size = 0;
+    if (maxsym > 1 && maxcount != maxsym && maxcount != 1) {
+        int wlog = (int)hb32(maxsym - 1) - 1;  // a little below log2(#weights)
+        if (wlog > 6) wlog = 6;
+        if (wlog < 5) wlog = 5;
+        fse_normalize(S.norm, wc, maxsym, (int)maxw, wlog);
+        u8* p = dst + 1;
+        const u32 hs = fse_write_ncount(p, S.norm, (int)maxw, wlog);
+        fse_build_ctable(S.wstate, S.wdnb, S.wdfs, S.tsym, S.norm, (int)maxw, wlog);
+        // two interleaved states, last weight first (zstd.c:16090 FSE_compress_usingCTable_generic)
+        BitW w;
+        bw_init(w, p + hs);
+        int ip = (int)maxsym;
+        u32 s1, s2;
+        if (maxsym & 1) {
+            ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+            ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
+        } else {
+            ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+            ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+        }
+        while (ip > 0) {
+            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s2); bw_add(w, o & 0xFFFF, o >> 16); }
+            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
+        }
+        bw_add(w, s2, (u32)wlog);
+        bw_add(w, s1, (u32)wlog);
+        bw_add(w, 1, 1);
+        fse_size = hs + bw_finish(w);
+    }
+    if (fse_size > 1 && fse_size < maxsym / 2 && fse_size < 128) {
+        dst[0] = (u8)fse_size;
+        return 1 + fse_size;
+    }
+    if (maxsym > 128) return 0;
+    dst[0] = (u8)(127 + maxsym);
+    for (u32 s = 0; s < maxsym; s += 2) {
+        const u32 hi = S.weights[s], lo = (s + 1 < maxsym) ? S.weights[s + 1] : 0;
+        dst[1 + s / 2] = (u8)((hi << 4) | lo);
+    }
+    return 1 + (maxsym + 1) / 2;
+}
+
+// One backward Huffman stream by one wave (zstd.c:17690 HUF_compress1X_usingCTable_internal):
+// the last symbol is written first.  Tiles of 512 symbols; each lane codes 8 consecutive
+// symbols, a wave scan places its bits, LDS atomicOr assembles words, whole bytes are flushed.
+__device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed */, const u8* lit, u32 cnt, u8* out) {
+    const u32 lane = threadIdx.x & 63;
+    u32 written = 0, carry_bits = 0;
+    for (u32 e0 = 0; e0 < cnt; e0 += 512) {
+        u64 lo = 0, hi = 0;
+        u32 nlo = 0, nhi = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+            const u32 e = e0 + lane * 8 + j;
+            if (e < cnt) {
+                const u32 sym = lit[cnt - 1 - e];
+                const u32 len = S.hlen[sym];
+                const u64 code = S.hcode[sym];
+                if (j < 4) { lo |= code << nlo; nlo += len; }
+                else { hi |= code << nhi; nhi += len; }
+            }
+        }
+        const u32 mine = nlo + nhi;
+        u32 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 v = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += v;
+        }
+        const u32 tile_bits = __shfl(inc, 63, 64);
+        const u32 pos = carry_bits + inc - mine;
+        stage_or(stage, pos, lo, nlo);
+        stage_or(stage, pos + nlo, hi, nhi);
+        __builtin_amdgcn_wave_barrier();
+        const u32 total = carry_bits + tile_bits;
+        const u32 nbytes = total >> 3;
+        const u8* sb = (const u8*)stage;
+        for (u32 i = lane; i < nbytes; i += 64) out[written + i] = sb[i];
+        __builtin_amdgcn_wave_barrier();
+        // keep the partial byte, clear the rest
+        const u32 keep = (total & 7) ? sb[nbytes] : 0;
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = lane; i < 256; i += 64) stage[i] = (i == 0) ? keep : 0;
+        __builtin_amdgcn_wave_barrier();
+        written += nbytes;
+        carry_bits = total & 7;
+    }
+    // end marker
+    if (lane == 0) {
+        const u32 last = (stage[0] & 0xFF) | (1u << carry_bits);
+        out[written] = (u8)last;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (u32 i = lane; i < 256; i += 64) stage[i] = 0;
+    return written + 1;
+}
+
+__device__ __forceinline__ u32 min_gain(u32 n) { return (n >> 6) + 2; }  // zstd.c:19607 ZSTD_minGain (strategy < btultra)
+
+__device__ __forceinline__ void wr_le(u8* p, u64 v, u32 nbytes) {
+    for (u32 i = 0; i < nbytes; i++) p[i] = (u8)(v >> (8 * i));
+}
+
+// zstd.c:27089 ZSTD_writeFrameHeader for a single-segment frame of n bytes.
+__device__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
+    wr_le(p, ZL_MAGIC, 4);
+    const u32 fcs_flag = n < 256 ? 0 : (n < 65536 + 256 ? 1 : 2);
+    const u32 dflag = dict_id == 0 ? 0 : (dict_id < 256 ? 1 : (dict_id < 65536 ? 2 : 3));
+    p[4] = (u8)((fcs_flag << 6) | (1u << 5) | (checksum ? 4 : 0) | dflag);
+    u32 pos = 5;
+    const u32 dbytes = dflag == 3 ? 4 : dflag;
+    wr_le(p + pos, dict_id, dbytes);
+    pos += dbytes;
+    if (fcs_flag == 0) { p[pos++] = (u8)n; }
+    else if (fcs_flag == 1) { wr_le(p + pos, n - 256, 2); pos += 2; }
+    else { wr_le(p + pos, n, 4); pos += 4; }
+    return pos;
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void zl_entropy_kernel(zl_entropy_args a) {
+    __shared__ EntShared S;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u32 c = blockIdx.x;
+    const zl_chunk_desc cd = a.chunks[c];
+    const u8* src = a.src + cd.src_off;
+    const u32 n = cd.src_size;
+    const u8* lit = a.lits + (size_t)c * a.lit_stride;
+    const zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
+    const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
+    u8* out = a.out + (size_t)c * a.out_stride;
+
+    // ---- frame header; everything after it is the single block
+    const u32 fh = (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
+    u8* blk = out + fh + 3;  // block content
+    for (u32 i = t; i < 4 * 256; i += ENC_THREADS) (&S.hist[0][0])[i] = 0;
+    for (u32 i = t; i < 3 * 64; i += ENC_THREADS) (&S.seq_hist[0][0])[i] = 0;
+    for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
+    if (t == 0) { S.fail = 0; write_frame_header(out, n, a.checksum, a.dict_id); }
+    __syncthreads();
+
+    // =========================== literals (zstd.c:20692 ZSTD_compressLiterals)
+    const bool four = nlit >= 256;  // zstd.c:20716 singleStream = srcSize < 256
+    const u32 seg = four ? (nlit + 3) / 4 : nlit;
+    {
+        const u32 s0 = four ? wave * seg : 0;
+        const u32 s1 = four ? (wave == 3 ? nlit : s0 + seg) : nlit;
+        if (four || wave == 0)
+            for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&S.hist[wave][lit[i]], 1u);
+    }
+    __syncthreads();
+    const u32 keep0 = S.hist[0][t];  // stream 0's own histogram stays in a register
+    const u32 cnt_t = keep0 + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
+    __syncthreads();
+    S.hist[0][t] = cnt_t;  // hist[0] becomes the total, hist[1..3] stay per-stream
+    __syncthreads();
+    // rank sort of present symbols (ascending count, then symbol)
+    {
+        u32 rank = 0, present = 0;
+        for (u32 s = 0; s < 256; s++) {
+            const u32 cs = S.hist[0][s];
+            if (cs) {
+                present++;
+                if (cnt_t && (cs < cnt_t || (cs == cnt_t && s < t))) rank++;
+            }
+        }
+        if (cnt_t) S.sorted[rank] = (u16)t;
+        if (t == 0) S.huf_present = present;
+    }
+    S.hlen[t] = 0;
+    __syncthreads();
+    const u32 lhs_c = 3 + (nlit >= 1024) + (nlit >= 16384);       // compressed-literals header size
+    const u32 lhs_r = 1 + (nlit >= 32) + (nlit >= 4096);          // raw / rle header size
+    if (t == 0) {
+        u32 mode = 0;
+        const u32 m = S.huf_present;
+        if (nlit > 63 && m == 1) mode = 1;   // zstd.c:20725 minLitSize, :20750 RLE
+        else if (nlit > 63 && m >= 2) mode = 2;
+        S.lit_mode = mode;
+    }
+    __syncthreads();
+    if (S.lit_mode == 2) {
+        // tree (one thread)
+        if (t == 0) {
+            S.huf_log = huf_build_lengths(S, S.huf_present);
+            u32 maxsym = 255;
+            while (S.hist[0][maxsym] == 0) maxsym--;
+            S.huf_maxsym = maxsym;
+        }
+        __syncthreads();
+        // codes: same cell order as the decoder's table (ascending weight, ascending symbol)
+        {
+            const u32 len = S.hlen[t];
+            if (len) {
+                const u32 log = S.huf_log, w = log + 1 - len;
+                u32 start = 0;
+                for (u32 s = 0; s < 256; s++) {
+                    const u32 ls = S.hlen[s];
+                    if (!ls) continue;
+                    const u32 ws = log + 1 - ls;
+                    if (ws < w || (ws == w && s < t)) start += 1u << (ws - 1);
+                }
+                S.hcode[t] = (u16)(start >> (w - 1));
+            }
+        }
+        // per-stream payload bits from the per-stream histograms
+        {
+            const u32 len = S.hlen[t];
+            u32 b[4] = {keep0 * len, S.hist[1][t] * len, S.hist[2][t] * len, S.hist[3][t] * len};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 v = b[k];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                b[k] = v;
+            }
+            if (lane == 0) { S.node_w[wave * 4 + 0] = b[0]; S.node_w[wave * 4 + 1] = b[1]; S.node_w[wave * 4 + 2] = b[2]; S.node_w[wave * 4 + 3] = b[3]; }
+        }
+        __syncthreads();
+        if (t == 0) {
+            u32 total = 0;
+            for (u32 k = 0; k < 4; k++) {
+                const u32 bits = S.node_w[k] + S.node_w[4 + k] + S.node_w[8 + k] + S.node_w[12 + k];
+                S.stream_bits[k] = bits;
+                if (four || k == 0) total += (bits + 8) >> 3;  // payload + end marker
+            }
+            const u32 tree = huf_write_tree(S, blk + lhs_c);
+            const u32 csize = tree + (four ? 6 : 0) + total;
+            S.tree_size = tree;
+            if (tree == 0 || csize >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
+            else S.lit_sec_size = lhs_c + csize;
+        }
+        __syncthreads();
+    }
+    if (S.lit_mode == 2) {
+        const u32 tree = S.tree_size;
+        u8* p = blk + lhs_c + tree;
+        if (t == 0) {
+            const u32 csize = S.lit_sec_size - lhs_c;
+            const u32 sf = four ? (lhs_c == 3 ? 1 : (lhs_c == 4 ? 2 : 3)) : 0;
+            const u32 bits = lhs_c == 3 ? 10 : (lhs_c == 4 ? 14 : 18);
+            const u64 h = 2u | (sf << 2) | ((u64)nlit << 4) | ((u64)csize << (4 + bits));
+            wr_le(blk, h, lhs_c);
+            if (four) {
+                wr_le(p, (S.stream_bits[0] + 8) >> 3, 2);
+                wr_le(p + 2, (S.stream_bits[1] + 8) >> 3, 2);
+                wr_le(p + 4, (S.stream_bits[2] + 8) >> 3, 2);
+            }
+        }
+        if (four) {
+            u32 off = 6;
+            for (u32 k = 0; k < wave; k++) off += (S.stream_bits[k] + 8) >> 3;
+            const u32 s0 = wave * seg, cnt = (wave == 3) ? nlit - 3 * seg : seg;
+            huf_encode_stream(S, S.stage + 256 * wave, lit + s0, cnt, p + off);
+        } else if (wave == 0) {
+            huf_encode_stream(S, S.stage, lit, nlit, p);
+        }
+    } else if (S.lit_mode == 1) {
+        if (t == 0) {
+            const u64 h = 1u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4));
+            wr_le(blk, h, lhs_r);
+            blk[lhs_r] = lit[0];
+            S.lit_sec_size = lhs_r + 1;
+        }
+    } else {
+        if (t == 0) {
+            const u64 h = 0u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4));
+            wr_le(blk, h, lhs_r);
+            S.lit_sec_size = lhs_r + nlit;
+        }
+        for (u32 i = t; i < nlit; i += ENC_THREADS) blk[lhs_r + i] = lit[i];
+    }
+    __syncthreads();
+    for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
+    __syncthreads();
+
+    // =========================== sequences (zstd.c:25265, :21146)
+    u8* sq = blk + S.lit_sec_size;
+    u32 seq_sec = 0;
+    if (nseq == 0) {
+        if (t == 0) sq[0] = 0;
+        seq_sec = 1;
+    } else {
+        // pass 1: code histograms
+        for (u32 i = t; i < nseq; i += ENC_THREADS) {
+            const zl_seq s = seqs[i];
+            const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u;
+            const u32 prev_off = i ? seqs[i - 1].offset : 1u;
+            const u32 ll = s.lit_cum - prev_cum;
+            const u32 ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
+            atomicAdd(&S.seq_hist[T_LL][ll_code(ll)], 1u);
+            atomicAdd(&S.seq_hist[T_OF][hb32(ob)], 1u);
+            atomicAdd(&S.seq_hist[T_ML][ml_code(s.match_len)], 1u);
+        }
+        __syncthreads();
+        // table choice + construction: one lane per table, three waves in parallel
+        // (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059)
+        if (lane == 0 && wave < 3) {
+            const int k = (int)wave;
+            const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
+            const int def_log = k == T_OF ? 5 : 6, max_log = k == T_OF ? 8 : 9;
+            const u32* h = S.seq_hist[k];
+            int max_sym = 0;
+            u32 most = 0;
+            for (int s = 0; s <= max_code; s++) if (h[s]) { max_sym = s; if (h[s] > most) most = h[s]; }
+            FseCTable& ct = S.ct[k];
+            short* norm = S.tnorm[k];
+            u8* tsym = S.ttsym[k];
+            u32 mode;
+            if (most == nseq) mode = (nseq <= 2) ? 0 : 1;
+            else if (nseq < ((1u << def_log) * 8u >> 3) || most < (nseq >> (def_log - 1))) mode = 0;
+            else mode = 2;
+            if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
+            S.seq_mode[k] = mode;
+            if (mode == 0) {
+                const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
+                const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
+                for (int s = 0; s <= dmax; s++) norm[s] = def[s];
+                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, norm, dmax, def_log);
+                ct.log = (u32)def_log;
+            } else if (mode == 1) {
+                ct.log = 0;
+            } else {
+                int log = (int)hb32(nseq - 1) - 2;  // zstd.c:16220 FSE_optimalTableLog idea
+                if (log > max_log) log = max_log;
+                const int min_log = (int)hb32((u32)max_sym) + 2;
+                if (log < min_log) log = min_log;
+                if (log < 5) log = 5;
+                if (log > max_log) log = max_log;
+                fse_normalize(norm, h, nseq, max_sym, log);
+                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, norm, max_sym, log);
+                ct.log = (u32)log;
+                ct.max_sym = max_sym;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            u32 pos = 0;
+            if (nseq < 128) sq[pos++] = (u8)nseq;
+            else if (nseq < 0x7F00) { sq[pos++] = (u8)((nseq >> 8) + 0x80); sq[pos++] = (u8)nseq; }
+            else { sq[pos++] = 0xFF; wr_le(sq + pos, nseq - 0x7F00, 2); pos += 2; }
+            sq[pos++] = (u8)((S.seq_mode[T_LL] << 6) | (S.seq_mode[T_OF] << 4) | (S.seq_mode[T_ML] << 2));
+            for (int k = 0; k < 3; k++) {
+                const u32 mode = S.seq_mode[k];
+                if (mode == 1) {
+                    int sym = 0;
+                    const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
+                    for (int s = 0; s <= max_code; s++) if (S.seq_hist[k][s]) sym = s;
+                    sq[pos++] = (u8)sym;
+                } else if (mode == 2) {
+                    pos += fse_write_ncount(sq + pos, S.tnorm[k], S.ct[k].max_sym, (int)S.ct[k].log);
+                }
+            }
+            S.seq_hdr_size = pos;
+        }
+        __syncthreads();
+        // pass 2: tiles of 256 sequences, last sequence first
+        u8* bs = sq + S.seq_hdr_size;
+        u32 written = 0, carry_bits = 0;
+        for (u32 e0 = 0; e0 < nseq; e0 += SEQ_TILE) {
+            const u32 e = e0 + t;  // emission index; sequence index = nseq-1-e
+            u64 extra = 0;   // LL extra | ML extra | OF extra (in stream order)
+            u32 nextra = 0;
+            u32 cl = 0, cm = 0, co = 0;
+            if (e < nseq) {
+                const u32 i = nseq - 1 - e;
+                const zl_seq s = seqs[i];
+                const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u;
+                const u32 prev_off = i ? seqs[i - 1].offset : 1u;
+                const u32 ll = s.lit_cum - prev_cum;
+                const u32 ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
+                cl = ll_code(ll); cm = ml_code(s.match_len); co = hb32(ob);
+                const u32 nl = e_LL_bits[cl], nm = e_ML_bits[cm];
+                extra = (u64)(ll - e_LL_base[cl]);
+                extra |= (u64)(s.match_len - e_ML_base[cm]) << nl;
+                extra |= (u64)(ob - (1u << co)) << (nl + nm);
+                nextra = nl + nm + co;
+            }
+            S.code[T_LL][t] = (u8)cl; S.code[T_ML][t] = (u8)cm; S.code[T_OF][t] = (u8)co;
+            __syncthreads();
+            // the three FSE state chains, one lane each on three different waves
+            if (lane == 0 && wave < 3) {
+                const int k = (int)wave;
+                const FseCTable& ct = S.ct[k];
+                const u32 cnt = (nseq - e0 < SEQ_TILE) ? nseq - e0 : SEQ_TILE;
+                u32 st = S.chain_state[k];
+                if (ct.log == 0) {
+                    for (u32 j = 0; j < cnt; j++) S.stbits[k][j] = 0;
+                } else {
+                    for (u32 j = 0; j < cnt; j++) {
+                        const u32 sym = S.code[k][j];
+                        if (e0 + j == 0) { st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]); S.stbits[k][j] = 0; }
+                        else S.stbits[k][j] = fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st);
+                    }
+                }
+                S.chain_state[k] = st;
+            }
+            __syncthreads();
+            // per sequence: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+            u64 lo = 0;
+            u32 nlo = 0;
+            if (e < nseq) {
+                const u32 so = S.stbits[T_OF][t], sm = S.stbits[T_ML][t], sl = S.stbits[T_LL][t];
+                lo = (u64)(so & 0xFFFF);
+                nlo = so >> 16;
+                lo |= (u64)(sm & 0xFFFF) << nlo;
+                nlo += sm >> 16;
+                lo |= (u64)(sl & 0xFFFF) << nlo;
+                nlo += sl >> 16;
+            }
+            u32 ex_a, ex_b, tot_a, tot_b;
+            block_scan2(S.scan_a, S.scan_b, nlo + nextra, 0u, ex_a, ex_b, tot_a, tot_b);
+            const u32 pos = carry_bits + ex_a;
+            stage_or(S.stage, pos, lo, nlo);
+            stage_or(S.stage, pos + nlo, extra, nextra);
+            __syncthreads();
+            const u32 total = carry_bits + tot_a;
+            const u32 nbytes = total >> 3;
+            const u8* sb = (const u8*)S.stage;
+            for (u32 i = t; i < nbytes; i += ENC_THREADS) bs[written + i] = sb[i];
+            const u32 keep = (total & 7) ? sb[nbytes] : 0;
+            __syncthreads();
+            for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = (i == 0) ? keep : 0;
+            __syncthreads();
+            written += nbytes;
+            carry_bits = total & 7;
+        }
+        // flush the three states (ML, OF, LL) and the end marker (zstd.c:21225-21233)
+        if (t == 0) {
+            BitW w;
+            bw_init(w, bs + written);
+            w.acc = S.stage[0] & 0xFF;
+            w.nb = carry_bits;
+            bw_add(w, S.chain_state[T_ML], S.ct[T_ML].log);
+            bw_add(w, S.chain_state[T_OF], S.ct[T_OF].log);
+            bw_add(w, S.chain_state[T_LL], S.ct[T_LL].log);
+            bw_add(w, 1, 1);
+            S.wpos = S.seq_hdr_size + written + bw_finish(w);
+        }
+        __syncthreads();
+        seq_sec = S.wpos;
+    }
+    __syncthreads();
+
+    // =========================== block + frame assembly (zstd.c:26833, :27060-27068, :27733)
+    u32 bsize = S.lit_sec_size + seq_sec;
+    const bool raw = (n == 0) || bsize + min_gain(n) >= n;  // zstd.c:25534: not enough gain -> raw block
+    if (raw) {
+        for (u32 i = t; i < n; i += ENC_THREADS) blk[i] = src[i];
+        bsize = n;
+    }
+    if (t == 0) wr_le(out + fh, 1u | ((raw ? 0u : 2u) << 1) | (bsize << 3), 3);
+    u32 fsize = fh + 3 + bsize;
+    if (a.checksum) {
+        __syncthreads();
+        const u32 x = zl_xxh64_low32((u8*)&S, S.xxh_acc, S.scan_a, src, n);  // first 8 KiB of S are dead by now
+        if (t == 0) wr_le(out + fsize, x, 4);
+        fsize += 4;
+    }
+    if (t == 0) a.frame_size[c] = fsize;
+}
+
+// exclusive scan of frame sizes (one workgroup; chunk counts are small: 8192 per GiB)
+__global__ __launch_bounds__(ENC_THREADS) void zl_scan_sizes_kernel(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 n) {
+    __shared__ u64 part[ENC_THREADS];
+    const u32 t = threadIdx.x;
+    const u32 per = (n + ENC_THREADS - 1) / ENC_THREADS;
+    const u32 b = t * per, e = (b + per < n) ? b + per : n;
+    u64 s = 0;
+    for (u32 i = b; i < e; i++) s += frame_size[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        u64 run = *total_in;  // frames of earlier launch groups come first
+        for (u32 i = 0; i < ENC_THREADS; i++) { const u64 v = part[i]; part[i] = run; run += v; }
+        *total_out = run;
+    }
+    __syncthreads();
+    u64 run = part[t];
+    for (u32 i = b; i < e; i++) { frame_off[i] = run; run += frame_size[i]; }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void zl_gather_kernel(zl_gather_args a) {
+    const u32 c = blockIdx.x, t = threadIdx.x;
+    const u8* s = a.staged + (size_t)c * a.out_stride;
+    u8* d = a.dst + a.frame_off[c];
+    const u32 n = a.frame_size[c];
+    for (u32 i = t; i < n; i += ENC_THREADS) d[i] = s[i];
+}
+
+extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_entropy_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
+    return hipGetLastError();
+}
+extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream) {
+    hipLaunchKernelGGL(zl_scan_sizes_kernel, dim3(1), dim3(ENC_THREADS), 0, stream, frame_size, frame_off, total_in, total_out, nchunks);
+    return hipGetLastError();
+}
+extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_gather_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
+    return hipGetLastError();
+}

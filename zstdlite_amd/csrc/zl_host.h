@@ -1,0 +1,70 @@
+// zl_host.h -- host-side plumbing shared by the two halves of the C-ABI: grow-only device and
+// pinned-host buffers, device probing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "zl_format.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + (n >> 3) + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + (n >> 3) + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+static int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
+static int g_num_cu = 256;
+static bool device_ok() {
+    if (g_device_state == 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            g_device_state = -1;
+        } else {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cu = prop.multiProcessorCount;
+            g_device_state = 1;
+        }
+    }
+    return g_device_state == 1;
+}
+
+static const size_t kGpuUnavailable = ZL_ERR(ZL_E_MEMORY);
+
+
+}  // namespace
