@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X:
+    "GB/s zstd_compress+zstd_decompress on 1 GiB raw, level 3; ratio vs CPU".
+
+One step = one pass of the hot path over one synthetic 1 GiB raw vector already resident in
+HBM: zstd_compress (level 3, HIP encoder) followed by zstd_decompress of its output (HIP
+decoder), both through the device entry points of the C-ABI.  value = uncompressed bytes of all
+ranks / max-over-ranks step time (GB = 1e9 B).  The vector is one quarter each of the four
+SURVEY 8(d) inputs (rand / iid10 / text / int20), so the reported compression ratio can be read
+against BASELINE.md section 2, which quotes the reference's level-3 ratio on 256 MiB of each.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): frames are independent, so every
+rank compresses and decompresses its own 1 GiB shard with no data-path collective ("weak"
+scaling); the one exchange step the path has -- collecting the compressed shards on rank 0, sizes
+by all-gather then payloads by grouped send/recv over RCCL -- is inside the timed step.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the launch
+stream), "cpu_baseline" (the reference's bundled libzstd, oracle/_ref, on the host cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(host_bytes, log):
+    """The reference's CPU path on this box's host cores: ZSTD_compress2(level 3) then
+    ZSTD_decompressDCtx on the same 1 GiB vector, one pass, buffers pre-touched.  TEST/BENCH
+    infrastructure (oracle/_ref), never on the product path."""
+    from zl_testlib import REF_SO, have_ref
+    if not have_ref():
+        return None
+    L = C.CDLL(REF_SO)
+    L.ZSTD_compressBound.restype = C.c_size_t
+    L.ZSTD_compressBound.argtypes = [C.c_size_t]
+    L.ZSTD_createCCtx.restype = C.c_void_p
+    L.ZSTD_createDCtx.restype = C.c_void_p
+    L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ZSTD_compress2.restype = C.c_size_t
+    L.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ZSTD_decompressDCtx.restype = C.c_size_t
+    L.ZSTD_decompressDCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+    n = host_bytes.size
+    cap = L.ZSTD_compressBound(n)
+    comp = np.zeros(cap, dtype=np.uint8)  # zeros: pre-touched
+    back = np.zeros(n, dtype=np.uint8)
+    res = {}
+    ncores = os.cpu_count() or 1
+    for label, workers in (("1t", 0), ("mt", ncores)):
+        cctx = L.ZSTD_createCCtx()
+        L.ZSTD_CCtx_setParameter(cctx, 100, 3)
+        if workers:
+            L.ZSTD_CCtx_setParameter(cctx, 400, workers)
+        t0 = time.perf_counter()
+        csize = L.ZSTD_compress2(cctx, comp.ctypes.data, cap, host_bytes.ctypes.data, n)
+        tc = time.perf_counter() - t0
+        L.ZSTD_freeCCtx(cctx)
+        res[label] = (tc, csize)
+        log(f"cpu libzstd compress {label}: {n / tc / 1e9:.3f} GB/s, {csize} bytes")
+    tc, csize = res["1t"]
+    dctx = L.ZSTD_createDCtx()
+    t0 = time.perf_counter()
+    r = L.ZSTD_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, csize)
+    td = time.perf_counter() - t0
+    L.ZSTD_freeDCtx(dctx)
+    assert r == n
+    return {
+        "value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
+        "sample": f"the full {n >> 20} MiB bench vector, one pass: ZSTD_compress2(level 3) + ZSTD_decompressDCtx, bundled libzstd 1.5.6 built -O2 from the reference source (oracle/_ref), 1 thread",
+        "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / csize, "compressed_bytes": int(csize),
+        "compress_GBps_nbWorkers": n / res["mt"][0] / 1e9, "nbWorkers": ncores, "host_cores": ncores,
+    }
+
+
+def c2_decode(codec, device, log, nframes=10000):
+    """BASELINE config C2: zstd_decompress() of 10k independent 64 KiB frames made by the
+    reference libzstd at level 3 (one third each text / iid10 / rand), decoded in one launch."""
+    import torch
+    from zl_testlib import Ref, have_ref
+    from zstdlite_amd.device import gen_device
+    if not have_ref():
+        return None
+    ref = Ref()
+    fsz = 65536
+    per = (nframes + 2) // 3
+    t0 = time.perf_counter()
+    srcs = {k: gen_device(k, per * fsz, device, seed=77).cpu().numpy() for k in ("text", "iid10", "rand")}
+    frames, plain = [], []
+    L = ref.L
+    cctx = L.ZSTD_createCCtx()
+    L.ZSTD_CCtx_setParameter(cctx, 100, 3)
+    cap = L.ZSTD_compressBound(fsz)
+    buf = C.create_string_buffer(cap)
+    for i in range(nframes):
+        a = srcs[("text", "iid10", "rand")[i % 3]][(i // 3) * fsz:(i // 3 + 1) * fsz]
+        r = L.ZSTD_compress2(cctx, buf, cap, a.ctypes.data, fsz)
+        frames.append(buf.raw[:r])
+        plain.append(a)
+    L.ZSTD_freeCCtx(cctx)
+    log(f"C2: built {nframes} reference frames in {time.perf_counter() - t0:.1f}s")
+    blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+    want = torch.from_numpy(np.concatenate(plain)).to(device)
+    d_src = torch.from_numpy(blob.copy()).to(device)
+    d_dst = torch.empty(nframes * fsz, dtype=torch.uint8, device=device)
+    tbl = codec.frame_table([len(f) for f in frames], [fsz] * nframes)
+    best = 1e9
+    for it in range(4):
+        d_dst.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, _ = codec.decompress(d_src, tbl, d_dst)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if it:
+            best = min(best, dt)
+    assert total == nframes * fsz and torch.equal(d_dst, want), "C2 decode mismatch"
+    kms = codec.kernel_ms().get("decode")
+    return {"frames": nframes, "frame_bytes": fsz, "decompress_GBps": nframes * fsz / best / 1e9,
+            "decode_kernel_ms": kms, "compressed_bytes": int(blob.size), "bit_exact": True}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=1 << 30, help="raw bytes per GPU (default 1 GiB)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-c2", action="store_true", help="skip the 10k x 64 KiB frame decode leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from zstdlite_amd.device import DeviceCodec, gen_mixed
+    from zstdlite_amd.shard import gather_compressed
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    n = args.size
+    src, kinds, quarter = gen_mixed(n, device)
+    codec = DeviceCodec(level=3, profile=True)
+    comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
+    back = torch.empty(n, dtype=torch.uint8, device=device)
+    content = codec.chunk_content_sizes(n)
+    gathered = None
+    kms_sum = {}
+
+    def step():
+        nonlocal gathered
+        _, total, fsizes = codec.compress(src, comp)
+        if world > 1:
+            # the path's one exchange step: compressed shard sizes, then payloads to rank 0
+            gathered, _ = gather_compressed(comp, total, root=0, out=gathered)
+        tbl = codec.frame_table(fsizes, content)
+        out_total, _ = codec.decompress(comp, tbl, back)
+        assert out_total == n
+        return total
+
+    for _ in range(args.warmup):
+        step()
+    kms_sum = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        csize = step()
+        for k, v in codec.kernel_ms().items():
+            kms_sum[k] = kms_sum.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.equal(back, src), "round trip is not bit-exact"
+    ms_per_step = elapsed / args.steps * 1e3
+    kms = {k: v / args.steps for k, v in kms_sum.items()}
+
+    if rank == 0:
+        value = world * n / (ms_per_step / 1e3) / 1e9
+        t_comp = sum(kms.get(k, 0.0) for k in ("match", "entropy", "scan", "gather"))
+        out = {
+            "metric": "GB/s zstd_compress+zstd_decompress on 1 GiB raw, level 3; ratio vs CPU",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"zstd_compress() then zstd_decompress() of a {n >> 20} MiB raw vector per GPU, level 3 (BASELINE configs[2] + its decode); vector = 4 equal parts rand/iid10/text/int20 (SURVEY 8d); one independent frame per 128 KiB chunk",
+                       "bytes_per_gpu": n, "chunk_bytes": 128 << 10, "frames_per_gpu": int(len(content)),
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective" + ("; compressed shards gathered to rank 0 over RCCL" if world > 1 else "")},
+            "ratio": n / csize, "compressed_bytes": int(csize), "bit_exact_roundtrip": True,
+            "compress_GBps_kernels": (n / (t_comp / 1e3) / 1e9) if t_comp else None,
+            "decompress_GBps_kernel": (n / (kms["decode"] / 1e3) / 1e9) if kms.get("decode") else None,
+            "kernel_ms": kms,
+        }
+        # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the timed steps)
+        if kms:
+            dom = max(kms, key=kms.get)
+            alg = n + csize  # N_in + N_comp (compress) == N_out + N_comp (decompress)
+            ach = alg / (kms[dom] / 1e3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_kernel", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
+                                                           "gather": "zl_gather_kernel", "decode": "zl_decode_kernel"}[dom],
+                               "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": kms[dom]}
+        # ---- per-input ratios next to BASELINE.md section 2
+        per = {}
+        for i, k in enumerate(kinds):
+            part = src[i * quarter:(i + 1) * quarter if i < 3 else n]
+            _, tot, _ = codec.compress(part.contiguous(), comp)
+            per[k] = {"bytes": int(part.numel()), "compressed": int(tot), "ratio": part.numel() / tot}
+        out["per_input"] = per
+        if world == 1 and not args.no_cpu:
+            # ---- cpu_baseline leg: the only place bench.py touches oracle/ (the reference libzstd
+            # built into oracle/_ref): timed on the host cores, and -- for BASELINE config C2 -- used
+            # to produce the 10k x 64 KiB level-3 frames whose GPU decode is checked against plaintext
+            host = src.cpu().numpy()
+            cb = cpu_baseline(host, log)
+            if cb is not None:
+                out["cpu_baseline"] = cb
+                out["ratio_vs_cpu"] = {"speedup_roundtrip": value / cb["value"], "compressed_size_ours_over_cpu": csize / cb["compressed_bytes"]}
+                if not args.no_c2:
+                    try:
+                        out["c2_frames64k"] = c2_decode(codec, device, log)
+                    except Exception as e:  # informative leg; never lose the headline line to it
+                        out["c2_frames64k"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,16 @@ size_t zl_compress_device_finish(zl_cctx *cctx, size_t *frameSizes);
  * of data frames found or an error code.  dst offsets are assigned back to back. */
 size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size_t cap);
 
+/* ---- diagnostics (new): per-kernel device time of the last device-resident call, measured with
+ * HIP events recorded on the stream the kernels were launched on.  Enable with
+ * zl_CCtx_setParameter(cctx, ZL_c_profile, 1) / zl_DCtx_setParameter(dctx, ZL_d_profile, 1).
+ * zl_cctx_kernel_ms fills ms[0..3] = {match, entropy, size-scan, gather}; zl_dctx_kernel_ms
+ * fills ms[0] = decode.  Return 0, or an error code when profiling was not enabled. */
+#define ZL_c_profile 9001
+#define ZL_d_profile 9002
+size_t zl_cctx_kernel_ms(const zl_cctx *cctx, double *ms);
+size_t zl_dctx_kernel_ms(const zl_dctx *dctx, double *ms);
+
 /* library / device info */
 const char *zl_versionString(void); /* ZSTD_versionString twin for src/serialize.c:26 */
 int zl_deviceCount(void);

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("zl_compress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("zl_compress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
     ("zl_index_frames", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(FrameT), C.c_size_t]),
+    ("zl_cctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("zl_dctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_versionString", C.c_char_p, []),
     ("zl_deviceCount", C.c_int, []),
 ]

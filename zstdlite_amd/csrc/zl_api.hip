@@ -131,6 +131,11 @@ struct zl_dctx_s {
     size_t pending_n = 0;
     bool pending = false;
     u32 slots = 0;
+    // diagnostics
+    int profile = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ev_valid = false;
+    double kernel_ms = 0;
 };
 
 extern "C" {
@@ -265,6 +270,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out};
     for (PinBuf* b : pins) b->release();
+    for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
     delete d;
     return 0;
@@ -275,8 +281,15 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     switch (param) {
     case ZL_d_forceIgnoreChecksum: d->ignore_checksum = value ? 1 : 0; return 0;
     case ZL_d_stableOutBuffer: return 0;
+    case ZL_d_profile: d->profile = value ? 1 : 0; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
+}
+
+size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
+    if (!d || !ms || !d->profile || !d->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
+    ms[0] = d->kernel_ms;
+    return 0;
 }
 
 size_t zl_DCtx_getParameter(const zl_dctx* d, int param, int* value) {
@@ -367,7 +380,13 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         if (d->dict_formatted) a.dict_tables = d->d_dict_tables.p;
     }
     a.ignore_checksum = (u32)d->ignore_checksum;
+    d->ev_valid = false;
+    if (d->profile) {
+        if (!d->ev[0]) { (void)hipEventCreate(&d->ev[0]); (void)hipEventCreate(&d->ev[1]); }
+        (void)hipEventRecord(d->ev[0], st);
+    }
     if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (d->profile) { (void)hipEventRecord(d->ev[1], st); d->ev_valid = true; }
     return 0;
 }
 
@@ -397,6 +416,7 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
     if (!d || !d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     d->pending = false;
     if (hipStreamSynchronize(d->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (d->ev_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->kernel_ms = ms; }
     const u64* r = (const u64*)d->h_results.p;
     size_t total = 0, first_err = 0;
     for (size_t i = 0; i < d->pending_n; i++) {

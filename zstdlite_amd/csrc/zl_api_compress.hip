@@ -27,6 +27,11 @@ struct zl_cctx_s {
     bool pending = false;
     hipStream_t pending_stream = nullptr;
     size_t pending_chunks = 0, pending_groups = 0;
+    // diagnostics
+    int profile = 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    double kernel_ms[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -52,6 +57,9 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         return kGpuUnavailable;
     if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const bool prof = c->profile && ngroups == 1;
+    if (prof && !c->ev[0]) for (auto& e : c->ev) (void)hipEventCreate(&e);
+    c->ev_valid = false;
     for (size_t g = 0; g < ngroups; g++) {
         const size_t first = g * ZL_GROUP_CHUNKS;
         const u32 cnt = (u32)std::min<size_t>(ZL_GROUP_CHUNKS, nchunks - first);
@@ -63,7 +71,9 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.meta = (zl_chunk_meta*)c->d_meta.p;
         m.lit_stride = ZL_LIT_STRIDE_ENC;
         m.seq_stride = ZL_SEQ_STRIDE;
+        if (prof) (void)hipEventRecord(c->ev[0], st);
         if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (prof) (void)hipEventRecord(c->ev[1], st);
         zl_entropy_args e;
         e.chunks = m.chunks;
         e.src = d_src;
@@ -78,8 +88,10 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.checksum = (u32)c->checksum;
         e.dict_id = 0;
         if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (prof) (void)hipEventRecord(c->ev[2], st);
         u64* totals = (u64*)c->d_totals.p;
         if (zl_launch_scan_sizes(e.frame_size, (u64*)c->d_foff.p + first, totals + g, totals + g + 1, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (prof) (void)hipEventRecord(c->ev[3], st);
         zl_gather_args ga;
         ga.staged = e.out;
         ga.frame_size = e.frame_size;
@@ -87,6 +99,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         ga.dst = d_dst;
         ga.out_stride = ZL_OUT_STRIDE;
         if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (prof) { (void)hipEventRecord(c->ev[4], st); c->ev_valid = true; }
     }
     if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64))) return kGpuUnavailable;
     if (hipMemcpyAsync(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -131,6 +144,7 @@ size_t zl_freeCCtx(zl_cctx* c) {
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return 0;
@@ -150,6 +164,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
     case ZL_c_stableInBuffer:
     case ZL_c_stableOutBuffer: return 0;
+    case ZL_c_profile: c->profile = value ? 1 : 0; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -192,11 +207,24 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
     if (!c || !c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     c->pending = false;
     if (hipStreamSynchronize(c->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (c->ev_valid) {
+        for (int k = 0; k < 4; k++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
+            c->kernel_ms[k] = ms;
+        }
+    }
     if (frame_sizes) {
         const u32* fs = (const u32*)c->h_fsize.p;
         for (size_t i = 0; i < c->pending_chunks; i++) frame_sizes[i] = fs[i];
     }
     return (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+}
+
+size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
+    if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int k = 0; k < 4; k++) ms[k] = c->kernel_ms[k];
+    return 0;
 }
 
 // replaces ZSTD_compress2 (zstd.h:599): host buffers in and out.

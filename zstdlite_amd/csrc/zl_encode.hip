@@ -56,6 +56,7 @@ struct MatchShared {
     u32 tbl_short[1 << SHORT_LOG];
     u16 jump[2][WIN];
     u8 mark[WIN];
+    u32 cand[WIN];  // [7:0] match length, [31:8] offset of each lane's best match
     u32 scan_a[4], scan_b[4];
     u32 carry;    // where the parse enters the next window (0 = its first position)
     u32 rep;      // offset of the most recent sequence (repeat-offset candidate)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
                 if (cl) {
                     const u32 q = cl - 1;
                     const u32 l = common_bytes(v, ld64(src + q));
-                    if (l == 8 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
+                    if (l >= MIN_MATCH + 1 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
                 }
                 if (cs && best_len < 8) {
                     const u32 q = cs - 1;
@@ -144,7 +145,19 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
                 }
             }
         }
-        const bool has_match = best_len >= MIN_MATCH;
+        bool has_match = best_len >= MIN_MATCH;
+        // ---- one-step lazy evaluation (cf. the ip+1 long-match check of zstd.c:30025-30040): if the
+        // next position holds a clearly better match, emit this byte as a literal instead
+        S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
+        __syncthreads();
+        if (has_match && t + 1 < WIN) {
+            const u32 nx = S.cand[t + 1];
+            if (nx) {
+                const int g1 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1)) + 4;
+                const int g2 = 4 * (int)(nx & 0xFF) - (int)(31 - __clz((nx >> 8) + 1));
+                if (g2 > g1) has_match = false;
+            }
+        }
         // ---- greedy parse over the window by pointer jumping
         const u32 nxt = t + (has_match ? best_len : 1u);
         S.jump[0][t] = (u16)nxt;
