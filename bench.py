@@ -46,6 +46,7 @@ def cpu_baseline(host_bytes, log):
     L.ZSTD_createCCtx.restype = C.c_void_p
     L.ZSTD_createDCtx.restype = C.c_void_p
     L.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ZSTD_CCtx_setParameter.restype = C.c_size_t
     L.ZSTD_compress2.restype = C.c_size_t
     L.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ZSTD_decompressDCtx.restype = C.c_size_t
@@ -54,11 +55,13 @@ def cpu_baseline(host_bytes, log):
     L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
     n = host_bytes.size
     cap = L.ZSTD_compressBound(n)
-    comp = np.zeros(cap, dtype=np.uint8)  # zeros: pre-touched
-    back = np.zeros(n, dtype=np.uint8)
+    comp = np.empty(cap, dtype=np.uint8)
+    back = np.empty(n, dtype=np.uint8)
+    comp.fill(1)  # pre-touch: first-touch page faults otherwise dominate
+    back.fill(1)
     res = {}
     ncores = os.cpu_count() or 1
-    for label, workers in (("1t", 0), ("mt", ncores)):
+    for label, workers in (("mt", ncores), ("1t", 0)):  # 1-thread output stays in the buffer for the decode leg
         cctx = L.ZSTD_createCCtx()
         L.ZSTD_CCtx_setParameter(cctx, 100, 3)
         if workers:
@@ -75,7 +78,10 @@ def cpu_baseline(host_bytes, log):
     r = L.ZSTD_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, csize)
     td = time.perf_counter() - t0
     L.ZSTD_freeDCtx(dctx)
-    assert r == n
+    L.ZSTD_getErrorName.restype = C.c_char_p
+    L.ZSTD_getErrorName.argtypes = [C.c_size_t]
+    assert r == n, (r, L.ZSTD_getErrorName(r))
+    assert np.array_equal(back, host_bytes)
     return {
         "value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
         "sample": f"the full {n >> 20} MiB bench vector, one pass: ZSTD_compress2(level 3) + ZSTD_decompressDCtx, bundled libzstd 1.5.6 built -O2 from the reference source (oracle/_ref), 1 thread",

@@ -3,9 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "zl_format.h"
 
 namespace {
+
+// ZL_DEBUG=1 in the environment prints every failing HIP call to stderr
+static inline bool zl_hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    static const bool dbg = getenv("ZL_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[zl_hip] %s failed: %s\n", what, hipGetErrorString(e));
+    return false;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -16,7 +27,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = n + (n >> 3) + 256;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        if (!zl_hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
         cap = want;
         return true;
     }
@@ -35,7 +46,7 @@ struct PinBuf {
         p = nullptr;
         cap = 0;
         size_t want = n + (n >> 3) + 256;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        if (!zl_hip_ok(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc")) { p = nullptr; return false; }
         cap = want;
         return true;
     }
@@ -51,7 +62,7 @@ static int g_num_cu = 256;
 static bool device_ok() {
     if (g_device_state == 0) {
         int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        if (!zl_hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount") || n <= 0) {
             g_device_state = -1;
         } else {
             hipDeviceProp_t prop;
