@@ -1,0 +1,28 @@
+"""Per-input kernel timings (HIP events inside the library): the optimisation loop's tool."""
+import sys, time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np, torch
+from zstdlite_amd.device import DeviceCodec, gen_device
+dev = torch.device("cuda", 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else (256 << 20)
+kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rand", "iid10", "text", "int20"]
+codec = DeviceCodec(profile=True)
+for kind in kinds:
+    src = gen_device(kind, n, dev)
+    comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    best = {}
+    for it in range(4):
+        _, total, fs = codec.compress(src, comp)
+        tbl = codec.frame_table(fs, codec.chunk_content_sizes(n))
+        codec.decompress(comp, tbl, back)
+        for k, v in codec.kernel_ms().items():
+            best[k] = min(best.get(k, 1e9), v)
+    assert torch.equal(back, src)
+    gb = n / 1e9
+    import ctypes as C
+    st = (C.c_ulonglong * 8)()
+    if hasattr(codec.L, "zl_dctx_phase_stats") and codec.L.zl_dctx_phase_stats(C.c_void_p(codec.dctx), st) == 0 and st[5]:
+        nb = st[5]
+        print(f"        decode phases, kcycles/block: H {st[0]/nb/1e3:.0f}  B {st[1]/nb/1e3:.0f}  A {st[2]/nb/1e3:.0f}  A||B {st[3]/nb/1e3:.0f}  C {st[4]/nb/1e3:.0f}   seq/block {st[6]/nb:.0f}  huflits/block {st[7]/nb:.0f}")
+    print(f"{kind:6s} ratio {n/total:6.3f} | " + " ".join(f"{k} {v:7.3f}ms ({gb/(v/1e3):7.1f} GB/s)" for k, v in best.items()), flush=True)

@@ -125,7 +125,8 @@ struct zl_dctx_s {
     u32 dict_content_off = 0;
     hipStream_t own_stream = nullptr;
     DevBuf d_src, d_dst, d_frames, d_results, d_counter, d_lit, d_seq, d_dict, d_dict_tables;
-    PinBuf h_frames, h_results, h_stage_in, h_stage_out;
+    DevBuf d_plan, d_frec, d_brec, d_lit2, d_seq2;  // lane-parallel pipeline (zl_decode2.hip)
+    PinBuf h_frames, h_results, h_stage_in, h_stage_out, h_plan;
     // pending device-resident call
     hipStream_t pending_stream = nullptr;
     size_t pending_n = 0;
@@ -136,6 +137,8 @@ struct zl_dctx_s {
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool ev_valid = false;
     double kernel_ms = 0;
+    DevBuf d_stats;
+    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 extern "C" {
@@ -266,9 +269,10 @@ zl_dctx* zl_createDCtx(void) { return new (std::nothrow) zl_dctx_s(); }
 size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
-    DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables};
+    DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_stats,
+                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2};
     for (DevBuf* b : bufs) b->release();
-    PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out};
+    PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
@@ -289,6 +293,13 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
 size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
     if (!d || !ms || !d->profile || !d->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     ms[0] = d->kernel_ms;
+    return 0;
+}
+
+// not part of the public header: decode-kernel phase cycle sums {H, B, A, A||B wall, C, blocks, sequences, huffman literals}
+size_t zl_dctx_phase_stats(const zl_dctx* d, unsigned long long* out8) {
+    if (!d || !out8 || !d->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int i = 0; i < 8; i++) out8[i] = d->stats[i];
     return 0;
 }
 
@@ -350,23 +361,66 @@ size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
     return 0;
 }
 
-// enqueue one decode launch over `n` frames whose table sits in d->h_frames (pinned)
+// enqueue the decode of `n` frames whose table sits in d->h_frames (pinned).  Frames of at most
+// one block size and without dictionary go through the lane-parallel pipeline (zl_decode2.hip);
+// the rest -- and whatever that pipeline hands back -- through the general kernel.
 size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_t st) {
     size_t e = dctx_prepare_dict(d, st);
     if (ZL_IS_ERR(e)) return e;
-    const u32 max_slots = (u32)g_num_cu * 6;
-    const u32 slots = (u32)std::min<size_t>(n, max_slots);
+    const zl_frame_desc* tbl = (const zl_frame_desc*)d->h_frames.p;
+    if (!d->h_plan.ensure(n * sizeof(zl2_frame_plan))) return kGpuUnavailable;
+    zl2_frame_plan* plan = (zl2_frame_plan*)d->h_plan.p;
+    const bool has_dict = !d->dict.empty();
+    u64 lit_total = 0, seq_total = 0;
+    size_t nslow = 0;
+    for (size_t i = 0; i < n; i++) {
+        zl2_frame_plan& p = plan[i];
+        p.pad = 0;
+        const bool fast = !has_dict && tbl[i].dst_cap <= ZL_BLOCK_MAX && tbl[i].src_size < (1u << 30);
+        p.route = fast ? 1u : 0u;
+        p.lit_off = lit_total;
+        p.seq_off = seq_total;
+        p.lit_cap = fast ? (u32)((tbl[i].dst_cap + 3 + 4 * ZL2_MAXB) & ~(u64)3) : 0;
+        p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2) : 0;
+        lit_total += (p.lit_cap + 15) & ~15u;
+        seq_total += (u64)3 * p.seq_cap;
+        if (!fast) nslow++;
+    }
+    const u32 max_slots = (u32)g_num_cu * 4;
+    const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 16), max_slots);
     if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) ||
-        !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)))
+        !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)) ||
+        !d->d_plan.ensure(n * sizeof(zl2_frame_plan)) || !d->d_frec.ensure(n * sizeof(zl2_frame_rec)) ||
+        !d->d_brec.ensure(n * (size_t)ZL2_MAXB * sizeof(zl2_blk_rec)) || !d->d_lit2.ensure(lit_total + 64) ||
+        !d->d_seq2.ensure(seq_total * sizeof(u32) + 64))
         return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_frames.p, d->h_frames.p, n * sizeof(zl_frame_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemcpyAsync(d->d_plan.p, d->h_plan.p, n * sizeof(zl2_frame_plan), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(d->d_counter.p, 0, 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    d->ev_valid = false;
+    if (d->profile) {
+        if (!d->ev[0]) { (void)hipEventCreate(&d->ev[0]); (void)hipEventCreate(&d->ev[1]); }
+        (void)hipEventRecord(d->ev[0], st);
+    }
+    zl2_args f2;
+    f2.frames = (const zl_frame_desc*)d->d_frames.p;
+    f2.plan = (const zl2_frame_plan*)d->d_plan.p;
+    f2.frec = (zl2_frame_rec*)d->d_frec.p;
+    f2.brec = (zl2_blk_rec*)d->d_brec.p;
+    f2.nframes = (u32)n;
+    f2.src = d_src;
+    f2.dst = d_dst;
+    f2.results = (u64*)d->d_results.p;
+    f2.lit_scratch = (u8*)d->d_lit2.p;
+    f2.seq_scratch = (u32*)d->d_seq2.p;
+    f2.ignore_checksum = (u32)d->ignore_checksum;
+    if (zl2_launch(&f2, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     zl_decode_args a;
-    a.frames = (const zl_frame_desc*)d->d_frames.p;
+    a.frames = f2.frames;
     a.nframes = (u32)n;
     a.src = d_src;
     a.dst = d_dst;
-    a.results = (u64*)d->d_results.p;
+    a.results = f2.results;
     a.counter = (u32*)d->d_counter.p;
     a.lit_scratch = (u8*)d->d_lit.p;
     a.seq_scratch = (u32*)d->d_seq.p;
@@ -374,16 +428,18 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     a.dict_len = 0;
     a.dict_id = d->dict_id;
     a.dict_tables = nullptr;
-    if (!d->dict.empty()) {
+    if (has_dict) {
         a.dict_content = (const u8*)d->d_dict.p + d->dict_content_off;
         a.dict_len = (u32)(d->dict.size() - d->dict_content_off);
         if (d->dict_formatted) a.dict_tables = d->d_dict_tables.p;
     }
     a.ignore_checksum = (u32)d->ignore_checksum;
-    d->ev_valid = false;
-    if (d->profile) {
-        if (!d->ev[0]) { (void)hipEventCreate(&d->ev[0]); (void)hipEventCreate(&d->ev[1]); }
-        (void)hipEventRecord(d->ev[0], st);
+    a.plan = f2.plan;
+    a.frec = f2.frec;
+    a.stats = nullptr;
+    if (d->profile && d->d_stats.ensure(64)) {
+        (void)hipMemsetAsync(d->d_stats.p, 0, 64, st);
+        a.stats = (u64*)d->d_stats.p;
     }
     if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (d->profile) { (void)hipEventRecord(d->ev[1], st); d->ev_valid = true; }
@@ -416,7 +472,12 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
     if (!d || !d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     d->pending = false;
     if (hipStreamSynchronize(d->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (d->ev_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]); d->kernel_ms = ms; }
+    if (d->ev_valid) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
+        d->kernel_ms = ms;
+        if (d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 64, hipMemcpyDeviceToHost);
+    }
     const u64* r = (const u64*)d->h_results.p;
     size_t total = 0, first_err = 0;
     for (size_t i = 0; i < d->pending_n; i++) {

@@ -96,6 +96,7 @@ struct DecShared {
     u32 lit_csize;     // size of Huffman streams (after tree description)
     u32 nseq;
     u32 seq_off, seq_len;  // FSE bitstream inside the block
+    u64 stamp_a;           // profiling: cycles the literal lanes spent (max over lanes)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -332,9 +333,28 @@ __device__ bool huf_decode_stream(const DecShared& S, u8* dst, u32 nout, const u
     i32 pos = zl_bwd_init(src, n);
     if (pos < 0) return false;
     const u32 log = S.huf_log;
-    for (u32 i = 0; i < nout; i++) {
-        u32 v = zl_bits_bwd(src, n, pos - (i32)log, log);
-        u32 e = S.huf[v];
+    zl_bwd_reader r;
+    zl_bwd_open(r, src, n, pos);
+    u32 i = 0;
+    // four symbols per iteration, packed into one dword store when the destination allows
+    const u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3);
+    for (; i < head && i < nout; i++) {
+        const u32 e = S.huf[zl_bwd_read(r, pos - (i32)log, log)];
+        dst[i] = (u8)e;
+        pos -= (i32)(e >> 8);
+    }
+    for (; i + 4 <= nout; i += 4) {
+        u32 word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 e = S.huf[zl_bwd_read(r, pos - (i32)log, log)];
+            word |= (e & 0xFF) << (8 * j);
+            pos -= (i32)(e >> 8);
+        }
+        *(u32*)(dst + i) = word;
+    }
+    for (; i < nout; i++) {
+        const u32 e = S.huf[zl_bwd_read(r, pos - (i32)log, log)];
         dst[i] = (u8)e;
         pos -= (i32)(e >> 8);
     }
@@ -346,25 +366,27 @@ __device__ bool huf_decode_stream(const DecShared& S, u8* dst, u32 nout, const u
 __device__ int decode_sequences(DecShared& S, const u8* bs, u32 bn, u32 nseq, u32* o_ll, u32* o_ml, u32* o_off) {
     i32 bp = zl_bwd_init(bs, bn);
     if (bp < 0) return ZL_E_CORRUPTION;
+    zl_bwd_reader r;
+    zl_bwd_open(r, bs, bn, bp);
     bp -= (i32)S.ll_log;
-    u32 sl = zl_bits_bwd(bs, bn, bp, S.ll_log);
+    u32 sl = zl_bwd_read(r, bp, S.ll_log);
     bp -= (i32)S.of_log;
-    u32 so = zl_bits_bwd(bs, bn, bp, S.of_log);
+    u32 so = zl_bwd_read(r, bp, S.of_log);
     bp -= (i32)S.ml_log;
-    u32 sm = zl_bits_bwd(bs, bn, bp, S.ml_log);
+    u32 sm = zl_bwd_read(r, bp, S.ml_log);
     if (bp < 0) return ZL_E_CORRUPTION;
     u32 r0 = S.rep[0], r1 = S.rep[1], r2 = S.rep[2];
     for (u32 i = 0; i < nseq; i++) {
         const u64 el = S.fse_ll[sl], eo = S.fse_of[so], em = S.fse_ml[sm];
         u32 nb = (u32)(eo >> 48) & 0xFF;
         bp -= (i32)nb;
-        const u32 ofv = (u32)eo + zl_bits_bwd(bs, bn, bp, nb);
+        const u32 ofv = (u32)eo + zl_bwd_read(r, bp, nb);
         nb = (u32)(em >> 48) & 0xFF;
         bp -= (i32)nb;
-        const u32 ml = (u32)em + zl_bits_bwd(bs, bn, bp, nb);
+        const u32 ml = (u32)em + zl_bwd_read(r, bp, nb);
         nb = (u32)(el >> 48) & 0xFF;
         bp -= (i32)nb;
-        const u32 ll = (u32)el + zl_bits_bwd(bs, bn, bp, nb);
+        const u32 ll = (u32)el + zl_bwd_read(r, bp, nb);
         if (bp < 0) return ZL_E_CORRUPTION;
         u32 off;
         if (ofv > 3) {
@@ -388,13 +410,13 @@ __device__ int decode_sequences(DecShared& S, const u8* bs, u32 bn, u32 nseq, u3
         if (i + 1 < nseq) {
             nb = (u32)(el >> 56);
             bp -= (i32)nb;
-            sl = ((u32)(el >> 32) & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
+            sl = ((u32)(el >> 32) & 0xFFFF) + zl_bwd_read(r, bp, nb);
             nb = (u32)(em >> 56);
             bp -= (i32)nb;
-            sm = ((u32)(em >> 32) & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
+            sm = ((u32)(em >> 32) & 0xFFFF) + zl_bwd_read(r, bp, nb);
             nb = (u32)(eo >> 56);
             bp -= (i32)nb;
-            so = ((u32)(eo >> 32) & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
+            so = ((u32)(eo >> 32) & 0xFFFF) + zl_bwd_read(r, bp, nb);
             if (bp < 0) return ZL_E_CORRUPTION;
         }
     }
@@ -654,7 +676,7 @@ __device__ u32 execute_block(DecShared& S, u8* blk_out, u64 cap_left, i64 blk_ab
     return out_pos + rest;
 }
 
-__global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a) {
+__global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_args a) {
     __shared__ DecShared S;
     const u32 t = threadIdx.x;
     const u32 slot = blockIdx.x;
@@ -671,6 +693,7 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a
         __syncthreads();
         const u32 f = S.frame;
         if (f >= a.nframes) break;
+        if (a.plan && a.plan[f].route != 0 && a.frec[f].err != ZL_E_FALLBACK) continue;  // decoded by zl_decode2.hip
         const zl_frame_desc fd = a.frames[f];
         const u8* src = a.src + fd.src_off;
         u8* out = a.dst + fd.dst_off;
@@ -727,6 +750,8 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a
                 op += bsize; pos += 1;
             } else {
                 // ---- stage H: headers + tables
+                u64 ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+                if (a.stats && t == 0) { ts0 = __builtin_amdgcn_s_memtime(); S.stamp_a = 0; }
                 if (t == 0) {
                     const u32 lsec = parse_literals(S, blk, bsize);
                     if (!S.err) parse_seq_header(S, blk + lsec, bsize - lsec);
@@ -743,10 +768,13 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a
                 LitSrc L;
                 L.rle = (S.lit_mode == 1) ? (0x100u | S.lit_rle) : 0;
                 L.ptr = S.lit_from_src ? (blk + S.lit_src_off) : lit_buf;
+                if (a.stats && t == 0) ts1 = __builtin_amdgcn_s_memtime();
                 if (t == 0 && S.nseq) {
                     int e = decode_sequences(S, blk + S.seq_off, S.seq_len, S.nseq, q_ll, q_ml, q_off);
                     if (e) S.err = e;
                 }
+                if (a.stats && t == 0) ts2 = __builtin_amdgcn_s_memtime();
+                const u64 ta0 = (a.stats && S.lit_mode >= 2 && t >= 64 && t < 68) ? __builtin_amdgcn_s_memtime() : 0;
                 if (S.lit_mode >= 2) {
                     const u8* hs = blk + S.lit_src_off;
                     const u32 regen = S.lit_size, cs = S.lit_csize;
@@ -769,10 +797,23 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_decode_kernel(zl_decode_args a
                         }
                     }
                 }
+                if (a.stats && S.lit_mode >= 2 && t >= 64 && t < 68) atomicMax((unsigned long long*)&S.stamp_a, (unsigned long long)(__builtin_amdgcn_s_memtime() - ta0));
                 __syncthreads();
                 if (S.err) break;
+                if (a.stats && t == 0) ts3 = __builtin_amdgcn_s_memtime();
                 // ---- stage C
                 const u32 produced = execute_block(S, out + op, cap - op, (i64)op, L, q_ll, q_ml, q_off, dict_end, a.dict_len);
+                if (a.stats && t == 0) {
+                    const u64 ts4 = __builtin_amdgcn_s_memtime();
+                    atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)(ts1 - ts0));  // H: headers + tables
+                    atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)(ts2 - ts1));  // B: FSE chain
+                    atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)S.stamp_a);    // A: slowest Huffman lane
+                    atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)(ts3 - ts1));  // A||B wall
+                    atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)(ts4 - ts3));  // C: execution
+                    atomicAdd((unsigned long long*)&a.stats[5], 1ull);                            // compressed blocks
+                    atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)S.nseq);
+                    atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(S.lit_mode >= 2 ? S.lit_size : 0));
+                }
                 if (S.err) break;
                 op += produced; pos += bsize;
             }

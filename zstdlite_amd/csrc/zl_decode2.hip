@@ -1,0 +1,1009 @@
+// zl_decode2.hip -- lane-parallel decode pipeline for frames of at most one block size
+// (<= 128 KiB of content): the shape of BASELINE config C2 (10k independent 64 KiB frames) and of
+// everything the HIP encoder emits.  zl_decode.hip's one-workgroup-per-frame kernel stays as the
+// general path (dictionaries, larger frames, unusual tables); frames are routed per frame.
+//
+// The reference decodes a block with three serial loops (zstd.c:45084 ZSTD_decompressBlock_internal:
+// Huffman literals zstd.c:38653, FSE sequences zstd.c:44241, sequence execution zstd.c:44013).
+// Measured on MI355X, running those chains on one lane of a wavefront costs ~500 cycles per
+// literal and ~2200 cycles per sequence while the other 63 lanes idle.  Here every lane of a
+// wavefront runs its own chain, so a wave instruction advances 64 Huffman streams (or 16 FSE
+// chains) at once:
+//
+//   zl2_index_kernel  lane per frame: frame header, block walk, literal/sequence section headers
+//                     (zstd.c:41050, :43075, :43146, :43707) -> block records
+//   zl2_lit_kernel    lane per Huffman stream (16 frames x 4 streams per wave); single-symbol
+//                     decode tables of the 16 frames side by side in LDS (zstd.c:38436)
+//   zl2_seq_kernel    lane per frame: FSE table build + the 3-state sequence chain with repcode
+//                     resolution (zstd.c:43497, :44241); compact LDS cells (3 bytes per state)
+//   zl2_exec_kernel   1024-thread workgroup per frame: the block's output is assembled in LDS
+//                     (128 KiB), every 4-byte word produced independently by chasing its source
+//                     through the batch's sequence table, then flushed with 16-byte coalesced
+//                     stores (replaces zstd.c:44013 ZSTD_execSequence); XXH64 check.
+//
+// All integer work; output must be bit-exact with the reference decoder.
+#include <hip/hip_runtime.h>
+
+#include "zl_device.h"
+#include "zl_format.h"
+#include "zl_kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// tables (zstd.c:15462-15512)
+// ---------------------------------------------------------------------------------------
+__constant__ u32 k_LL_base[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                  20, 22, 24, 28, 32, 40, 48, 64, 0x80, 0x100, 0x200, 0x400, 0x800, 0x1000,
+                                  0x2000, 0x4000, 0x8000, 0x10000};
+__constant__ u8 k_LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ u32 k_ML_base[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                  21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                  43, 47, 51, 59, 67, 83, 99, 0x83, 0x103, 0x203, 0x403, 0x803, 0x1003, 0x2003,
+                                  0x4003, 0x8003, 0x10003};
+__constant__ u8 k_ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ short k_LL_default[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                       2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ short k_ML_default[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ short k_OF_default[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+                                       1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+// ---------------------------------------------------------------------------------------
+// zl2_index_kernel: one lane per frame
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void set_err(zl2_frame_rec* fr, u32 code) {
+    if (fr->err == 0) fr->err = code;
+}
+
+__global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
+    const u32 f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.nframes) return;
+    zl2_frame_rec* fr = a.frec + f;
+    fr->err = 0;
+    fr->nblocks = 0;
+    fr->skippable = 0;
+    if (a.plan[f].route == 0) { fr->err = ZL_E_FALLBACK; return; }
+    const zl_frame_desc fd = a.frames[f];
+    const u8* src = a.src + fd.src_off;
+    const u64 n = fd.src_size;
+    // ---- frame header (zstd.c:41050-41148)
+    if (n < 5) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+    const u32 magic = zl_rd_le(src, 4);
+    if ((magic & 0xFFFFFFF0u) == ZL_MAGIC_SKIPPABLE) { fr->skippable = 1; return; }
+    if (magic != ZL_MAGIC) { fr->err = ZL_E_PREFIX_UNKNOWN; return; }
+    const u32 fhd = src[4];
+    const u32 dflag = fhd & 3, single = (fhd >> 5) & 1, fflag = fhd >> 6;
+    if (fhd & 8) { fr->err = ZL_E_FRAMEPARAM_UNSUPPORTED; return; }
+    const u32 dbytes = dflag == 3 ? 4 : dflag;
+    const u32 fbytes = fflag == 0 ? (single ? 1 : 0) : (1u << fflag);
+    const u32 hs = 5 + (single ? 0 : 1) + dbytes + fbytes;
+    if (n < hs) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+    u32 pos = 5;
+    if (!single) {
+        const u32 wlog = (src[pos++] >> 3) + 10;
+        if (wlog > 31) { fr->err = ZL_E_WINDOW_TOO_LARGE; return; }
+    }
+    const u32 did = zl_rd_le(src + pos, dbytes);
+    pos += dbytes;
+    u64 fcs = ZL_CONTENTSIZE_UNKNOWN;
+    if (fflag == 0) { if (single) fcs = src[pos]; }
+    else if (fflag == 1) fcs = (u64)zl_rd_le(src + pos, 2) + 256;
+    else if (fflag == 2) fcs = zl_rd_le(src + pos, 4);
+    else fcs = (u64)zl_rd_le(src + pos, 4) | ((u64)zl_rd_le(src + pos + 4, 4) << 32);
+    if (did) { fr->err = ZL_E_DICT_WRONG; return; }  // this path never has a dictionary (zstd.c:41318)
+    fr->fcs = fcs;
+    fr->has_checksum = (fhd >> 2) & 1;
+    // ---- blocks (zstd.c:43075) and their section headers
+    zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
+    pos = hs;
+    u32 nb = 0, lit_total = 0, seq_total = 0;
+    for (;;) {
+        if (n - pos < 3) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+        const u32 bh = zl_rd_le(src + pos, 3);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
+        pos += 3;
+        if (type == 3) { fr->err = ZL_E_CORRUPTION; return; }
+        const u32 csize = (type == 1) ? 1 : bsize;
+        if (n - pos < csize) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+        if (nb >= ZL2_MAXB) { fr->err = ZL_E_FALLBACK; return; }
+        zl2_blk_rec r;
+        r.type = type; r.size = bsize; r.src_off = pos;
+        r.lit_mode = 0; r.lit_size = 0; r.lit_a = 0; r.lit_b = 0; r.seq_off = 0; r.seq_len = 0;
+        r.lit_dst = lit_total; r.seq_dst = seq_total; r.nseq = 0; r.streams = 0;
+        if (type == 2) {
+            if (bsize > ZL_BLOCK_MAX) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+            const u8* blk = src + pos;
+            // literals section header (zstd.c:43146-43230)
+            if (bsize < 1) { fr->err = ZL_E_CORRUPTION; return; }
+            const u32 lt = blk[0] & 3, sf = (blk[0] >> 2) & 3;
+            u32 lsec;
+            if (lt < 2) {
+                u32 lh, regen;
+                if (sf == 0 || sf == 2) { lh = 1; regen = blk[0] >> 3; }
+                else if (sf == 1) { if (bsize < 2) { fr->err = ZL_E_CORRUPTION; return; } lh = 2; regen = zl_rd_le(blk, 2) >> 4; }
+                else { if (bsize < 3) { fr->err = ZL_E_CORRUPTION; return; } lh = 3; regen = zl_rd_le(blk, 3) >> 4; }
+                if (regen > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
+                r.lit_size = regen;
+                if (lt == 0) {
+                    if (lh + regen > bsize) { fr->err = ZL_E_CORRUPTION; return; }
+                    r.lit_mode = 0; r.lit_a = lh; lsec = lh + regen;
+                } else {
+                    if (lh + 1 > bsize) { fr->err = ZL_E_CORRUPTION; return; }
+                    r.lit_mode = 1; r.lit_a = blk[lh]; lsec = lh + 1;
+                }
+            } else {
+                if (bsize < 5) { fr->err = ZL_E_CORRUPTION; return; }
+                const u32 h4 = zl_rd_le(blk, 4);
+                u32 lh, regen, cs, streams = 4;
+                if (sf == 0 || sf == 1) { streams = sf == 0 ? 1 : 4; lh = 3; regen = (h4 >> 4) & 0x3FF; cs = (h4 >> 14) & 0x3FF; }
+                else if (sf == 2) { lh = 4; regen = (h4 >> 4) & 0x3FFF; cs = h4 >> 18; }
+                else { lh = 5; regen = (h4 >> 4) & 0x3FFFF; cs = (h4 >> 22) + ((u32)blk[4] << 10); }
+                if (regen > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
+                if (streams == 4 && regen < 6) { fr->err = ZL_E_LITERALS_HEADER; return; }
+                if (lh + cs > bsize) { fr->err = ZL_E_CORRUPTION; return; }
+                r.lit_mode = lt; r.lit_size = regen; r.lit_a = lh; r.lit_b = cs; r.streams = streams;
+                lsec = lh + cs;
+                lit_total += (regen + 3) & ~3u;
+            }
+            // sequences section header (zstd.c:43707-43735)
+            const u8* sp = blk + lsec;
+            const u32 sn = bsize - lsec;
+            if (sn < 1) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+            u32 nseq = sp[0], sh = 1;
+            if (nseq > 0x7F) {
+                if (nseq == 0xFF) { if (sn < 3) { fr->err = ZL_E_SRCSIZE_WRONG; return; } nseq = zl_rd_le(sp + 1, 2) + 0x7F00; sh = 3; }
+                else { if (sn < 2) { fr->err = ZL_E_SRCSIZE_WRONG; return; } nseq = ((nseq - 0x80) << 8) + sp[1]; sh = 2; }
+            }
+            if (nseq == 0 && sh != sn) { fr->err = ZL_E_CORRUPTION; return; }
+            r.nseq = nseq; r.seq_off = lsec + sh; r.seq_len = sn - sh;
+            seq_total += nseq;
+        } else {
+            if ((u64)bsize > fd.dst_cap) { fr->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
+        }
+        br[nb++] = r;
+        pos += csize;
+        if (last) break;
+    }
+    // scratch capacity of this frame (planned on the host from dst_cap)
+    if ((u64)lit_total > a.plan[f].lit_cap || (u64)seq_total > a.plan[f].seq_cap) { fr->err = ZL_E_CORRUPTION; return; }
+    fr->nblocks = nb;
+    fr->end_pos = pos;
+    if (fr->has_checksum && n - pos < 4) { fr->err = ZL_E_CHECKSUM_WRONG; return; }
+}
+
+// ---------------------------------------------------------------------------------------
+// FSE table description reader shared by the literal and sequence kernels
+// (zstd.c:3269 FSE_readNCount_body).  Returns bytes consumed, 0 on error.
+// ---------------------------------------------------------------------------------------
+template <typename NormPtr>
+__device__ __forceinline__ u32 read_ncount2(NormPtr norm, int* max_sym_io, int* log_out, int max_log, const u8* src, u32 n) {
+    if (n < 1) return 0;
+    i32 bit = 0;
+    const i32 total = (i32)n * 8;
+    int log = (int)zl_bits_bwd(src, n, bit, 4) + 5;
+    bit += 4;
+    if (log > max_log) return 0;
+    int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1;
+    int sym = 0;
+    const int limit = *max_sym_io;
+    bool prev_zero = false;
+    for (int s = 0; s <= limit; s++) norm[s] = 0;
+    while (remaining > 1 && sym <= limit) {
+        if (prev_zero) {
+            for (;;) {
+                if (bit + 2 > total) return 0;
+                const int r = (int)zl_bits_bwd(src, n, bit, 2);
+                bit += 2;
+                sym += r;
+                if (r != 3) break;
+            }
+            if (sym > limit) return 0;
+            prev_zero = false;
+        }
+        if (bit > total) return 0;
+        const int max = (2 * threshold - 1) - remaining;
+        const u32 peek = zl_bits_bwd(src, n, bit, (u32)nbits);
+        int count;
+        if ((int)(peek & (u32)(threshold - 1)) < max) { count = (int)(peek & (u32)(threshold - 1)); bit += nbits - 1; }
+        else { count = (int)(peek & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; bit += nbits; }
+        count--;
+        remaining -= (count < 0) ? -count : count;
+        norm[sym++] = (short)count;
+        prev_zero = (count == 0);
+        while (remaining < threshold && threshold > 1) { nbits--; threshold >>= 1; }
+    }
+    if (remaining != 1 || bit > total) return 0;
+    *max_sym_io = sym - 1;
+    *log_out = log;
+    return (u32)((bit + 7) >> 3);
+}
+
+// ---------------------------------------------------------------------------------------
+// zl2_lit_kernel: 64 lanes = 16 frames x 4 Huffman streams
+// ---------------------------------------------------------------------------------------
+#define LIT_FRAMES 16
+struct LitGroup {
+    u16 tab[2048];   // [7:0] symbol, [15:8] code length
+    u8 weights[256];
+    u32 wfse[64];    // weight FSE cells: [15:0] base, [23:16] nbits, [31:24] symbol
+    short norm[16];
+    u16 next[16];
+    u8 cellsym[64];
+    u32 rank_start[16];
+    u32 log;
+    u32 ok;          // table usable for "treeless" blocks
+};
+
+// Huffman tree description -> g.tab (zstd.c:3470 HUF_readStats_body, zstd.c:38436
+// HUF_readDTableX1_wksp).  One lane.  Returns bytes consumed, 0 on error, 0xFFFFFFFF when the
+// table needs 12 bits (handled by the general kernel).
+__device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n) {
+    if (n < 1) return 0;
+    int nsym = 0;
+    u32 used;
+    const u32 hb = src[0];
+    if (hb >= 128) {
+        nsym = (int)hb - 127;
+        used = 1 + (u32)(nsym + 1) / 2;
+        if (used > n) return 0;
+        for (int i = 0; i < nsym; i++) {
+            const u8 b = src[1 + i / 2];
+            g.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+        }
+    } else {
+        used = 1 + hb;
+        if (used > n || hb < 2) return 0;
+        int max_sym = 12, log = 0;  // weights are 0..12
+        const u32 hs = read_ncount2(g.norm, &max_sym, &log, 6, src + 1, hb);
+        if (hs == 0 || hs >= hb) return 0;
+        // weight FSE table (zstd.c:3690)
+        const int size = 1 << log;
+        int high = size - 1;
+        for (int s = 0; s <= max_sym; s++) {
+            if (g.norm[s] == -1) { g.cellsym[high--] = (u8)s; g.next[s] = 1; }
+            else g.next[s] = (u16)g.norm[s];
+        }
+        const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+        int pos = 0;
+        for (int s = 0; s <= max_sym; s++)
+            for (int i = 0; i < g.norm[s]; i++) {
+                g.cellsym[pos] = (u8)s;
+                do { pos = (pos + step) & mask; } while (pos > high);
+            }
+        if (pos != 0) return 0;
+        for (int u = 0; u < size; u++) {
+            const u32 s = g.cellsym[u];
+            const u32 ns = g.next[s]++;
+            const u32 nb = (u32)log - (31 - __clz(ns));
+            g.wfse[u] = (((ns << nb) - (u32)size) & 0xFFFF) | (nb << 16) | (s << 24);
+        }
+        const u8* bs = src + 1 + hs;
+        const u32 bn = hb - hs;
+        i32 bp = zl_bwd_init(bs, bn);
+        if (bp < 0) return 0;
+        bp -= log;
+        u32 s1 = zl_bits_bwd(bs, bn, bp, (u32)log);
+        bp -= log;
+        u32 s2 = zl_bits_bwd(bs, bn, bp, (u32)log);
+        if (bp < 0) return 0;
+        for (;;) {
+            if (nsym > 253) return 0;
+            u32 e = g.wfse[s1];
+            g.weights[nsym++] = (u8)(e >> 24);
+            u32 nb = (e >> 16) & 0xFF;
+            bp -= (i32)nb;
+            s1 = (e & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
+            if (bp < 0) { g.weights[nsym++] = (u8)(g.wfse[s2] >> 24); break; }
+            if (nsym > 253) return 0;
+            e = g.wfse[s2];
+            g.weights[nsym++] = (u8)(e >> 24);
+            nb = (e >> 16) & 0xFF;
+            bp -= (i32)nb;
+            s2 = (e & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
+            if (bp < 0) { g.weights[nsym++] = (u8)(g.wfse[s1] >> 24); break; }
+        }
+    }
+    u32 total = 0;
+    for (int w = 0; w < 16; w++) g.rank_start[w] = 0;
+    for (int i = 0; i < nsym; i++) {
+        const u32 w = g.weights[i];
+        if (w > ZL_HUF_LOG_MAX) return 0;
+        g.rank_start[w]++;
+        if (w) total += 1u << (w - 1);
+    }
+    if (total == 0) return 0;
+    const u32 log = 32 - __clz(total);
+    if (log > ZL_HUF_LOG_MAX) return 0;
+    const u32 rest = (1u << log) - total;
+    if (rest & (rest - 1)) return 0;
+    const u32 last_w = 32 - __clz(rest);
+    g.weights[nsym++] = (u8)last_w;
+    g.rank_start[last_w]++;
+    if (g.rank_start[1] < 2 || (g.rank_start[1] & 1)) return 0;  // zstd.c:3549
+    if (log > 11) return 0xFFFFFFFFu;
+    // counts -> first cell of each weight class
+    u32 cell = 0;
+    for (u32 w = 1; w <= log; w++) {
+        const u32 c = g.rank_start[w];
+        g.rank_start[w] = cell;
+        cell += c << (w - 1);
+    }
+    for (int s = 0; s < nsym; s++) {
+        const u32 w = g.weights[s];
+        if (!w) continue;
+        const u32 cnt = 1u << (w - 1);
+        const u32 start = g.rank_start[w];
+        g.rank_start[w] = start + cnt;
+        const u16 e = (u16)((u32)s | ((log + 1 - w) << 8));
+        for (u32 k = 0; k < cnt; k++) g.tab[start + k] = e;
+    }
+    g.log = log;
+    return used;
+}
+
+// one backward Huffman stream on one lane (zstd.c:38560).  Main loop: left-aligned accumulator,
+// two symbols per refill check, four symbols per dword store, no branches; the last few symbols
+// (and short streams) go through the generic reader so that the end-of-stream test stays exact.
+__device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u32 nout, const u8* src, u32 n) {
+    i32 pos = zl_bwd_init(src, n);
+    if (pos < 0) return false;
+    u32 i = 0;
+    const u32 head = (u32)((4 - ((uintptr_t)dst & 3)) & 3);
+    for (; i < head && i < nout; i++) {
+        const u32 e = tab[zl_bits_bwd(src, n, pos - (i32)log, log)];
+        dst[i] = (u8)e;
+        pos -= (i32)(e >> 8);
+    }
+    if (pos >= 96 && log >= 1) {
+        zl_lreader r;
+        zl_lr_open(r, src, n, pos);
+        const u32 sh = 32 - log;
+        const u32* w = r.w;
+        u64 acc = r.acc;
+        i32 nav = r.nav, idx = r.idx, left = r.pos;
+        // The two dwords a group of four symbols may need are loaded one group ahead and BEFORE
+        // that group's store.  hipcc would wait with vmcnt(0) at the top of the loop -- i.e. for the
+        // store round trip as well -- so the load and its wait are hand-placed (guide section 5.7):
+        // exactly one younger vector-memory op (the store) is outstanding at the wait, hence
+        // vmcnt(1); a dummy store (overwritten by the first group) makes that true on loop entry too.
+        if (i + 4 <= nout && idx >= 3) {
+            u64 wab;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wab) : "v"(w + idx - 1) : "memory");
+            asm volatile("global_store_dword %0, %1, off" : : "v"(dst + i), "v"(0u) : "memory");
+            while (i + 4 <= nout && idx >= 3) {
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(wab) : : "memory");
+                const u32 wa = (u32)(wab >> 32), wb = (u32)wab;  // w[idx], w[idx-1]
+                const u32 e0 = tab[(u32)(acc >> 32) >> sh];
+                acc <<= (e0 >> 8);
+                const u32 e1 = tab[(u32)(acc >> 32) >> sh];
+                acc <<= (e1 >> 8);
+                nav -= (i32)((e0 >> 8) + (e1 >> 8));
+                const bool f0 = nav <= 32;
+                acc |= f0 ? ((u64)wa << (32 - nav)) : 0ull;
+                nav += f0 ? 32 : 0;
+                const u32 e2 = tab[(u32)(acc >> 32) >> sh];
+                acc <<= (e2 >> 8);
+                const u32 e3 = tab[(u32)(acc >> 32) >> sh];
+                acc <<= (e3 >> 8);
+                nav -= (i32)((e2 >> 8) + (e3 >> 8));
+                const bool f1 = nav <= 32;
+                const u32 wsel = f0 ? wb : wa;
+                acc |= f1 ? ((u64)wsel << (32 - nav)) : 0ull;
+                nav += f1 ? 32 : 0;
+                idx -= (f0 ? 1 : 0) + (f1 ? 1 : 0);
+                left -= (i32)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
+                const u32 word = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wab) : "v"(w + idx - 1) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(dst + i), "v"(word) : "memory");
+                i += 4;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wab) : : "memory");
+        }
+        r.pos = left;
+        pos = r.pos;
+    }
+    for (; i < nout; i++) {
+        const u32 e = tab[zl_bits_bwd(src, n, pos - (i32)log, log)];
+        dst[i] = (u8)e;
+        pos -= (i32)(e >> 8);
+    }
+    return pos == 0;  // zstd.c:38640 BIT_endOfDStream
+}
+
+__global__ __launch_bounds__(64) void zl2_lit_kernel(zl2_args a) {
+    __shared__ LitGroup G[LIT_FRAMES];
+    const u32 lane = threadIdx.x, grp = lane >> 2, sub = lane & 3;
+    const u32 f = blockIdx.x * LIT_FRAMES + grp;
+    const bool live = f < a.nframes;
+    LitGroup& g = G[grp];
+    if (sub == 0) g.ok = 0;
+    u32 nblocks = 0;
+    const u8* src = nullptr;
+    u8* lit = nullptr;
+    const zl2_blk_rec* br = nullptr;
+    zl2_frame_rec* fr = nullptr;
+    if (live) {
+        fr = a.frec + f;
+        if (fr->err == 0 && !fr->skippable) nblocks = fr->nblocks;
+        src = a.src + a.frames[f].src_off;
+        lit = a.lit_scratch + a.plan[f].lit_off;
+        br = a.brec + (size_t)f * ZL2_MAXB;
+    }
+    for (u32 b = 0; b < ZL2_MAXB; b++) {
+        bool active = false;
+        zl2_blk_rec r;
+        if (b < nblocks) {
+            r = br[b];
+            active = (r.type == 2 && r.lit_mode >= 2);
+        }
+        u32 tree = 0;
+        if (active && sub == 0) {
+            const u8* blk = src + r.src_off;
+            if (r.lit_mode == 2) {
+                tree = build_huf_table(g, blk + r.lit_a, r.lit_b);
+                if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); tree = 0; g.ok = 0; }
+                else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
+                else g.ok = 1;
+            } else if (!g.ok) {
+                set_err(fr, ZL_E_DICT_CORRUPTED);  // treeless block without a previous table (zstd.c:43171)
+            }
+            g.rank_start[15] = tree;
+        }
+        __syncthreads();
+        if (active && g.ok && fr->err == 0) {
+            tree = g.rank_start[15];
+            const u8* blk = src + r.src_off;
+            const u8* hs = blk + r.lit_a + tree;
+            const u32 cs = r.lit_b - tree, regen = r.lit_size;
+            u8* out = lit + r.lit_dst;
+            bool good = true;
+            if (r.streams == 1) {
+                if (sub == 0) good = huf_stream2(g.tab, g.log, out, regen, hs, cs);
+            } else if (cs < 10) {
+                good = false;
+            } else {
+                const u32 s1 = zl_rd_le(hs, 2), s2 = zl_rd_le(hs + 2, 2), s3 = zl_rd_le(hs + 4, 2);
+                const u32 seg = (regen + 3) / 4;
+                if (6 + s1 + s2 + s3 > cs || seg * 3 > regen) good = false;
+                else {
+                    const u32 s4 = cs - 6 - s1 - s2 - s3;
+                    const u32 so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
+                    const u32 sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
+                    const u32 cnt = (sub == 3) ? regen - 3 * seg : seg;
+                    good = huf_stream2(g.tab, g.log, out + sub * seg, cnt, hs + 6 + so, sl);
+                }
+            }
+            if (!good) set_err(fr, ZL_E_CORRUPTION);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// zl2_seq_kernel: one lane per frame, 16 frames per 64-lane workgroup
+// ---------------------------------------------------------------------------------------
+#define SEQ_FRAMES 16
+struct SeqLane {
+    u16 cell[1280];  // LL [0,512) ML [512,1024) OF [1024,1280): [9:0] next-state base, [13:10] state bits
+    u8 sym[1280];
+    u16 next[64];
+    short norm[64];
+};
+struct SeqShared {
+    SeqLane L[SEQ_FRAMES];
+    u32 ll_tab[36];  // [23:0] baseline, [31:24] extra bits
+    u32 ml_tab[53];
+};
+
+// zstd.c:43497-43600 ZSTD_buildFSETable_body, compact cells.  One lane.
+__device__ __forceinline__ bool build_seq_table(SeqLane& L, u32 base, int max_sym, int log) {
+    const int size = 1 << log;
+    int high = size - 1;
+    for (int s = 0; s <= max_sym; s++) {
+        if (L.norm[s] == -1) { L.sym[base + high--] = (u8)s; L.next[s] = 1; }
+        else L.next[s] = (u16)L.norm[s];
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s <= max_sym; s++)
+        for (int i = 0; i < L.norm[s]; i++) {
+            L.sym[base + pos] = (u8)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    if (pos != 0) return false;
+    for (int u = 0; u < size; u++) {
+        const u32 s = L.sym[base + u];
+        const u32 ns = L.next[s]++;
+        const u32 nb = (u32)log - (31 - __clz(ns));
+        L.cell[base + u] = (u16)((((ns << nb) - (u32)size) & 0x3FF) | (nb << 10));
+    }
+    return true;
+}
+
+// kind: 0 LL, 1 OF, 2 ML.  Returns bytes consumed or 0xFFFFFFFF (zstd.c:43640 ZSTD_buildSeqTable).
+__device__ __forceinline__ u32 read_seq_table2(SeqLane& L, int kind, int mode, const u8* src, u32 n, u32* log_io, bool have_prev) {
+    const int max_sym = kind == 0 ? ZL_MAX_LL : (kind == 2 ? ZL_MAX_ML : ZL_MAX_OF);
+    const int max_log = kind == 1 ? ZL_OF_LOG_MAX : ZL_LL_LOG_MAX;
+    const u32 base = kind == 0 ? 0u : (kind == 2 ? 512u : 1024u);
+    if (mode == 0) {
+        const short* def = kind == 0 ? k_LL_default : (kind == 2 ? k_ML_default : k_OF_default);
+        const int dmax = kind == 0 ? 35 : (kind == 2 ? 52 : 28), dlog = kind == 1 ? 5 : 6;
+        for (int s = 0; s <= dmax; s++) L.norm[s] = def[s];
+        if (!build_seq_table(L, base, dmax, dlog)) return 0xFFFFFFFFu;
+        *log_io = (u32)dlog;
+        return 0;
+    }
+    if (mode == 1) {
+        if (n < 1 || (int)src[0] > max_sym) return 0xFFFFFFFFu;
+        L.sym[base] = src[0];
+        L.cell[base] = 0;
+        *log_io = 0;
+        return 1;
+    }
+    if (mode == 2) {
+        int ms = max_sym, log = 0;
+        const u32 used = read_ncount2(L.norm, &ms, &log, max_log, src, n);
+        if (used == 0) return 0xFFFFFFFFu;
+        if (!build_seq_table(L, base, ms, log)) return 0xFFFFFFFFu;
+        *log_io = (u32)log;
+        return used;
+    }
+    return have_prev ? 0 : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
+    __shared__ SeqShared S;
+    const u32 lane = threadIdx.x;
+    if (lane < 36) S.ll_tab[lane] = k_LL_base[lane] | ((u32)k_LL_bits[lane] << 24);
+    if (lane < 53) S.ml_tab[lane] = k_ML_base[lane] | ((u32)k_ML_bits[lane] << 24);
+    __syncthreads();
+    const u32 f = blockIdx.x * SEQ_FRAMES + lane;
+    if (lane >= SEQ_FRAMES || f >= a.nframes) return;
+    zl2_frame_rec* fr = a.frec + f;
+    if (fr->err || fr->skippable) return;
+    SeqLane& L = S.L[lane];
+    const u8* src = a.src + a.frames[f].src_off;
+    zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
+    u32* q_ll = a.seq_scratch + a.plan[f].seq_off;
+    u32* q_ml = q_ll + a.plan[f].seq_cap;
+    u32* q_off = q_ml + a.plan[f].seq_cap;
+    u32 r0 = 1, r1 = 4, r2 = 8;
+    u32 ll_log = 0, ml_log = 0, of_log = 0;
+    bool have_tables = false;
+    const u32 nblocks = fr->nblocks;
+    for (u32 b = 0; b < nblocks; b++) {
+        const zl2_blk_rec r = br[b];
+        if (r.type != 2 || r.nseq == 0) continue;
+        const u8* sp = src + r.src_off + r.seq_off;
+        const u32 sn = r.seq_len;
+        if (sn < 1) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
+        const u32 modes = sp[0];
+        if (modes & 3) { fr->err = ZL_E_CORRUPTION; return; }
+        u32 pos = 1;
+        u32 used = read_seq_table2(L, 0, modes >> 6, sp + pos, sn - pos, &ll_log, have_tables);
+        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
+        pos += used;
+        used = read_seq_table2(L, 1, (modes >> 4) & 3, sp + pos, sn - pos, &of_log, have_tables);
+        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
+        pos += used;
+        used = read_seq_table2(L, 2, (modes >> 2) & 3, sp + pos, sn - pos, &ml_log, have_tables);
+        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
+        pos += used;
+        have_tables = true;
+        // ---- the 3-state chain (zstd.c:44241-44356)
+        const u8* bs = sp + pos;
+        const u32 bn = sn - pos;
+        i32 bp = zl_bwd_init(bs, bn);
+        if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+        u32* oll = q_ll + r.seq_dst;
+        u32* oml = q_ml + r.seq_dst;
+        u32* oof = q_off + r.seq_dst;
+        const u32 nseq = r.nseq;
+        u32 lit_used = 0;
+        u32 i = 0;
+        u32 sl, so, sm;
+        bool fast = bp >= 128;
+        zl_lreader rd;
+        if (fast) {
+            zl_lr_open(rd, bs, bn, bp);
+            sl = zl_lr_take(rd, ll_log);
+            if (rd.nav <= 32) zl_lr_refill(rd);
+            so = zl_lr_take(rd, of_log);
+            sm = zl_lr_take(rd, ml_log);
+            if (rd.nav <= 32) zl_lr_refill(rd);
+            // fast loop: every field group is at most 32 bits and is followed by one refill check;
+            // the (up to three) dwords an iteration may need are loaded one iteration ahead, before
+            // that iteration's stores, so the wait for them never includes a store round trip
+            const u32* w = rd.w;
+            u64 acc = rd.acc;
+            i32 nav = rd.nav, idx = rd.idx, left = rd.pos;
+            u32 bad = 0;
+            // w[idx-3..idx] for the next sequence are loaded before this sequence's three stores and
+            // waited for with vmcnt(3) (hand-placed, see huf_stream2); three dummy stores on entry.
+            typedef u32 zl_v4u __attribute__((ext_vector_type(4)));
+            zl_v4u t4 = {0, 0, 0, 0};
+            const bool go = nseq > 0 && idx >= 5;
+            if (go) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t4) : "v"(w + idx - 3) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oll), "v"(0u) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oml), "v"(0u) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oof), "v"(0u) : "memory");
+            }
+#define ZL_TAKE(dst_, n_)                                              \
+            {                                                            \
+                const u32 n__ = (n_);                                    \
+                dst_ = n__ ? ((u32)(acc >> 32) >> (32 - n__)) : 0u;      \
+                acc <<= n__;                                             \
+                nav -= (i32)n__;                                         \
+                left -= (i32)n__;                                        \
+                const bool f__ = nav <= 32;                              \
+                const u32 ws__ = used == 0 ? t4.w : (used == 1 ? t4.z : t4.y); \
+                acc |= f__ ? ((u64)ws__ << (32 - nav)) : 0ull;           \
+                nav += f__ ? 32 : 0;                                     \
+                used += f__ ? 1 : 0;                                     \
+            }
+            for (; go && i < nseq && idx >= 5; i++) {
+                asm volatile("s_waitcnt vmcnt(3)" : "+v"(t4) : : "memory");
+                u32 used = 0;
+                const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
+                const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
+                const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
+                const u32 nl = tl >> 24, nm = tm >> 24;
+                u32 ofx, x, u = 0;
+                ZL_TAKE(ofx, yo);
+                ZL_TAKE(x, nm + nl);  // match-length bits above literal-length bits
+                const u32 ofv = (1u << yo) + ofx;
+                const u32 ml = (tm & 0xFFFFFF) + (x >> nl);
+                const u32 ll = (tl & 0xFFFFFF) + (x & ((1u << nl) - 1));
+                // repcode rules (zstd.c:44291-44327), branch-free
+                const bool real = ofv > 3;
+                const u32 ri = ofv - 1 + (ll == 0 ? 1u : 0u);  // meaningful when !real: 0..3
+                const u32 cand = ri == 1 ? r1 : (ri == 2 ? r2 : (ri == 3 ? r0 - 1 : r0));
+                const u32 off = real ? ofv - 3 : cand;
+                const bool sh2 = real || ri >= 2, sh1 = real || ri >= 1;
+                r2 = sh2 ? r1 : r2;
+                r1 = sh1 ? r0 : r1;
+                r0 = off;
+                bad |= (off == 0) ? 1u : 0u;
+                lit_used += ll;
+                if (i + 1 < nseq) {
+                    const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
+                    ZL_TAKE(u, bl + bm + bo);  // LL bits on top, then ML, then OF
+                    so = (co & 0x3FF) + (u & ((1u << bo) - 1));
+                    sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
+                    sl = (cl & 0x3FF) + (u >> (bo + bm));
+                }
+                idx -= (i32)used;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t4) : "v"(w + idx - 3) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oll + i), "v"(ll) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oml + i), "v"(ml) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oof + i), "v"(off) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t4) : : "memory");
+#undef ZL_TAKE
+            if (bad) { fr->err = ZL_E_CORRUPTION; return; }
+            rd.pos = left;
+            // hand the exact bit position to the generic tail
+            bp = rd.pos;
+            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+        } else {
+            bp -= (i32)ll_log;
+            sl = zl_bits_bwd(bs, bn, bp, ll_log);
+            bp -= (i32)of_log;
+            so = zl_bits_bwd(bs, bn, bp, of_log);
+            bp -= (i32)ml_log;
+            sm = zl_bits_bwd(bs, bn, bp, ml_log);
+            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+        }
+        // generic tail (also the whole chain of short streams)
+        for (; i < nseq; i++) {
+            const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
+            const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
+            if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) { fr->err = ZL_E_CORRUPTION; return; }
+            const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
+            const u32 nl = tl >> 24, nm = tm >> 24;
+            bp -= (i32)yo;
+            const u32 ofv = (1u << yo) + zl_bits_bwd(bs, bn, bp, yo);
+            bp -= (i32)nm;
+            const u32 ml = (tm & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nm);
+            bp -= (i32)nl;
+            const u32 ll = (tl & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nl);
+            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+            u32 off;
+            if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
+            else {
+                const u32 idx = ofv - 1 + (ll == 0);
+                if (idx == 0) off = r0;
+                else {
+                    off = (idx == 3) ? r0 - 1 : (idx == 1 ? r1 : r2);
+                    if (off == 0) { fr->err = ZL_E_CORRUPTION; return; }
+                    if (idx != 1) r2 = r1;
+                    r1 = r0;
+                    r0 = off;
+                }
+            }
+            oll[i] = ll; oml[i] = ml; oof[i] = off;
+            lit_used += ll;
+            if (i + 1 < nseq) {
+                u32 nb = cl >> 10;
+                bp -= (i32)nb;
+                sl = (cl & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+                nb = cm >> 10;
+                bp -= (i32)nb;
+                sm = (cm & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+                nb = co >> 10;
+                bp -= (i32)nb;
+                so = (co & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+                if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+            }
+        }
+        if (bp != 0) { fr->err = ZL_E_CORRUPTION; return; }  // zstd.c:44690
+        if (lit_used > r.lit_size) { fr->err = ZL_E_CORRUPTION; return; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// zl2_exec_kernel: 1024 threads per frame, block output staged in LDS.
+//
+// Sequences are consumed in batches of 1024.  Per batch: a block-wide scan gives every sequence
+// its output and literal offsets; pass 1 scatters the batch's literal bytes into the LDS image
+// with coalesced dword loads from the literal buffer; pass 2 produces the match bytes, each by
+// following its offset through the batch table until it lands on a byte that already exists in
+// the image (an earlier batch, or a literal placed by pass 1) -- the dependent chain of a byte is
+// LDS-only.  A table of "which sequence owns this 32-byte granule" replaces binary searches.
+// ---------------------------------------------------------------------------------------
+#define EX_THREADS 1024
+#define EX_GRAN_LOG 5
+struct ExecShared {
+    u8 out[ZL_BLOCK_MAX];
+    u32 b_out[EX_THREADS + 1];
+    u32 b_lit[EX_THREADS + 1];
+    u32 b_ll[EX_THREADS];
+    u32 b_off[EX_THREADS];
+    u16 own[(ZL_BLOCK_MAX >> EX_GRAN_LOG) + 8];
+    u32 scan_a[16], scan_b[16];
+    u64 xxh_acc[4];
+    u32 bcast[4];
+    int err;
+};
+
+__device__ __forceinline__ void exec_scan2(ExecShared& S, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if ((int)lane >= d) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { S.scan_a[wave] = ia; S.scan_b[wave] = ib; }
+    __syncthreads();
+    u32 pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; w++) {
+        const u32 xa = S.scan_a[w], xb = S.scan_b[w];
+        if (w < wave) { pa += xa; pb += xb; }
+        ta += xa; tb += xb;
+    }
+    ex_a = pa + ia - a;
+    ex_b = pb + ib - b;
+    tot_a = ta;
+    tot_b = tb;
+    __syncthreads();
+}
+
+// sequence of the current batch that owns block-relative output position p
+__device__ __forceinline__ u32 owner_of(const ExecShared& S, u32 p, u32 gbase) {
+    u32 k = S.own[(p - gbase) >> EX_GRAN_LOG];
+    while (p >= S.b_out[k + 1]) k++;
+    return k;
+}
+
+__global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
+    extern __shared__ __align__(16) u8 smem_raw[];
+    ExecShared& S = *reinterpret_cast<ExecShared*>(smem_raw);
+    const u32 t = threadIdx.x;
+    const u32 f = blockIdx.x;
+    zl2_frame_rec* fr = a.frec + f;
+    const u32 ferr = fr->err;
+    if (ferr == ZL_E_FALLBACK) return;  // the general kernel owns this frame
+    if (ferr || fr->skippable) {
+        if (t == 0) a.results[f] = ferr ? ZL_ERR(ferr) : 0;
+        return;
+    }
+    const zl_frame_desc fd = a.frames[f];
+    const u8* src = a.src + fd.src_off;
+    u8* dst = a.dst + fd.dst_off;
+    const u64 cap = fd.dst_cap;
+    const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
+    const u8* lit_base = a.lit_scratch + a.plan[f].lit_off;
+    const u32* q_ll = a.seq_scratch + a.plan[f].seq_off;
+    const u32* q_ml = q_ll + a.plan[f].seq_cap;
+    const u32* q_off = q_ml + a.plan[f].seq_cap;
+    if (t == 0) S.err = 0;
+    __syncthreads();
+    u64 op = 0;
+    const u32 nblocks = fr->nblocks;
+    for (u32 b = 0; b < nblocks; b++) {
+        const zl2_blk_rec r = br[b];
+        const u8* blk = src + r.src_off;
+        u8* bdst = dst + op;
+        if (r.type != 2) {
+            if (r.size > cap - op) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
+            else if (r.type == 0) { for (u32 i = t; i < r.size; i += EX_THREADS) bdst[i] = blk[i]; }
+            else { const u8 v = blk[0]; for (u32 i = t; i < r.size; i += EX_THREADS) bdst[i] = v; }
+            __syncthreads();
+            if (S.err) break;
+            op += r.size;
+            continue;
+        }
+        const bool lit_rle = r.lit_mode == 1;
+        const u32 rle_byte = r.lit_a & 0xFF;
+        const u8* lit = (r.lit_mode == 0) ? (blk + r.lit_a) : (lit_base + r.lit_dst);
+        const u32 nseq = r.nseq, lit_size = r.lit_size;
+        const u32* sll = q_ll + r.seq_dst;
+        const u32* sml = q_ml + r.seq_dst;
+        const u32* sof = q_off + r.seq_dst;
+        const u64 cap_left = cap - op;
+        u32 lit_pos = 0, out_pos = 0;
+        for (u32 b0 = 0; b0 < nseq; b0 += EX_THREADS) {
+            const u32 nb = (nseq - b0 < EX_THREADS) ? (nseq - b0) : EX_THREADS;
+            u32 ll = 0, ml = 0, off = 1;
+            if (t < nb) { ll = sll[b0 + t]; ml = sml[b0 + t]; off = sof[b0 + t]; }
+            u32 ex_l, ex_o, tot_l, tot_o;
+            exec_scan2(S, ll, ll + ml, ex_l, ex_o, tot_l, tot_o);
+            const u32 batch_start = out_pos, batch_end = out_pos + tot_o;
+            const u32 gbase = batch_start & ~((1u << EX_GRAN_LOG) - 1);
+            if (t < nb) {
+                const u32 my_out = out_pos + ex_o, my_lit = lit_pos + ex_l;
+                S.b_out[t] = my_out;
+                S.b_lit[t] = my_lit;
+                S.b_ll[t] = ll;
+                S.b_off[t] = off;
+                if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
+                if ((u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;    // zstd.c:44045 (no dictionary on this path)
+            }
+            if (t == 0) { S.b_out[nb] = batch_end; S.b_lit[nb] = lit_pos + tot_l; }
+            if (batch_end > ZL_BLOCK_MAX) { if (t == 0) S.err = ZL_E_CORRUPTION; }
+            else if ((u64)batch_end > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
+            __syncthreads();
+            if (S.err) break;
+            // ---- owner table: granule g starts at gbase + 32 g
+            if (t < nb) {
+                const u32 lo = S.b_out[t], hi = S.b_out[t + 1];
+                u32 g = (lo - gbase + (1u << EX_GRAN_LOG) - 1) >> EX_GRAN_LOG;
+                if (t == 0) g = 0;
+                for (; gbase + (g << EX_GRAN_LOG) < hi; g++) S.own[g] = (u16)t;
+            }
+            // ---- pass 1: literal bytes of the batch, aligned dwords of the literal buffer
+            if (tot_l) {
+                const u32 l_end = lit_pos + tot_l;
+                const u32 mis = lit_rle ? 0 : (u32)((uintptr_t)(lit + lit_pos) & 3);
+                const i32 ja = (i32)lit_pos - (i32)mis;
+                for (i32 j0 = ja + 4 * (i32)t; j0 < (i32)l_end; j0 += 4 * EX_THREADS) {
+                    const u32 word = lit_rle ? rle_byte * 0x01010101u : *(const u32*)(lit + j0);
+                    const u32 jf = j0 < (i32)lit_pos ? lit_pos : (u32)j0;
+                    const u32 jl = (u32)(j0 + 4) > l_end ? l_end : (u32)(j0 + 4);
+                    // last sequence whose literal run starts at or before jf
+                    u32 lo = 0, hi = nb;
+                    while (hi - lo > 1) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (S.b_lit[mid] <= jf) lo = mid; else hi = mid;
+                    }
+                    u32 k = lo;
+                    for (u32 j = jf; j < jl; j++) {
+                        while (j >= S.b_lit[k + 1]) k++;
+                        S.out[S.b_out[k] + (j - S.b_lit[k])] = (u8)(word >> (8 * (j - (u32)j0)));
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- pass 2: match bytes, 4-byte words of the LDS image
+            {
+                const u32 w_first = batch_start >> 2, w_end = (batch_end + 3) >> 2;
+                for (u32 w = w_first + t; w < w_end; w += EX_THREADS) {
+                    const u32 ws = w << 2;
+                    const u32 first = ws < batch_start ? batch_start : ws;
+                    const u32 last = ws + 4 > batch_end ? batch_end : ws + 4;
+                    u32 k = owner_of(S, first, gbase);
+                    u32 word = 0, mask = 0;
+                    for (u32 p = first; p < last; p++) {
+                        while (p >= S.b_out[k + 1]) k++;
+                        u32 kk = k, pp = p;
+                        u32 rel = pp - S.b_out[kk], l = S.b_ll[kk];
+                        if (rel < l) continue;  // literal: already placed
+                        u8 v;
+                        for (;;) {
+                            const u32 mstart = S.b_out[kk] + l;
+                            const u32 m = pp - mstart, o = S.b_off[kk];
+                            const i64 q = (m < o) ? (i64)pp - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
+                            if (q < (i64)batch_start) { v = (q >= 0) ? S.out[q] : bdst[q]; break; }
+                            pp = (u32)q;
+                            kk = owner_of(S, pp, gbase);
+                            rel = pp - S.b_out[kk];
+                            l = S.b_ll[kk];
+                            if (rel < l) { v = S.out[pp]; break; }  // a literal of this batch
+                        }
+                        word |= (u32)v << (8 * (p - ws));
+                        mask |= 0xFFu << (8 * (p - ws));
+                    }
+                    if (mask == 0xFFFFFFFFu) *(u32*)(S.out + ws) = word;
+                    else if (mask) {
+                        for (u32 p = first; p < last; p++)
+                            if (mask & (0xFFu << (8 * (p - ws)))) S.out[p] = (u8)(word >> (8 * (p - ws)));
+                    }
+                }
+            }
+            lit_pos += tot_l;
+            out_pos += tot_o;
+            __syncthreads();
+        }
+        if (S.err) break;
+        // trailing literals (zstd.c:44693-44700)
+        const u32 rest = lit_size - lit_pos;
+        if (lit_pos > lit_size || out_pos + rest > ZL_BLOCK_MAX) { if (t == 0) S.err = ZL_E_CORRUPTION; }
+        else if ((u64)out_pos + rest > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
+        __syncthreads();
+        if (S.err) break;
+        for (u32 i = t; i < rest; i += EX_THREADS) S.out[out_pos + i] = lit_rle ? (u8)rle_byte : lit[lit_pos + i];
+        __syncthreads();
+        const u32 produced = out_pos + rest;
+        // ---- flush the LDS image: 16-byte stores where the destination allows
+        {
+            const u32 head = (u32)((16 - ((uintptr_t)bdst & 15)) & 15);
+            const u32 h = head < produced ? head : produced;
+            if (t < h) bdst[t] = S.out[t];
+            const u32 body = (produced - h) >> 4;
+            for (u32 i = t; i < body; i += EX_THREADS) {
+                const u32 o = h + (i << 4);
+                uint4 v;
+                if ((h & 3) == 0) {
+                    const u32* s4 = (const u32*)(S.out + o);
+                    v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+                } else {
+                    u32 x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        x[j] = (u32)S.out[o + 4 * j] | ((u32)S.out[o + 4 * j + 1] << 8) | ((u32)S.out[o + 4 * j + 2] << 16) | ((u32)S.out[o + 4 * j + 3] << 24);
+                    v = make_uint4(x[0], x[1], x[2], x[3]);
+                }
+                *(uint4*)(bdst + o) = v;
+            }
+            const u32 tail0 = h + (body << 4);
+            if (tail0 + t < produced) bdst[tail0 + t] = S.out[tail0 + t];
+        }
+        __syncthreads();
+        op += produced;
+    }
+    __syncthreads();
+    if (!S.err) {
+        if (t == 0 && fr->fcs != ZL_CONTENTSIZE_UNKNOWN && fr->fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
+        __syncthreads();
+        if (!S.err && fr->has_checksum && !a.ignore_checksum) {
+            const u32 got = zl_xxh64_low32(S.out, S.xxh_acc, S.bcast, dst, op);
+            if (t == 0 && got != zl_rd_le(src + fr->end_pos, 4)) S.err = ZL_E_CHECKSUM_WRONG;     // zstd.c:41655
+        }
+        __syncthreads();
+    }
+    if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : op;
+}
+
+// ---------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------
+extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream) {
+    if (a->nframes == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)zl2_exec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ExecShared));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const u32 n = a->nframes;
+    hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_lit_kernel, dim3((n + LIT_FRAMES - 1) / LIT_FRAMES), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_seq_kernel, dim3((n + SEQ_FRAMES - 1) / SEQ_FRAMES), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), sizeof(ExecShared), stream, *a);
+    return hipGetLastError();
+}

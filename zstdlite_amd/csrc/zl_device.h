@@ -57,7 +57,128 @@ __device__ __forceinline__ i32 zl_bwd_init(const u8* p, u32 len) {
 }
 
 // ---------------------------------------------------------------------------------------
-// XXH64 (zstd.c:11524-11800); 256-thread workgroups only.
+// Register-buffered backward bit reader for the serial entropy chains.  The stream is viewed as
+// aligned 64-bit words; a 128-bit window (hi:lo) plus two prefetched words travel down the
+// stream, so the global-memory latency of a refill is paid two words (128+ stream bits) before
+// the data is needed instead of on every field.  Reads must be issued at non-increasing bit
+// positions (which is how a backward zstd stream is consumed).  Positions below zero and the
+// rare case of a field straddling the start of the stream fall back to zl_bits_bwd.
+// The word holding the last stream byte may extend up to 7 bytes past it: source buffers must
+// be readable up to the next 8-byte boundary (device allocations always are).
+// ---------------------------------------------------------------------------------------
+struct zl_bwd_reader {
+    const u64* w;   // aligned word 0 contains stream byte 0
+    const u8* p;    // stream start (for the slow path)
+    u32 len;
+    u32 bitofs;     // bit index of stream bit 0 inside word 0
+    i32 k;          // lo = w[k], hi = w[k+1]
+    u64 hi, lo, p1, p2;
+};
+
+__device__ __forceinline__ void zl_bwd_open(zl_bwd_reader& r, const u8* p, u32 len, i32 top_bits) {
+    const uintptr_t a = (uintptr_t)p;
+    r.w = (const u64*)(a & ~(uintptr_t)7);
+    r.p = p;
+    r.len = len;
+    r.bitofs = (u32)(a & 7) * 8;
+    const i32 top = (i32)r.bitofs + (top_bits > 0 ? top_bits - 1 : 0);  // highest bit that will be read
+    const i32 kt = top >> 6;
+    r.k = kt > 0 ? kt - 1 : 0;
+    r.lo = r.w[r.k];
+    r.hi = kt > 0 ? r.w[r.k + 1] : 0;
+    r.p1 = r.k >= 1 ? r.w[r.k - 1] : 0;
+    r.p2 = r.k >= 2 ? r.w[r.k - 2] : 0;
+}
+
+// n <= 32 bits whose lowest bit is stream bit `pos`
+__device__ __forceinline__ u32 zl_bwd_read(zl_bwd_reader& r, i32 pos, u32 n) {
+    if (n == 0) return 0;
+    if (pos < 0) return zl_bits_bwd(r.p, r.len, pos, n);
+    const i32 a = (i32)r.bitofs + pos;
+    while ((a >> 6) < r.k) {
+        r.hi = r.lo;
+        r.lo = r.p1;
+        r.p1 = r.p2;
+        r.k--;
+        r.p2 = r.k >= 2 ? r.w[r.k - 2] : 0;
+    }
+    const u32 sh = (u32)(a - (r.k << 6));
+    u64 v;
+    if (sh < 64) v = (r.lo >> sh) | (sh ? (r.hi << (64 - sh)) : 0);
+    else v = r.hi >> (sh - 64);
+    return (u32)v & (u32)((1ull << n) - 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Left-aligned accumulator over a backward stream, refilled 32 bits at a time from aligned
+// dwords: the next unread stream bit is always the top bit of `acc`, so a peek is one shift of
+// the high dword and a consume is one 64-bit shift -- no per-field address arithmetic and no
+// branches in the hot loops that use it.  `pos` keeps the exact count of unread payload bits
+// so callers can finish a stream with the generic reader and check that it ends on bit 0.
+// Bits "below" the stream start (garbage from the enclosing dword, or zeros once idx < 0) can
+// be peeked but a valid stream never consumes them; consuming them drives pos negative, which
+// every caller treats as corruption.
+// ---------------------------------------------------------------------------------------
+struct zl_lreader {
+    const u32* w;  // aligned dword 0 contains stream byte 0
+    u64 acc;
+    i32 nav;       // valid bits in acc
+    i32 idx;       // next dword to refill from (refills below 0 supply zeros)
+    i32 pos;       // unread payload bits
+};
+
+// requires top_bits >= 64
+__device__ __forceinline__ void zl_lr_open(zl_lreader& r, const u8* p, u32 len, i32 top_bits) {
+    const u32 mis = (u32)((uintptr_t)p & 3);
+    r.w = (const u32*)(p - mis);  // pointer arithmetic (not an integer round trip) keeps the global address space
+    const u32 a_top = mis * 8 + (u32)top_bits;
+    const u32 nav0 = 32 + (a_top & 31);
+    const u64 top64 = ((u64)zl_bits_bwd(p, len, top_bits - 32, 32) << 32) | zl_bits_bwd(p, len, top_bits - 64, 32);
+    r.acc = top64 & ~((1ull << (64 - nav0)) - 1);
+    r.nav = (i32)nav0;
+    r.idx = (i32)(a_top >> 5) - 2;
+    r.pos = top_bits;
+}
+__device__ __forceinline__ u32 zl_lr_peek(const zl_lreader& r, u32 n) {  // 1 <= n <= 32, needs nav >= n
+    return (u32)(r.acc >> 32) >> (32 - n);
+}
+__device__ __forceinline__ void zl_lr_skip(zl_lreader& r, u32 n) {
+    r.acc <<= n;
+    r.nav -= (i32)n;
+    r.pos -= (i32)n;
+}
+__device__ __forceinline__ u32 zl_lr_take(zl_lreader& r, u32 n) {  // 0 <= n <= 32
+    const u32 v = n ? zl_lr_peek(r, n) : 0;
+    zl_lr_skip(r, n);
+    return v;
+}
+__device__ __forceinline__ void zl_lr_refill(zl_lreader& r) {  // call when nav <= 32
+    const u32 wv = r.idx >= 0 ? r.w[r.idx] : 0;
+    r.acc |= (u64)wv << (32 - r.nav);
+    r.nav += 32;
+    r.idx--;
+}
+
+// up to 64 bits whose lowest bit is stream bit `pos` (pos >= 0)
+__device__ __forceinline__ u64 zl_bwd_read64(zl_bwd_reader& r, i32 pos, u32 n) {
+    if (n == 0) return 0;
+    const i32 a = (i32)r.bitofs + pos;
+    while ((a >> 6) < r.k) {
+        r.hi = r.lo;
+        r.lo = r.p1;
+        r.p1 = r.p2;
+        r.k--;
+        r.p2 = r.k >= 2 ? r.w[r.k - 2] : 0;
+    }
+    const u32 sh = (u32)(a - (r.k << 6));
+    u64 v;
+    if (sh < 64) v = (r.lo >> sh) | (sh ? (r.hi << (64 - sh)) : 0);
+    else v = r.hi >> (sh - 64);
+    return n >= 64 ? v : (v & ((1ull << n) - 1));
+}
+
+// ---------------------------------------------------------------------------------------
+// XXH64 (zstd.c:11524-11800); any workgroup size >= 4.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 zl_xxh_round(u64 acc, u64 in) {
     acc += in * 0xC2B2AE3D27D4EB4FULL;
@@ -78,7 +199,7 @@ __device__ inline u32 zl_xxh64_low32(u8* tile /* 8 KiB LDS */, u64* acc4 /* LDS 
     for (u64 s0 = 0; s0 < stripes; s0 += 256) {
         const u32 ns = (u32)((stripes - s0 < 256) ? (stripes - s0) : 256);
         const u8* base = data + s0 * 32;
-        for (u32 i = t; i < ns * 32; i += 256) tile[i] = base[i];
+        for (u32 i = t; i < ns * 32; i += blockDim.x) tile[i] = base[i];
         __syncthreads();
         if (t < 4) {
             u64 acc = acc4[t];

@@ -8,6 +8,35 @@
 #define ZL_LIT_STRIDE (ZL_BLOCK_MAX + 256)
 #define ZL_SEQ_CAP 43776  // >= ZL_MAX_SEQ_PER_BLOCK, multiple of 64
 
+// ---- lane-parallel pipeline for frames of at most one block size (zl_decode2.hip) ----------
+#define ZL2_MAXB 4          // blocks per frame handled there; more -> general kernel
+#define ZL_E_FALLBACK 118   // internal: "route this frame to the general kernel", never returned to callers
+
+struct zl2_frame_plan {     // per frame, computed on the host from the frame table
+    u64 lit_off;            // byte offset of the frame's literal scratch
+    u64 seq_off;            // u32 offset of the frame's sequence scratch (3 arrays of seq_cap)
+    u32 lit_cap;            // bytes
+    u32 seq_cap;            // sequences
+    u32 route;              // 1 = lane-parallel pipeline, 0 = general kernel
+    u32 pad;
+};
+struct zl2_blk_rec {        // per (frame, block), written by zl2_index_kernel
+    u32 type, size, src_off;
+    u32 lit_mode;           // 0 raw bytes inside the block, 1 RLE, 2 Huffman with table, 3 Huffman reusing the table
+    u32 lit_size;
+    u32 lit_a;              // raw: offset of the bytes; RLE: the byte; Huffman: header size
+    u32 lit_b;              // Huffman: compressed size (tree description + streams)
+    u32 seq_off, seq_len;   // sequences section after the sequence-count field
+    u32 lit_dst, seq_dst;   // where this block's Huffman literals / sequences go in the frame's scratch
+    u32 nseq, streams;
+    u32 pad[3];
+};
+struct zl2_frame_rec {
+    u32 err, nblocks, has_checksum, skippable;
+    u64 fcs;
+    u32 end_pos, pad;
+};
+
 struct zl_decode_args {
     const zl_frame_desc* frames;
     u32 nframes;
@@ -22,6 +51,9 @@ struct zl_decode_args {
     u32 dict_id;
     const void* dict_tables;  // zl_dict_tables* or null
     u32 ignore_checksum;
+    const zl2_frame_plan* plan;  // optional: with frec, only frames routed to this kernel are decoded
+    const zl2_frame_rec* frec;
+    u64* stats;  // optional (profiling): per-phase shader cycles summed over blocks, see zl_decode.hip
 };
 
 // digested dictionary entropy (zstd.c:42053 ZSTD_loadDEntropy), produced by
@@ -34,6 +66,21 @@ struct zl_dict_tables {
     u32 content_off;  // first content byte inside the dictionary buffer
     u32 status;       // 0 ok, else error code
 };
+
+struct zl2_args {
+    const zl_frame_desc* frames;
+    const zl2_frame_plan* plan;
+    zl2_frame_rec* frec;
+    zl2_blk_rec* brec;
+    u32 nframes;
+    const u8* src;
+    u8* dst;
+    u64* results;
+    u8* lit_scratch;
+    u32* seq_scratch;
+    u32 ignore_checksum;
+};
+extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream);
 
 extern "C" hipError_t zl_launch_decode(const zl_decode_args* a, u32 nslots, hipStream_t stream);
 extern "C" hipError_t zl_launch_digest_dict(const u8* d_dict, u32 n, void* d_tables, hipStream_t stream);
