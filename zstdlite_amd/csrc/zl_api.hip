@@ -138,7 +138,7 @@ struct zl_dctx_s {
     bool ev_valid = false;
     double kernel_ms = 0;
     DevBuf d_stats;
-    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 extern "C" {
@@ -296,10 +296,11 @@ size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
     return 0;
 }
 
-// not part of the public header: decode-kernel phase cycle sums {H, B, A, A||B wall, C, blocks, sequences, huffman literals}
-size_t zl_dctx_phase_stats(const zl_dctx* d, unsigned long long* out8) {
-    if (!d || !out8 || !d->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
-    for (int i = 0; i < 8; i++) out8[i] = d->stats[i];
+// not part of the public header: phase cycle sums.  [0..7] general kernel {H, B, A, A||B wall, C, blocks,
+// sequences, huffman literals}; [8..13] lane-parallel exec kernel {scan, literals, matches, flush, batches, blocks}
+size_t zl_dctx_phase_stats(const zl_dctx* d, unsigned long long* out16) {
+    if (!d || !out16 || !d->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int i = 0; i < 16; i++) out16[i] = d->stats[i];
     return 0;
 }
 
@@ -381,7 +382,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         p.lit_off = lit_total;
         p.seq_off = seq_total;
         p.lit_cap = fast ? (u32)((tbl[i].dst_cap + 3 + 4 * ZL2_MAXB) & ~(u64)3) : 0;
-        p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2) : 0;
+        p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2 + ZL2_MAXB) : 0;  // + one totals sentinel per block
         lit_total += (p.lit_cap + 15) & ~15u;
         seq_total += (u64)3 * p.seq_cap;
         if (!fast) nslow++;
@@ -414,6 +415,11 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.lit_scratch = (u8*)d->d_lit2.p;
     f2.seq_scratch = (u32*)d->d_seq2.p;
     f2.ignore_checksum = (u32)d->ignore_checksum;
+    f2.stats = nullptr;
+    if (d->profile && d->d_stats.ensure(128)) {
+        (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
+        f2.stats = (u64*)d->d_stats.p + 8;
+    }
     if (zl2_launch(&f2, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     zl_decode_args a;
     a.frames = f2.frames;
@@ -436,11 +442,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     a.ignore_checksum = (u32)d->ignore_checksum;
     a.plan = f2.plan;
     a.frec = f2.frec;
-    a.stats = nullptr;
-    if (d->profile && d->d_stats.ensure(64)) {
-        (void)hipMemsetAsync(d->d_stats.p, 0, 64, st);
-        a.stats = (u64*)d->d_stats.p;
-    }
+    a.stats = (d->profile && d->d_stats.p) ? (u64*)d->d_stats.p : nullptr;
     if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (d->profile) { (void)hipEventRecord(d->ev[1], st); d->ev_valid = true; }
     return 0;
@@ -476,7 +478,7 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
         d->kernel_ms = ms;
-        if (d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 64, hipMemcpyDeviceToHost);
+        if (d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
     const u64* r = (const u64*)d->h_results.p;
     size_t total = 0, first_err = 0;

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
             }
             if (nseq == 0 && sh != sn) { fr->err = ZL_E_CORRUPTION; return; }
             r.nseq = nseq; r.seq_off = lsec + sh; r.seq_len = sn - sh;
-            seq_total += nseq;
+            seq_total += nseq + 1;  // + the totals sentinel zl2_seq_kernel appends
         } else {
             if ((u64)bsize > fd.dst_cap) { fr->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
         }
@@ -412,10 +412,9 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
     return pos == 0;  // zstd.c:38640 BIT_endOfDStream
 }
 
-__global__ __launch_bounds__(64) void zl2_lit_kernel(zl2_args a) {
-    __shared__ LitGroup G[LIT_FRAMES];
+__device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg) {
     const u32 lane = threadIdx.x, grp = lane >> 2, sub = lane & 3;
-    const u32 f = blockIdx.x * LIT_FRAMES + grp;
+    const u32 f = wg * LIT_FRAMES + grp;
     const bool live = f < a.nframes;
     LitGroup& g = G[grp];
     if (sub == 0) g.ok = 0;
@@ -553,13 +552,12 @@ __device__ __forceinline__ u32 read_seq_table2(SeqLane& L, int kind, int mode, c
     return have_prev ? 0 : 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
-    __shared__ SeqShared S;
+__device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg) {
     const u32 lane = threadIdx.x;
     if (lane < 36) S.ll_tab[lane] = k_LL_base[lane] | ((u32)k_LL_bits[lane] << 24);
     if (lane < 53) S.ml_tab[lane] = k_ML_base[lane] | ((u32)k_ML_bits[lane] << 24);
     __syncthreads();
-    const u32 f = blockIdx.x * SEQ_FRAMES + lane;
+    const u32 f = wg * SEQ_FRAMES + lane;
     if (lane >= SEQ_FRAMES || f >= a.nframes) return;
     zl2_frame_rec* fr = a.frec + f;
     if (fr->err || fr->skippable) return;
@@ -601,7 +599,7 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
         u32* oml = q_ml + r.seq_dst;
         u32* oof = q_off + r.seq_dst;
         const u32 nseq = r.nseq;
-        u32 lit_used = 0;
+        u32 lit_used = 0, out_used = 0;  // running literal / output positions: what the exec kernel consumes
         u32 i = 0;
         u32 sl, so, sm;
         bool fast = bp >= 128;
@@ -667,7 +665,10 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
                 r1 = sh1 ? r0 : r1;
                 r0 = off;
                 bad |= (off == 0) ? 1u : 0u;
+                const u32 lit_here = lit_used, out_here = out_used;
                 lit_used += ll;
+                out_used += ll + ml;
+                bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
                 if (i + 1 < nseq) {
                     const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
                     ZL_TAKE(u, bl + bm + bo);  // LL bits on top, then ML, then OF
@@ -677,8 +678,8 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
                 }
                 idx -= (i32)used;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t4) : "v"(w + idx - 3) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oll + i), "v"(ll) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oml + i), "v"(ml) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oll + i), "v"(lit_here) : "memory");
+                asm volatile("global_store_dword %0, %1, off" : : "v"(oml + i), "v"(out_here) : "memory");
                 asm volatile("global_store_dword %0, %1, off" : : "v"(oof + i), "v"(off) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(t4) : : "memory");
@@ -724,8 +725,10 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
                     r0 = off;
                 }
             }
-            oll[i] = ll; oml[i] = ml; oof[i] = off;
+            oll[i] = lit_used; oml[i] = out_used; oof[i] = off;
             lit_used += ll;
+            out_used += ll + ml;
+            if (out_used > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
             if (i + 1 < nseq) {
                 u32 nb = cl >> 10;
                 bp -= (i32)nb;
@@ -741,7 +744,24 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
         }
         if (bp != 0) { fr->err = ZL_E_CORRUPTION; return; }  // zstd.c:44690
         if (lit_used > r.lit_size) { fr->err = ZL_E_CORRUPTION; return; }
+        oll[nseq] = lit_used;  // sentinel: totals of the block
+        oml[nseq] = out_used;
+        oof[nseq] = 1;
     }
+}
+
+// Literal lanes and sequence lanes are independent and each under-fills the chip (512 waves per
+// GiB), so both run in ONE launch: even workgroups decode literals, odd ones sequences.
+static_assert(LIT_FRAMES == SEQ_FRAMES, "the fused launch pairs one literal and one sequence workgroup per 16 frames");
+union EntropyShared {
+    LitGroup G[LIT_FRAMES];
+    SeqShared S;
+};
+__global__ __launch_bounds__(64) void zl2_entropy_kernel(zl2_args a) {
+    __shared__ EntropyShared U;
+    const u32 wg = blockIdx.x >> 1;
+    if (blockIdx.x & 1) seq_role(a, U.S, wg);
+    else lit_role(a, U.G, wg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -756,6 +776,7 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
 // ---------------------------------------------------------------------------------------
 #define EX_THREADS 1024
 #define EX_GRAN_LOG 5
+#define EX_SPAN 4096u  // target output bytes per batch: one 4-byte word per thread, short in-batch chains
 struct ExecShared {
     u8 out[ZL_BLOCK_MAX];
     u32 b_out[EX_THREADS + 1];
@@ -847,28 +868,43 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         const u32* sof = q_off + r.seq_dst;
         const u64 cap_left = cap - op;
         u32 lit_pos = 0, out_pos = 0;
-        for (u32 b0 = 0; b0 < nseq; b0 += EX_THREADS) {
-            const u32 nb = (nseq - b0 < EX_THREADS) ? (nseq - b0) : EX_THREADS;
-            u32 ll = 0, ml = 0, off = 1;
-            if (t < nb) { ll = sll[b0 + t]; ml = sml[b0 + t]; off = sof[b0 + t]; }
-            u32 ex_l, ex_o, tot_l, tot_o;
-            exec_scan2(S, ll, ll + ml, ex_l, ex_o, tot_l, tot_o);
-            const u32 batch_start = out_pos, batch_end = out_pos + tot_o;
+        u64 c_scan = 0, c_lit = 0, c_match = 0, c_batches = 0;
+        const bool prof = a.stats != nullptr && t == 0;
+        // zl2_seq_kernel left running positions, not lengths: sll[i] = literals before sequence i,
+        // sml[i] = output bytes before it (entry nseq holds the totals), so a batch needs no scan.
+        // A batch is as many sequences as cover about EX_SPAN output bytes (at most EX_THREADS).
+        for (u32 b0 = 0; b0 < nseq;) {
+            const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            const u32 window = (nseq - b0 < EX_THREADS) ? (nseq - b0) : EX_THREADS;
+            if (t == 0) S.bcast[1] = 1;
+            if (t <= window) {  // one extra entry: the next sequence (or the sentinel)
+                const u32 o = sml[b0 + t], l = sll[b0 + t];
+                S.b_out[t] = o;
+                S.b_lit[t] = l;
+                if (t < window) S.b_off[t] = sof[b0 + t];
+            }
+            __syncthreads();
+            const u32 batch_start = out_pos;
+            if (t < window && t > 0 && S.b_out[t] < batch_start + EX_SPAN) atomicMax(&S.bcast[1], t + 1);
+            __syncthreads();
+            const u32 nb = S.bcast[1];
+            const u32 batch_end = S.b_out[nb];
+            const u32 tot_l = S.b_lit[nb] - lit_pos, tot_o = batch_end - batch_start;
             const u32 gbase = batch_start & ~((1u << EX_GRAN_LOG) - 1);
             if (t < nb) {
-                const u32 my_out = out_pos + ex_o, my_lit = lit_pos + ex_l;
-                S.b_out[t] = my_out;
-                S.b_lit[t] = my_lit;
+                const u32 my_out = S.b_out[t], my_lit = S.b_lit[t];
+                const u32 ll = S.b_lit[t + 1] - my_lit;
+                const u32 off = S.b_off[t];
                 S.b_ll[t] = ll;
-                S.b_off[t] = off;
+                if (S.b_out[t + 1] < my_out + ll || S.b_lit[t + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions must not decrease
                 if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
                 if ((u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;    // zstd.c:44045 (no dictionary on this path)
             }
-            if (t == 0) { S.b_out[nb] = batch_end; S.b_lit[nb] = lit_pos + tot_l; }
-            if (batch_end > ZL_BLOCK_MAX) { if (t == 0) S.err = ZL_E_CORRUPTION; }
+            if (batch_end > ZL_BLOCK_MAX || batch_end < batch_start) { if (t == 0) S.err = ZL_E_CORRUPTION; }
             else if ((u64)batch_end > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
             __syncthreads();
             if (S.err) break;
+            const u64 st1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- owner table: granule g starts at gbase + 32 g
             if (t < nb) {
                 const u32 lo = S.b_out[t], hi = S.b_out[t + 1];
@@ -899,47 +935,70 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                 }
             }
             __syncthreads();
-            // ---- pass 2: match bytes, 4-byte words of the LDS image
+            const u64 st2 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            // ---- pass 2: match bytes, 4-byte words of the LDS image.  The four bytes of a word are
+            // chased together, one hop per round for every byte still unresolved, so their LDS
+            // latencies overlap instead of adding up.
             {
                 const u32 w_first = batch_start >> 2, w_end = (batch_end + 3) >> 2;
                 for (u32 w = w_first + t; w < w_end; w += EX_THREADS) {
                     const u32 ws = w << 2;
-                    const u32 first = ws < batch_start ? batch_start : ws;
-                    const u32 last = ws + 4 > batch_end ? batch_end : ws + 4;
-                    u32 k = owner_of(S, first, gbase);
-                    u32 word = 0, mask = 0;
-                    for (u32 p = first; p < last; p++) {
-                        while (p >= S.b_out[k + 1]) k++;
-                        u32 kk = k, pp = p;
-                        u32 rel = pp - S.b_out[kk], l = S.b_ll[kk];
-                        if (rel < l) continue;  // literal: already placed
-                        u8 v;
-                        for (;;) {
-                            const u32 mstart = S.b_out[kk] + l;
-                            const u32 m = pp - mstart, o = S.b_off[kk];
-                            const i64 q = (m < o) ? (i64)pp - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
-                            if (q < (i64)batch_start) { v = (q >= 0) ? S.out[q] : bdst[q]; break; }
-                            pp = (u32)q;
-                            kk = owner_of(S, pp, gbase);
-                            rel = pp - S.b_out[kk];
-                            l = S.b_ll[kk];
-                            if (rel < l) { v = S.out[pp]; break; }  // a literal of this batch
+                    u32 pp[4], kk[4], val[4];
+                    u32 pending = 0, mask = 0;
+                    u32 k = owner_of(S, ws < batch_start ? batch_start : ws, gbase);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const u32 p = ws + j;
+                        pp[j] = p; kk[j] = k; val[j] = 0;
+                        if (p >= batch_start && p < batch_end) {
+                            while (p >= S.b_out[k + 1]) k++;
+                            kk[j] = k;
+                            if (p - S.b_out[k] >= S.b_ll[k]) { pending |= 1u << j; mask |= 0xFFu << (8 * j); }
                         }
-                        word |= (u32)v << (8 * (p - ws));
-                        mask |= 0xFFu << (8 * (p - ws));
                     }
+                    while (pending) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (pending & (1u << j)) {
+                                const u32 kj = kk[j], pj = pp[j];
+                                const u32 mstart = S.b_out[kj] + S.b_ll[kj];
+                                const u32 m = pj - mstart, o = S.b_off[kj];
+                                const i64 q = (m < o) ? (i64)pj - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
+                                if (q < (i64)batch_start) {
+                                    val[j] = (q >= 0) ? S.out[q] : bdst[q];
+                                    pending &= ~(1u << j);
+                                } else {
+                                    const u32 qq = (u32)q;
+                                    const u32 k2 = owner_of(S, qq, gbase);
+                                    pp[j] = qq; kk[j] = k2;
+                                    if (qq - S.b_out[k2] < S.b_ll[k2]) {  // a literal of this batch, already in place
+                                        val[j] = S.out[qq];
+                                        pending &= ~(1u << j);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    const u32 word = val[0] | (val[1] << 8) | (val[2] << 16) | (val[3] << 24);
                     if (mask == 0xFFFFFFFFu) *(u32*)(S.out + ws) = word;
                     else if (mask) {
-                        for (u32 p = first; p < last; p++)
-                            if (mask & (0xFFu << (8 * (p - ws)))) S.out[p] = (u8)(word >> (8 * (p - ws)));
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (mask & (0xFFu << (8 * j))) S.out[ws + j] = (u8)val[j];
                     }
                 }
             }
             lit_pos += tot_l;
             out_pos += tot_o;
+            b0 += nb;
             __syncthreads();
+            if (prof) {
+                const u64 st3 = __builtin_amdgcn_s_memtime();
+                c_scan += st1 - st0; c_lit += st2 - st1; c_match += st3 - st2; c_batches++;
+            }
         }
         if (S.err) break;
+        const u64 st4 = prof ? __builtin_amdgcn_s_memtime() : 0;
         // trailing literals (zstd.c:44693-44700)
         const u32 rest = lit_size - lit_pos;
         if (lit_pos > lit_size || out_pos + rest > ZL_BLOCK_MAX) { if (t == 0) S.err = ZL_E_CORRUPTION; }
@@ -974,6 +1033,15 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
             if (tail0 + t < produced) bdst[tail0 + t] = S.out[tail0 + t];
         }
         __syncthreads();
+        if (prof) {
+            const u64 st5 = __builtin_amdgcn_s_memtime();
+            atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_scan);
+            atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)c_lit);
+            atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)c_match);
+            atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)(st5 - st4));
+            atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)c_batches);
+            atomicAdd((unsigned long long*)&a.stats[5], 1ull);
+        }
         op += produced;
     }
     __syncthreads();
@@ -1002,8 +1070,7 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream) {
     }
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(zl2_lit_kernel, dim3((n + LIT_FRAMES - 1) / LIT_FRAMES), dim3(64), 0, stream, *a);
-    hipLaunchKernelGGL(zl2_seq_kernel, dim3((n + SEQ_FRAMES - 1) / SEQ_FRAMES), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ((n + LIT_FRAMES - 1) / LIT_FRAMES)), dim3(64), 0, stream, *a);
     hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), sizeof(ExecShared), stream, *a);
     return hipGetLastError();
 }

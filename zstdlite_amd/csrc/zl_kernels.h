@@ -79,6 +79,7 @@ struct zl2_args {
     u8* lit_scratch;
     u32* seq_scratch;
     u32 ignore_checksum;
+    u64* stats;  // optional (profiling): exec-kernel phase cycles {scan, literals, matches, flush, batches, blocks}
 };
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream);
 
