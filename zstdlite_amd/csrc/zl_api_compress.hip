@@ -32,6 +32,8 @@ struct zl_cctx_s {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     double kernel_ms[4] = {0, 0, 0, 0};
+    DevBuf d_stats;
+    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -71,6 +73,11 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.meta = (zl_chunk_meta*)c->d_meta.p;
         m.lit_stride = ZL_LIT_STRIDE_ENC;
         m.seq_stride = ZL_SEQ_STRIDE;
+        m.stats = nullptr;
+        if (prof && c->d_stats.ensure(64)) {
+            (void)hipMemsetAsync(c->d_stats.p, 0, 64, st);
+            m.stats = (u64*)c->d_stats.p;
+        }
         if (prof) (void)hipEventRecord(c->ev[0], st);
         if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (prof) (void)hipEventRecord(c->ev[1], st);
@@ -140,7 +147,7 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
-    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals};
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
@@ -213,6 +220,7 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
             (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
             c->kernel_ms[k] = ms;
         }
+        if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 64, hipMemcpyDeviceToHost);
     }
     if (frame_sizes) {
         const u32* fs = (const u32*)c->h_fsize.p;
@@ -224,6 +232,13 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
 size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
     if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     for (int k = 0; k < 4; k++) ms[k] = c->kernel_ms[k];
+    return 0;
+}
+
+// not part of the public header: match-kernel phase cycle sums {find, parse, emit, insert, iterations}
+size_t zl_cctx_phase_stats(const zl_cctx* c, unsigned long long* out8) {
+    if (!c || !out8 || !c->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int i = 0; i < 8; i++) out8[i] = c->stats[i];
     return 0;
 }
 

@@ -37,6 +37,7 @@ struct zl_match_args {
     zl_chunk_meta* meta;
     u32 lit_stride;
     u32 seq_stride;
+    u64* stats;  // optional (profiling): cycles {find, parse, emit, insert, iterations}
 };
 
 struct zl_entropy_args {

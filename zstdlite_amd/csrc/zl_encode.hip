@@ -33,7 +33,9 @@
 #include "zl_format.h"
 
 #define ENC_THREADS 256
-#define WIN 256            // positions examined per iteration
+#define PPT 1              // positions per thread and iteration (2 was measured: same speed, 0.8 % worse ratio)
+#define WIN (ENC_THREADS * PPT)  // positions examined per iteration
+#define WIN_LOG (PPT == 1 ? 8 : 9)
 #define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
 #define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
 #define LANE_MATCH_CAP 40  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
@@ -50,6 +52,11 @@ __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
     const u64 x = a ^ b;
     return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// wait for every literal / sequence store of the emit phase at each of the ~14 barriers of an
+// iteration; nothing in this kernel hands global data from one thread to another.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct MatchShared {
     u32 tbl_long[1 << LONG_LOG];
@@ -86,6 +93,30 @@ __device__ __forceinline__ void block_scan2(u32* sa, u32* sb, u32 a, u32 b, u32&
     __syncthreads();
 }
 
+__device__ __forceinline__ void match_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if ((int)lane >= d) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
+    lds_barrier();
+    u32 pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (u32 w = 0; w < 4; w++) {
+        const u32 xa = sa[w], xb = sb[w];
+        if (w < wave) { pa += xa; pb += xb; }
+        ta += xa; tb += xb;
+    }
+    ex_a = pa + ia - a;
+    ex_b = pb + ib - b;
+    tot_a = ta;
+    tot_b = tb;
+    lds_barrier();
+}
+
 // ---------------------------------------------------------------------------------------
 // E1: match finding.  chunk c covers src[c*chunk_size, +len); output per chunk:
 //   lits[c*lit_stride ...]   literal bytes in order
@@ -105,102 +136,180 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
     for (u32 i = t; i < (1u << LONG_LOG); i += ENC_THREADS) S.tbl_long[i] = 0;
     for (u32 i = t; i < (1u << SHORT_LOG); i += ENC_THREADS) S.tbl_short[i] = 0;
     if (t == 0) { S.carry = 0; S.rep = 0; }
-    __syncthreads();
+    lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
+    const bool prof = a.stats != nullptr && t == 0;
+    u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
+    // every thread owns two positions of the window: t and t + 256
     for (u32 ip = 0; ip < n; ip += WIN) {
-        const u32 p = ip + t;
-        const bool in_range = p < n;
-        const bool can_match = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
-        u64 v = 0;
-        if (can_match) v = ld64(src + p);
-        else if (in_range) v = src[p];
-        u32 hl = 0, hs = 0, best_len = 0, best_off = 0;
+        const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
         const u32 carry = S.carry, rep = S.rep;
-        if (can_match) {
-            hl = hash8(v);
-            hs = hash5(v);
-            const u32 cl = S.tbl_long[hl], cs = S.tbl_short[hs];
-            if (carry < WIN) {  // otherwise the whole window lies inside an earlier match
-                u32 q_best = 0;
-                if (rep && p >= rep) {
-                    const u32 l = common_bytes(v, ld64(src + p - rep));
-                    if (l >= MIN_MATCH) { best_len = l; best_off = rep; q_best = p - rep; }
+        u64 v[PPT];
+        u32 hl[PPT], hs[PPT], best_len[PPT], best_off[PPT], q_best[PPT];
+        bool in_range[PPT], can_match[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 p = ip + t + ENC_THREADS * j;
+            in_range[j] = p < n;
+            can_match[j] = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
+            v[j] = 0;
+            if (can_match[j]) v[j] = ld64(src + p);
+            else if (in_range[j]) v[j] = src[p];
+            hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
+        }
+        const bool search = carry < WIN;  // otherwise the whole window lies inside an earlier match
+        // candidates of both positions are fetched together: one memory round trip.  A lane without
+        // a candidate reads its own position and is masked out afterwards.
+        u64 w_r[PPT], w_l[PPT], w_s[PPT];
+        u32 q_r[PPT], q_l[PPT], q_s[PPT];
+        bool have_r[PPT], have_l[PPT], have_s[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 p = ip + t + ENC_THREADS * j;
+            have_r[j] = have_l[j] = have_s[j] = false;
+            q_r[j] = q_l[j] = q_s[j] = p;
+            if (can_match[j]) {
+                hl[j] = hash8(v[j]);
+                hs[j] = hash5(v[j]);
+                if (search) {
+                    const u32 cl = S.tbl_long[hl[j]], cs = S.tbl_short[hs[j]];
+                    have_r[j] = rep && p >= rep;
+                    have_l[j] = cl != 0;
+                    have_s[j] = cs != 0;
+                    if (have_r[j]) q_r[j] = p - rep;
+                    if (have_l[j]) q_l[j] = cl - 1;
+                    if (have_s[j]) q_s[j] = cs - 1;
                 }
-                if (cl) {
-                    const u32 q = cl - 1;
-                    const u32 l = common_bytes(v, ld64(src + q));
-                    if (l >= MIN_MATCH + 1 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
-                }
-                if (cs && best_len < 8) {
-                    const u32 q = cs - 1;
-                    const u32 l = common_bytes(v, ld64(src + q));
-                    if (l >= MIN_MATCH + 1 && l > best_len) { best_len = l; best_off = p - q; q_best = q; }
-                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            if (can_match[j] && search) { w_r[j] = ld64(src + q_r[j]); w_l[j] = ld64(src + q_l[j]); w_s[j] = ld64(src + q_s[j]); }
+            else { w_r[j] = w_l[j] = w_s[j] = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 p = ip + t + ENC_THREADS * j;
+            if (can_match[j] && search) {
+                const u32 l_r = common_bytes(v[j], w_r[j]), l_l = common_bytes(v[j], w_l[j]), l_s = common_bytes(v[j], w_s[j]);
+                if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
+                if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = p - q_l[j]; q_best[j] = q_l[j]; }
+                if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = p - q_s[j]; q_best[j] = q_s[j]; }
                 // extend while whole 8-byte words keep matching
-                while (best_len >= 8 && (best_len & 7) == 0 && best_len < LANE_MATCH_CAP && p + best_len + 8 <= n) {
-                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + q_best + best_len));
-                    best_len += l;
+                while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < LANE_MATCH_CAP && p + best_len[j] + 8 <= n) {
+                    const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(src + q_best[j] + best_len[j]));
+                    best_len[j] += l;
                     if (l < 8) break;
                 }
             }
         }
-        bool has_match = best_len >= MIN_MATCH;
+        bool has_match[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            has_match[j] = best_len[j] >= MIN_MATCH;
+            S.cand[t + ENC_THREADS * j] = has_match[j] ? (best_len[j] | (best_off[j] << 8)) : 0u;
+        }
+        const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        lds_barrier();
         // ---- one-step lazy evaluation (cf. the ip+1 long-match check of zstd.c:30025-30040): if the
         // next position holds a clearly better match, emit this byte as a literal instead
-        S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
-        __syncthreads();
-        if (has_match && t + 1 < WIN) {
-            const u32 nx = S.cand[t + 1];
-            if (nx) {
-                const int g1 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1)) + 4;
-                const int g2 = 4 * (int)(nx & 0xFF) - (int)(31 - __clz((nx >> 8) + 1));
-                if (g2 > g1) has_match = false;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 w = t + ENC_THREADS * j;
+            if (has_match[j] && w + 1 < WIN) {
+                const u32 nx = S.cand[w + 1];
+                if (nx) {
+                    const int g1 = 4 * (int)best_len[j] - (int)(31 - __clz(best_off[j] + 1)) + 4;
+                    const int g2 = 4 * (int)(nx & 0xFF) - (int)(31 - __clz((nx >> 8) + 1));
+                    if (g2 > g1) has_match[j] = false;
+                }
             }
         }
         // ---- greedy parse over the window by pointer jumping
-        const u32 nxt = t + (has_match ? best_len : 1u);
-        S.jump[0][t] = (u16)nxt;
-        S.mark[t] = (t == carry) ? 1 : 0;
-        __syncthreads();
+        u32 nxt[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 w = t + ENC_THREADS * j;
+            nxt[j] = w + (has_match[j] ? best_len[j] : 1u);
+            S.jump[0][w] = (u16)nxt[j];
+            S.mark[w] = (w == carry) ? 1 : 0;
+        }
+        lds_barrier();
         int cur = 0;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const u32 j = S.jump[cur][t];
-            if (j < WIN) {
-                if (S.mark[t]) S.mark[j] = 1;
-                S.jump[cur ^ 1][t] = S.jump[cur][j];
-            } else {
-                S.jump[cur ^ 1][t] = (u16)j;
+        for (int r = 0; r < WIN_LOG; r++) {
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const u32 w = t + ENC_THREADS * j;
+                const u32 jp = S.jump[cur][w];
+                if (jp < WIN) {
+                    if (S.mark[w]) S.mark[jp] = 1;
+                    S.jump[cur ^ 1][w] = S.jump[cur][jp];
+                } else {
+                    S.jump[cur ^ 1][w] = (u16)jp;
+                }
             }
             cur ^= 1;
-            __syncthreads();
+            lds_barrier();
         }
-        const bool on_path = S.mark[t] != 0;
-        const bool is_seq = on_path && has_match;
-        const bool is_lit = on_path && !has_match && in_range;
-        u32 ex_s, ex_l, tot_s, tot_l;
-        block_scan2(S.scan_a, S.scan_b, is_seq ? 1u : 0u, is_lit ? 1u : 0u, ex_s, ex_l, tot_s, tot_l);
-        if (is_lit) lits[nlit + ex_l] = (u8)v;
-        if (is_seq) {
-            zl_seq s;
-            s.lit_cum = nlit + ex_l;
-            s.match_len = best_len;
-            s.offset = best_off;
-            s.pos = p;
-            seqs[nseq + ex_s] = s;
-            if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
+        const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        bool is_seq[PPT], is_lit[PPT], on_path[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            on_path[j] = S.mark[t + ENC_THREADS * j] != 0;
+            is_seq[j] = on_path[j] && has_match[j];
+            is_lit[j] = on_path[j] && !has_match[j] && in_range[j];
         }
-        if (on_path && nxt >= WIN) S.carry = nxt - WIN;  // exactly one path node leaves the window
+        // positions t (j = 0) precede positions t + 256 (j = 1): two counts per scan lane, 16 bits each
+        u32 ex0, ex1, tot0, tot1;
+        match_scan2(S.scan_a, S.scan_b, (is_seq[0] ? 1u : 0u) | ((is_lit[0] ? 1u : 0u) << 16),
+                    (is_seq[PPT - 1] && PPT > 1 ? 1u : 0u) | ((is_lit[PPT - 1] && PPT > 1 ? 1u : 0u) << 16), ex0, ex1, tot0, tot1);
+        u32 ex_s[PPT], ex_l[PPT];
+        ex_s[0] = ex0 & 0xFFFF;
+        ex_l[0] = ex0 >> 16;
+        if (PPT > 1) { ex_s[PPT - 1] = (tot0 & 0xFFFF) + (ex1 & 0xFFFF); ex_l[PPT - 1] = (tot0 >> 16) + (ex1 >> 16); }
+        const u32 tot_s = (tot0 & 0xFFFF) + (tot1 & 0xFFFF), tot_l = (tot0 >> 16) + (tot1 >> 16);
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            const u32 p = ip + t + ENC_THREADS * j;
+            if (is_lit[j]) lits[nlit + ex_l[j]] = (u8)v[j];
+            if (is_seq[j]) {
+                zl_seq sq;
+                sq.lit_cum = nlit + ex_l[j];
+                sq.match_len = best_len[j];
+                sq.offset = best_off[j];
+                sq.pos = p;
+                seqs[nseq + ex_s[j]] = sq;
+                if (ex_s[j] + 1 == tot_s) S.rep = best_off[j];  // last sequence of the window
+            }
+            if (on_path[j] && nxt[j] >= WIN) S.carry = nxt[j] - WIN;  // exactly one path node leaves the window
+        }
         if (carry >= WIN && t == 0) S.carry = carry - WIN;
+        const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
         // ---- insert every position of the window (most recent position wins: atomicMax)
-        if (can_match) {
-            atomicMax(&S.tbl_long[hl], p + 1);
-            atomicMax(&S.tbl_short[hs], p + 1);
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+            if (can_match[j]) {
+                const u32 p = ip + t + ENC_THREADS * j;
+                atomicMax(&S.tbl_long[hl[j]], p + 1);
+                atomicMax(&S.tbl_short[hs[j]], p + 1);
+            }
         }
         nseq += tot_s;
         nlit += tot_l;
-        __syncthreads();
+        lds_barrier();
+        if (prof) {
+            const u64 s4 = __builtin_amdgcn_s_memtime();
+            c_find += s1 - s0; c_parse += s2 - s1; c_emit += s3 - s2; c_ins += s4 - s3; c_it++;
+        }
+    }
+    if (prof) {
+        atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
+        atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)c_parse);
+        atomicAdd((unsigned long long*)&a.stats[2], (unsigned long long)c_emit);
+        atomicAdd((unsigned long long*)&a.stats[3], (unsigned long long)c_ins);
+        atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)c_it);
     }
     if (t == 0) {
         a.meta[c].nseq = nseq;
