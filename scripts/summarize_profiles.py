@@ -1,0 +1,87 @@
+"""Turns the rocprofv3 outputs of a bench.py run (gpurun_out/prof_bench, pmc_fetch, pmc_write) into the
+small summaries committed under profiles/:  <round>_kernel_stats.csv (rocprofv3 --stats as is),
+<round>_kernel_summary.json (per kernel, launches of the full 1 GiB grid only: average duration,
+FETCH_SIZE / WRITE_SIZE per launch) and <round>_pmc_summary.json (what bench.py reads for
+roofline.traffic).  Usage: python scripts/summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+os.makedirs(P, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(G, pattern))
+    return f[0] if f else None
+
+
+stats = one("prof_bench/*/*kernel_stats.csv")
+trace = one("prof_bench/*/*kernel_trace.csv")
+if stats:
+    shutil.copy(stats, os.path.join(P, f"{rnd}_kernel_stats.csv"))
+line = os.path.join(G, "prof_bench_line.json")
+if os.path.exists(line):
+    shutil.copy(line, os.path.join(P, f"{rnd}_bench_under_rocprof.json"))
+
+# full-grid launches: the largest grid each kernel was launched with (the 1 GiB steps; the smaller
+# ones are the per-input 256 MiB calls and the C2 leg)
+dur = collections.defaultdict(list)
+if trace:
+    rows = list(csv.DictReader(open(trace)))
+    for r in rows:
+        r["Grid_Size"] = r.get("Grid_Size") or r["Grid_Size_X"]
+    big = collections.defaultdict(int)
+    for r in rows:
+        if r["Kernel_Name"].startswith("zl"):
+            big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows:
+        k = r["Kernel_Name"]
+        if k.startswith("zl") and int(r["Grid_Size"]) == big[k]:
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+
+
+def pmc(path):
+    d = collections.defaultdict(list)
+    if not path:
+        return d
+    rows = list(csv.DictReader(open(path)))
+    big = collections.defaultdict(int)
+    for r in rows:
+        if r["Kernel_Name"].startswith("zl"):
+            big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows:
+        k = r["Kernel_Name"]
+        if k.startswith("zl") and int(r["Grid_Size"]) == big[k]:
+            d[k].append(float(r["Counter_Value"]))
+    return d
+
+
+fetch = pmc(one("pmc_fetch/*/*counter_collection.csv"))
+write = pmc(one("pmc_write/*/*counter_collection.csv"))
+summary, short = {}, {}
+names = {"zl_match_kernel": "match", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
+         "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_exec_kernel": "d_exec"}
+for k in sorted(set(dur) | set(fetch) | set(write)):
+    base = k.split("(")[0]
+    f_kb = sum(fetch[k]) / len(fetch[k]) if fetch[k] else None
+    w_kb = sum(write[k]) / len(write[k]) if write[k] else None
+    e = {"full_grid_launches": len(dur[k]), "avg_ms": sum(dur[k]) / len(dur[k]) if dur[k] else None,
+         "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb}
+    if f_kb is not None and w_kb is not None:
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950;
+        # WRITE_SIZE is exact.  Both bounds are given; these kernels read in 1-16 byte pieces per lane.
+        e["hbm_bytes_per_launch_raw"] = (f_kb + w_kb) * 1024
+        e["hbm_bytes_per_launch_fetch_doubled"] = (2 * f_kb + w_kb) * 1024
+        short[names.get(base, base)] = {"hbm_bytes_per_launch": (2 * f_kb + w_kb) * 1024, "kernel": base}
+    summary[base] = e
+json.dump(summary, open(os.path.join(P, f"{rnd}_kernel_summary.json"), "w"), indent=1)
+json.dump(short, open(os.path.join(P, f"{rnd}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))

@@ -1,0 +1,109 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle would take
+minutes here): 1 GiB round trip bit-exact and deterministic on the device-resident entry points,
+every frame regenerating exactly its chunk, corruption of any one frame reported for that frame
+only, and config C2 (10k independent 64 KiB reference-made frames) decoded in one launch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from zstdlite_amd.device import CHUNK, DeviceCodec, gen_device, gen_mixed
+from zl_testlib import have_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def codec():
+    c = DeviceCodec()
+    yield c
+    c.close()
+
+
+def test_one_gib_roundtrip_deterministic(codec):
+    dev = torch.device("cuda", 0)
+    n = 1 << 30
+    src, kinds, q = gen_mixed(n, dev)
+    comp, total, fs = codec.compress(src)
+    assert total == int(fs.sum()) and len(fs) == n // CHUNK
+    assert total <= codec.bound(n)
+    digest1 = int(comp[:total].to(torch.int64).sum().item())
+    back = torch.empty_like(src)
+    tbl = codec.frame_table(fs, codec.chunk_content_sizes(n))
+    got, res = codec.decompress(comp, tbl, back)
+    assert got == n and (res == CHUNK).all()
+    assert torch.equal(back, src)
+    # determinism (tests/testthat/test-cctx.R): same bytes on a second run with a fresh context
+    c2 = DeviceCodec()
+    comp2, total2, fs2 = c2.compress(src)
+    assert total2 == total and (fs2 == fs).all() and torch.equal(comp2[:total], comp[:total])
+    assert int(comp2[:total].to(torch.int64).sum().item()) == digest1
+    c2.close()
+    # ratio sanity against BASELINE.md section 2 (reference level 3 on 256 MiB of each input)
+    ref_bytes = {"rand": 268441610, "iid10": 131457759, "text": 63726261, "int20": 210971766}
+    starts = np.concatenate([[0], np.cumsum(fs)])
+    per = n // 4 // CHUNK
+    for i, k in enumerate(kinds):
+        ours = int(starts[(i + 1) * per] - starts[i * per])
+        assert ours <= ref_bytes[k] * 1.05, (k, ours, ref_bytes[k])
+    # damage one byte in the middle of three frames.  Without a content checksum a flipped bit inside a
+    # raw block -- or inside a Huffman stream that happens to resynchronise -- is not detectable, so
+    # this part runs with include_checksum=TRUE: exactly the damaged frames must fail, every other
+    # frame must still be bit-exact (tests/testthat/test-checksums.R at scale).
+    c3 = DeviceCodec(include_checksum=True)
+    m = 64 << 20
+    part = torch.cat([src[i * q: i * q + m // 4] for i in range(4)])
+    compc, totalc, fsc = c3.compress(part)
+    assert totalc == int(fsc.sum())
+    tblc = c3.frame_table(fsc, c3.chunk_content_sizes(m))
+    startsc = np.concatenate([[0], np.cumsum(fsc)])
+    victims = [3, 200, 300, 511]  # one frame of each input kind
+    for v in victims:
+        compc[int(startsc[v] + fsc[v] // 2)] ^= 0x40
+    backc = torch.zeros(m, dtype=torch.uint8, device=dev)
+    from zstdlite_amd._lib import FrameT
+    L = c3.L
+    r = L.zl_decompress_device_async(c3.dctx, C.c_void_p(backc.data_ptr()), C.c_void_p(compc.data_ptr()),
+                                     tblc.ctypes.data_as(C.POINTER(FrameT)), len(tblc), None)
+    assert r == 0
+    resc = (C.c_size_t * len(tblc))()
+    first = L.zl_decompress_device_finish(c3.dctx, resc)
+    assert first > (1 << 63)  # an error code, not a size
+    resc = np.frombuffer(resc, dtype=np.uint64)
+    failed = set(np.nonzero(resc > (1 << 63))[0].tolist())
+    assert failed == set(victims)
+    ok = np.ones(len(tblc), dtype=bool)
+    ok[victims] = False
+    keep = torch.from_numpy(np.repeat(ok, CHUNK)).to(dev)
+    assert torch.equal(backc[keep], part[keep])
+    c3.close()
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (reference libzstd) to make the frames")
+def test_c2_ten_thousand_64k_reference_frames(codec):
+    from zl_testlib import Ref
+    ref = Ref()
+    dev = torch.device("cuda", 0)
+    nframes, fsz = 10000, 65536
+    per = (nframes + 2) // 3
+    srcs = {k: gen_device(k, per * fsz, dev, seed=5).cpu().numpy() for k in ("text", "iid10", "rand")}
+    L = ref.L
+    cctx = L.ZSTD_createCCtx()
+    L.ZSTD_CCtx_setParameter(cctx, 100, 3)
+    cap = L.ZSTD_compressBound(fsz)
+    buf = C.create_string_buffer(cap)
+    frames, plain = [], []
+    for i in range(nframes):
+        a = srcs[("text", "iid10", "rand")[i % 3]][(i // 3) * fsz:(i // 3 + 1) * fsz]
+        r = L.ZSTD_compress2(cctx, buf, cap, a.ctypes.data, fsz)
+        frames.append(buf.raw[:r])
+        plain.append(a)
+    L.ZSTD_freeCCtx(cctx)
+    blob = torch.from_numpy(np.frombuffer(b"".join(frames), dtype=np.uint8).copy()).to(dev)
+    want = torch.from_numpy(np.concatenate(plain)).to(dev)
+    out = torch.empty(nframes * fsz, dtype=torch.uint8, device=dev)
+    tbl = codec.frame_table([len(f) for f in frames], [fsz] * nframes)
+    total, res = codec.decompress(blob, tbl, out)
+    assert total == nframes * fsz and (res == fsz).all()
+    assert torch.equal(out, want)

@@ -134,9 +134,10 @@ struct zl_dctx_s {
     u32 slots = 0;
     // diagnostics
     int profile = 0;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // start, after index, after entropy lanes, after exec, end
     bool ev_valid = false;
     double kernel_ms = 0;
+    double stage_ms[4] = {0, 0, 0, 0};
     DevBuf d_stats;
     u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -293,6 +294,7 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
 size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
     if (!d || !ms || !d->profile || !d->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     ms[0] = d->kernel_ms;
+    for (int k = 0; k < 4; k++) ms[1 + k] = d->stage_ms[k];
     return 0;
 }
 
@@ -388,7 +390,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         if (!fast) nslow++;
     }
     const u32 max_slots = (u32)g_num_cu * 4;
-    const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 16), max_slots);
+    const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 256), max_slots);  // >= 256 so that skipping routed frames is quick
     if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) ||
         !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)) ||
         !d->d_plan.ensure(n * sizeof(zl2_frame_plan)) || !d->d_frec.ensure(n * sizeof(zl2_frame_rec)) ||
@@ -400,7 +402,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     if (hipMemsetAsync(d->d_counter.p, 0, 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     d->ev_valid = false;
     if (d->profile) {
-        if (!d->ev[0]) { (void)hipEventCreate(&d->ev[0]); (void)hipEventCreate(&d->ev[1]); }
+        if (!d->ev[0]) for (auto& e : d->ev) (void)hipEventCreate(&e);
         (void)hipEventRecord(d->ev[0], st);
     }
     zl2_args f2;
@@ -420,7 +422,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;
     }
-    if (zl2_launch(&f2, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (zl2_launch(&f2, st, d->profile ? d->ev + 1 : nullptr) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     zl_decode_args a;
     a.frames = f2.frames;
     a.nframes = (u32)n;
@@ -444,7 +446,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     a.frec = f2.frec;
     a.stats = (d->profile && d->d_stats.p) ? (u64*)d->d_stats.p : nullptr;
     if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (d->profile) { (void)hipEventRecord(d->ev[1], st); d->ev_valid = true; }
+    if (d->profile) { (void)hipEventRecord(d->ev[4], st); d->ev_valid = true; }
     return 0;
 }
 
@@ -476,8 +478,9 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
     if (hipStreamSynchronize(d->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (d->ev_valid) {
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[1]);
+        (void)hipEventElapsedTime(&ms, d->ev[0], d->ev[4]);
         d->kernel_ms = ms;
+        for (int k = 0; k < 4; k++) { (void)hipEventElapsedTime(&ms, d->ev[k], d->ev[k + 1]); d->stage_ms[k] = ms; }
         if (d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
     const u64* r = (const u64*)d->h_results.p;

@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream) {
+extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
     if (a->nframes == 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1070,7 +1070,10 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream) {
     }
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
+    if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ((n + LIT_FRAMES - 1) / LIT_FRAMES)), dim3(64), 0, stream, *a);
+    if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), sizeof(ExecShared), stream, *a);
+    if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }

@@ -107,12 +107,12 @@ class DeviceCodec:
     def kernel_ms(self):
         """{'match','entropy','scan','gather','decode'} device milliseconds of the last calls."""
         c = (C.c_double * 4)()
-        d = (C.c_double * 1)()
+        d = (C.c_double * 5)()
         out = {}
         if not is_error(self.L.zl_cctx_kernel_ms(self.cctx, c)):
             out.update(match=c[0], entropy=c[1], scan=c[2], gather=c[3])
         if not is_error(self.L.zl_dctx_kernel_ms(self.dctx, d)):
-            out.update(decode=d[0])
+            out.update(decode=d[0], d_index=d[1], d_entropy=d[2], d_exec=d[3], d_general=d[4])
         return out
 
 
