@@ -767,52 +767,34 @@ __global__ __launch_bounds__(64) void zl2_entropy_kernel(zl2_args a) {
 // ---------------------------------------------------------------------------------------
 // zl2_exec_kernel: 1024 threads per frame, block output staged in LDS.
 //
-// Sequences are consumed in batches of 1024.  Per batch: a block-wide scan gives every sequence
-// its output and literal offsets; pass 1 scatters the batch's literal bytes into the LDS image
-// with coalesced dword loads from the literal buffer; pass 2 produces the match bytes, each by
-// following its offset through the batch table until it lands on a byte that already exists in
-// the image (an earlier batch, or a literal placed by pass 1) -- the dependent chain of a byte is
-// LDS-only.  A table of "which sequence owns this 32-byte granule" replaces binary searches.
+// zl2_seq_kernel left running positions (literals / output bytes before each sequence), so a
+// batch needs no scan.  A batch is as many sequences as fit EX_CAP output bytes (a sequence
+// longer than that is a batch of its own).  Per batch:
+//   pass 1  the batch's literal bytes are scattered into the LDS image with coalesced dword loads;
+//   pass 2a every match byte takes ONE hop through the batch table (owner-per-32-byte-granule
+//           lookup): if the hop lands on a byte that already exists (earlier batch, or a literal
+//           of this batch) the byte is copied, otherwise the landing position is stored as a
+//           16-bit link;
+//   pass 2b links are shortened by pointer jumping (link := link of link) until every byte has
+//           found an existing byte -- log2(chain length) rounds of plain LDS traffic instead of a
+//           per-byte walk whose tail is as long as span/offset.
 // ---------------------------------------------------------------------------------------
 #define EX_THREADS 1024
 #define EX_GRAN_LOG 5
-#define EX_SPAN 4096u  // target output bytes per batch: one 4-byte word per thread, short in-batch chains
+#define EX_CAP 8192u     // output bytes per batch (links are 16-bit, relative to the batch start)
+#define EX_MAXSEQ 1023u  // sequences per batch (+1 look-ahead entry = one per thread)
+#define EX_FINAL 0xFFFFu
 struct ExecShared {
     u8 out[ZL_BLOCK_MAX];
-    u32 b_out[EX_THREADS + 1];
-    u32 b_lit[EX_THREADS + 1];
-    u32 b_ll[EX_THREADS];
-    u32 b_off[EX_THREADS];
-    u16 own[(ZL_BLOCK_MAX >> EX_GRAN_LOG) + 8];
-    u32 scan_a[16], scan_b[16];
+    u32 b_out[EX_MAXSEQ + 1];
+    u32 b_lit[EX_MAXSEQ + 1];
+    u32 b_off[EX_MAXSEQ];
+    u16 own[(EX_CAP >> EX_GRAN_LOG) + 8];
+    u16 link[EX_CAP];
     u64 xxh_acc[4];
-    u32 bcast[4];
+    u32 bcast[8];  // [0] xxh result, [1] batch size, [4..6] rotating "still pending" flags
     int err;
 };
-
-__device__ __forceinline__ void exec_scan2(ExecShared& S, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
-        if ((int)lane >= d) { ia += ta; ib += tb; }
-    }
-    if (lane == 63) { S.scan_a[wave] = ia; S.scan_b[wave] = ib; }
-    __syncthreads();
-    u32 pa = 0, pb = 0, ta = 0, tb = 0;
-#pragma unroll
-    for (u32 w = 0; w < 16; w++) {
-        const u32 xa = S.scan_a[w], xb = S.scan_b[w];
-        if (w < wave) { pa += xa; pb += xb; }
-        ta += xa; tb += xb;
-    }
-    ex_a = pa + ia - a;
-    ex_b = pb + ib - b;
-    tot_a = ta;
-    tot_b = tb;
-    __syncthreads();
-}
 
 // sequence of the current batch that owns block-relative output position p
 __device__ __forceinline__ u32 owner_of(const ExecShared& S, u32 p, u32 gbase) {
@@ -863,50 +845,55 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         const u32 rle_byte = r.lit_a & 0xFF;
         const u8* lit = (r.lit_mode == 0) ? (blk + r.lit_a) : (lit_base + r.lit_dst);
         const u32 nseq = r.nseq, lit_size = r.lit_size;
-        const u32* sll = q_ll + r.seq_dst;
-        const u32* sml = q_ml + r.seq_dst;
+        const u32* sll = q_ll + r.seq_dst;  // literals before sequence i
+        const u32* sml = q_ml + r.seq_dst;  // output bytes before sequence i (entry nseq: totals)
         const u32* sof = q_off + r.seq_dst;
         const u64 cap_left = cap - op;
         u32 lit_pos = 0, out_pos = 0;
         u64 c_scan = 0, c_lit = 0, c_match = 0, c_batches = 0;
         const bool prof = a.stats != nullptr && t == 0;
-        // zl2_seq_kernel left running positions, not lengths: sll[i] = literals before sequence i,
-        // sml[i] = output bytes before it (entry nseq holds the totals), so a batch needs no scan.
-        // A batch is as many sequences as cover about EX_SPAN output bytes (at most EX_THREADS).
+        // the first window's entries; every later window is fetched into registers while the previous
+        // batch is being executed (its first index is known as soon as that batch's size is)
+        u32 pf_out = 0, pf_lit = 0, pf_off = 1;
+        if (t <= nseq && t <= EX_MAXSEQ) { pf_out = sml[t]; pf_lit = sll[t]; pf_off = sof[t]; }
         for (u32 b0 = 0; b0 < nseq;) {
             const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            const u32 window = (nseq - b0 < EX_THREADS) ? (nseq - b0) : EX_THREADS;
+            const u32 window = (nseq - b0 < EX_MAXSEQ) ? (nseq - b0) : EX_MAXSEQ;
             if (t == 0) S.bcast[1] = 1;
-            if (t <= window) {  // one extra entry: the next sequence (or the sentinel)
-                const u32 o = sml[b0 + t], l = sll[b0 + t];
-                S.b_out[t] = o;
-                S.b_lit[t] = l;
-                if (t < window) S.b_off[t] = sof[b0 + t];
+            if (t <= window) {  // one extra entry: the next sequence (or the totals)
+                S.b_out[t] = pf_out;
+                S.b_lit[t] = pf_lit;
+                if (t < window) S.b_off[t] = pf_off;
             }
             __syncthreads();
             const u32 batch_start = out_pos;
-            if (t < window && t > 0 && S.b_out[t] < batch_start + EX_SPAN) atomicMax(&S.bcast[1], t + 1);
+            // sequence t >= 1 joins the batch while its END stays within EX_CAP of the batch start
+            if (t >= 1 && t < window && S.b_out[t + 1] - batch_start <= EX_CAP && S.b_out[t + 1] >= batch_start) atomicMax(&S.bcast[1], t + 1);
             __syncthreads();
             const u32 nb = S.bcast[1];
             const u32 batch_end = S.b_out[nb];
             const u32 tot_l = S.b_lit[nb] - lit_pos, tot_o = batch_end - batch_start;
             const u32 gbase = batch_start & ~((1u << EX_GRAN_LOG) - 1);
+            const bool linked = tot_o <= EX_CAP;  // otherwise: one long sequence, every byte resolves in one hop
+            {   // prefetch the next window (entries b0+nb .. b0+nb+EX_MAXSEQ, sentinel included)
+                const u32 nb0 = b0 + nb;
+                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { pf_out = sml[nb0 + t]; pf_lit = sll[nb0 + t]; pf_off = sof[nb0 + t]; }
+            }
             if (t < nb) {
                 const u32 my_out = S.b_out[t], my_lit = S.b_lit[t];
                 const u32 ll = S.b_lit[t + 1] - my_lit;
                 const u32 off = S.b_off[t];
-                S.b_ll[t] = ll;
-                if (S.b_out[t + 1] < my_out + ll || S.b_lit[t + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions must not decrease
+                if (S.b_out[t + 1] < my_out + ll || S.b_lit[t + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions never decrease
                 if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
                 if ((u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;    // zstd.c:44045 (no dictionary on this path)
             }
-            if (batch_end > ZL_BLOCK_MAX || batch_end < batch_start) { if (t == 0) S.err = ZL_E_CORRUPTION; }
+            if (batch_end > ZL_BLOCK_MAX || batch_end < batch_start || S.b_out[0] != batch_start || S.b_lit[0] != lit_pos) { if (t == 0) S.err = ZL_E_CORRUPTION; }
             else if ((u64)batch_end > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
             __syncthreads();
             if (S.err) break;
             const u64 st1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- owner table: granule g starts at gbase + 32 g
-            if (t < nb) {
+            if (linked && t < nb) {
                 const u32 lo = S.b_out[t], hi = S.b_out[t + 1];
                 u32 g = (lo - gbase + (1u << EX_GRAN_LOG) - 1) >> EX_GRAN_LOG;
                 if (t == 0) g = 0;
@@ -917,75 +904,96 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                 const u32 l_end = lit_pos + tot_l;
                 const u32 mis = lit_rle ? 0 : (u32)((uintptr_t)(lit + lit_pos) & 3);
                 const i32 ja = (i32)lit_pos - (i32)mis;
-                for (i32 j0 = ja + 4 * (i32)t; j0 < (i32)l_end; j0 += 4 * EX_THREADS) {
-                    const u32 word = lit_rle ? rle_byte * 0x01010101u : *(const u32*)(lit + j0);
-                    const u32 jf = j0 < (i32)lit_pos ? lit_pos : (u32)j0;
-                    const u32 jl = (u32)(j0 + 4) > l_end ? l_end : (u32)(j0 + 4);
-                    // last sequence whose literal run starts at or before jf
-                    u32 lo = 0, hi = nb;
-                    while (hi - lo > 1) {
-                        const u32 mid = (lo + hi) >> 1;
-                        if (S.b_lit[mid] <= jf) lo = mid; else hi = mid;
-                    }
-                    u32 k = lo;
-                    for (u32 j = jf; j < jl; j++) {
-                        while (j >= S.b_lit[k + 1]) k++;
-                        S.out[S.b_out[k] + (j - S.b_lit[k])] = (u8)(word >> (8 * (j - (u32)j0)));
+                for (i32 j0 = ja + 4 * (i32)t; j0 < (i32)l_end; j0 += 8 * EX_THREADS) {
+                    // two dwords per trip so that their latencies overlap
+                    const i32 j1 = j0 + 4 * EX_THREADS;
+                    const bool two = j1 < (i32)l_end;
+                    const u32 word0 = lit_rle ? rle_byte * 0x01010101u : *(const u32*)(lit + j0);
+                    const u32 word1 = two ? (lit_rle ? rle_byte * 0x01010101u : *(const u32*)(lit + j1)) : 0u;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (h == 1 && !two) break;
+                        const i32 jj = h ? j1 : j0;
+                        const u32 word = h ? word1 : word0;
+                        const u32 jf = jj < (i32)lit_pos ? lit_pos : (u32)jj;
+                        const u32 jl = (u32)(jj + 4) > l_end ? l_end : (u32)(jj + 4);
+                        // last sequence whose literal run starts at or before jf
+                        u32 lo = 0, hi = nb;
+                        while (hi - lo > 1) {
+                            const u32 mid = (lo + hi) >> 1;
+                            if (S.b_lit[mid] <= jf) lo = mid; else hi = mid;
+                        }
+                        u32 k = lo;
+                        for (u32 j = jf; j < jl; j++) {
+                            while (j >= S.b_lit[k + 1]) k++;
+                            const u32 d = S.b_out[k] + (j - S.b_lit[k]);
+                            S.out[d] = (u8)(word >> (8 * (j - (u32)jj)));
+                            if (linked) S.link[d - batch_start] = EX_FINAL;
+                        }
                     }
                 }
             }
             __syncthreads();
             const u64 st2 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            // ---- pass 2: match bytes, 4-byte words of the LDS image.  The four bytes of a word are
-            // chased together, one hop per round for every byte still unresolved, so their LDS
-            // latencies overlap instead of adding up.
+            // ---- pass 2a: one hop for every match byte
             {
                 const u32 w_first = batch_start >> 2, w_end = (batch_end + 3) >> 2;
                 for (u32 w = w_first + t; w < w_end; w += EX_THREADS) {
                     const u32 ws = w << 2;
-                    u32 pp[4], kk[4], val[4];
-                    u32 pending = 0, mask = 0;
-                    u32 k = owner_of(S, ws < batch_start ? batch_start : ws, gbase);
+                    u32 k = 0;
+                    if (linked) k = owner_of(S, ws < batch_start ? batch_start : ws, gbase);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const u32 p = ws + j;
-                        pp[j] = p; kk[j] = k; val[j] = 0;
-                        if (p >= batch_start && p < batch_end) {
-                            while (p >= S.b_out[k + 1]) k++;
-                            kk[j] = k;
-                            if (p - S.b_out[k] >= S.b_ll[k]) { pending |= 1u << j; mask |= 0xFFu << (8 * j); }
-                        }
-                    }
-                    while (pending) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (pending & (1u << j)) {
-                                const u32 kj = kk[j], pj = pp[j];
-                                const u32 mstart = S.b_out[kj] + S.b_ll[kj];
-                                const u32 m = pj - mstart, o = S.b_off[kj];
-                                const i64 q = (m < o) ? (i64)pj - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
-                                if (q < (i64)batch_start) {
-                                    val[j] = (q >= 0) ? S.out[q] : bdst[q];
-                                    pending &= ~(1u << j);
-                                } else {
-                                    const u32 qq = (u32)q;
-                                    const u32 k2 = owner_of(S, qq, gbase);
-                                    pp[j] = qq; kk[j] = k2;
-                                    if (qq - S.b_out[k2] < S.b_ll[k2]) {  // a literal of this batch, already in place
-                                        val[j] = S.out[qq];
-                                        pending &= ~(1u << j);
-                                    }
-                                }
+                        if (p < batch_start || p >= batch_end) continue;
+                        while (p >= S.b_out[k + 1]) k++;
+                        const u32 ll = S.b_lit[k + 1] - S.b_lit[k];
+                        const u32 mstart = S.b_out[k] + ll;
+                        if (p < mstart) continue;  // literal, placed by pass 1
+                        const u32 m = p - mstart, o = S.b_off[k];
+                        const i64 q = (m < o) ? (i64)p - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
+                        if (q < (i64)batch_start) {
+                            S.out[p] = (q >= 0) ? S.out[q] : bdst[q];
+                            if (linked) S.link[p - batch_start] = EX_FINAL;
+                        } else if (!linked) {
+                            S.out[p] = S.out[q];  // a literal of this (single-sequence) batch
+                        } else {
+                            const u32 qq = (u32)q;
+                            const u32 k2 = owner_of(S, qq, gbase);
+                            if (qq - S.b_out[k2] < S.b_lit[k2 + 1] - S.b_lit[k2]) {  // literal of this batch: already in place
+                                S.out[p] = S.out[qq];
+                                S.link[p - batch_start] = EX_FINAL;
+                            } else {
+                                S.link[p - batch_start] = (u16)(qq - batch_start);
                             }
                         }
                     }
-                    const u32 word = val[0] | (val[1] << 8) | (val[2] << 16) | (val[3] << 24);
-                    if (mask == 0xFFFFFFFFu) *(u32*)(S.out + ws) = word;
-                    else if (mask) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (mask & (0xFFu << (8 * j))) S.out[ws + j] = (u8)val[j];
+                }
+            }
+            // ---- pass 2b: pointer jumping over the 16-bit links until nothing is pending.  One barrier
+            // per round: the "somebody is still pending" flag rotates over three words.
+            if (linked) {
+                if (t == 0) { S.bcast[4] = 0; S.bcast[5] = 0; S.bcast[6] = 0; }
+                __syncthreads();
+                for (u32 round = 0;; round++) {
+                    const u32 fl = 4 + round % 3;
+                    u32 pending = 0;
+                    for (u32 i = t; i < tot_o; i += EX_THREADS) {
+                        const u32 l1 = S.link[i];
+                        if (l1 == EX_FINAL) continue;
+                        const u32 l2 = S.link[l1];
+                        if (l2 == EX_FINAL) {
+                            S.out[batch_start + i] = S.out[batch_start + l1];
+                            S.link[i] = EX_FINAL;
+                        } else {
+                            S.link[i] = (u16)l2;
+                            pending = 1;
+                        }
                     }
+                    if (pending) S.bcast[fl] = 1;
+                    if (t == 0) S.bcast[4 + (round + 1) % 3] = 0;  // next round's flag: last read two barriers ago
+                    __syncthreads();
+                    if (!S.bcast[fl]) break;
                 }
             }
             lit_pos += tot_l;
