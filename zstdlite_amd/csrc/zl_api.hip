@@ -386,7 +386,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         p.lit_cap = fast ? (u32)((tbl[i].dst_cap + 3 + 4 * ZL2_MAXB) & ~(u64)3) : 0;
         p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2 + ZL2_MAXB) : 0;  // + one totals sentinel per block
         lit_total += (p.lit_cap + 15) & ~15u;
-        seq_total += (u64)3 * p.seq_cap;
+        seq_total += (u64)p.seq_cap;  // 16-byte records
         if (!fast) nslow++;
     }
     const u32 max_slots = (u32)g_num_cu * 4;
@@ -395,7 +395,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)) ||
         !d->d_plan.ensure(n * sizeof(zl2_frame_plan)) || !d->d_frec.ensure(n * sizeof(zl2_frame_rec)) ||
         !d->d_brec.ensure(n * (size_t)ZL2_MAXB * sizeof(zl2_blk_rec)) || !d->d_lit2.ensure(lit_total + 64) ||
-        !d->d_seq2.ensure(seq_total * sizeof(u32) + 64))
+        !d->d_seq2.ensure(seq_total * 16 + 64))
         return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_frames.p, d->h_frames.p, n * sizeof(zl_frame_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemcpyAsync(d->d_plan.p, d->h_plan.p, n * sizeof(zl2_frame_plan), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);

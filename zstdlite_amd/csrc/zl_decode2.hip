@@ -234,7 +234,9 @@ struct LitGroup {
     u32 rank_start[16];
     u32 log;
     u32 ok;          // table usable for "treeless" blocks
+    u32 pad[2];      // keeps the group size a multiple of 16 (weights[] doubles as a 16-byte-aligned ring)
 };
+static_assert(sizeof(LitGroup) % 16 == 0, "LitGroup must stay 16-byte aligned");
 
 // Huffman tree description -> g.tab (zstd.c:3470 HUF_readStats_body, zstd.c:38436
 // HUF_readDTableX1_wksp).  One lane.  Returns bytes consumed, 0 on error, 0xFFFFFFFF when the
@@ -346,7 +348,7 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
 // one backward Huffman stream on one lane (zstd.c:38560).  Main loop: left-aligned accumulator,
 // two symbols per refill check, four symbols per dword store, no branches; the last few symbols
 // (and short streams) go through the generic reader so that the end-of-stream test stays exact.
-__device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u32 nout, const u8* src, u32 n) {
+__device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u32 nout, const u8* src, u32 n, u32* ring /* 16 dwords of LDS owned by this lane */) {
     i32 pos = zl_bwd_init(src, n);
     if (pos < 0) return false;
     u32 i = 0;
@@ -362,19 +364,17 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
         const u32 sh = 32 - log;
         const u32* w = r.w;
         u64 acc = r.acc;
-        i32 nav = r.nav, idx = r.idx, left = r.pos;
-        // The two dwords a group of four symbols may need are loaded one group ahead and BEFORE
-        // that group's store.  hipcc would wait with vmcnt(0) at the top of the loop -- i.e. for the
-        // store round trip as well -- so the load and its wait are hand-placed (guide section 5.7):
-        // exactly one younger vector-memory op (the store) is outstanding at the wait, hence
-        // vmcnt(1); a dummy store (overwritten by the first group) makes that true on loop entry too.
+        i32 nav = r.nav, idx = r.idx;
+        const i32 nav_start = nav, idx_start = idx;
+        // The refill dwords are loaded one group ahead of their use; waits are left to the compiler.
+        // Loads and stores share vmcnt and may complete out of order, so only vmcnt(0) is safe and it
+        // also waits for stores in flight: decoded dwords therefore go to a 16-entry LDS ring owned by
+        // the lane and are written out 64 bytes at a time.
         if (i + 4 <= nout && idx >= 3) {
-            u64 wab;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wab) : "v"(w + idx - 1) : "memory");
-            asm volatile("global_store_dword %0, %1, off" : : "v"(dst + i), "v"(0u) : "memory");
+            u32 wa = w[idx], wb = w[idx - 1];
+            u32 it = 0;
+            u8* const out0 = dst + i;
             while (i + 4 <= nout && idx >= 3) {
-                asm volatile("s_waitcnt vmcnt(1)" : "+v"(wab) : : "memory");
-                const u32 wa = (u32)(wab >> 32), wb = (u32)wab;  // w[idx], w[idx-1]
                 const u32 e0 = tab[(u32)(acc >> 32) >> sh];
                 acc <<= (e0 >> 8);
                 const u32 e1 = tab[(u32)(acc >> 32) >> sh];
@@ -393,16 +393,21 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
                 acc |= f1 ? ((u64)wsel << (32 - nav)) : 0ull;
                 nav += f1 ? 32 : 0;
                 idx -= (f0 ? 1 : 0) + (f1 ? 1 : 0);
-                left -= (i32)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
-                const u32 word = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(wab) : "v"(w + idx - 1) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(dst + i), "v"(word) : "memory");
+                ring[it & 15] = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                wa = w[idx];
+                wb = w[idx - 1];
+                if ((it & 15) == 15) {
+                    u32* o = (u32*)(out0 + (size_t)(it - 15) * 4);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) o[q] = ring[q];
+                }
+                it++;
                 i += 4;
             }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(wab) : : "memory");
+            for (u32 k = it & ~15u; k < it; k++) *(u32*)(out0 + (size_t)k * 4) = ring[k & 15];
         }
-        r.pos = left;
-        pos = r.pos;
+        // exact bit position: every consumed bit left the accumulator or was replaced by a refill
+        pos = r.pos - ((nav_start - nav) + 32 * (idx_start - idx));
     }
     for (; i < nout; i++) {
         const u32 e = tab[zl_bits_bwd(src, n, pos - (i32)log, log)];
@@ -459,7 +464,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg)
             u8* out = lit + r.lit_dst;
             bool good = true;
             if (r.streams == 1) {
-                if (sub == 0) good = huf_stream2(g.tab, g.log, out, regen, hs, cs);
+                if (sub == 0) good = huf_stream2(g.tab, g.log, out, regen, hs, cs, (u32*)g.weights);
             } else if (cs < 10) {
                 good = false;
             } else {
@@ -471,7 +476,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg)
                     const u32 so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
                     const u32 sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
                     const u32 cnt = (sub == 3) ? regen - 3 * seg : seg;
-                    good = huf_stream2(g.tab, g.log, out + sub * seg, cnt, hs + 6 + so, sl);
+                    good = huf_stream2(g.tab, g.log, out + sub * seg, cnt, hs + 6 + so, sl, (u32*)g.weights + 16 * sub);
                 }
             }
             if (!good) set_err(fr, ZL_E_CORRUPTION);
@@ -484,7 +489,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg)
 // zl2_seq_kernel: one lane per frame, 16 frames per 64-lane workgroup
 // ---------------------------------------------------------------------------------------
 #define SEQ_FRAMES 16
-struct SeqLane {
+struct __align__(16) SeqLane {
     u16 cell[1280];  // LL [0,512) ML [512,1024) OF [1024,1280): [9:0] next-state base, [13:10] state bits
     u8 sym[1280];
     u16 next[64];
@@ -519,6 +524,17 @@ __device__ __forceinline__ bool build_seq_table(SeqLane& L, u32 base, int max_sy
         L.cell[base + u] = (u16)((((ns << nb) - (u32)size) & 0x3FF) | (nb << 10));
     }
     return true;
+}
+
+// Extra-bit counts of literal-length / match-length codes (zstd.c:15462-15490 LL_bits / ML_bits)
+// computed arithmetically so that the state chain does not wait for a second table lookup:
+// codes below 16 (32) carry none, the top codes carry code-19 (code-36), the nine (eleven) codes in
+// between come from a packed 3-bit-per-entry constant.
+__device__ __forceinline__ u32 ll_extra_bits(u32 s) {
+    return s < 16 ? 0u : (s >= 25 ? s - 19 : (0x46d2249u >> (3 * (s - 16))) & 7u);
+}
+__device__ __forceinline__ u32 ml_extra_bits(u32 s) {
+    return s < 32 ? 0u : (s >= 43 ? s - 36 : (u32)(0x1646d2249ull >> (3 * (s - 32))) & 7u);
 }
 
 // kind: 0 LL, 1 OF, 2 ML.  Returns bytes consumed or 0xFFFFFFFF (zstd.c:43640 ZSTD_buildSeqTable).
@@ -564,9 +580,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
     SeqLane& L = S.L[lane];
     const u8* src = a.src + a.frames[f].src_off;
     zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
-    u32* q_ll = a.seq_scratch + a.plan[f].seq_off;
-    u32* q_ml = q_ll + a.plan[f].seq_cap;
-    u32* q_off = q_ml + a.plan[f].seq_cap;
+    uint4* q_seq = (uint4*)a.seq_scratch + a.plan[f].seq_off;  // {literals before, output bytes before, offset, -}
     u32 r0 = 1, r1 = 4, r2 = 8;
     u32 ll_log = 0, ml_log = 0, of_log = 0;
     bool have_tables = false;
@@ -595,9 +609,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
         const u32 bn = sn - pos;
         i32 bp = zl_bwd_init(bs, bn);
         if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
-        u32* oll = q_ll + r.seq_dst;
-        u32* oml = q_ml + r.seq_dst;
-        u32* oof = q_off + r.seq_dst;
+        uint4* oseq = q_seq + r.seq_dst;
         const u32 nseq = r.nseq;
         u32 lit_used = 0, out_used = 0;  // running literal / output positions: what the exec kernel consumes
         u32 i = 0;
@@ -611,31 +623,29 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
             so = zl_lr_take(rd, of_log);
             sm = zl_lr_take(rd, ml_log);
             if (rd.nav <= 32) zl_lr_refill(rd);
-            // fast loop: every field group is at most 32 bits and is followed by one refill check;
-            // the (up to three) dwords an iteration may need are loaded one iteration ahead, before
-            // that iteration's stores, so the wait for them never includes a store round trip
+            // Fast loop.  The dwords a sequence may need (w[idx-3..idx]) are loaded one sequence ahead.
+            // When all fields of a sequence fit in 32 bits (the usual case) they are
+            // cut from one window with a single refill check; otherwise group by group.
             const u32* w = rd.w;
             u64 acc = rd.acc;
-            i32 nav = rd.nav, idx = rd.idx, left = rd.pos;
+            i32 nav = rd.nav, idx = rd.idx;
+            const i32 nav_start = nav, idx_start = idx;
             u32 bad = 0;
-            // w[idx-3..idx] for the next sequence are loaded before this sequence's three stores and
-            // waited for with vmcnt(3) (hand-placed, see huf_stream2); three dummy stores on entry.
             typedef u32 zl_v4u __attribute__((ext_vector_type(4)));
             zl_v4u t4 = {0, 0, 0, 0};
             const bool go = nseq > 0 && idx >= 5;
-            if (go) {
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t4) : "v"(w + idx - 3) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oll), "v"(0u) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oml), "v"(0u) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oof), "v"(0u) : "memory");
-            }
+            if (go) t4 = *(const zl_v4u*)(w + idx - 3);
+            // Records go to a 16-entry LDS ring (the lane's table-build scratch, idle by now) and are
+            // written out 256 bytes at a time.  Loads and stores share vmcnt and may complete out of
+            // order, so the wait for the refill dwords is vmcnt(0), which also waits for every store
+            // in flight: one store per sequence cost ~1 ms per 12k sequences (measured 9.6 -> 8.6 ms).
+            zl_v4u* ring = (zl_v4u*)L.next;
 #define ZL_TAKE(dst_, n_)                                              \
             {                                                            \
                 const u32 n__ = (n_);                                    \
                 dst_ = n__ ? ((u32)(acc >> 32) >> (32 - n__)) : 0u;      \
                 acc <<= n__;                                             \
                 nav -= (i32)n__;                                         \
-                left -= (i32)n__;                                        \
                 const bool f__ = nav <= 32;                              \
                 const u32 ws__ = used == 0 ? t4.w : (used == 1 ? t4.z : t4.y); \
                 acc |= f__ ? ((u64)ws__ << (32 - nav)) : 0ull;           \
@@ -643,17 +653,38 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
                 used += f__ ? 1 : 0;                                     \
             }
             for (; go && i < nseq && idx >= 5; i++) {
-                asm volatile("s_waitcnt vmcnt(3)" : "+v"(t4) : : "memory");
                 u32 used = 0;
                 const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
                 const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
-                const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
-                const u32 nl = tl >> 24, nm = tm >> 24;
-                u32 ofx, x, u = 0;
-                ZL_TAKE(ofx, yo);
-                ZL_TAKE(x, nm + nl);  // match-length bits above literal-length bits
+                const u32 nl = ll_extra_bits(yl), nm = ml_extra_bits(ym);
+                const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
+                const u32 n2 = nm + nl;
+                const u32 sb = (i + 1 < nseq) ? bl + bm + bo : 0u;
+                const u32 tot = yo + n2 + sb;
+                u32 ofx, x, u;
+                if (tot <= 32) {
+                    const u32 top = (u32)(acc >> 32);
+                    ofx = yo ? top >> (32 - yo) : 0u;
+                    x = n2 ? (top << yo) >> (32 - n2) : 0u;
+                    u = sb ? (top << (yo + n2)) >> (32 - sb) : 0u;
+                    acc <<= tot;
+                    nav -= (i32)tot;
+                    const bool f = nav <= 32;
+                    acc |= f ? ((u64)t4.w << (32 - nav)) : 0ull;
+                    nav += f ? 32 : 0;
+                    used = f ? 1u : 0u;
+                } else {
+                    ZL_TAKE(ofx, yo);
+                    ZL_TAKE(x, n2);
+                    ZL_TAKE(u, sb);
+                }
+                // next states first: they are the loop-carried chain (LL bits on top, then ML, then OF)
+                so = (co & 0x3FF) + (u & ((1u << bo) - 1));
+                sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
+                sl = (cl & 0x3FF) + (u >> (bo + bm));
+                const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];  // baselines: off the critical chain
                 const u32 ofv = (1u << yo) + ofx;
-                const u32 ml = (tm & 0xFFFFFF) + (x >> nl);
+                const u32 ml = (tm & 0xFFFFFF) + (x >> nl);  // match-length bits above literal-length bits
                 const u32 ll = (tl & 0xFFFFFF) + (x & ((1u << nl) - 1));
                 // repcode rules (zstd.c:44291-44327), branch-free
                 const bool real = ofv > 3;
@@ -665,27 +696,24 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
                 r1 = sh1 ? r0 : r1;
                 r0 = off;
                 bad |= (off == 0) ? 1u : 0u;
-                const u32 lit_here = lit_used, out_here = out_used;
+                zl_v4u rec = {lit_used, out_used, off, 0u};
                 lit_used += ll;
                 out_used += ll + ml;
                 bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
-                if (i + 1 < nseq) {
-                    const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
-                    ZL_TAKE(u, bl + bm + bo);  // LL bits on top, then ML, then OF
-                    so = (co & 0x3FF) + (u & ((1u << bo) - 1));
-                    sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
-                    sl = (cl & 0x3FF) + (u >> (bo + bm));
-                }
                 idx -= (i32)used;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t4) : "v"(w + idx - 3) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oll + i), "v"(lit_here) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oml + i), "v"(out_here) : "memory");
-                asm volatile("global_store_dword %0, %1, off" : : "v"(oof + i), "v"(off) : "memory");
+                ring[i & 15] = rec;
+                t4 = *(const zl_v4u*)(w + idx - 3);
+                if ((i & 15) == 15) {
+                    zl_v4u* o = (zl_v4u*)(oseq + (i - 15));
+#pragma unroll
+                    for (int q = 0; q < 16; q++) o[q] = ring[q];
+                }
             }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t4) : : "memory");
+            for (u32 k = i & ~15u; k < i; k++) { const zl_v4u v = ring[k & 15]; oseq[k] = make_uint4(v.x, v.y, v.z, v.w); }
 #undef ZL_TAKE
             if (bad) { fr->err = ZL_E_CORRUPTION; return; }
-            rd.pos = left;
+            // exact bit position: every consumed bit left the accumulator or was replaced by a refill
+            rd.pos -= (nav_start - nav) + 32 * (idx_start - idx);
             // hand the exact bit position to the generic tail
             bp = rd.pos;
             if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
@@ -725,7 +753,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
                     r0 = off;
                 }
             }
-            oll[i] = lit_used; oml[i] = out_used; oof[i] = off;
+            oseq[i] = make_uint4(lit_used, out_used, off, 0u);
             lit_used += ll;
             out_used += ll + ml;
             if (out_used > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
@@ -744,9 +772,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg
         }
         if (bp != 0) { fr->err = ZL_E_CORRUPTION; return; }  // zstd.c:44690
         if (lit_used > r.lit_size) { fr->err = ZL_E_CORRUPTION; return; }
-        oll[nseq] = lit_used;  // sentinel: totals of the block
-        oml[nseq] = out_used;
-        oof[nseq] = 1;
+        oseq[nseq] = make_uint4(lit_used, out_used, 1u, 0u);  // sentinel: totals of the block
     }
 }
 
@@ -821,9 +847,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
     const u64 cap = fd.dst_cap;
     const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
     const u8* lit_base = a.lit_scratch + a.plan[f].lit_off;
-    const u32* q_ll = a.seq_scratch + a.plan[f].seq_off;
-    const u32* q_ml = q_ll + a.plan[f].seq_cap;
-    const u32* q_off = q_ml + a.plan[f].seq_cap;
+    const uint4* q_seq = (const uint4*)a.seq_scratch + a.plan[f].seq_off;
     if (t == 0) S.err = 0;
     __syncthreads();
     u64 op = 0;
@@ -845,9 +869,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         const u32 rle_byte = r.lit_a & 0xFF;
         const u8* lit = (r.lit_mode == 0) ? (blk + r.lit_a) : (lit_base + r.lit_dst);
         const u32 nseq = r.nseq, lit_size = r.lit_size;
-        const u32* sll = q_ll + r.seq_dst;  // literals before sequence i
-        const u32* sml = q_ml + r.seq_dst;  // output bytes before sequence i (entry nseq: totals)
-        const u32* sof = q_off + r.seq_dst;
+        const uint4* sq = q_seq + r.seq_dst;  // {literals before sequence i, output bytes before it, offset}; entry nseq: totals
         const u64 cap_left = cap - op;
         u32 lit_pos = 0, out_pos = 0;
         u64 c_scan = 0, c_lit = 0, c_match = 0, c_batches = 0;
@@ -855,7 +877,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         // the first window's entries; every later window is fetched into registers while the previous
         // batch is being executed (its first index is known as soon as that batch's size is)
         u32 pf_out = 0, pf_lit = 0, pf_off = 1;
-        if (t <= nseq && t <= EX_MAXSEQ) { pf_out = sml[t]; pf_lit = sll[t]; pf_off = sof[t]; }
+        if (t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[t]; pf_lit = e.x; pf_out = e.y; pf_off = e.z; }
         for (u32 b0 = 0; b0 < nseq;) {
             const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             const u32 window = (nseq - b0 < EX_MAXSEQ) ? (nseq - b0) : EX_MAXSEQ;
@@ -877,7 +899,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
             const bool linked = tot_o <= EX_CAP;  // otherwise: one long sequence, every byte resolves in one hop
             {   // prefetch the next window (entries b0+nb .. b0+nb+EX_MAXSEQ, sentinel included)
                 const u32 nb0 = b0 + nb;
-                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { pf_out = sml[nb0 + t]; pf_lit = sll[nb0 + t]; pf_off = sof[nb0 + t]; }
+                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[nb0 + t]; pf_lit = e.x; pf_out = e.y; pf_off = e.z; }
             }
             if (t < nb) {
                 const u32 my_out = S.b_out[t], my_lit = S.b_lit[t];

@@ -14,7 +14,7 @@
 
 struct zl2_frame_plan {     // per frame, computed on the host from the frame table
     u64 lit_off;            // byte offset of the frame's literal scratch
-    u64 seq_off;            // u32 offset of the frame's sequence scratch (3 arrays of seq_cap)
+    u64 seq_off;            // index of the frame's first 16-byte sequence record
     u32 lit_cap;            // bytes
     u32 seq_cap;            // sequences
     u32 route;              // 1 = lane-parallel pipeline, 0 = general kernel
