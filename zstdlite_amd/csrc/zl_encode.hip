@@ -397,13 +397,29 @@ struct FseCTable {   // encoding side of one FSE table (zstd.c:15917 FSE_buildCT
 };
 
 struct EntShared {
-    u32 hist[4][256];
+    // Two 4 KiB regions are shared by arrays with disjoint lifetimes (LDS per workgroup decides how
+    // many chunks a CU works on at once): the literal histograms die when the Huffman decision is
+    // made, the per-tile sequence arrays are born afterwards; the Huffman tree nodes die before the
+    // first stream is coded, the bit-staging words are (re)zeroed right then.  Both regions are dead
+    // when the XXH64 tile (first 8 KiB) is used at the very end.
+    union {
+        u32 hist[4][256];
+        struct {
+            u8 code[3][SEQ_TILE];
+            u32 stbits[3][SEQ_TILE];  // [15:0] value, [23:16] nbits
+        };
+    };
+    union {
+        u32 stage[1024];  // bit staging: sequences use [0,640), Huffman wave w uses [256w, 256w+256)
+        struct {
+            u32 node_w[512];
+            u16 node_parent[512];
+            u8 node_depth[512];
+        };
+    };
     u8 hlen[256];
     u16 hcode[256];
     u16 sorted[256];
-    u32 node_w[512];
-    u16 node_parent[512];
-    u8 node_depth[512];
     u8 weights[256];
     short norm[64];
     u8 tsym[512];
@@ -413,9 +429,6 @@ struct EntShared {
     u16 wstate[64];   // Huffman-weight FSE
     i32 wdnb[16], wdfs[16];
     u32 seq_hist[3][64];
-    u8 code[3][SEQ_TILE];
-    u32 stbits[3][SEQ_TILE];  // [15:0] value, [23:16] nbits
-    u32 stage[1024];          // bit staging: sequences use [0,640), Huffman wave w uses [256w, 256w+256)
     u32 scan_a[4], scan_b[4];
     u64 xxh_acc[4];
     u32 stream_bits[4];
@@ -430,7 +443,7 @@ struct EntShared {
     u32 fail;
 };
 enum { T_LL = 0, T_OF = 1, T_ML = 2 };
-static_assert(offsetof(EntShared, node_depth) >= 8192, "XXH64 tile aliases the literal-stage arrays");
+static_assert(offsetof(EntShared, hlen) >= 8192, "the XXH64 tile aliases the two shared 4 KiB regions");
 
 // serial LSB-first bit writer used by the table-description writers (one thread)
 struct BitW {
@@ -759,7 +772,7 @@ __device__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
     return pos;
 }
 
-__global__ __launch_bounds__(ENC_THREADS) void zl_entropy_kernel(zl_entropy_args a) {
+__global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a) {
     __shared__ EntShared S;
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const u32 c = blockIdx.x;
@@ -874,6 +887,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_entropy_kernel(zl_entropy_args
         __syncthreads();
     }
     if (S.lit_mode == 2) {
+        // the tree nodes shared this region: staging words must be zero before bits are OR-ed in
+        for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
+        __syncthreads();
         const u32 tree = S.tree_size;
         u8* p = blk + lhs_c + tree;
         if (t == 0) {
