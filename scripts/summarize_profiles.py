@@ -19,8 +19,8 @@ os.makedirs(P, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(G, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(G, pattern)), key=os.path.getmtime)
+    return f[-1] if f else None  # newest run
 
 
 stats = one("prof_bench/*/*kernel_stats.csv")
