@@ -112,3 +112,80 @@ def test_c2_shape_many_64k_frames(ref):
         plains.append(data)
     assert z.zstd_decompress(b"".join(frames)) == b"".join(plains)
     assert z.zstd_decompress_batch(frames) == plains
+
+
+def _ref_stream_frame(ref, pieces, level=3, pledged=True):
+    """One frame, one block per piece: the reference's streaming entry with ZSTD_e_flush between
+    pieces (what src/raw-file-out.c does) -- gives multi-block frames whose later blocks reuse the
+    entropy tables (repeat / treeless modes) and copy from earlier blocks."""
+    import ctypes as C
+
+    class Buf(C.Structure):
+        _fields_ = [("p", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+
+    L = ref.L
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.POINTER(Buf), C.POINTER(Buf), C.c_int]
+    L.ZSTD_CCtx_setPledgedSrcSize.restype = C.c_size_t
+    L.ZSTD_CCtx_setPledgedSrcSize.argtypes = [C.c_void_p, C.c_ulonglong]
+    cctx = L.ZSTD_createCCtx()
+    L.ZSTD_CCtx_setParameter(cctx, 100, level)
+    total = sum(len(p) for p in pieces)
+    if pledged:
+        L.ZSTD_CCtx_setPledgedSrcSize(cctx, total)
+    cap = L.ZSTD_compressBound(total) + 64 * len(pieces)
+    dst = C.create_string_buffer(cap)
+    ob = Buf(C.cast(dst, C.c_void_p), cap, 0)
+    for i, piece in enumerate(pieces):
+        src = C.create_string_buffer(bytes(piece), len(piece))
+        ib = Buf(C.cast(src, C.c_void_p), len(piece), 0)
+        mode = 2 if i == len(pieces) - 1 else 1  # ZSTD_e_end / ZSTD_e_flush
+        while True:
+            r = L.ZSTD_compressStream2(cctx, C.byref(ob), C.byref(ib), mode)
+            assert not L.ZSTD_isError(r)
+            if r == 0 and ib.pos == ib.size:
+                break
+    L.ZSTD_freeCCtx(cctx)
+    return dst.raw[:ob.pos]
+
+
+def test_multiblock_frames_with_repeated_tables(ref, oracle):
+    """Frames of <= 128 KiB made of several blocks go through the lane-parallel pipeline with
+    table reuse and cross-block matches; larger ones and those without a recorded size through the
+    general kernel.  Both must equal the plaintext (and the oracle)."""
+    from zl_testlib import GENERATORS
+    text = GENERATORS["text"](120000, seed=9)
+    iid = GENERATORS["iid10"](60000, seed=9)
+    cases = [
+        [text[i:i + 30000] for i in range(0, 120000, 30000)],             # 4 blocks, same statistics -> repeat modes
+        [text[:20000], text[:20000], text[5000:25000]],                    # later blocks are copies of earlier ones
+        [iid[:10000], text[:10000], iid[10000:30000], text[10000:30000]],  # alternating statistics
+        [text[i:i + 9000] for i in range(0, 90000, 9000)],                 # 10 blocks: more than the pipeline takes -> handed back
+        [text[:70000], iid, text[70000:]],                                 # > 128 KiB -> general kernel
+    ]
+    for pieces in cases:
+        plain = b"".join(pieces)
+        for pledged in (True, False):
+            frame = _ref_stream_frame(ref, pieces, pledged=pledged)
+            assert oracle.decompress(frame, cap=len(plain)) == plain
+            if pledged:
+                assert z.zstd_decompress(frame) == plain
+            else:  # no recorded size: the C-ABI decodes into whatever capacity the caller gives
+                import ctypes as C
+                L = _lib.lib()
+                dctx = z.zstd_dctx()
+                dst = np.empty(len(plain) + 100, dtype=np.uint8)
+                r = L.zl_decompressDCtx(dctx._ptr, dst.ctypes.data_as(C.c_void_p), dst.size, frame, len(frame))
+                assert not is_error(r), _lib.error_name(r)
+                assert dst[:r].tobytes() == plain
+    # two such frames concatenated, second one without size
+    a = _ref_stream_frame(ref, cases[0], pledged=True)
+    b = _ref_stream_frame(ref, cases[2], pledged=False)
+    import ctypes as C
+    L = _lib.lib()
+    want = b"".join(cases[0]) + b"".join(cases[2])
+    dst = np.empty(len(want), dtype=np.uint8)
+    dctx = z.zstd_dctx()  # keep the context alive for the call
+    r = L.zl_decompressDCtx(dctx._ptr, dst.ctypes.data_as(C.c_void_p), dst.size, a + b, len(a) + len(b))
+    assert not is_error(r), _lib.error_name(r)
+    assert dst[:r].tobytes() == want
