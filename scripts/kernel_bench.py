@@ -32,4 +32,7 @@ for kind in kinds:
     if st[13]:
         nb = st[13]
         print(f"        exec phases, kcycles/block: scan {st[8]/nb/1e3:.0f}  lit {st[9]/nb/1e3:.0f}  match {st[10]/nb/1e3:.0f}  flush {st[11]/nb/1e3:.0f}  batches/block {st[12]/nb:.1f}")
+    if st[14]:
+        nwg = (n + (128 << 10) - 1) // (128 << 10) / 16
+        print(f"        entropy roles, kcycles/workgroup: literals {st[14]/nwg/1e3:.0f}  sequences {st[15]/nwg/1e3:.0f}")
     print(f"{kind:6s} ratio {n/total:6.3f} | " + " ".join(f"{k} {v:7.3f}ms ({gb/(v/1e3):7.1f} GB/s)" for k, v in best.items()), flush=True)

@@ -384,7 +384,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         p.lit_off = lit_total;
         p.seq_off = seq_total;
         p.lit_cap = fast ? (u32)((tbl[i].dst_cap + 3 + 4 * ZL2_MAXB) & ~(u64)3) : 0;
-        p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2 + ZL2_MAXB) : 0;  // + one totals sentinel per block
+        p.seq_cap = fast ? (u32)(tbl[i].dst_cap / 3 + 2 + 2 * ZL2_MAXB) : 0;  // + totals and final-repcode records per block
         lit_total += (p.lit_cap + 15) & ~15u;
         seq_total += (u64)p.seq_cap;  // 16-byte records
         if (!fast) nslow++;

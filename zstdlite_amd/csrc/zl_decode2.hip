@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
         zl2_blk_rec r;
         r.type = type; r.size = bsize; r.src_off = pos;
         r.lit_mode = 0; r.lit_size = 0; r.lit_a = 0; r.lit_b = 0; r.seq_off = 0; r.seq_len = 0;
-        r.lit_dst = lit_total; r.seq_dst = seq_total; r.nseq = 0; r.streams = 0;
+        r.lit_dst = lit_total; r.seq_dst = seq_total; r.nseq = 0; r.streams = 0; r.seq_modes = 0; r.pad[0] = 0; r.pad[1] = 0;
         if (type == 2) {
             if (bsize > ZL_BLOCK_MAX) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
             const u8* blk = src + pos;
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
             }
             if (nseq == 0 && sh != sn) { fr->err = ZL_E_CORRUPTION; return; }
             r.nseq = nseq; r.seq_off = lsec + sh; r.seq_len = sn - sh;
-            seq_total += nseq + 1;  // + the totals sentinel zl2_seq_kernel appends
+            r.seq_modes = (nseq && sn > sh) ? sp[sh] : 0x100u;
+            seq_total += nseq + 2;  // + the totals and final-repcode records the sequence lanes append
         } else {
             if ((u64)bsize > fd.dst_cap) { fr->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
         }
@@ -223,25 +224,30 @@ __device__ __forceinline__ u32 read_ncount2(NormPtr norm, int* max_sym_io, int* 
 // ---------------------------------------------------------------------------------------
 // zl2_lit_kernel: 64 lanes = 16 frames x 4 Huffman streams
 // ---------------------------------------------------------------------------------------
-#define LIT_FRAMES 16
+#define LIT_FRAMES ZL2_WG_FRAMES
+#define LIT_LANES (ZL2_MAXB * 4)            // stream lanes per frame
+#define LIT_THREADS (LIT_FRAMES * LIT_LANES)
 struct LitGroup {
     u16 tab[2048];   // [7:0] symbol, [15:8] code length
-    u8 weights[256];
+    u32 ring[16 * LIT_LANES];  // 16 output dwords per stream lane, slot-major; the first 256 bytes hold the weights while a table is built
     u32 wfse[64];    // weight FSE cells: [15:0] base, [23:16] nbits, [31:24] symbol
     short norm[16];
     u16 next[16];
     u8 cellsym[64];
     u32 rank_start[16];
     u32 log;
-    u32 ok;          // table usable for "treeless" blocks
-    u32 pad[2];      // keeps the group size a multiple of 16 (weights[] doubles as a 16-byte-aligned ring)
+    u32 ok;          // table usable by the blocks that follow it
+    u32 tree;        // size of the tree description of the block that brought the table
+    u32 pad;
 };
 static_assert(sizeof(LitGroup) % 16 == 0, "LitGroup must stay 16-byte aligned");
+static_assert(sizeof(u32) * 16 * LIT_LANES >= 256, "the ring region doubles as weights[256]");
 
 // Huffman tree description -> g.tab (zstd.c:3470 HUF_readStats_body, zstd.c:38436
 // HUF_readDTableX1_wksp).  One lane.  Returns bytes consumed, 0 on error, 0xFFFFFFFF when the
 // table needs 12 bits (handled by the general kernel).
 __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n) {
+    u8* const weights = (u8*)g.ring;
     if (n < 1) return 0;
     int nsym = 0;
     u32 used;
@@ -252,7 +258,7 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
         if (used > n) return 0;
         for (int i = 0; i < nsym; i++) {
             const u8 b = src[1 + i / 2];
-            g.weights[i] = (i & 1) ? (b & 15) : (b >> 4);
+            weights[i] = (i & 1) ? (b & 15) : (b >> 4);
         }
     } else {
         used = 1 + hb;
@@ -293,24 +299,24 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
         for (;;) {
             if (nsym > 253) return 0;
             u32 e = g.wfse[s1];
-            g.weights[nsym++] = (u8)(e >> 24);
+            weights[nsym++] = (u8)(e >> 24);
             u32 nb = (e >> 16) & 0xFF;
             bp -= (i32)nb;
             s1 = (e & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
-            if (bp < 0) { g.weights[nsym++] = (u8)(g.wfse[s2] >> 24); break; }
+            if (bp < 0) { weights[nsym++] = (u8)(g.wfse[s2] >> 24); break; }
             if (nsym > 253) return 0;
             e = g.wfse[s2];
-            g.weights[nsym++] = (u8)(e >> 24);
+            weights[nsym++] = (u8)(e >> 24);
             nb = (e >> 16) & 0xFF;
             bp -= (i32)nb;
             s2 = (e & 0xFFFF) + zl_bits_bwd(bs, bn, bp, nb);
-            if (bp < 0) { g.weights[nsym++] = (u8)(g.wfse[s1] >> 24); break; }
+            if (bp < 0) { weights[nsym++] = (u8)(g.wfse[s1] >> 24); break; }
         }
     }
     u32 total = 0;
     for (int w = 0; w < 16; w++) g.rank_start[w] = 0;
     for (int i = 0; i < nsym; i++) {
-        const u32 w = g.weights[i];
+        const u32 w = weights[i];
         if (w > ZL_HUF_LOG_MAX) return 0;
         g.rank_start[w]++;
         if (w) total += 1u << (w - 1);
@@ -321,7 +327,7 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
     const u32 rest = (1u << log) - total;
     if (rest & (rest - 1)) return 0;
     const u32 last_w = 32 - __clz(rest);
-    g.weights[nsym++] = (u8)last_w;
+    weights[nsym++] = (u8)last_w;
     g.rank_start[last_w]++;
     if (g.rank_start[1] < 2 || (g.rank_start[1] & 1)) return 0;  // zstd.c:3549
     if (log > 11) return 0xFFFFFFFFu;
@@ -333,7 +339,7 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
         cell += c << (w - 1);
     }
     for (int s = 0; s < nsym; s++) {
-        const u32 w = g.weights[s];
+        const u32 w = weights[s];
         if (!w) continue;
         const u32 cnt = 1u << (w - 1);
         const u32 start = g.rank_start[w];
@@ -348,7 +354,7 @@ __device__ __forceinline__ u32 build_huf_table(LitGroup& g, const u8* src, u32 n
 // one backward Huffman stream on one lane (zstd.c:38560).  Main loop: left-aligned accumulator,
 // two symbols per refill check, four symbols per dword store, no branches; the last few symbols
 // (and short streams) go through the generic reader so that the end-of-stream test stays exact.
-__device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u32 nout, const u8* src, u32 n, u32* ring /* 16 dwords of LDS owned by this lane */) {
+__device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u32 nout, const u8* src, u32 n, u32* ring /* this lane's 16 LDS dwords, LIT_LANES apart */) {
     i32 pos = zl_bwd_init(src, n);
     if (pos < 0) return false;
     u32 i = 0;
@@ -393,18 +399,18 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
                 acc |= f1 ? ((u64)wsel << (32 - nav)) : 0ull;
                 nav += f1 ? 32 : 0;
                 idx -= (f0 ? 1 : 0) + (f1 ? 1 : 0);
-                ring[it & 15] = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                ring[(it & 15) * LIT_LANES] = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
                 wa = w[idx];
                 wb = w[idx - 1];
                 if ((it & 15) == 15) {
                     u32* o = (u32*)(out0 + (size_t)(it - 15) * 4);
 #pragma unroll
-                    for (int q = 0; q < 16; q++) o[q] = ring[q];
+                    for (int q = 0; q < 16; q++) o[q] = ring[q * LIT_LANES];
                 }
                 it++;
                 i += 4;
             }
-            for (u32 k = it & ~15u; k < it; k++) *(u32*)(out0 + (size_t)k * 4) = ring[k & 15];
+            for (u32 k = it & ~15u; k < it; k++) *(u32*)(out0 + (size_t)k * 4) = ring[(k & 15) * LIT_LANES];
         }
         // exact bit position: every consumed bit left the accumulator or was replaced by a refill
         pos = r.pos - ((nav_start - nav) + 32 * (idx_start - idx));
@@ -417,54 +423,64 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
     return pos == 0;  // zstd.c:38640 BIT_endOfDStream
 }
 
-__device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg) {
-    const u32 lane = threadIdx.x, grp = lane >> 2, sub = lane & 3;
+// One lane per (frame, block, stream).  A block that brings a tree is the "leader" of the treeless
+// blocks behind it; leaders are processed in block order (round r builds block r's table, then every
+// lane whose leader is r decodes), so frames whose blocks share one table -- everything the HIP
+// encoder writes -- finish in one round with all lanes busy.
+__device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32* rounds, u32 wg) {
+    const u32 t = threadIdx.x;
+    const u32 sub = t & 3, grp = (t >> 2) % LIT_FRAMES, b = t / (4 * LIT_FRAMES);
     const u32 f = wg * LIT_FRAMES + grp;
-    const bool live = f < a.nframes;
     LitGroup& g = G[grp];
-    if (sub == 0) g.ok = 0;
-    u32 nblocks = 0;
+    if (t < LIT_FRAMES) G[t].ok = 0;
+    if (t == 0) *rounds = 0;
+    __syncthreads();
+    bool active = false;
+    int lb = -1;
+    zl2_blk_rec r;
+    r.type = 0;
     const u8* src = nullptr;
     u8* lit = nullptr;
-    const zl2_blk_rec* br = nullptr;
     zl2_frame_rec* fr = nullptr;
-    if (live) {
+    if (f < a.nframes) {
         fr = a.frec + f;
-        if (fr->err == 0 && !fr->skippable) nblocks = fr->nblocks;
-        src = a.src + a.frames[f].src_off;
-        lit = a.lit_scratch + a.plan[f].lit_off;
-        br = a.brec + (size_t)f * ZL2_MAXB;
-    }
-    for (u32 b = 0; b < ZL2_MAXB; b++) {
-        bool active = false;
-        zl2_blk_rec r;
+        const u32 nblocks = (fr->err == 0 && !fr->skippable) ? fr->nblocks : 0;
         if (b < nblocks) {
+            const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
+            src = a.src + a.frames[f].src_off;
+            lit = a.lit_scratch + a.plan[f].lit_off;
+            for (u32 k = 0; k <= b; k++)
+                if (br[k].type == 2 && br[k].lit_mode == 2) lb = (int)k;
             r = br[b];
             active = (r.type == 2 && r.lit_mode >= 2);
+            if (active && lb < 0) { set_err(fr, ZL_E_DICT_CORRUPTED); active = false; }  // treeless block without a previous table (zstd.c:43171)
         }
-        u32 tree = 0;
-        if (active && sub == 0) {
+    }
+    if (active) atomicOr(rounds, 1u << lb);
+    __syncthreads();
+    const u32 mask = *rounds;
+    for (u32 round = 0; round < ZL2_MAXB; round++) {
+        if (!((mask >> round) & 1)) continue;
+        const bool mine = active && lb == (int)round;
+        if (mine && b == round && sub == 0) {
             const u8* blk = src + r.src_off;
-            if (r.lit_mode == 2) {
-                tree = build_huf_table(g, blk + r.lit_a, r.lit_b);
-                if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); tree = 0; g.ok = 0; }
-                else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
-                else g.ok = 1;
-            } else if (!g.ok) {
-                set_err(fr, ZL_E_DICT_CORRUPTED);  // treeless block without a previous table (zstd.c:43171)
-            }
-            g.rank_start[15] = tree;
+            u32 tree = build_huf_table(g, blk + r.lit_a, r.lit_b);
+            if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); tree = 0; g.ok = 0; }
+            else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
+            else g.ok = 1;
+            g.tree = tree;
         }
         __syncthreads();
-        if (active && g.ok && fr->err == 0) {
-            tree = g.rank_start[15];
+        if (mine && g.ok && fr->err == 0) {
+            const u32 tree = (b == round) ? g.tree : 0u;
             const u8* blk = src + r.src_off;
             const u8* hs = blk + r.lit_a + tree;
             const u32 cs = r.lit_b - tree, regen = r.lit_size;
             u8* out = lit + r.lit_dst;
+            u32* ring = g.ring + (b * 4 + sub);
             bool good = true;
             if (r.streams == 1) {
-                if (sub == 0) good = huf_stream2(g.tab, g.log, out, regen, hs, cs, (u32*)g.weights);
+                if (sub == 0) good = huf_stream2(g.tab, g.log, out, regen, hs, cs, ring);
             } else if (cs < 10) {
                 good = false;
             } else {
@@ -476,7 +492,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg)
                     const u32 so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
                     const u32 sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
                     const u32 cnt = (sub == 3) ? regen - 3 * seg : seg;
-                    good = huf_stream2(g.tab, g.log, out + sub * seg, cnt, hs + 6 + so, sl, (u32*)g.weights + 16 * sub);
+                    good = huf_stream2(g.tab, g.log, out + sub * seg, cnt, hs + 6 + so, sl, ring);
                 }
             }
             if (!good) set_err(fr, ZL_E_CORRUPTION);
@@ -488,7 +504,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroup* G, u32 wg)
 // ---------------------------------------------------------------------------------------
 // zl2_seq_kernel: one lane per frame, 16 frames per 64-lane workgroup
 // ---------------------------------------------------------------------------------------
-#define SEQ_FRAMES 16
+#define SEQ_FRAMES ZL2_WG_FRAMES
 struct __align__(16) SeqLane {
     u16 cell[1280];  // LL [0,512) ML [512,1024) OF [1024,1280): [9:0] next-state base, [13:10] state bits
     u8 sym[1280];
@@ -496,10 +512,18 @@ struct __align__(16) SeqLane {
     short norm[64];
 };
 struct SeqShared {
-    SeqLane L[SEQ_FRAMES];
+    SeqLane L[SEQ_FRAMES];     // one table set per frame, shared by the lanes of its blocks
+    uint4 ring[16][64];        // 16 finished records per lane, slot-major (conflict-free)
+    u32 logs[SEQ_FRAMES][4];   // table logs LL, OF, ML of the frame's current tables; [3]: 0 none yet, 1 valid, 2 broken
     u32 ll_tab[36];  // [23:0] baseline, [31:24] extra bits
     u32 ml_tab[53];
 };
+// Repcode history of a block that is decoded before its predecessor has finished: the three
+// unknown start values travel as symbols, 0x80000000 | k + 4 * (times "minus one" was applied)
+// (zstd.c:44291-44327 only copies history entries around and, for offset code 3 with no literals,
+// subtracts one).  zl2_exec_kernel, which walks the blocks in order, puts the numbers in.
+#define ZL2_REP_SYM 0x80000000u
+__device__ __forceinline__ u32 rep_minus1(u32 r) { return (r >> 31) ? r + 4 : r - 1; }
 
 // zstd.c:43497-43600 ZSTD_buildFSETable_body, compact cells.  One lane.
 __device__ __forceinline__ bool build_seq_table(SeqLane& L, u32 base, int max_sym, int log) {
@@ -568,215 +592,264 @@ __device__ __forceinline__ u32 read_seq_table2(SeqLane& L, int kind, int mode, c
     return have_prev ? 0 : 0xFFFFFFFFu;
 }
 
-__device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32 wg) {
-    const u32 lane = threadIdx.x;
-    if (lane < 36) S.ll_tab[lane] = k_LL_base[lane] | ((u32)k_LL_bits[lane] << 24);
-    if (lane < 53) S.ml_tab[lane] = k_ML_base[lane] | ((u32)k_ML_bits[lane] << 24);
-    __syncthreads();
-    const u32 f = wg * SEQ_FRAMES + lane;
-    if (lane >= SEQ_FRAMES || f >= a.nframes) return;
-    zl2_frame_rec* fr = a.frec + f;
-    if (fr->err || fr->skippable) return;
-    SeqLane& L = S.L[lane];
-    const u8* src = a.src + a.frames[f].src_off;
-    zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
-    uint4* q_seq = (uint4*)a.seq_scratch + a.plan[f].seq_off;  // {literals before, output bytes before, offset, -}
-    u32 r0 = 1, r1 = 4, r2 = 8;
-    u32 ll_log = 0, ml_log = 0, of_log = 0;
-    bool have_tables = false;
-    const u32 nblocks = fr->nblocks;
-    for (u32 b = 0; b < nblocks; b++) {
-        const zl2_blk_rec r = br[b];
-        if (r.type != 2 || r.nseq == 0) continue;
-        const u8* sp = src + r.src_off + r.seq_off;
-        const u32 sn = r.seq_len;
-        if (sn < 1) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
-        const u32 modes = sp[0];
-        if (modes & 3) { fr->err = ZL_E_CORRUPTION; return; }
-        u32 pos = 1;
-        u32 used = read_seq_table2(L, 0, modes >> 6, sp + pos, sn - pos, &ll_log, have_tables);
-        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
-        pos += used;
-        used = read_seq_table2(L, 1, (modes >> 4) & 3, sp + pos, sn - pos, &of_log, have_tables);
-        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
-        pos += used;
-        used = read_seq_table2(L, 2, (modes >> 2) & 3, sp + pos, sn - pos, &ml_log, have_tables);
-        if (used == 0xFFFFFFFFu) { fr->err = ZL_E_CORRUPTION; return; }
-        pos += used;
-        have_tables = true;
-        // ---- the 3-state chain (zstd.c:44241-44356)
-        const u8* bs = sp + pos;
-        const u32 bn = sn - pos;
-        i32 bp = zl_bwd_init(bs, bn);
-        if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
-        uint4* oseq = q_seq + r.seq_dst;
-        const u32 nseq = r.nseq;
-        u32 lit_used = 0, out_used = 0;  // running literal / output positions: what the exec kernel consumes
-        u32 i = 0;
-        u32 sl, so, sm;
-        bool fast = bp >= 128;
-        zl_lreader rd;
-        if (fast) {
-            zl_lr_open(rd, bs, bn, bp);
-            sl = zl_lr_take(rd, ll_log);
-            if (rd.nav <= 32) zl_lr_refill(rd);
-            so = zl_lr_take(rd, of_log);
-            sm = zl_lr_take(rd, ml_log);
-            if (rd.nav <= 32) zl_lr_refill(rd);
-            // Fast loop.  The dwords a sequence may need (w[idx-3..idx]) are loaded one sequence ahead;
-            // fields are cut group by group (offset bits | length bits | state bits), one refill check
-            // after each.  (Cutting all three from one window when they fit 32 bits was measured: the
-            // extra divergent path made the loop 9 % slower.)
-            const u32* w = rd.w;
-            u64 acc = rd.acc;
-            i32 nav = rd.nav, idx = rd.idx;
-            const i32 nav_start = nav, idx_start = idx;
-            u32 bad = 0;
-            typedef u32 zl_v4u __attribute__((ext_vector_type(4)));
-            zl_v4u t4 = {0, 0, 0, 0};
-            const bool go = nseq > 0 && idx >= 5;
-            if (go) t4 = *(const zl_v4u*)(w + idx - 3);
-            // Records go to a 16-entry LDS ring (the lane's table-build scratch, idle by now) and are
-            // written out 256 bytes at a time.  Loads and stores share vmcnt and may complete out of
-            // order, so the wait for the refill dwords is vmcnt(0), which also waits for every store
-            // in flight: one store per sequence cost ~1 ms per 12k sequences (measured 9.6 -> 8.6 ms).
-            zl_v4u* ring = (zl_v4u*)L.next;
+// The 3-state chain of one block on one lane (zstd.c:44241-44356).  Returns 0 or an error code.
+__device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lane, const zl2_blk_rec& r, const u8* sp, u32 pos,
+                                         u32 ll_log, u32 of_log, u32 ml_log, bool symbolic, uint4* oseq) {
+    u32 r0 = symbolic ? ZL2_REP_SYM : 1u, r1 = symbolic ? (ZL2_REP_SYM | 1u) : 4u, r2 = symbolic ? (ZL2_REP_SYM | 2u) : 8u;
+    // ---- the 3-state chain (zstd.c:44241-44356)
+    const u8* bs = sp + pos;
+    const u32 bn = r.seq_len - pos;
+    i32 bp = zl_bwd_init(bs, bn);
+    if (bp < 0) return ZL_E_CORRUPTION;
+    const u32 nseq = r.nseq;
+    u32 lit_used = 0, out_used = 0;  // running literal / output positions: what the exec kernel consumes
+    u32 i = 0;
+    u32 sl, so, sm;
+    bool fast = bp >= 128;
+    zl_lreader rd;
+    if (fast) {
+        zl_lr_open(rd, bs, bn, bp);
+        sl = zl_lr_take(rd, ll_log);
+        if (rd.nav <= 32) zl_lr_refill(rd);
+        so = zl_lr_take(rd, of_log);
+        sm = zl_lr_take(rd, ml_log);
+        if (rd.nav <= 32) zl_lr_refill(rd);
+        // Fast loop.  The dwords a sequence may need (w[idx-3..idx]) are loaded one sequence ahead;
+        // fields are cut group by group (offset bits | length bits | state bits), one refill check
+        // after each.  (Cutting all three from one window when they fit 32 bits was measured: the
+        // extra divergent path made the loop 9 % slower.)
+        const u32* w = rd.w;
+        u64 acc = rd.acc;
+        i32 nav = rd.nav, idx = rd.idx;
+        const i32 nav_start = nav, idx_start = idx;
+        u32 bad = 0;
+        typedef u32 zl_v4u __attribute__((ext_vector_type(4)));
+        zl_v4u t4 = {0, 0, 0, 0};
+        const bool go = nseq > 0 && idx >= 5;
+        if (go) t4 = *(const zl_v4u*)(w + idx - 3);
+        // Records go to a 16-entry LDS ring and are
+        // written out 256 bytes at a time.  Loads and stores share vmcnt and may complete out of
+        // order, so the wait for the refill dwords is vmcnt(0), which also waits for every store
+        // in flight: one store per sequence cost ~1 ms per 12k sequences (measured 9.6 -> 8.6 ms).
+        zl_v4u* ring = (zl_v4u*)&S.ring[0][lane];
 #define ZL_TAKE(dst_, n_)                                              \
-            {                                                            \
-                const u32 n__ = (n_);                                    \
-                dst_ = n__ ? ((u32)(acc >> 32) >> (32 - n__)) : 0u;      \
-                acc <<= n__;                                             \
-                nav -= (i32)n__;                                         \
-                const bool f__ = nav <= 32;                              \
-                const u32 ws__ = used == 0 ? t4.w : (used == 1 ? t4.z : t4.y); \
-                acc |= f__ ? ((u64)ws__ << (32 - nav)) : 0ull;           \
-                nav += f__ ? 32 : 0;                                     \
-                used += f__ ? 1 : 0;                                     \
-            }
-            for (; go && i < nseq && idx >= 5; i++) {
-                u32 used = 0;
-                const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
-                const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
-                const u32 nl = ll_extra_bits(yl), nm = ml_extra_bits(ym);
-                const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
-                const u32 n2 = nm + nl;
-                const u32 sb = (i + 1 < nseq) ? bl + bm + bo : 0u;
-                u32 ofx, x, u;
-                {
-                    ZL_TAKE(ofx, yo);
-                    ZL_TAKE(x, n2);
-                    ZL_TAKE(u, sb);
-                }
-                // next states first: they are the loop-carried chain (LL bits on top, then ML, then OF)
-                so = (co & 0x3FF) + (u & ((1u << bo) - 1));
-                sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
-                sl = (cl & 0x3FF) + (u >> (bo + bm));
-                const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];  // baselines: off the critical chain
-                const u32 ofv = (1u << yo) + ofx;
-                const u32 ml = (tm & 0xFFFFFF) + (x >> nl);  // match-length bits above literal-length bits
-                const u32 ll = (tl & 0xFFFFFF) + (x & ((1u << nl) - 1));
-                // repcode rules (zstd.c:44291-44327), branch-free
-                const bool real = ofv > 3;
-                const u32 ri = ofv - 1 + (ll == 0 ? 1u : 0u);  // meaningful when !real: 0..3
-                const u32 cand = ri == 1 ? r1 : (ri == 2 ? r2 : (ri == 3 ? r0 - 1 : r0));
-                const u32 off = real ? ofv - 3 : cand;
-                const bool sh2 = real || ri >= 2, sh1 = real || ri >= 1;
-                r2 = sh2 ? r1 : r2;
-                r1 = sh1 ? r0 : r1;
-                r0 = off;
-                bad |= (off == 0) ? 1u : 0u;
-                zl_v4u rec = {lit_used, out_used, off, 0u};
-                lit_used += ll;
-                out_used += ll + ml;
-                bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
-                idx -= (i32)used;
-                ring[i & 15] = rec;
-                t4 = *(const zl_v4u*)(w + idx - 3);
-                if ((i & 15) == 15) {
-                    zl_v4u* o = (zl_v4u*)(oseq + (i - 15));
-#pragma unroll
-                    for (int q = 0; q < 16; q++) o[q] = ring[q];
-                }
-            }
-            for (u32 k = i & ~15u; k < i; k++) { const zl_v4u v = ring[k & 15]; oseq[k] = make_uint4(v.x, v.y, v.z, v.w); }
-#undef ZL_TAKE
-            if (bad) { fr->err = ZL_E_CORRUPTION; return; }
-            // exact bit position: every consumed bit left the accumulator or was replaced by a refill
-            rd.pos -= (nav_start - nav) + 32 * (idx_start - idx);
-            // hand the exact bit position to the generic tail
-            bp = rd.pos;
-            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
-        } else {
-            bp -= (i32)ll_log;
-            sl = zl_bits_bwd(bs, bn, bp, ll_log);
-            bp -= (i32)of_log;
-            so = zl_bits_bwd(bs, bn, bp, of_log);
-            bp -= (i32)ml_log;
-            sm = zl_bits_bwd(bs, bn, bp, ml_log);
-            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+        {                                                            \
+            const u32 n__ = (n_);                                    \
+            dst_ = n__ ? ((u32)(acc >> 32) >> (32 - n__)) : 0u;      \
+            acc <<= n__;                                             \
+            nav -= (i32)n__;                                         \
+            const bool f__ = nav <= 32;                              \
+            const u32 ws__ = used == 0 ? t4.w : (used == 1 ? t4.z : t4.y); \
+            acc |= f__ ? ((u64)ws__ << (32 - nav)) : 0ull;           \
+            nav += f__ ? 32 : 0;                                     \
+            used += f__ ? 1 : 0;                                     \
         }
-        // generic tail (also the whole chain of short streams)
-        for (; i < nseq; i++) {
+        for (; go && i < nseq && idx >= 5; i++) {
+            u32 used = 0;
             const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
             const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
-            if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) { fr->err = ZL_E_CORRUPTION; return; }
-            const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
-            const u32 nl = tl >> 24, nm = tm >> 24;
-            bp -= (i32)yo;
-            const u32 ofv = (1u << yo) + zl_bits_bwd(bs, bn, bp, yo);
-            bp -= (i32)nm;
-            const u32 ml = (tm & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nm);
-            bp -= (i32)nl;
-            const u32 ll = (tl & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nl);
-            if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
-            u32 off;
-            if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
-            else {
-                const u32 idx = ofv - 1 + (ll == 0);
-                if (idx == 0) off = r0;
-                else {
-                    off = (idx == 3) ? r0 - 1 : (idx == 1 ? r1 : r2);
-                    if (off == 0) { fr->err = ZL_E_CORRUPTION; return; }
-                    if (idx != 1) r2 = r1;
-                    r1 = r0;
-                    r0 = off;
-                }
+            const u32 nl = ll_extra_bits(yl), nm = ml_extra_bits(ym);
+            const u32 bl = cl >> 10, bm = cm >> 10, bo = co >> 10;
+            const u32 n2 = nm + nl;
+            const u32 sb = (i + 1 < nseq) ? bl + bm + bo : 0u;
+            u32 ofx, x, u;
+            {
+                ZL_TAKE(ofx, yo);
+                ZL_TAKE(x, n2);
+                ZL_TAKE(u, sb);
             }
-            oseq[i] = make_uint4(lit_used, out_used, off, 0u);
+            // next states first: they are the loop-carried chain (LL bits on top, then ML, then OF)
+            so = (co & 0x3FF) + (u & ((1u << bo) - 1));
+            sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
+            sl = (cl & 0x3FF) + (u >> (bo + bm));
+            const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];  // baselines: off the critical chain
+            const u32 ofv = (1u << yo) + ofx;
+            const u32 ml = (tm & 0xFFFFFF) + (x >> nl);  // match-length bits above literal-length bits
+            const u32 ll = (tl & 0xFFFFFF) + (x & ((1u << nl) - 1));
+            // repcode rules (zstd.c:44291-44327), branch-free
+            const bool real = ofv > 3;
+            const u32 ri = ofv - 1 + (ll == 0 ? 1u : 0u);  // meaningful when !real: 0..3
+            const u32 cand = ri == 1 ? r1 : (ri == 2 ? r2 : (ri == 3 ? rep_minus1(r0) : r0));
+            const u32 off = real ? ofv - 3 : cand;
+            const bool sh2 = real || ri >= 2, sh1 = real || ri >= 1;
+            r2 = sh2 ? r1 : r2;
+            r1 = sh1 ? r0 : r1;
+            r0 = off;
+            bad |= (off == 0) ? 1u : 0u;
+            zl_v4u rec = {lit_used, out_used, off, 0u};
             lit_used += ll;
             out_used += ll + ml;
-            if (out_used > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
-            if (i + 1 < nseq) {
-                u32 nb = cl >> 10;
-                bp -= (i32)nb;
-                sl = (cl & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-                nb = cm >> 10;
-                bp -= (i32)nb;
-                sm = (cm & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-                nb = co >> 10;
-                bp -= (i32)nb;
-                so = (co & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-                if (bp < 0) { fr->err = ZL_E_CORRUPTION; return; }
+            bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
+            idx -= (i32)used;
+            ring[(i & 15) * 64] = rec;
+            t4 = *(const zl_v4u*)(w + idx - 3);
+            if ((i & 15) == 15) {
+                zl_v4u* o = (zl_v4u*)(oseq + (i - 15));
+#pragma unroll
+                for (int q = 0; q < 16; q++) o[q] = ring[q * 64];
             }
         }
-        if (bp != 0) { fr->err = ZL_E_CORRUPTION; return; }  // zstd.c:44690
-        if (lit_used > r.lit_size) { fr->err = ZL_E_CORRUPTION; return; }
-        oseq[nseq] = make_uint4(lit_used, out_used, 1u, 0u);  // sentinel: totals of the block
+        for (u32 k = i & ~15u; k < i; k++) { const zl_v4u v = ring[(k & 15) * 64]; oseq[k] = make_uint4(v.x, v.y, v.z, v.w); }
+#undef ZL_TAKE
+        if (bad) return ZL_E_CORRUPTION;
+        // exact bit position: every consumed bit left the accumulator or was replaced by a refill
+        rd.pos -= (nav_start - nav) + 32 * (idx_start - idx);
+        // hand the exact bit position to the generic tail
+        bp = rd.pos;
+        if (bp < 0) return ZL_E_CORRUPTION;
+    } else {
+        bp -= (i32)ll_log;
+        sl = zl_bits_bwd(bs, bn, bp, ll_log);
+        bp -= (i32)of_log;
+        so = zl_bits_bwd(bs, bn, bp, of_log);
+        bp -= (i32)ml_log;
+        sm = zl_bits_bwd(bs, bn, bp, ml_log);
+        if (bp < 0) return ZL_E_CORRUPTION;
+    }
+    // generic tail (also the whole chain of short streams)
+    for (; i < nseq; i++) {
+        const u32 cl = L.cell[sl], cm = L.cell[512 + sm], co = L.cell[1024 + so];
+        const u32 yl = L.sym[sl], ym = L.sym[512 + sm], yo = L.sym[1024 + so];
+        if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) return ZL_E_CORRUPTION;
+        const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
+        const u32 nl = tl >> 24, nm = tm >> 24;
+        bp -= (i32)yo;
+        const u32 ofv = (1u << yo) + zl_bits_bwd(bs, bn, bp, yo);
+        bp -= (i32)nm;
+        const u32 ml = (tm & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nm);
+        bp -= (i32)nl;
+        const u32 ll = (tl & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nl);
+        if (bp < 0) return ZL_E_CORRUPTION;
+        u32 off;
+        if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
+        else {
+            const u32 idx = ofv - 1 + (ll == 0);
+            if (idx == 0) off = r0;
+            else {
+                off = (idx == 3) ? rep_minus1(r0) : (idx == 1 ? r1 : r2);
+                if (off == 0) return ZL_E_CORRUPTION;
+                if (idx != 1) r2 = r1;
+                r1 = r0;
+                r0 = off;
+            }
+        }
+        oseq[i] = make_uint4(lit_used, out_used, off, 0u);
+        lit_used += ll;
+        out_used += ll + ml;
+        if (out_used > ZL_BLOCK_MAX) return ZL_E_CORRUPTION;
+        if (i + 1 < nseq) {
+            u32 nb = cl >> 10;
+            bp -= (i32)nb;
+            sl = (cl & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            nb = cm >> 10;
+            bp -= (i32)nb;
+            sm = (cm & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            nb = co >> 10;
+            bp -= (i32)nb;
+            so = (co & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            if (bp < 0) return ZL_E_CORRUPTION;
+        }
+    }
+    if (bp != 0) return ZL_E_CORRUPTION;  // zstd.c:44690
+    if (lit_used > r.lit_size) return ZL_E_CORRUPTION;
+    oseq[nseq] = make_uint4(lit_used, out_used, 1u, 0u);  // totals of the block
+    oseq[nseq + 1] = make_uint4(r0, r1, r2, 0u);          // history handed to the next block
+    return 0;
+}
+
+__device__ __forceinline__ void wave_sync() {  // the sequence role runs on one wave: LDS order is program order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One lane per (frame, block): lane = block * SEQ_FRAMES + frame.  A block that describes at least
+// one table is the "leader" of the blocks behind it that repeat all three (mode byte 0xFC);
+// round r builds block r's tables, then every lane whose leader is r runs its chain.  Frames from
+// the HIP encoder share one table set per frame and finish in one round with all lanes busy.
+__device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* rounds, u32 wg) {
+    const u32 lane = threadIdx.x;
+    if (lane >= 64) return;
+    if (lane < 36) S.ll_tab[lane] = k_LL_base[lane] | ((u32)k_LL_bits[lane] << 24);
+    if (lane < 53) S.ml_tab[lane] = k_ML_base[lane] | ((u32)k_ML_bits[lane] << 24);
+    if (lane < SEQ_FRAMES) { S.logs[lane][0] = 0; S.logs[lane][1] = 0; S.logs[lane][2] = 0; S.logs[lane][3] = 0; }
+    if (lane == 0) *rounds = 0;
+    wave_sync();
+    const u32 fi = lane % SEQ_FRAMES, b = lane / SEQ_FRAMES;
+    const u32 f = wg * SEQ_FRAMES + fi;
+    bool active = false;
+    int lb = -1;
+    zl2_blk_rec r;
+    r.type = 0;
+    const u8* src = nullptr;
+    uint4* q_seq = nullptr;
+    zl2_frame_rec* fr = nullptr;
+    if (f < a.nframes) {
+        fr = a.frec + f;
+        const u32 nblocks = (fr->err == 0 && !fr->skippable) ? fr->nblocks : 0;
+        if (b < nblocks) {
+            const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
+            src = a.src + a.frames[f].src_off;
+            q_seq = (uint4*)a.seq_scratch + a.plan[f].seq_off;  // {literals before, output bytes before, offset, -}
+            for (u32 k = 0; k <= b; k++)
+                if (br[k].type == 2 && br[k].nseq > 0 && br[k].seq_modes != 0xFCu) lb = (int)k;
+            r = br[b];
+            active = (r.type == 2 && r.nseq > 0);
+            if (active && r.seq_modes == 0x100u) { set_err(fr, ZL_E_SRCSIZE_WRONG); active = false; }
+            else if (active && lb < 0) { set_err(fr, ZL_E_CORRUPTION); active = false; }  // repeat mode with nothing to repeat (zstd.c:43666)
+        }
+    }
+    if (active) atomicOr(rounds, 1u << lb);
+    wave_sync();
+    const u32 mask = *rounds;
+    SeqLane& L = S.L[fi];
+    for (u32 round = 0; round < ZL2_MAXB; round++) {
+        if (!((mask >> round) & 1)) continue;
+        const bool mine = active && lb == (int)round;
+        u32 pos = 1;  // a block that repeats all tables: the chain starts right after the mode byte
+        if (mine && b == round) {  // leader: table descriptions (zstd.c:43640 ZSTD_buildSeqTable)
+            const u8* sp = src + r.src_off + r.seq_off;
+            const u32 sn = r.seq_len, modes = sp[0];
+            u32 ll_log = S.logs[fi][0], of_log = S.logs[fi][1], ml_log = S.logs[fi][2];
+            const bool have_tables = S.logs[fi][3] == 1;
+            bool ok = (modes & 3) == 0;
+            if (ok) {
+                u32 used = read_seq_table2(L, 0, modes >> 6, sp + pos, sn - pos, &ll_log, have_tables);
+                ok = used != 0xFFFFFFFFu;
+                if (ok) { pos += used; used = read_seq_table2(L, 1, (modes >> 4) & 3, sp + pos, sn - pos, &of_log, have_tables); ok = used != 0xFFFFFFFFu; }
+                if (ok) { pos += used; used = read_seq_table2(L, 2, (modes >> 2) & 3, sp + pos, sn - pos, &ml_log, have_tables); ok = used != 0xFFFFFFFFu; }
+                if (ok) pos += used;
+            }
+            if (ok) { S.logs[fi][0] = ll_log; S.logs[fi][1] = of_log; S.logs[fi][2] = ml_log; S.logs[fi][3] = 1; }
+            else { set_err(fr, ZL_E_CORRUPTION); S.logs[fi][3] = 2; }
+        }
+        wave_sync();
+        if (mine && S.logs[fi][3] == 1 && fr->err == 0) {
+            const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0,
+                                      q_seq + r.seq_dst);
+            if (err) set_err(fr, err);
+        }
+        wave_sync();
     }
 }
 
 // Literal lanes and sequence lanes are independent and each under-fills the chip (512 waves per
 // GiB), so both run in ONE launch: even workgroups decode literals, odd ones sequences.
-static_assert(LIT_FRAMES == SEQ_FRAMES, "the fused launch pairs one literal and one sequence workgroup per 16 frames");
+static_assert(LIT_FRAMES == SEQ_FRAMES, "the fused launch pairs one literal and one sequence workgroup per group of frames");
 union EntropyShared {
     LitGroup G[LIT_FRAMES];
     SeqShared S;
 };
-__global__ __launch_bounds__(64) void zl2_entropy_kernel(zl2_args a) {
+__global__ __launch_bounds__(LIT_THREADS) void zl2_entropy_kernel(zl2_args a) {
     __shared__ EntropyShared U;
+    __shared__ u32 rounds;  // bit r: some lane of this workgroup has block r as its leader
     const u32 wg = blockIdx.x >> 1;
-    if (blockIdx.x & 1) seq_role(a, U.S, wg);
-    else lit_role(a, U.G, wg);
+    const bool prof = a.stats != nullptr && threadIdx.x == 0;
+    const long long t0 = prof ? clock64() : 0;
+    if (blockIdx.x & 1) seq_role(a, U.S, &rounds, wg);
+    else lit_role(a, U.G, &rounds, wg);
+    // profile: cycles spent in each role (stats[6] literal workgroups, stats[7] sequence workgroups)
+    if (prof) atomicAdd((unsigned long long*)&a.stats[6 + (blockIdx.x & 1)], (unsigned long long)(clock64() - t0));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -839,16 +912,19 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
     const uint4* q_seq = (const uint4*)a.seq_scratch + a.plan[f].seq_off;
     if (t == 0) S.err = 0;
     __syncthreads();
+    // The whole frame (<= 128 KiB on this path) is assembled in LDS, so a match that reaches into
+    // an earlier block is an LDS read like any other; the image goes to memory once, at the end.
     u64 op = 0;
+    u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
     const u32 nblocks = fr->nblocks;
     for (u32 b = 0; b < nblocks; b++) {
         const zl2_blk_rec r = br[b];
         const u8* blk = src + r.src_off;
-        u8* bdst = dst + op;
+        u8* img = S.out + (u32)op;  // this block's part of the image
         if (r.type != 2) {
             if (r.size > cap - op) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
-            else if (r.type == 0) { for (u32 i = t; i < r.size; i += EX_THREADS) bdst[i] = blk[i]; }
-            else { const u8 v = blk[0]; for (u32 i = t; i < r.size; i += EX_THREADS) bdst[i] = v; }
+            else if (r.type == 0) { for (u32 i = t; i < r.size; i += EX_THREADS) img[i] = blk[i]; }
+            else { const u8 v = blk[0]; for (u32 i = t; i < r.size; i += EX_THREADS) img[i] = v; }
             __syncthreads();
             if (S.err) break;
             op += r.size;
@@ -865,8 +941,10 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         const bool prof = a.stats != nullptr && t == 0;
         // the first window's entries; every later window is fetched into registers while the previous
         // batch is being executed (its first index is known as soon as that batch's size is)
+        // offsets that name the history the block started with (ZL2_REP_SYM, see zl2 sequence lanes) get their numbers here
+#define ZL2_RESOLVE(v_) (((v_) >> 31) ? (((v_) & 3u) == 0 ? rep0 : (((v_) & 3u) == 1 ? rep1 : rep2)) - (((v_) & 0x7FFFFFFFu) >> 2) : (v_))
         u32 pf_out = 0, pf_lit = 0, pf_off = 1;
-        if (t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[t]; pf_lit = e.x; pf_out = e.y; pf_off = e.z; }
+        if (t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[t]; pf_lit = e.x; pf_out = e.y; pf_off = ZL2_RESOLVE(e.z); }
         for (u32 b0 = 0; b0 < nseq;) {
             const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             const u32 window = (nseq - b0 < EX_MAXSEQ) ? (nseq - b0) : EX_MAXSEQ;
@@ -888,7 +966,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
             const bool linked = tot_o <= EX_CAP;  // otherwise: one long sequence, every byte resolves in one hop
             {   // prefetch the next window (entries b0+nb .. b0+nb+EX_MAXSEQ, sentinel included)
                 const u32 nb0 = b0 + nb;
-                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[nb0 + t]; pf_lit = e.x; pf_out = e.y; pf_off = e.z; }
+                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[nb0 + t]; pf_lit = e.x; pf_out = e.y; pf_off = ZL2_RESOLVE(e.z); }
             }
             if (t < nb) {
                 const u32 my_out = S.b_out[t], my_lit = S.b_lit[t];
@@ -896,7 +974,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                 const u32 off = S.b_off[t];
                 if (S.b_out[t + 1] < my_out + ll || S.b_lit[t + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions never decrease
                 if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
-                if ((u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;    // zstd.c:44045 (no dictionary on this path)
+                if (off == 0 || (u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;  // zstd.c:44045 (no dictionary on this path)
             }
             if (batch_end > ZL_BLOCK_MAX || batch_end < batch_start || S.b_out[0] != batch_start || S.b_lit[0] != lit_pos) { if (t == 0) S.err = ZL_E_CORRUPTION; }
             else if ((u64)batch_end > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
@@ -938,7 +1016,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         for (u32 j = jf; j < jl; j++) {
                             while (j >= S.b_lit[k + 1]) k++;
                             const u32 d = S.b_out[k] + (j - S.b_lit[k]);
-                            S.out[d] = (u8)(word >> (8 * (j - (u32)jj)));
+                            img[d] = (u8)(word >> (8 * (j - (u32)jj)));
                             if (linked) S.link[d - batch_start] = EX_FINAL;
                         }
                     }
@@ -964,15 +1042,15 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         const u32 m = p - mstart, o = S.b_off[k];
                         const i64 q = (m < o) ? (i64)p - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
                         if (q < (i64)batch_start) {
-                            S.out[p] = (q >= 0) ? S.out[q] : bdst[q];
+                            img[p] = img[q];  // q >= -op: an earlier batch or an earlier block
                             if (linked) S.link[p - batch_start] = EX_FINAL;
                         } else if (!linked) {
-                            S.out[p] = S.out[q];  // a literal of this (single-sequence) batch
+                            img[p] = img[q];  // a literal of this (single-sequence) batch
                         } else {
                             const u32 qq = (u32)q;
                             const u32 k2 = owner_of(S, qq, gbase);
                             if (qq - S.b_out[k2] < S.b_lit[k2 + 1] - S.b_lit[k2]) {  // literal of this batch: already in place
-                                S.out[p] = S.out[qq];
+                                img[p] = img[qq];
                                 S.link[p - batch_start] = EX_FINAL;
                             } else {
                                 S.link[p - batch_start] = (u16)(qq - batch_start);
@@ -994,7 +1072,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         if (l1 == EX_FINAL) continue;
                         const u32 l2 = S.link[l1];
                         if (l2 == EX_FINAL) {
-                            S.out[batch_start + i] = S.out[batch_start + l1];
+                            img[batch_start + i] = img[batch_start + l1];
                             S.link[i] = EX_FINAL;
                         } else {
                             S.link[i] = (u16)l2;
@@ -1024,34 +1102,15 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         else if ((u64)out_pos + rest > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
         __syncthreads();
         if (S.err) break;
-        for (u32 i = t; i < rest; i += EX_THREADS) S.out[out_pos + i] = lit_rle ? (u8)rle_byte : lit[lit_pos + i];
+        for (u32 i = t; i < rest; i += EX_THREADS) img[out_pos + i] = lit_rle ? (u8)rle_byte : lit[lit_pos + i];
+        if (nseq) {  // history after this block (zstd.c:44686)
+            const uint4 e = sq[nseq + 1];
+            const u32 n0 = ZL2_RESOLVE(e.x), n1 = ZL2_RESOLVE(e.y), n2 = ZL2_RESOLVE(e.z);
+            rep0 = n0; rep1 = n1; rep2 = n2;
+        }
+#undef ZL2_RESOLVE
         __syncthreads();
         const u32 produced = out_pos + rest;
-        // ---- flush the LDS image: 16-byte stores where the destination allows
-        {
-            const u32 head = (u32)((16 - ((uintptr_t)bdst & 15)) & 15);
-            const u32 h = head < produced ? head : produced;
-            if (t < h) bdst[t] = S.out[t];
-            const u32 body = (produced - h) >> 4;
-            for (u32 i = t; i < body; i += EX_THREADS) {
-                const u32 o = h + (i << 4);
-                uint4 v;
-                if ((h & 3) == 0) {
-                    const u32* s4 = (const u32*)(S.out + o);
-                    v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
-                } else {
-                    u32 x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        x[j] = (u32)S.out[o + 4 * j] | ((u32)S.out[o + 4 * j + 1] << 8) | ((u32)S.out[o + 4 * j + 2] << 16) | ((u32)S.out[o + 4 * j + 3] << 24);
-                    v = make_uint4(x[0], x[1], x[2], x[3]);
-                }
-                *(uint4*)(bdst + o) = v;
-            }
-            const u32 tail0 = h + (body << 4);
-            if (tail0 + t < produced) bdst[tail0 + t] = S.out[tail0 + t];
-        }
-        __syncthreads();
         if (prof) {
             const u64 st5 = __builtin_amdgcn_s_memtime();
             atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_scan);
@@ -1062,6 +1121,31 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
             atomicAdd((unsigned long long*)&a.stats[5], 1ull);
         }
         op += produced;
+    }
+    __syncthreads();
+    if (!S.err) {  // ---- the image goes out: 16-byte stores where the destination allows
+        const u32 produced = (u32)op;
+        const u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15);
+        const u32 h = head < produced ? head : produced;
+        if (t < h) dst[t] = S.out[t];
+        const u32 body = (produced - h) >> 4;
+        for (u32 i = t; i < body; i += EX_THREADS) {
+            const u32 o = h + (i << 4);
+            uint4 v;
+            if ((h & 3) == 0) {
+                const u32* s4 = (const u32*)(S.out + o);
+                v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+            } else {
+                u32 x[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    x[j] = (u32)S.out[o + 4 * j] | ((u32)S.out[o + 4 * j + 1] << 8) | ((u32)S.out[o + 4 * j + 2] << 16) | ((u32)S.out[o + 4 * j + 3] << 24);
+                v = make_uint4(x[0], x[1], x[2], x[3]);
+            }
+            *(uint4*)(dst + o) = v;
+        }
+        const u32 tail0 = h + (body << 4);
+        if (tail0 + t < produced) dst[tail0 + t] = S.out[tail0 + t];
     }
     __syncthreads();
     if (!S.err) {
@@ -1090,7 +1174,7 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ((n + LIT_FRAMES - 1) / LIT_FRAMES)), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ((n + LIT_FRAMES - 1) / LIT_FRAMES)), dim3(LIT_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), sizeof(ExecShared), stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);

@@ -5,7 +5,8 @@
 
 #include "zl_format.h"
 
-#define ZL_CHUNK ZL_BLOCK_MAX                    // one frame (one block) per 128 KiB of input
+#define ZL_CHUNK ZL_BLOCK_MAX                    // one frame per 128 KiB of input
+#define ZL_ENC_BLOCKS 8                          // blocks per frame (they share one set of entropy tables)
 #define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
 #define ZL_LIT_STRIDE_ENC (ZL_CHUNK + 64)
 #define ZL_FRAME_OVERHEAD 24                     // magic 4 + FHD 1 + dictID 4 + FCS 4 + block header 3 + checksum 4 (+ slack)

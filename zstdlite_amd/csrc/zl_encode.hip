@@ -431,7 +431,10 @@ struct EntShared {
     u32 seq_hist[3][64];
     u32 scan_a[4], scan_b[4];
     u64 xxh_acc[4];
-    u32 stream_bits[4];
+    u32 blk_seq[ZL_ENC_BLOCKS + 1];  // first sequence of block j (entry j+1: one past its last)
+    u32 blk_lit[ZL_ENC_BLOCKS + 1];  // first literal of block j
+    u32 sbits[ZL_ENC_BLOCKS][4];     // Huffman payload bits of stream k of block j
+    u8 tree_buf[136];                // the tree description, copied into the first block that codes literals
     u32 chain_state[3];
     // control
     u32 lit_mode;  // 0 raw, 1 rle, 2 huffman
@@ -772,6 +775,35 @@ __device__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
     return pos;
 }
 
+// position of block boundary `j` of `nbk`: the byte target j*n/nbk moved to the end of the match
+// that covers it, if one does.  Returns {first sequence, first literal} of the block behind it.
+__device__ void block_boundary(const zl_seq* seqs, u32 nseq, u32 nlit, u32 n, u32 j, u32 nbk, u32* first_seq, u32* first_lit) {
+    if (j == 0) { *first_seq = 0; *first_lit = 0; return; }
+    if (j >= nbk) { *first_seq = nseq; *first_lit = nlit; return; }
+    const u32 target = (u32)(((u64)j * n) / nbk);
+    u32 lo = 0, hi = nseq;  // first sequence whose match ends behind the target
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        const zl_seq s = seqs[mid];
+        if (s.pos + s.match_len > target) hi = mid; else lo = mid + 1;
+    }
+    if (lo == nseq) { *first_seq = nseq; *first_lit = nlit - (n - target); return; }  // inside the trailing literals
+    const zl_seq s = seqs[lo];
+    if (target <= s.pos) { *first_seq = lo; *first_lit = s.lit_cum - (s.pos - target); }  // inside the literal run in front of match lo
+    else { *first_seq = lo + 1; *first_lit = s.lit_cum; }                                  // inside match lo: the block ends with it
+}
+
+// literal length and offset code value of sequence i inside its block (zstd.c:25186 ZSTD_seqToCodes input):
+// the first sequence of a block counts its literals from the block start and always spells its
+// offset out, so that no block depends on the history its predecessor leaves behind.
+__device__ __forceinline__ void seq_fields(const zl_seq* seqs, u32 i, u32 blk_first_seq, u32 blk_first_lit, const zl_seq& s, u32& ll, u32& ob) {
+    const bool first = i == blk_first_seq;
+    const u32 prev_cum = first ? blk_first_lit : seqs[i - 1].lit_cum;
+    const u32 prev_off = first ? 0u : seqs[i - 1].offset;
+    ll = s.lit_cum - prev_cum;
+    ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
+}
+
 __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a) {
     __shared__ EntShared S;
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -783,30 +815,31 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     const zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
     const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
     u8* out = a.out + (size_t)c * a.out_stride;
+    const u32 out_limit = a.out_stride - 16;  // what a frame may occupy while it is being built
 
-    // ---- frame header; everything after it is the single block
+    // ---- frame header; the blocks follow
     const u32 fh = (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
-    u8* blk = out + fh + 3;  // block content
     for (u32 i = t; i < 4 * 256; i += ENC_THREADS) (&S.hist[0][0])[i] = 0;
     for (u32 i = t; i < 3 * 64; i += ENC_THREADS) (&S.seq_hist[0][0])[i] = 0;
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     if (t == 0) { S.fail = 0; write_frame_header(out, n, a.checksum, a.dict_id); }
+    // ---- blocks: up to ZL_ENC_BLOCKS per chunk, cut at sequence boundaries near equal byte counts.
+    // They share one set of entropy tables (the first block describes them, the others use the
+    // repeat modes, zstd.c:20745 / :21059), which keeps the format overhead at ~12 bytes per block
+    // and lets a decoder run the blocks' Huffman streams and FSE chains side by side.
+    const u32 nbk = (n >> 13) < 1 ? 1u : ((n >> 13) > ZL_ENC_BLOCKS ? (u32)ZL_ENC_BLOCKS : (n >> 13));
+    if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
     __syncthreads();
 
-    // =========================== literals (zstd.c:20692 ZSTD_compressLiterals)
-    const bool four = nlit >= 256;  // zstd.c:20716 singleStream = srcSize < 256
-    const u32 seg = four ? (nlit + 3) / 4 : nlit;
+    // =========================== literals: one Huffman table per chunk (zstd.c:20692 ZSTD_compressLiterals)
     {
-        const u32 s0 = four ? wave * seg : 0;
-        const u32 s1 = four ? (wave == 3 ? nlit : s0 + seg) : nlit;
-        if (four || wave == 0)
-            for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&S.hist[wave][lit[i]], 1u);
+        const u32 q = (nlit + 3) / 4, s0 = wave * q, s1 = (s0 + q < nlit) ? s0 + q : nlit;
+        for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&S.hist[wave][lit[i]], 1u);
     }
     __syncthreads();
-    const u32 keep0 = S.hist[0][t];  // stream 0's own histogram stays in a register
-    const u32 cnt_t = keep0 + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
+    const u32 cnt_t = S.hist[0][t] + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
     __syncthreads();
-    S.hist[0][t] = cnt_t;  // hist[0] becomes the total, hist[1..3] stay per-stream
+    S.hist[0][t] = cnt_t;
     __syncthreads();
     // rank sort of present symbols (ascending count, then symbol)
     {
@@ -823,14 +856,13 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     }
     S.hlen[t] = 0;
     __syncthreads();
-    const u32 lhs_c = 3 + (nlit >= 1024) + (nlit >= 16384);       // compressed-literals header size
-    const u32 lhs_r = 1 + (nlit >= 32) + (nlit >= 4096);          // raw / rle header size
     if (t == 0) {
         u32 mode = 0;
         const u32 m = S.huf_present;
         if (nlit > 63 && m == 1) mode = 1;   // zstd.c:20725 minLitSize, :20750 RLE
         else if (nlit > 63 && m >= 2) mode = 2;
         S.lit_mode = mode;
+        S.tree_size = 0;
     }
     __syncthreads();
     if (S.lit_mode == 2) {
@@ -857,97 +889,51 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 S.hcode[t] = (u16)(start >> (w - 1));
             }
         }
-        // per-stream payload bits from the per-stream histograms
-        {
-            const u32 len = S.hlen[t];
-            u32 b[4] = {keep0 * len, S.hist[1][t] * len, S.hist[2][t] * len, S.hist[3][t] * len};
+        // payload bits of every (block, stream): a wave per stream, code lengths looked up per literal
+        for (u32 item = wave; item < nbk * 4; item += 4) {
+            const u32 j = item >> 2, k = item & 3;
+            const u32 l0 = S.blk_lit[j], nl = S.blk_lit[j + 1] - l0;
+            const bool four = nl >= 256;  // zstd.c:20716 singleStream = srcSize < 256
+            const u32 seg = (nl + 3) / 4;
+            u32 s0 = 0, s1 = 0;
+            if (four) { s0 = k * seg; s1 = (k == 3) ? nl : s0 + seg; }
+            else if (k == 0) s1 = nl;
+            u32 bits = 0;
+            for (u32 i = s0 + lane; i < s1; i += 64) bits += S.hlen[lit[l0 + i]];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                u32 v = b[k];
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                b[k] = v;
-            }
-            if (lane == 0) { S.node_w[wave * 4 + 0] = b[0]; S.node_w[wave * 4 + 1] = b[1]; S.node_w[wave * 4 + 2] = b[2]; S.node_w[wave * 4 + 3] = b[3]; }
+            for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d, 64);
+            if (lane == 0) S.sbits[j][k] = bits;
         }
         __syncthreads();
         if (t == 0) {
             u32 total = 0;
-            for (u32 k = 0; k < 4; k++) {
-                const u32 bits = S.node_w[k] + S.node_w[4 + k] + S.node_w[8 + k] + S.node_w[12 + k];
-                S.stream_bits[k] = bits;
-                if (four || k == 0) total += (bits + 8) >> 3;  // payload + end marker
+            for (u32 j = 0; j < nbk; j++) {
+                const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
+                for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
+                total += four ? 6 : 0;
             }
-            const u32 tree = huf_write_tree(S, blk + lhs_c);
-            const u32 csize = tree + (four ? 6 : 0) + total;
+            const u32 tree = huf_write_tree(S, S.tree_buf);
             S.tree_size = tree;
-            if (tree == 0 || csize >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
-            else S.lit_sec_size = lhs_c + csize;
+            if (tree == 0 || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
         }
         __syncthreads();
     }
-    if (S.lit_mode == 2) {
-        // the tree nodes shared this region: staging words must be zero before bits are OR-ed in
-        for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
-        __syncthreads();
-        const u32 tree = S.tree_size;
-        u8* p = blk + lhs_c + tree;
-        if (t == 0) {
-            const u32 csize = S.lit_sec_size - lhs_c;
-            const u32 sf = four ? (lhs_c == 3 ? 1 : (lhs_c == 4 ? 2 : 3)) : 0;
-            const u32 bits = lhs_c == 3 ? 10 : (lhs_c == 4 ? 14 : 18);
-            const u64 h = 2u | (sf << 2) | ((u64)nlit << 4) | ((u64)csize << (4 + bits));
-            wr_le(blk, h, lhs_c);
-            if (four) {
-                wr_le(p, (S.stream_bits[0] + 8) >> 3, 2);
-                wr_le(p + 2, (S.stream_bits[1] + 8) >> 3, 2);
-                wr_le(p + 4, (S.stream_bits[2] + 8) >> 3, 2);
-            }
-        }
-        if (four) {
-            u32 off = 6;
-            for (u32 k = 0; k < wave; k++) off += (S.stream_bits[k] + 8) >> 3;
-            const u32 s0 = wave * seg, cnt = (wave == 3) ? nlit - 3 * seg : seg;
-            huf_encode_stream(S, S.stage + 256 * wave, lit + s0, cnt, p + off);
-        } else if (wave == 0) {
-            huf_encode_stream(S, S.stage, lit, nlit, p);
-        }
-    } else if (S.lit_mode == 1) {
-        if (t == 0) {
-            const u64 h = 1u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4));
-            wr_le(blk, h, lhs_r);
-            blk[lhs_r] = lit[0];
-            S.lit_sec_size = lhs_r + 1;
-        }
-    } else {
-        if (t == 0) {
-            const u64 h = 0u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4));
-            wr_le(blk, h, lhs_r);
-            S.lit_sec_size = lhs_r + nlit;
-        }
-        for (u32 i = t; i < nlit; i += ENC_THREADS) blk[lhs_r + i] = lit[i];
-    }
-    __syncthreads();
+    // the tree nodes shared this region: staging words must be zero before bits are OR-ed in
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     __syncthreads();
 
-    // =========================== sequences (zstd.c:25265, :21146)
-    u8* sq = blk + S.lit_sec_size;
-    u32 seq_sec = 0;
-    if (nseq == 0) {
-        if (t == 0) sq[0] = 0;
-        seq_sec = 1;
-    } else {
-        // pass 1: code histograms
-        for (u32 i = t; i < nseq; i += ENC_THREADS) {
-            const zl_seq s = seqs[i];
-            const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u;
-            const u32 prev_off = i ? seqs[i - 1].offset : 1u;
-            const u32 ll = s.lit_cum - prev_cum;
-            const u32 ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
-            atomicAdd(&S.seq_hist[T_LL][ll_code(ll)], 1u);
-            atomicAdd(&S.seq_hist[T_OF][hb32(ob)], 1u);
-            atomicAdd(&S.seq_hist[T_ML][ml_code(s.match_len)], 1u);
+    // =========================== sequences: one table set per chunk (zstd.c:25265 ZSTD_buildSequencesStatistics)
+    if (nseq) {
+        for (u32 j = 0; j < nbk; j++) {
+            const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
+            for (u32 i = f_seq + t; i < e_seq; i += ENC_THREADS) {
+                const zl_seq s = seqs[i];
+                u32 ll, ob;
+                seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
+                atomicAdd(&S.seq_hist[T_LL][ll_code(ll)], 1u);
+                atomicAdd(&S.seq_hist[T_OF][hb32(ob)], 1u);
+                atomicAdd(&S.seq_hist[T_ML][ml_code(s.match_len)], 1u);
+            }
         }
         __syncthreads();
         // table choice + construction: one lane per table, three waves in parallel
@@ -969,6 +955,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             else mode = 2;
             if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
             S.seq_mode[k] = mode;
+            ct.max_sym = max_sym;
             if (mode == 0) {
                 const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
                 const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
@@ -987,127 +974,222 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 fse_normalize(norm, h, nseq, max_sym, log);
                 fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, norm, max_sym, log);
                 ct.log = (u32)log;
-                ct.max_sym = max_sym;
             }
         }
         __syncthreads();
-        if (t == 0) {
-            u32 pos = 0;
-            if (nseq < 128) sq[pos++] = (u8)nseq;
-            else if (nseq < 0x7F00) { sq[pos++] = (u8)((nseq >> 8) + 0x80); sq[pos++] = (u8)nseq; }
-            else { sq[pos++] = 0xFF; wr_le(sq + pos, nseq - 0x7F00, 2); pos += 2; }
-            sq[pos++] = (u8)((S.seq_mode[T_LL] << 6) | (S.seq_mode[T_OF] << 4) | (S.seq_mode[T_ML] << 2));
-            for (int k = 0; k < 3; k++) {
-                const u32 mode = S.seq_mode[k];
-                if (mode == 1) {
-                    int sym = 0;
-                    const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
-                    for (int s = 0; s <= max_code; s++) if (S.seq_hist[k][s]) sym = s;
-                    sq[pos++] = (u8)sym;
-                } else if (mode == 2) {
-                    pos += fse_write_ncount(sq + pos, S.tnorm[k], S.ct[k].max_sym, (int)S.ct[k].log);
+    }
+
+    // =========================== the blocks, one after the other (zstd.c:26833 ZSTD_compressBlock_internal)
+    u32 cur = fh;             // write cursor inside the frame
+    bool fail = false;        // uniform: the frame outgrew its staging slot -> raw block
+    bool tree_out = false;    // uniform: a block has carried the Huffman tree
+    bool tables_out = false;  // uniform: a block has carried the sequence tables
+    u32 last_hdr = 0;         // where the last block header went (for the Last_Block bit)
+    const u32 tree_sz = S.tree_size;
+    for (u32 j = 0; j < nbk && !fail; j++) {
+        const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
+        const u32 ns = e_seq - f_seq, nl = S.blk_lit[j + 1] - f_lit;
+        // regenerated size of the block: its literals plus its matches
+        if (ns == 0 && nl == 0) continue;
+        u8* blk = out + cur + 3;
+        const u8* blit = lit + f_lit;
+        // ---- literals section
+        const bool four = nl >= 256;
+        const u32 lhs_c = 3 + (nl >= 1024) + (nl >= 16384);       // compressed-literals header size
+        const u32 lhs_r = 1 + (nl >= 32) + (nl >= 4096);          // raw / rle header size
+        u32 mode = 0, csize = 0, tree = 0;
+        if (S.lit_mode == 1 && nl > 0) mode = 1;
+        else if (S.lit_mode == 2 && nl > 0) {
+            for (u32 k = 0; k < (four ? 4u : 1u); k++) csize += (S.sbits[j][k] + 8) >> 3;
+            csize += four ? 6 : 0;
+            tree = tree_out ? 0 : tree_sz;
+            if (lhs_c + tree + csize < lhs_r + nl) mode = tree_out ? 3 : 2;
+        }
+        u32 lit_sec;
+        if (mode >= 2) {
+            lit_sec = lhs_c + tree + csize;
+            if (cur + 3 + lit_sec > out_limit) { fail = true; break; }
+            u8* p = blk + lhs_c + tree;
+            if (t == 0) {
+                const u32 cs = tree + csize;
+                const u32 sf = four ? (lhs_c == 3 ? 1 : (lhs_c == 4 ? 2 : 3)) : 0;
+                const u32 bits = lhs_c == 3 ? 10 : (lhs_c == 4 ? 14 : 18);
+                const u64 h = (u64)mode | (sf << 2) | ((u64)nl << 4) | ((u64)cs << (4 + bits));
+                wr_le(blk, h, lhs_c);
+                if (four) {
+                    wr_le(p, (S.sbits[j][0] + 8) >> 3, 2);
+                    wr_le(p + 2, (S.sbits[j][1] + 8) >> 3, 2);
+                    wr_le(p + 4, (S.sbits[j][2] + 8) >> 3, 2);
                 }
             }
-            S.seq_hdr_size = pos;
+            if (tree) for (u32 i = t; i < tree; i += ENC_THREADS) blk[lhs_c + i] = S.tree_buf[i];
+            if (four) {
+                const u32 seg = (nl + 3) / 4;
+                u32 off = 6;
+                for (u32 k = 0; k < wave; k++) off += (S.sbits[j][k] + 8) >> 3;
+                const u32 s0 = wave * seg, cnt = (wave == 3) ? nl - 3 * seg : seg;
+                huf_encode_stream(S, S.stage + 256 * wave, blit + s0, cnt, p + off);
+            } else if (wave == 0) {
+                huf_encode_stream(S, S.stage, blit, nl, p);
+            }
+            tree_out = true;
+        } else if (mode == 1) {
+            lit_sec = lhs_r + 1;
+            if (cur + 3 + lit_sec > out_limit) { fail = true; break; }
+            if (t == 0) {
+                const u64 h = 1u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nl << (lhs_r == 1 ? 3 : 4));
+                wr_le(blk, h, lhs_r);
+                blk[lhs_r] = blit[0];
+            }
+        } else {
+            lit_sec = lhs_r + nl;
+            if (cur + 3 + lit_sec > out_limit) { fail = true; break; }
+            if (t == 0) {
+                const u64 h = 0u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nl << (lhs_r == 1 ? 3 : 4));
+                wr_le(blk, h, lhs_r);
+            }
+            for (u32 i = t; i < nl; i += ENC_THREADS) blk[lhs_r + i] = blit[i];
         }
         __syncthreads();
-        // pass 2: tiles of 256 sequences, last sequence first
-        u8* bs = sq + S.seq_hdr_size;
-        u32 written = 0, carry_bits = 0;
-        for (u32 e0 = 0; e0 < nseq; e0 += SEQ_TILE) {
-            const u32 e = e0 + t;  // emission index; sequence index = nseq-1-e
-            u64 extra = 0;   // LL extra | ML extra | OF extra (in stream order)
-            u32 nextra = 0;
-            u32 cl = 0, cm = 0, co = 0;
-            if (e < nseq) {
-                const u32 i = nseq - 1 - e;
-                const zl_seq s = seqs[i];
-                const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u;
-                const u32 prev_off = i ? seqs[i - 1].offset : 1u;
-                const u32 ll = s.lit_cum - prev_cum;
-                const u32 ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
-                cl = ll_code(ll); cm = ml_code(s.match_len); co = hb32(ob);
-                const u32 nl = e_LL_bits[cl], nm = e_ML_bits[cm];
-                extra = (u64)(ll - e_LL_base[cl]);
-                extra |= (u64)(s.match_len - e_ML_base[cm]) << nl;
-                extra |= (u64)(ob - (1u << co)) << (nl + nm);
-                nextra = nl + nm + co;
-            }
-            S.code[T_LL][t] = (u8)cl; S.code[T_ML][t] = (u8)cm; S.code[T_OF][t] = (u8)co;
-            __syncthreads();
-            // the three FSE state chains, one lane each on three different waves
-            if (lane == 0 && wave < 3) {
-                const int k = (int)wave;
-                const FseCTable& ct = S.ct[k];
-                const u32 cnt = (nseq - e0 < SEQ_TILE) ? nseq - e0 : SEQ_TILE;
-                u32 st = S.chain_state[k];
-                if (ct.log == 0) {
-                    for (u32 j = 0; j < cnt; j++) S.stbits[k][j] = 0;
-                } else {
-                    for (u32 j = 0; j < cnt; j++) {
-                        const u32 sym = S.code[k][j];
-                        if (e0 + j == 0) { st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]); S.stbits[k][j] = 0; }
-                        else S.stbits[k][j] = fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st);
+        for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
+        __syncthreads();
+
+        // ---- sequences section (zstd.c:21146 ZSTD_encodeSequences)
+        u8* sq = blk + lit_sec;
+        u32 seq_sec = 0;
+        if (ns == 0) {
+            if (t == 0) sq[0] = 0;
+            seq_sec = 1;
+        } else {
+            if (cur + 3 + lit_sec + 512 > out_limit) { fail = true; break; }
+            if (t == 0) {
+                u32 pos = 0;
+                if (ns < 128) sq[pos++] = (u8)ns;
+                else if (ns < 0x7F00) { sq[pos++] = (u8)((ns >> 8) + 0x80); sq[pos++] = (u8)ns; }
+                else { sq[pos++] = 0xFF; wr_le(sq + pos, ns - 0x7F00, 2); pos += 2; }
+                if (tables_out) sq[pos++] = 0xFC;  // Repeat_Mode x 3
+                else {
+                    sq[pos++] = (u8)((S.seq_mode[T_LL] << 6) | (S.seq_mode[T_OF] << 4) | (S.seq_mode[T_ML] << 2));
+                    for (int k = 0; k < 3; k++) {
+                        const u32 m = S.seq_mode[k];
+                        if (m == 1) sq[pos++] = (u8)S.ct[k].max_sym;
+                        else if (m == 2) pos += fse_write_ncount(sq + pos, S.tnorm[k], S.ct[k].max_sym, (int)S.ct[k].log);
                     }
                 }
-                S.chain_state[k] = st;
+                S.seq_hdr_size = pos;
+            }
+            tables_out = true;
+            __syncthreads();
+            // tiles of 256 sequences, last sequence first
+            u8* bs = sq + S.seq_hdr_size;
+            const u32 bs_pos = cur + 3 + lit_sec + S.seq_hdr_size;
+            u32 written = 0, carry_bits = 0;
+            for (u32 e0 = 0; e0 < ns; e0 += SEQ_TILE) {
+                const u32 e = e0 + t;  // emission index; sequence index = e_seq-1-e
+                u64 extra = 0;   // LL extra | ML extra | OF extra (in stream order)
+                u32 nextra = 0;
+                u32 cl = 0, cm = 0, co = 0;
+                if (e < ns) {
+                    const u32 i = e_seq - 1 - e;
+                    const zl_seq s = seqs[i];
+                    u32 ll, ob;
+                    seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
+                    cl = ll_code(ll); cm = ml_code(s.match_len); co = hb32(ob);
+                    const u32 nl_ = e_LL_bits[cl], nm = e_ML_bits[cm];
+                    extra = (u64)(ll - e_LL_base[cl]);
+                    extra |= (u64)(s.match_len - e_ML_base[cm]) << nl_;
+                    extra |= (u64)(ob - (1u << co)) << (nl_ + nm);
+                    nextra = nl_ + nm + co;
+                }
+                S.code[T_LL][t] = (u8)cl; S.code[T_ML][t] = (u8)cm; S.code[T_OF][t] = (u8)co;
+                __syncthreads();
+                // the three FSE state chains, one lane each on three different waves
+                if (lane == 0 && wave < 3) {
+                    const int k = (int)wave;
+                    const FseCTable& ct = S.ct[k];
+                    const u32 cnt = (ns - e0 < SEQ_TILE) ? ns - e0 : SEQ_TILE;
+                    u32 st = S.chain_state[k];
+                    if (ct.log == 0) {
+                        for (u32 q = 0; q < cnt; q++) S.stbits[k][q] = 0;
+                    } else {
+                        for (u32 q = 0; q < cnt; q++) {
+                            const u32 sym = S.code[k][q];
+                            if (e0 + q == 0) { st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]); S.stbits[k][q] = 0; }
+                            else S.stbits[k][q] = fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st);
+                        }
+                    }
+                    S.chain_state[k] = st;
+                }
+                __syncthreads();
+                // per sequence: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+                u64 lo = 0;
+                u32 nlo = 0;
+                if (e < ns) {
+                    const u32 so = S.stbits[T_OF][t], sm = S.stbits[T_ML][t], sl = S.stbits[T_LL][t];
+                    lo = (u64)(so & 0xFFFF);
+                    nlo = so >> 16;
+                    lo |= (u64)(sm & 0xFFFF) << nlo;
+                    nlo += sm >> 16;
+                    lo |= (u64)(sl & 0xFFFF) << nlo;
+                    nlo += sl >> 16;
+                }
+                u32 ex_a, ex_b, tot_a, tot_b;
+                block_scan2(S.scan_a, S.scan_b, nlo + nextra, 0u, ex_a, ex_b, tot_a, tot_b);
+                const u32 pos = carry_bits + ex_a;
+                stage_or(S.stage, pos, lo, nlo);
+                stage_or(S.stage, pos + nlo, extra, nextra);
+                __syncthreads();
+                const u32 total = carry_bits + tot_a;
+                const u32 nbytes = total >> 3;
+                if (bs_pos + written + nbytes + 32 > out_limit) fail = true;  // uniform
+                const u8* sb = (const u8*)S.stage;
+                if (!fail) for (u32 i = t; i < nbytes; i += ENC_THREADS) bs[written + i] = sb[i];
+                const u32 keep = (total & 7) ? sb[nbytes] : 0;
+                __syncthreads();
+                for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = (i == 0) ? keep : 0;
+                __syncthreads();
+                if (fail) break;
+                written += nbytes;
+                carry_bits = total & 7;
+            }
+            if (fail) break;
+            // flush the three states (ML, OF, LL) and the end marker (zstd.c:21225-21233)
+            if (t == 0) {
+                BitW w;
+                bw_init(w, bs + written);
+                w.acc = S.stage[0] & 0xFF;
+                w.nb = carry_bits;
+                bw_add(w, S.chain_state[T_ML], S.ct[T_ML].log);
+                bw_add(w, S.chain_state[T_OF], S.ct[T_OF].log);
+                bw_add(w, S.chain_state[T_LL], S.ct[T_LL].log);
+                bw_add(w, 1, 1);
+                S.wpos = S.seq_hdr_size + written + bw_finish(w);
             }
             __syncthreads();
-            // per sequence: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
-            u64 lo = 0;
-            u32 nlo = 0;
-            if (e < nseq) {
-                const u32 so = S.stbits[T_OF][t], sm = S.stbits[T_ML][t], sl = S.stbits[T_LL][t];
-                lo = (u64)(so & 0xFFFF);
-                nlo = so >> 16;
-                lo |= (u64)(sm & 0xFFFF) << nlo;
-                nlo += sm >> 16;
-                lo |= (u64)(sl & 0xFFFF) << nlo;
-                nlo += sl >> 16;
-            }
-            u32 ex_a, ex_b, tot_a, tot_b;
-            block_scan2(S.scan_a, S.scan_b, nlo + nextra, 0u, ex_a, ex_b, tot_a, tot_b);
-            const u32 pos = carry_bits + ex_a;
-            stage_or(S.stage, pos, lo, nlo);
-            stage_or(S.stage, pos + nlo, extra, nextra);
+            seq_sec = S.wpos;
             __syncthreads();
-            const u32 total = carry_bits + tot_a;
-            const u32 nbytes = total >> 3;
-            const u8* sb = (const u8*)S.stage;
-            for (u32 i = t; i < nbytes; i += ENC_THREADS) bs[written + i] = sb[i];
-            const u32 keep = (total & 7) ? sb[nbytes] : 0;
-            __syncthreads();
-            for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = (i == 0) ? keep : 0;
-            __syncthreads();
-            written += nbytes;
-            carry_bits = total & 7;
+            if (t == 0) S.stage[0] = 0;
         }
-        // flush the three states (ML, OF, LL) and the end marker (zstd.c:21225-21233)
-        if (t == 0) {
-            BitW w;
-            bw_init(w, bs + written);
-            w.acc = S.stage[0] & 0xFF;
-            w.nb = carry_bits;
-            bw_add(w, S.chain_state[T_ML], S.ct[T_ML].log);
-            bw_add(w, S.chain_state[T_OF], S.ct[T_OF].log);
-            bw_add(w, S.chain_state[T_LL], S.ct[T_LL].log);
-            bw_add(w, 1, 1);
-            S.wpos = S.seq_hdr_size + written + bw_finish(w);
-        }
+        // ---- block header (zstd.c:27060): Last_Block is set on the final one below
+        const u32 bsize = lit_sec + seq_sec;
+        if (t == 0) wr_le(out + cur, (2u << 1) | (bsize << 3), 3);
+        last_hdr = cur;
+        cur += 3 + bsize;
         __syncthreads();
-        seq_sec = S.wpos;
     }
-    __syncthreads();
 
-    // =========================== block + frame assembly (zstd.c:26833, :27060-27068, :27733)
-    u32 bsize = S.lit_sec_size + seq_sec;
-    const bool raw = (n == 0) || bsize + min_gain(n) >= n;  // zstd.c:25534: not enough gain -> raw block
+    // =========================== frame assembly (zstd.c:27060-27068, :27733)
+    const bool raw = fail || n == 0 || (cur - fh - 3) + min_gain(n) >= n;  // zstd.c:25534: not enough gain -> raw block
+    u32 fsize;
     if (raw) {
+        u8* blk = out + fh + 3;
         for (u32 i = t; i < n; i += ENC_THREADS) blk[i] = src[i];
-        bsize = n;
+        if (t == 0) wr_le(out + fh, 1u | (0u << 1) | (n << 3), 3);
+        fsize = fh + 3 + n;
+    } else {
+        if (t == 0) out[last_hdr] |= 1;  // Last_Block
+        fsize = cur;
     }
-    if (t == 0) wr_le(out + fh, 1u | ((raw ? 0u : 2u) << 1) | (bsize << 3), 3);
-    u32 fsize = fh + 3 + bsize;
     if (a.checksum) {
         __syncthreads();
         const u32 x = zl_xxh64_low32((u8*)&S, S.xxh_acc, S.scan_a, src, n);  // first 8 KiB of S are dead by now

@@ -9,7 +9,8 @@
 #define ZL_SEQ_CAP 43776  // >= ZL_MAX_SEQ_PER_BLOCK, multiple of 64
 
 // ---- lane-parallel pipeline for frames of at most one block size (zl_decode2.hip) ----------
-#define ZL2_MAXB 4          // blocks per frame handled there; more -> general kernel
+#define ZL2_MAXB 8          // blocks per frame handled there; more -> general kernel
+#define ZL2_WG_FRAMES (64 / ZL2_MAXB)  // frames per entropy workgroup: one sequence lane per (frame, block) fills a wave
 #define ZL_E_FALLBACK 118   // internal: "route this frame to the general kernel", never returned to callers
 
 struct zl2_frame_plan {     // per frame, computed on the host from the frame table
@@ -29,7 +30,8 @@ struct zl2_blk_rec {        // per (frame, block), written by zl2_index_kernel
     u32 seq_off, seq_len;   // sequences section after the sequence-count field
     u32 lit_dst, seq_dst;   // where this block's Huffman literals / sequences go in the frame's scratch
     u32 nseq, streams;
-    u32 pad[3];
+    u32 seq_modes;          // the sequences section's table-mode byte (0x100: missing)
+    u32 pad[2];
 };
 struct zl2_frame_rec {
     u32 err, nblocks, has_checksum, skippable;
