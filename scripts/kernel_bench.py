@@ -25,10 +25,13 @@ for kind in kinds:
     if hasattr(codec.L, "zl_dctx_phase_stats") and codec.L.zl_dctx_phase_stats(C.c_void_p(codec.dctx), st) == 0 and st[5]:
         nb = st[5]
         print(f"        decode phases, kcycles/block: H {st[0]/nb/1e3:.0f}  B {st[1]/nb/1e3:.0f}  A {st[2]/nb/1e3:.0f}  A||B {st[3]/nb/1e3:.0f}  C {st[4]/nb/1e3:.0f}   seq/block {st[6]/nb:.0f}  huflits/block {st[7]/nb:.0f}")
-    ct = (C.c_ulonglong * 8)()
+    ct = (C.c_ulonglong * 16)()
     if hasattr(codec.L, "zl_cctx_phase_stats") and codec.L.zl_cctx_phase_stats(C.c_void_p(codec.cctx), ct) == 0 and ct[4]:
         it = ct[4]
         print(f"        match phases, cycles/iteration: find {ct[0]/it:.0f}  parse {ct[1]/it:.0f}  emit {ct[2]/it:.0f}  insert {ct[3]/it:.0f}")
+    if ct[14]:
+        nc = ct[14]
+        print(f"        entropy phases, kcycles/chunk: huffman {ct[8]/nc/1e3:.0f}  seq tables {ct[9]/nc/1e3:.0f}  chains {ct[10]/nc/1e3:.0f}  blk literals {ct[11]/nc/1e3:.0f}  blk sequences {ct[12]/nc/1e3:.0f}  rest {ct[13]/nc/1e3:.0f}")
     if st[13]:
         nb = st[13]
         print(f"        exec phases, kcycles/block: scan {st[8]/nb/1e3:.0f}  lit {st[9]/nb/1e3:.0f}  match {st[10]/nb/1e3:.0f}  flush {st[11]/nb/1e3:.0f}  batches/block {st[12]/nb:.1f}")

@@ -21,7 +21,7 @@ struct zl_cctx_s {
     int nb_workers = 0;
     std::vector<u8> dict;
     hipStream_t own_stream = nullptr;
-    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_meta, d_staged, d_fsize, d_foff, d_totals;
+    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals;
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
     // pending device-resident call
     bool pending = false;
@@ -33,7 +33,7 @@ struct zl_cctx_s {
     bool ev_valid = false;
     double kernel_ms[4] = {0, 0, 0, 0};
     DevBuf d_stats;
-    u64 stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -55,7 +55,8 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) ||
         !c->d_meta.ensure(group * sizeof(zl_chunk_meta)) || !c->d_lits.ensure(group * (size_t)ZL_LIT_STRIDE_ENC) ||
-        !c->d_seqs.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(zl_seq)) || !c->d_staged.ensure(group * (size_t)ZL_OUT_STRIDE))
+        !c->d_seqs.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(zl_seq)) || !c->d_sst.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(ushort4)) ||
+        !c->d_staged.ensure(group * (size_t)ZL_OUT_STRIDE))
         return kGpuUnavailable;
     if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -74,8 +75,8 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.lit_stride = ZL_LIT_STRIDE_ENC;
         m.seq_stride = ZL_SEQ_STRIDE;
         m.stats = nullptr;
-        if (prof && c->d_stats.ensure(64)) {
-            (void)hipMemsetAsync(c->d_stats.p, 0, 64, st);
+        if (prof && c->d_stats.ensure(128)) {
+            (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
             m.stats = (u64*)c->d_stats.p;
         }
         if (prof) (void)hipEventRecord(c->ev[0], st);
@@ -87,6 +88,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.lits = m.lits;
         e.seqs = m.seqs;
         e.meta = m.meta;
+        e.seq_states = (ushort4*)c->d_sst.p;
         e.out = (u8*)c->d_staged.p;
         e.frame_size = (u32*)c->d_fsize.p + first;
         e.lit_stride = ZL_LIT_STRIDE_ENC;
@@ -94,6 +96,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.out_stride = ZL_OUT_STRIDE;
         e.checksum = (u32)c->checksum;
         e.dict_id = 0;
+        e.stats = m.stats ? m.stats + 8 : nullptr;
         if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (prof) (void)hipEventRecord(c->ev[2], st);
         u64* totals = (u64*)c->d_totals.p;
@@ -147,7 +150,7 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
-    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
@@ -220,7 +223,7 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
             (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
             c->kernel_ms[k] = ms;
         }
-        if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 64, hipMemcpyDeviceToHost);
+        if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
     if (frame_sizes) {
         const u32* fs = (const u32*)c->h_fsize.p;
@@ -238,7 +241,7 @@ size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
 // not part of the public header: match-kernel phase cycle sums {find, parse, emit, insert, iterations}
 size_t zl_cctx_phase_stats(const zl_cctx* c, unsigned long long* out8) {
     if (!c || !out8 || !c->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
-    for (int i = 0; i < 8; i++) out8[i] = c->stats[i];
+    for (int i = 0; i < 16; i++) out8[i] = c->stats[i];
     return 0;
 }
 

@@ -47,6 +47,7 @@ struct zl_entropy_args {
     const u8* lits;
     const zl_seq* seqs;
     const zl_chunk_meta* meta;
+    ushort4* seq_states;  // scratch, per chunk seq_stride records: FSE codes, then states (see zl_entropy_kernel)
     u8* out;           // per chunk out_stride bytes: the finished frame
     u32* frame_size;   // per chunk: bytes of the frame
     u32 lit_stride;
@@ -54,6 +55,7 @@ struct zl_entropy_args {
     u32 out_stride;
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
+    u64* stats;        // optional (profiling): cycles {huffman build, sequence tables, chains, block literals, block sequences, rest, chunks}
 };
 
 struct zl_gather_args {

@@ -59,13 +59,16 @@ __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct MatchShared {
-    u32 tbl_long[1 << LONG_LOG];
-    u32 tbl_short[1 << SHORT_LOG];
+    // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
+    // mean the nearest such position in front of it, so candidates reach 64 KiB back (an older entry
+    // aliases to a wrong position and fails verification).  Half the LDS of 32-bit entries: six
+    // workgroups per CU instead of three, and this kernel is latency-bound.
+    u32 tbl_long[(1 << LONG_LOG) / 2];
+    u32 tbl_short[(1 << SHORT_LOG) / 2];
     u16 jump[2][WIN];
     u8 mark[WIN];
     u32 cand[WIN];  // [7:0] match length, [31:8] offset of each lane's best match
     u32 scan_a[4], scan_b[4];
-    u32 carry;    // where the parse enters the next window (0 = its first position)
     u32 rep;      // offset of the most recent sequence (repeat-offset candidate)
 };
 
@@ -91,6 +94,35 @@ __device__ __forceinline__ void block_scan2(u32* sa, u32* sb, u32 a, u32 b, u32&
     tot_a = ta;
     tot_b = tb;
     __syncthreads();
+}
+
+// Deterministic insert of position p (inside the window that starts at ip) into a 16-bit entry:
+// the most recent position of the window wins, whatever was there before loses.  `old` is the word
+// as this lane saw it during the lookup; in the common case one compare-and-swap per table settles it.
+__device__ __forceinline__ bool insert16_wants(u32 old, u32 sh, u32 mine, u32 ip) {
+    const u32 cur = (old >> sh) & 0xFFFF;
+    const u32 age = (cur - 1 - ip) & 0xFFFF;  // < WIN: written by a position of this window
+    return !(cur != 0 && age < WIN && age >= mine);
+}
+__device__ __forceinline__ void insert16_retry(u32* w, u32 old, u32 sh, u32 val, u32 mine, u32 ip) {
+    while (insert16_wants(old, sh, mine, ip)) {
+        const u32 prev = atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (val << sh));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+__device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* ts, u32 bs, u32 old_s, u32 p, u32 ip) {
+    const u32 val = (p + 1) & 0xFFFF;
+    if (val == 0) return;
+    u32* wl = tl + (bl >> 1);
+    u32* ws = ts + (bs >> 1);
+    const u32 shl = (bl & 1) * 16, shs = (bs & 1) * 16, mine = p - ip;
+    const bool go_l = insert16_wants(old_l, shl, mine, ip), go_s = insert16_wants(old_s, shs, mine, ip);
+    u32 prev_l = old_l, prev_s = old_s;
+    if (go_l) prev_l = atomicCAS(wl, old_l, (old_l & ~(0xFFFFu << shl)) | (val << shl));
+    if (go_s) prev_s = atomicCAS(ws, old_s, (old_s & ~(0xFFFFu << shs)) | (val << shs));
+    if (go_l && prev_l != old_l) insert16_retry(wl, prev_l, shl, val, mine, ip);
+    if (go_s && prev_s != old_s) insert16_retry(ws, prev_s, shs, val, mine, ip);
 }
 
 __device__ __forceinline__ void match_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
@@ -133,21 +165,23 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
     u8* lits = a.lits + (size_t)c * a.lit_stride;
     zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
 
-    for (u32 i = t; i < (1u << LONG_LOG); i += ENC_THREADS) S.tbl_long[i] = 0;
-    for (u32 i = t; i < (1u << SHORT_LOG); i += ENC_THREADS) S.tbl_short[i] = 0;
-    if (t == 0) { S.carry = 0; S.rep = 0; }
+    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = 0;
+    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = 0;
+    if (t == 0) S.rep = 0;
     lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
+    u32 carry = 0;           // where the parse enters the next window (uniform; 0 = its first position)
     const bool prof = a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     // every thread owns two positions of the window: t and t + 256
     for (u32 ip = 0; ip < n; ip += WIN) {
         const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        const u32 carry = S.carry, rep = S.rep;
+        const u32 rep = S.rep;
         u64 v[PPT];
         u32 hl[PPT], hs[PPT], best_len[PPT], best_off[PPT], q_best[PPT];
+        u32 word_l[PPT], word_s[PPT];  // the table words as read by the lookup (reused by the insert)
         bool in_range[PPT], can_match[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
@@ -158,6 +192,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
             if (can_match[j]) v[j] = ld64(src + p);
             else if (in_range[j]) v[j] = src[p];
             hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
+            word_l[j] = word_s[j] = 0;
         }
         const bool search = carry < WIN;  // otherwise the whole window lies inside an earlier match
         // candidates of both positions are fetched together: one memory round trip.  A lane without
@@ -173,14 +208,17 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
             if (can_match[j]) {
                 hl[j] = hash8(v[j]);
                 hs[j] = hash5(v[j]);
+                word_l[j] = S.tbl_long[hl[j] >> 1];
+                word_s[j] = S.tbl_short[hs[j] >> 1];
                 if (search) {
-                    const u32 cl = S.tbl_long[hl[j]], cs = S.tbl_short[hs[j]];
+                    const u32 el = (word_l[j] >> ((hl[j] & 1) * 16)) & 0xFFFF, es = (word_s[j] >> ((hs[j] & 1) * 16)) & 0xFFFF;
+                    const u32 dl = (p + 1 - el) & 0xFFFF, ds = (p + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
                     have_r[j] = rep && p >= rep;
-                    have_l[j] = cl != 0;
-                    have_s[j] = cs != 0;
+                    have_l[j] = el != 0 && dl != 0 && dl <= p;
+                    have_s[j] = es != 0 && ds != 0 && ds <= p;
                     if (have_r[j]) q_r[j] = p - rep;
-                    if (have_l[j]) q_l[j] = cl - 1;
-                    if (have_s[j]) q_s[j] = cs - 1;
+                    if (have_l[j]) q_l[j] = p - dl;
+                    if (have_s[j]) q_s[j] = p - ds;
                 }
             }
         }
@@ -227,38 +265,47 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
                 }
             }
         }
-        // ---- greedy parse over the window by pointer jumping
+        // ---- greedy parse over the window.  Every wave owns 64 consecutive positions: it closes its own
+        // (position -> next position) links by pointer jumping through lane shuffles, which tells for
+        // every possible entry point where the path leaves the segment; the four segments are then
+        // chained by three dependent LDS reads, and each wave marks its on-path positions by replaying
+        // its jumps.  One workgroup barrier instead of one per doubling round.
+        static_assert(PPT == 1 && WIN == 256, "the wave-local parse assumes one position per thread and four waves");
+        const u32 wbase = t & ~63u, wave = t >> 6;
         u32 nxt[PPT];
+        nxt[0] = t + (has_match[0] ? best_len[0] : 1u);
+        u32 jr[6];
+        u32 jp = nxt[0];
 #pragma unroll
-        for (int j = 0; j < PPT; j++) {
-            const u32 w = t + ENC_THREADS * j;
-            nxt[j] = w + (has_match[j] ? best_len[j] : 1u);
-            S.jump[0][w] = (u16)nxt[j];
-            S.mark[w] = (w == carry) ? 1 : 0;
+        for (int r = 0; r < 6; r++) {
+            jr[r] = jp;
+            const u32 far = __shfl(jp, (int)((jp - wbase) & 63), 64);
+            jp = (jp < wbase + 64) ? far : jp;
         }
+        S.jump[0][t] = (u16)jp;  // where a path entering at t leaves this wave's segment
         lds_barrier();
-        int cur = 0;
+        u32 enter = carry, my_entry = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < WIN_LOG; r++) {
-#pragma unroll
-            for (int j = 0; j < PPT; j++) {
-                const u32 w = t + ENC_THREADS * j;
-                const u32 jp = S.jump[cur][w];
-                if (jp < WIN) {
-                    if (S.mark[w]) S.mark[jp] = 1;
-                    S.jump[cur ^ 1][w] = S.jump[cur][jp];
-                } else {
-                    S.jump[cur ^ 1][w] = (u16)jp;
-                }
+        for (u32 k = 0; k < 4; k++) {
+            if (enter < 64 * (k + 1)) {
+                if (k == wave) my_entry = enter;
+                enter = S.jump[0][enter];
             }
-            cur ^= 1;
-            lds_barrier();
         }
+        const u32 next_carry = enter - WIN;  // uniform: where the path enters the next window
+        volatile u8* mk = S.mark;
+        mk[t] = (t == my_entry) ? 1 : 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            __builtin_amdgcn_wave_barrier();
+            if (mk[t] && jr[r] < wbase + 64) mk[jr[r]] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
         const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
         bool is_seq[PPT], is_lit[PPT], on_path[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            on_path[j] = S.mark[t + ENC_THREADS * j] != 0;
+            on_path[j] = mk[t + ENC_THREADS * j] != 0;
             is_seq[j] = on_path[j] && has_match[j];
             is_lit[j] = on_path[j] && !has_match[j] && in_range[j];
         }
@@ -284,17 +331,15 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
                 seqs[nseq + ex_s[j]] = sq;
                 if (ex_s[j] + 1 == tot_s) S.rep = best_off[j];  // last sequence of the window
             }
-            if (on_path[j] && nxt[j] >= WIN) S.carry = nxt[j] - WIN;  // exactly one path node leaves the window
         }
-        if (carry >= WIN && t == 0) S.carry = carry - WIN;
+        carry = next_carry;
         const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        // ---- insert every position of the window (most recent position wins: atomicMax)
+        // ---- insert every position of the window (most recent position wins)
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
             if (can_match[j]) {
                 const u32 p = ip + t + ENC_THREADS * j;
-                atomicMax(&S.tbl_long[hl[j]], p + 1);
-                atomicMax(&S.tbl_short[hs[j]], p + 1);
+                insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip);
             }
         }
         nseq += tot_s;
@@ -308,7 +353,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
         // after 4 / 8 / 12 consecutive windows that produced no sequence, the next 1 / 2 / 3 windows are
         // emitted as literals without searching or inserting.  A pure function of the data, so the
         // output stays deterministic.  Any sequence resets it.
-        miss = (tot_s == 0 && S.carry == 0) ? miss + 1 : 0;
+        miss = (tot_s == 0 && carry == 0) ? miss + 1 : 0;
         u32 skip = miss >> 2;
         if (skip > 3) skip = 3;
         if (skip) {
@@ -402,13 +447,7 @@ struct EntShared {
     // made, the per-tile sequence arrays are born afterwards; the Huffman tree nodes die before the
     // first stream is coded, the bit-staging words are (re)zeroed right then.  Both regions are dead
     // when the XXH64 tile (first 8 KiB) is used at the very end.
-    union {
-        u32 hist[4][256];
-        struct {
-            u8 code[3][SEQ_TILE];
-            u32 stbits[3][SEQ_TILE];  // [15:0] value, [23:16] nbits
-        };
-    };
+    u32 hist[4][256];
     union {
         u32 stage[1024];  // bit staging: sequences use [0,640), Huffman wave w uses [256w, 256w+256)
         struct {
@@ -435,7 +474,9 @@ struct EntShared {
     u32 blk_lit[ZL_ENC_BLOCKS + 1];  // first literal of block j
     u32 sbits[ZL_ENC_BLOCKS][4];     // Huffman payload bits of stream k of block j
     u8 tree_buf[136];                // the tree description, copied into the first block that codes literals
-    u32 chain_state[3];
+    u16 cumul[4][64];  // fse_build_ctable scratch: the three sequence tables and the Huffman-weight table
+    u32 small[16];     // short serial counters (code-length / weight histograms)
+    u32 final_state[ZL_ENC_BLOCKS][3];  // FSE states after the last (= first in order) sequence of each block
     // control
     u32 lit_mode;  // 0 raw, 1 rle, 2 huffman
     u32 huf_log, huf_present, huf_maxsym, tree_size;
@@ -536,9 +577,8 @@ __device__ u32 fse_write_ncount(u8* dst, const short* norm, int max_sym, int log
 
 // zstd.c:15917 FSE_buildCTable_wksp: same spread as the decoder, then rank the cells of each
 // symbol.  One thread.  tsym: LDS scratch of table size.
-__device__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8* tsym, const short* norm, int max_sym, int log) {
+__device__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8* tsym, u16* cumul /* 64 entries of LDS */, const short* norm, int max_sym, int log) {
     const int size = 1 << log;
-    u16 cumul[64];
     int high = size - 1;
     cumul[0] = 0;
     for (int s = 0; s <= max_sym; s++) {
@@ -616,7 +656,7 @@ __device__ u32 huf_build_lengths(EntShared& S, u32 m) {
     }
     const u32 root = next - 1;
     S.node_depth[root] = 0;
-    u32 bl[HUF_MAX_BITS + 2];
+    u32* const bl = S.small;  // HUF_MAX_BITS + 2 counters (a dynamically indexed local array would live in scratch memory)
     for (u32 i = 0; i <= HUF_MAX_BITS + 1; i++) bl[i] = 0;
     u32 kraft = 0;  // in units of 2^-HUF_MAX_BITS
     for (int i = (int)root - 1; i >= 0; i--) {
@@ -649,7 +689,7 @@ __device__ u32 huf_write_tree(EntShared& S, u8* dst) {
     const u32 maxsym = S.huf_maxsym, log = S.huf_log;
     for (u32 s = 0; s < maxsym; s++) S.weights[s] = S.hlen[s] ? (u8)(log + 1 - S.hlen[s]) : 0;
     // ---- try FSE
-    u32 wc[16];
+    u32* const wc = S.small;
     for (u32 w = 0; w < 16; w++) wc[w] = 0;
     u32 maxw = 0, maxcount = 0;
     for (u32 s = 0; s < maxsym; s++) { const u32 w = S.weights[s]; wc[w]++; if (w > maxw) maxw = w; }
@@ -662,7 +702,7 @@ __device__ u32 huf_write_tree(EntShared& S, u8* dst) {
         fse_normalize(S.norm, wc, maxsym, (int)maxw, wlog);
         u8* p = dst + 1;
         const u32 hs = fse_write_ncount(p, S.norm, (int)maxw, wlog);
-        fse_build_ctable(S.wstate, S.wdnb, S.wdfs, S.tsym, S.norm, (int)maxw, wlog);
+        fse_build_ctable(S.wstate, S.wdnb, S.wdfs, S.tsym, S.cumul[3], S.norm, (int)maxw, wlog);
         // two interleaved states, last weight first (zstd.c:16090 FSE_compress_usingCTable_generic)
         BitW w;
         bw_init(w, p + hs);
@@ -753,6 +793,21 @@ __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed *
     return written + 1;
 }
 
+__device__ __forceinline__ uint4 ld128(const u8* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+// workgroup-wide byte copy, 16 bytes per thread and trip (global memory takes unaligned vectors)
+__device__ __forceinline__ void copy_wg(u8* dst, const u8* src, u32 n) {
+    const u32 t = threadIdx.x, body = n & ~15u;
+    for (u32 i = t * 16; i < body; i += ENC_THREADS * 16) {
+        const uint4 v = ld128(src + i);
+        __builtin_memcpy(dst + i, &v, 16);
+    }
+    if (t < n - body) dst[body + t] = src[body + t];
+}
+
 __device__ __forceinline__ u32 min_gain(u32 n) { return (n >> 6) + 2; }  // zstd.c:19607 ZSTD_minGain (strategy < btultra)
 
 __device__ __forceinline__ void wr_le(u8* p, u64 v, u32 nbytes) {
@@ -814,8 +869,13 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     const u8* lit = a.lits + (size_t)c * a.lit_stride;
     const zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
     const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
+    ushort4* sst = a.seq_states + (size_t)c * a.seq_stride;  // per sequence: {LL|ML codes, OF code -> OF state, LL state, ML state}
     u8* out = a.out + (size_t)c * a.out_stride;
     const u32 out_limit = a.out_stride - 16;  // what a frame may occupy while it is being built
+    const bool prof = a.stats != nullptr && t == 0;
+    u64 pt[6] = {0, 0, 0, 0, 0, 0};
+    u64 p_last = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define ENT_STAMP(k_) if (prof) { const u64 now__ = __builtin_amdgcn_s_memtime(); pt[k_] += now__ - p_last; p_last = now__; }
 
     // ---- frame header; the blocks follow
     const u32 fh = (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
@@ -832,9 +892,21 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     __syncthreads();
 
     // =========================== literals: one Huffman table per chunk (zstd.c:20692 ZSTD_compressLiterals)
-    {
-        const u32 q = (nlit + 3) / 4, s0 = wave * q, s1 = (s0 + q < nlit) ? s0 + q : nlit;
-        for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&S.hist[wave][lit[i]], 1u);
+    {   // 16 literals per thread and trip (one byte per trip leaves a single load in flight per thread);
+        // four histogram copies, one per wave, keep the atomics apart
+        const u32 body = nlit & ~15u;
+        for (u32 i = t * 16; i < body; i += ENC_THREADS * 16) {
+            const uint4 v = ld128(lit + i);
+            const u32 w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&S.hist[wave][w4[k] & 0xFF], 1u);
+                atomicAdd(&S.hist[wave][(w4[k] >> 8) & 0xFF], 1u);
+                atomicAdd(&S.hist[wave][(w4[k] >> 16) & 0xFF], 1u);
+                atomicAdd(&S.hist[wave][w4[k] >> 24], 1u);
+            }
+        }
+        if (t < nlit - body) atomicAdd(&S.hist[wave][lit[body + t]], 1u);
     }
     __syncthreads();
     const u32 cnt_t = S.hist[0][t] + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
@@ -899,7 +971,14 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             if (four) { s0 = k * seg; s1 = (k == 3) ? nl : s0 + seg; }
             else if (k == 0) s1 = nl;
             u32 bits = 0;
-            for (u32 i = s0 + lane; i < s1; i += 64) bits += S.hlen[lit[l0 + i]];
+            const u8* sp = lit + l0 + s0;
+            const u32 cnt = s1 - s0, body = cnt & ~7u;
+            for (u32 i = lane * 8; i < body; i += 64 * 8) {
+                const u64 v = ld64(sp + i);
+#pragma unroll
+                for (int q = 0; q < 8; q++) bits += S.hlen[(u32)(v >> (8 * q)) & 0xFF];
+            }
+            if (lane < cnt - body) bits += S.hlen[sp[body + lane]];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d, 64);
             if (lane == 0) S.sbits[j][k] = bits;
@@ -922,6 +1001,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     __syncthreads();
 
+    ENT_STAMP(0)
     // =========================== sequences: one table set per chunk (zstd.c:25265 ZSTD_buildSequencesStatistics)
     if (nseq) {
         for (u32 j = 0; j < nbk; j++) {
@@ -930,9 +1010,11 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 const zl_seq s = seqs[i];
                 u32 ll, ob;
                 seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
-                atomicAdd(&S.seq_hist[T_LL][ll_code(ll)], 1u);
-                atomicAdd(&S.seq_hist[T_OF][hb32(ob)], 1u);
-                atomicAdd(&S.seq_hist[T_ML][ml_code(s.match_len)], 1u);
+                const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(s.match_len);
+                atomicAdd(&S.seq_hist[T_LL][cl], 1u);
+                atomicAdd(&S.seq_hist[T_OF][co], 1u);
+                atomicAdd(&S.seq_hist[T_ML][cm], 1u);
+                sst[i] = make_ushort4((unsigned short)(cl | (cm << 8)), (unsigned short)co, 0, 0);
             }
         }
         __syncthreads();
@@ -960,7 +1042,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
                 const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
                 for (int s = 0; s <= dmax; s++) norm[s] = def[s];
-                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, norm, dmax, def_log);
+                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, dmax, def_log);
                 ct.log = (u32)def_log;
             } else if (mode == 1) {
                 ct.log = 0;
@@ -972,11 +1054,56 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 if (log < 5) log = 5;
                 if (log > max_log) log = max_log;
                 fse_normalize(norm, h, nseq, max_sym, log);
-                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, norm, max_sym, log);
+                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, max_sym, log);
                 ct.log = (u32)log;
             }
         }
         __syncthreads();
+        ENT_STAMP(1)
+        // The FSE state chains (zstd.c:21163-21222) are serial per table and per block -- and the blocks
+        // are independent, so the 3 x nbk chains run side by side on the lanes of one wave.  Each lane
+        // leaves the state *before* every sequence in the scratch record; the bits that state emits are
+        // cut from it when the bitstream is assembled.
+        if (wave == 0) {
+            const u32 j = lane / 3, k = lane % 3;
+            const bool on = lane < 3 * nbk;
+            const u32 e_seq = on ? S.blk_seq[j + 1] : 0u, ns = on ? e_seq - S.blk_seq[j] : 0u;
+            u32 max_ns = ns;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(max_ns, d, 64); max_ns = o > max_ns ? o : max_ns; }
+            const FseCTable& ct = S.ct[k];
+            const u32 log = ct.log;
+            unsigned short* slot = (unsigned short*)sst + (k == T_LL ? 2 : (k == T_ML ? 3 : 1));
+            u32 st = 0;
+            // Eight records are fetched while the previous eight are being coded: the chain itself only
+            // touches LDS, and a load that is needed right away would cost a memory round trip per step.
+            ushort4 cur[8], nxt[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { nxt[q] = make_ushort4(0, 0, 0, 0); if ((u32)q < ns) nxt[q] = sst[e_seq - 1 - q]; }
+            for (u32 e0 = 0; e0 < max_ns; e0 += 8) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (e0 + 8 + q < ns) nxt[q] = sst[e_seq - 1 - (e0 + 8 + q)];
+                u32 before[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const u32 e = e0 + q;
+                    before[q] = 0;
+                    if (e < ns && log) {
+                        const ushort4 rec = cur[q];
+                        const u32 sym = k == T_LL ? (rec.x & 0xFFu) : (k == T_ML ? (u32)(rec.x >> 8) : (u32)rec.y);
+                        if (e == 0) st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]);
+                        else { before[q] = st; (void)fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st); }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) if (e0 + q < ns) slot[4 * (size_t)(e_seq - 1 - (e0 + q))] = (unsigned short)before[q];
+            }
+            if (on) S.final_state[j][k] = st;
+        }
+        __syncthreads();
+        ENT_STAMP(2)
     }
 
     // =========================== the blocks, one after the other (zstd.c:26833 ZSTD_compressBlock_internal)
@@ -1048,12 +1175,13 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 const u64 h = 0u | ((lhs_r == 1 ? 0u : (lhs_r == 2 ? 1u : 3u)) << 2) | ((u64)nl << (lhs_r == 1 ? 3 : 4));
                 wr_le(blk, h, lhs_r);
             }
-            for (u32 i = t; i < nl; i += ENC_THREADS) blk[lhs_r + i] = blit[i];
+            copy_wg(blk + lhs_r, blit, nl);
         }
         __syncthreads();
         for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
         __syncthreads();
 
+        ENT_STAMP(3)
         // ---- sequences section (zstd.c:21146 ZSTD_encodeSequences)
         u8* sq = blk + lit_sec;
         u32 seq_sec = 0;
@@ -1101,37 +1229,22 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                     extra |= (u64)(ob - (1u << co)) << (nl_ + nm);
                     nextra = nl_ + nm + co;
                 }
-                S.code[T_LL][t] = (u8)cl; S.code[T_ML][t] = (u8)cm; S.code[T_OF][t] = (u8)co;
-                __syncthreads();
-                // the three FSE state chains, one lane each on three different waves
-                if (lane == 0 && wave < 3) {
-                    const int k = (int)wave;
-                    const FseCTable& ct = S.ct[k];
-                    const u32 cnt = (ns - e0 < SEQ_TILE) ? ns - e0 : SEQ_TILE;
-                    u32 st = S.chain_state[k];
-                    if (ct.log == 0) {
-                        for (u32 q = 0; q < cnt; q++) S.stbits[k][q] = 0;
-                    } else {
-                        for (u32 q = 0; q < cnt; q++) {
-                            const u32 sym = S.code[k][q];
-                            if (e0 + q == 0) { st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]); S.stbits[k][q] = 0; }
-                            else S.stbits[k][q] = fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st);
-                        }
-                    }
-                    S.chain_state[k] = st;
-                }
-                __syncthreads();
-                // per sequence: [OF state][ML state][LL state][LL extra][ML extra][OF extra]
+                // per sequence: [OF state][ML state][LL state][LL extra][ML extra][OF extra]; the first
+                // sequence emitted only sets the states up
                 u64 lo = 0;
                 u32 nlo = 0;
-                if (e < ns) {
-                    const u32 so = S.stbits[T_OF][t], sm = S.stbits[T_ML][t], sl = S.stbits[T_LL][t];
-                    lo = (u64)(so & 0xFFFF);
-                    nlo = so >> 16;
-                    lo |= (u64)(sm & 0xFFFF) << nlo;
-                    nlo += sm >> 16;
-                    lo |= (u64)(sl & 0xFFFF) << nlo;
-                    nlo += sl >> 16;
+                if (e < ns && e > 0) {
+                    const ushort4 rec = sst[e_seq - 1 - e];
+                    const u32 bo = rec.y, bl = rec.z, bm = rec.w;  // states before this sequence
+                    const u32 no = S.ct[T_OF].log ? (u32)((i32)bo + S.ct[T_OF].dnb[co]) >> 16 : 0u;
+                    const u32 nm_ = S.ct[T_ML].log ? (u32)((i32)bm + S.ct[T_ML].dnb[cm]) >> 16 : 0u;
+                    const u32 nl2 = S.ct[T_LL].log ? (u32)((i32)bl + S.ct[T_LL].dnb[cl]) >> 16 : 0u;
+                    lo = (u64)(bo & ((1u << no) - 1));
+                    nlo = no;
+                    lo |= (u64)(bm & ((1u << nm_) - 1)) << nlo;
+                    nlo += nm_;
+                    lo |= (u64)(bl & ((1u << nl2) - 1)) << nlo;
+                    nlo += nl2;
                 }
                 u32 ex_a, ex_b, tot_a, tot_b;
                 block_scan2(S.scan_a, S.scan_b, nlo + nextra, 0u, ex_a, ex_b, tot_a, tot_b);
@@ -1159,9 +1272,9 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 bw_init(w, bs + written);
                 w.acc = S.stage[0] & 0xFF;
                 w.nb = carry_bits;
-                bw_add(w, S.chain_state[T_ML], S.ct[T_ML].log);
-                bw_add(w, S.chain_state[T_OF], S.ct[T_OF].log);
-                bw_add(w, S.chain_state[T_LL], S.ct[T_LL].log);
+                bw_add(w, S.final_state[j][T_ML], S.ct[T_ML].log);
+                bw_add(w, S.final_state[j][T_OF], S.ct[T_OF].log);
+                bw_add(w, S.final_state[j][T_LL], S.ct[T_LL].log);
                 bw_add(w, 1, 1);
                 S.wpos = S.seq_hdr_size + written + bw_finish(w);
             }
@@ -1176,6 +1289,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         last_hdr = cur;
         cur += 3 + bsize;
         __syncthreads();
+        ENT_STAMP(4)
     }
 
     // =========================== frame assembly (zstd.c:27060-27068, :27733)
@@ -1183,7 +1297,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     u32 fsize;
     if (raw) {
         u8* blk = out + fh + 3;
-        for (u32 i = t; i < n; i += ENC_THREADS) blk[i] = src[i];
+        copy_wg(blk, src, n);
         if (t == 0) wr_le(out + fh, 1u | (0u << 1) | (n << 3), 3);
         fsize = fh + 3 + n;
     } else {
@@ -1197,6 +1311,12 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         fsize += 4;
     }
     if (t == 0) a.frame_size[c] = fsize;
+    ENT_STAMP(5)
+#undef ENT_STAMP
+    if (prof) {
+        for (int k = 0; k < 6; k++) atomicAdd((unsigned long long*)&a.stats[k], (unsigned long long)pt[k]);
+        atomicAdd((unsigned long long*)&a.stats[6], 1ull);
+    }
 }
 
 // exclusive scan of frame sizes (one workgroup; chunk counts are small: 8192 per GiB)
@@ -1220,11 +1340,11 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_scan_sizes_kernel(const u32* f
 }
 
 __global__ __launch_bounds__(ENC_THREADS) void zl_gather_kernel(zl_gather_args a) {
-    const u32 c = blockIdx.x, t = threadIdx.x;
+    const u32 c = blockIdx.x;
     const u8* s = a.staged + (size_t)c * a.out_stride;
     u8* d = a.dst + a.frame_off[c];
     const u32 n = a.frame_size[c];
-    for (u32 i = t; i < n; i += ENC_THREADS) d[i] = s[i];
+    copy_wg(d, s, n);
 }
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
