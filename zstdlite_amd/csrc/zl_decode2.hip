@@ -853,32 +853,37 @@ __global__ __launch_bounds__(LIT_THREADS) void zl2_entropy_kernel(zl2_args a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// zl2_exec_kernel: 1024 threads per frame, block output staged in LDS.
+// zl2_exec_kernel: one workgroup per frame; only the batch being built lives in LDS.
 //
-// zl2_seq_kernel left running positions (literals / output bytes before each sequence), so a
-// batch needs no scan.  A batch is as many sequences as fit EX_CAP output bytes (a sequence
-// longer than that is a batch of its own).  Per batch:
+// The sequence lanes left running positions (literals / output bytes before each sequence), so a
+// batch needs no scan.  A batch is as many sequences as fit EX_CAP output bytes.  Per batch:
 //   pass 1  the batch's literal bytes are scattered into the LDS image with coalesced dword loads;
 //   pass 2a every match byte takes ONE hop through the batch table (owner-per-32-byte-granule
-//           lookup): if the hop lands on a byte that already exists (earlier batch, or a literal
-//           of this batch) the byte is copied, otherwise the landing position is stored as a
+//           lookup): a hop that lands in front of the batch reads the byte from the output already
+//           in memory, a hop onto a literal of the batch copies it, anything else is stored as a
 //           16-bit link;
 //   pass 2b links are shortened by pointer jumping (link := link of link) until every byte has
 //           found an existing byte -- log2(chain length) rounds of plain LDS traffic instead of a
-//           per-byte walk whose tail is as long as span/offset.
+//           per-byte walk whose tail is as long as span/offset;
+//   flush   the image goes to memory with 16-byte stores (it is laid out congruent to the
+//           destination modulo 16) and becomes the "output already in memory" of the next batch.
+// A sequence longer than EX_CAP is copied memory to memory: all of its sources lie in front of its
+// match (zstd.c:44013 ZSTD_execSequence's overlap rule).  With 37 KiB of LDS per workgroup four
+// frames share a CU (the earlier whole-frame image allowed one), which hides the barrier and
+// memory latencies of one frame behind the work of the others.
 // ---------------------------------------------------------------------------------------
-#define EX_THREADS 1024
+#define EX_THREADS 512
 #define EX_GRAN_LOG 5
 #define EX_CAP 8192u     // output bytes per batch (links are 16-bit, relative to the batch start)
-#define EX_MAXSEQ 1023u  // sequences per batch (+1 look-ahead entry = one per thread)
+#define EX_MAXSEQ 1023u  // sequences per batch (+1 look-ahead entry)
 #define EX_FINAL 0xFFFFu
 struct ExecShared {
-    u8 out[ZL_BLOCK_MAX];
+    u8 img[EX_CAP + 16];  // byte d of the block sits at img[d + ibase]; (img + d + ibase) and (destination + d) agree modulo 16
+    u16 link[EX_CAP];
     u32 b_out[EX_MAXSEQ + 1];
     u32 b_lit[EX_MAXSEQ + 1];
-    u32 b_off[EX_MAXSEQ];
+    u32 b_off[EX_MAXSEQ + 1];
     u16 own[(EX_CAP >> EX_GRAN_LOG) + 8];
-    u16 link[EX_CAP];
     u64 xxh_acc[4];
     u32 bcast[8];  // [0] xxh result, [1] batch size, [4..6] rotating "still pending" flags
     int err;
@@ -891,9 +896,19 @@ __device__ __forceinline__ u32 owner_of(const ExecShared& S, u32 p, u32 gbase) {
     return k;
 }
 
-__global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
-    extern __shared__ __align__(16) u8 smem_raw[];
-    ExecShared& S = *reinterpret_cast<ExecShared*>(smem_raw);
+// workgroup-wide copy between global buffers of any alignment
+__device__ __forceinline__ void ex_copy(u8* dst, const u8* src, u32 n) {
+    const u32 t = threadIdx.x, body = n & ~15u;
+    for (u32 i = t * 16; i < body; i += EX_THREADS * 16) {
+        uint4 v;
+        __builtin_memcpy(&v, src + i, 16);
+        __builtin_memcpy(dst + i, &v, 16);
+    }
+    if (t < n - body) dst[body + t] = src[body + t];
+}
+
+__global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
+    __shared__ __align__(16) ExecShared S;
     const u32 t = threadIdx.x;
     const u32 f = blockIdx.x;
     zl2_frame_rec* fr = a.frec + f;
@@ -912,19 +927,23 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
     const uint4* q_seq = (const uint4*)a.seq_scratch + a.plan[f].seq_off;
     if (t == 0) S.err = 0;
     __syncthreads();
-    // The whole frame (<= 128 KiB on this path) is assembled in LDS, so a match that reaches into
-    // an earlier block is an LDS read like any other; the image goes to memory once, at the end.
     u64 op = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
     const u32 nblocks = fr->nblocks;
     for (u32 b = 0; b < nblocks; b++) {
         const zl2_blk_rec r = br[b];
         const u8* blk = src + r.src_off;
-        u8* img = S.out + (u32)op;  // this block's part of the image
+        u8* bdst = dst + op;
         if (r.type != 2) {
             if (r.size > cap - op) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
-            else if (r.type == 0) { for (u32 i = t; i < r.size; i += EX_THREADS) img[i] = blk[i]; }
-            else { const u8 v = blk[0]; for (u32 i = t; i < r.size; i += EX_THREADS) img[i] = v; }
+            else if (r.type == 0) ex_copy(bdst, blk, r.size);
+            else {
+                const u32 v4 = blk[0] * 0x01010101u;
+                const uint4 v = make_uint4(v4, v4, v4, v4);
+                const u32 body = r.size & ~15u;
+                for (u32 i = t * 16; i < body; i += EX_THREADS * 16) __builtin_memcpy(bdst + i, &v, 16);
+                if (t < r.size - body) bdst[body + t] = (u8)v4;
+            }
             __syncthreads();
             if (S.err) break;
             op += r.size;
@@ -939,40 +958,35 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         u32 lit_pos = 0, out_pos = 0;
         u64 c_scan = 0, c_lit = 0, c_match = 0, c_batches = 0;
         const bool prof = a.stats != nullptr && t == 0;
-        // the first window's entries; every later window is fetched into registers while the previous
-        // batch is being executed (its first index is known as soon as that batch's size is)
-        // offsets that name the history the block started with (ZL2_REP_SYM, see zl2 sequence lanes) get their numbers here
+        // offsets that name the history the block started with (ZL2_REP_SYM, see the sequence lanes) get their numbers here
 #define ZL2_RESOLVE(v_) (((v_) >> 31) ? (((v_) & 3u) == 0 ? rep0 : (((v_) & 3u) == 1 ? rep1 : rep2)) - (((v_) & 0x7FFFFFFFu) >> 2) : (v_))
-        u32 pf_out = 0, pf_lit = 0, pf_off = 1;
-        if (t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[t]; pf_lit = e.x; pf_out = e.y; pf_off = ZL2_RESOLVE(e.z); }
         for (u32 b0 = 0; b0 < nseq;) {
             const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             const u32 window = (nseq - b0 < EX_MAXSEQ) ? (nseq - b0) : EX_MAXSEQ;
             if (t == 0) S.bcast[1] = 1;
-            if (t <= window) {  // one extra entry: the next sequence (or the totals)
-                S.b_out[t] = pf_out;
-                S.b_lit[t] = pf_lit;
-                if (t < window) S.b_off[t] = pf_off;
+            for (u32 i = t; i <= window; i += EX_THREADS) {  // one extra entry: the next sequence (or the totals)
+                const uint4 e = sq[b0 + i];
+                S.b_lit[i] = e.x;
+                S.b_out[i] = e.y;
+                S.b_off[i] = ZL2_RESOLVE(e.z);
             }
             __syncthreads();
             const u32 batch_start = out_pos;
-            // sequence t >= 1 joins the batch while its END stays within EX_CAP of the batch start
-            if (t >= 1 && t < window && S.b_out[t + 1] - batch_start <= EX_CAP && S.b_out[t + 1] >= batch_start) atomicMax(&S.bcast[1], t + 1);
+            // sequence i >= 1 joins the batch while its END stays within EX_CAP of the batch start
+            for (u32 i = t; i < window; i += EX_THREADS)
+                if (i >= 1 && S.b_out[i + 1] - batch_start <= EX_CAP && S.b_out[i + 1] >= batch_start) atomicMax(&S.bcast[1], i + 1);
             __syncthreads();
             const u32 nb = S.bcast[1];
             const u32 batch_end = S.b_out[nb];
             const u32 tot_l = S.b_lit[nb] - lit_pos, tot_o = batch_end - batch_start;
             const u32 gbase = batch_start & ~((1u << EX_GRAN_LOG) - 1);
-            const bool linked = tot_o <= EX_CAP;  // otherwise: one long sequence, every byte resolves in one hop
-            {   // prefetch the next window (entries b0+nb .. b0+nb+EX_MAXSEQ, sentinel included)
-                const u32 nb0 = b0 + nb;
-                if (nb0 < nseq && nb0 + t <= nseq && t <= EX_MAXSEQ) { const uint4 e = sq[nb0 + t]; pf_lit = e.x; pf_out = e.y; pf_off = ZL2_RESOLVE(e.z); }
-            }
-            if (t < nb) {
-                const u32 my_out = S.b_out[t], my_lit = S.b_lit[t];
-                const u32 ll = S.b_lit[t + 1] - my_lit;
-                const u32 off = S.b_off[t];
-                if (S.b_out[t + 1] < my_out + ll || S.b_lit[t + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions never decrease
+            const bool linked = tot_o <= EX_CAP;  // otherwise: one long sequence, copied memory to memory
+            const u32 ibase = (u32)((uintptr_t)(bdst + batch_start) & 15) - batch_start;  // img index of block position d: d + ibase
+            for (u32 i = t; i < nb; i += EX_THREADS) {
+                const u32 my_out = S.b_out[i], my_lit = S.b_lit[i];
+                const u32 ll = S.b_lit[i + 1] - my_lit;
+                const u32 off = S.b_off[i];
+                if (S.b_out[i + 1] < my_out + ll || S.b_lit[i + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions never decrease
                 if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
                 if (off == 0 || (u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;  // zstd.c:44045 (no dictionary on this path)
             }
@@ -982,11 +996,13 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
             if (S.err) break;
             const u64 st1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- owner table: granule g starts at gbase + 32 g
-            if (linked && t < nb) {
-                const u32 lo = S.b_out[t], hi = S.b_out[t + 1];
-                u32 g = (lo - gbase + (1u << EX_GRAN_LOG) - 1) >> EX_GRAN_LOG;
-                if (t == 0) g = 0;
-                for (; gbase + (g << EX_GRAN_LOG) < hi; g++) S.own[g] = (u16)t;
+            if (linked) {
+                for (u32 i = t; i < nb; i += EX_THREADS) {
+                    const u32 lo = S.b_out[i], hi = S.b_out[i + 1];
+                    u32 g = (lo - gbase + (1u << EX_GRAN_LOG) - 1) >> EX_GRAN_LOG;
+                    if (i == 0) g = 0;
+                    for (; gbase + (g << EX_GRAN_LOG) < hi; g++) S.own[g] = (u16)i;
+                }
             }
             // ---- pass 1: literal bytes of the batch, aligned dwords of the literal buffer
             if (tot_l) {
@@ -1016,21 +1032,21 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         for (u32 j = jf; j < jl; j++) {
                             while (j >= S.b_lit[k + 1]) k++;
                             const u32 d = S.b_out[k] + (j - S.b_lit[k]);
-                            img[d] = (u8)(word >> (8 * (j - (u32)jj)));
-                            if (linked) S.link[d - batch_start] = EX_FINAL;
+                            const u8 v = (u8)(word >> (8 * (j - (u32)jj)));
+                            if (linked) { S.img[d + ibase] = v; S.link[d - batch_start] = EX_FINAL; }
+                            else bdst[d] = v;
                         }
                     }
                 }
             }
             __syncthreads();
             const u64 st2 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            // ---- pass 2a: one hop for every match byte
-            {
+            if (linked) {
+                // ---- pass 2a: one hop for every match byte
                 const u32 w_first = batch_start >> 2, w_end = (batch_end + 3) >> 2;
                 for (u32 w = w_first + t; w < w_end; w += EX_THREADS) {
                     const u32 ws = w << 2;
-                    u32 k = 0;
-                    if (linked) k = owner_of(S, ws < batch_start ? batch_start : ws, gbase);
+                    u32 k = owner_of(S, ws < batch_start ? batch_start : ws, gbase);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const u32 p = ws + j;
@@ -1042,15 +1058,13 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         const u32 m = p - mstart, o = S.b_off[k];
                         const i64 q = (m < o) ? (i64)p - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
                         if (q < (i64)batch_start) {
-                            img[p] = img[q];  // q >= -op: an earlier batch or an earlier block
-                            if (linked) S.link[p - batch_start] = EX_FINAL;
-                        } else if (!linked) {
-                            img[p] = img[q];  // a literal of this (single-sequence) batch
+                            S.img[p + ibase] = bdst[q];  // an earlier batch or an earlier block: already in memory
+                            S.link[p - batch_start] = EX_FINAL;
                         } else {
                             const u32 qq = (u32)q;
                             const u32 k2 = owner_of(S, qq, gbase);
                             if (qq - S.b_out[k2] < S.b_lit[k2 + 1] - S.b_lit[k2]) {  // literal of this batch: already in place
-                                img[p] = img[qq];
+                                S.img[p + ibase] = S.img[qq + ibase];
                                 S.link[p - batch_start] = EX_FINAL;
                             } else {
                                 S.link[p - batch_start] = (u16)(qq - batch_start);
@@ -1058,12 +1072,11 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         }
                     }
                 }
-            }
-            // ---- pass 2b: pointer jumping over the 16-bit links until nothing is pending.  One barrier
-            // per round: the "somebody is still pending" flag rotates over three words.
-            if (linked) {
+                // ---- pass 2b: pointer jumping over the 16-bit links until nothing is pending.  One barrier
+                // per round: the "somebody is still pending" flag rotates over three words.
                 if (t == 0) { S.bcast[4] = 0; S.bcast[5] = 0; S.bcast[6] = 0; }
                 __syncthreads();
+                const u32 ib = batch_start + ibase;  // img index of the batch's first byte
                 for (u32 round = 0;; round++) {
                     const u32 fl = 4 + round % 3;
                     u32 pending = 0;
@@ -1072,7 +1085,7 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                         if (l1 == EX_FINAL) continue;
                         const u32 l2 = S.link[l1];
                         if (l2 == EX_FINAL) {
-                            img[batch_start + i] = img[batch_start + l1];
+                            S.img[ib + i] = S.img[ib + l1];
                             S.link[i] = EX_FINAL;
                         } else {
                             S.link[i] = (u16)l2;
@@ -1084,11 +1097,46 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
                     __syncthreads();
                     if (!S.bcast[fl]) break;
                 }
+                // ---- flush: img and destination agree modulo 16
+                {
+                    u8* g = bdst + batch_start;
+                    const u32 head = (16 - (ib & 15)) & 15, h = head < tot_o ? head : tot_o;
+                    if (t < h) g[t] = S.img[ib + t];
+                    const u32 body = (tot_o - h) >> 4;
+                    for (u32 i = t; i < body; i += EX_THREADS) {
+                        const u32 o = h + (i << 4);
+                        *(uint4*)(g + o) = *(const uint4*)(S.img + ib + o);
+                    }
+                    const u32 tail0 = h + (body << 4);
+                    if (tail0 + t < tot_o) g[tail0 + t] = S.img[ib + tail0 + t];
+                }
+            } else {
+                // one sequence longer than the image: its literals are in memory (pass 1); every match
+                // byte m copies the byte at (match start - offset + m mod offset), which lies in front of the match
+                const u32 ll = S.b_lit[1] - S.b_lit[0];
+                const u32 mstart = S.b_out[0] + ll, ml = batch_end - mstart, o = S.b_off[0];
+                const u8* from = bdst + mstart - o;
+                u8* to = bdst + mstart;
+                if (o >= 16) {
+                    // whole 16-byte pieces while they do not wrap around the period
+                    for (u32 m = t * 16; m < ml; m += EX_THREADS * 16) {
+                        const u32 s = m % o;
+                        if (s + 16 <= o && m + 16 <= ml) {
+                            uint4 v;
+                            __builtin_memcpy(&v, from + s, 16);
+                            __builtin_memcpy(to + m, &v, 16);
+                        } else {
+                            for (u32 x = m; x < m + 16 && x < ml; x++) to[x] = from[x % o];
+                        }
+                    }
+                } else {
+                    for (u32 m = t; m < ml; m += EX_THREADS) to[m] = from[m % o];
+                }
             }
             lit_pos += tot_l;
             out_pos += tot_o;
             b0 += nb;
-            __syncthreads();
+            __syncthreads();  // the batch is in memory (and visible to this workgroup) before the next one reads it
             if (prof) {
                 const u64 st3 = __builtin_amdgcn_s_memtime();
                 c_scan += st1 - st0; c_lit += st2 - st1; c_match += st3 - st2; c_batches++;
@@ -1102,7 +1150,8 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         else if ((u64)out_pos + rest > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
         __syncthreads();
         if (S.err) break;
-        for (u32 i = t; i < rest; i += EX_THREADS) img[out_pos + i] = lit_rle ? (u8)rle_byte : lit[lit_pos + i];
+        if (lit_rle) { for (u32 i = t; i < rest; i += EX_THREADS) bdst[out_pos + i] = (u8)rle_byte; }
+        else ex_copy(bdst + out_pos, lit + lit_pos, rest);
         if (nseq) {  // history after this block (zstd.c:44686)
             const uint4 e = sq[nseq + 1];
             const u32 n0 = ZL2_RESOLVE(e.x), n1 = ZL2_RESOLVE(e.y), n2 = ZL2_RESOLVE(e.z);
@@ -1123,36 +1172,11 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
         op += produced;
     }
     __syncthreads();
-    if (!S.err) {  // ---- the image goes out: 16-byte stores where the destination allows
-        const u32 produced = (u32)op;
-        const u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15);
-        const u32 h = head < produced ? head : produced;
-        if (t < h) dst[t] = S.out[t];
-        const u32 body = (produced - h) >> 4;
-        for (u32 i = t; i < body; i += EX_THREADS) {
-            const u32 o = h + (i << 4);
-            uint4 v;
-            if ((h & 3) == 0) {
-                const u32* s4 = (const u32*)(S.out + o);
-                v = make_uint4(s4[0], s4[1], s4[2], s4[3]);
-            } else {
-                u32 x[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    x[j] = (u32)S.out[o + 4 * j] | ((u32)S.out[o + 4 * j + 1] << 8) | ((u32)S.out[o + 4 * j + 2] << 16) | ((u32)S.out[o + 4 * j + 3] << 24);
-                v = make_uint4(x[0], x[1], x[2], x[3]);
-            }
-            *(uint4*)(dst + o) = v;
-        }
-        const u32 tail0 = h + (body << 4);
-        if (tail0 + t < produced) dst[tail0 + t] = S.out[tail0 + t];
-    }
-    __syncthreads();
     if (!S.err) {
         if (t == 0 && fr->fcs != ZL_CONTENTSIZE_UNKNOWN && fr->fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
         __syncthreads();
         if (!S.err && fr->has_checksum && !a.ignore_checksum) {
-            const u32 got = zl_xxh64_low32(S.out, S.xxh_acc, S.bcast, dst, op);
+            const u32 got = zl_xxh64_low32(S.img, S.xxh_acc, S.bcast, dst, op);
             if (t == 0 && got != zl_rd_le(src + fr->end_pos, 4)) S.err = ZL_E_CHECKSUM_WRONG;     // zstd.c:41655
         }
         __syncthreads();
@@ -1165,18 +1189,12 @@ __global__ __launch_bounds__(EX_THREADS) void zl2_exec_kernel(zl2_args a) {
 // ---------------------------------------------------------------------------------------
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
     if (a->nframes == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)zl2_exec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ExecShared));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
     hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ((n + LIT_FRAMES - 1) / LIT_FRAMES)), dim3(LIT_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), sizeof(ExecShared), stream, *a);
+    hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }
