@@ -125,30 +125,6 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
     if (go_s && prev_s != old_s) insert16_retry(ws, prev_s, shs, val, mine, ip);
 }
 
-__device__ __forceinline__ void match_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
-        if ((int)lane >= d) { ia += ta; ib += tb; }
-    }
-    if (lane == 63) { sa[wave] = ia; sb[wave] = ib; }
-    lds_barrier();
-    u32 pa = 0, pb = 0, ta = 0, tb = 0;
-#pragma unroll
-    for (u32 w = 0; w < 4; w++) {
-        const u32 xa = sa[w], xb = sb[w];
-        if (w < wave) { pa += xa; pb += xb; }
-        ta += xa; tb += xb;
-    }
-    ex_a = pa + ia - a;
-    ex_b = pb + ib - b;
-    tot_a = ta;
-    tot_b = tb;
-    lds_barrier();
-}
-
 // ---------------------------------------------------------------------------------------
 // E1: match finding.  chunk c covers src[c*chunk_size, +len); output per chunk:
 //   lits[c*lit_stride ...]   literal bytes in order
@@ -173,6 +149,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
     u32 carry = 0;           // where the parse enters the next window (uniform; 0 = its first position)
+    u64 v_pref = 0;          // prefetched bytes of position pref_ip + t
+    u32 pref_ip = 0xFFFFFFFFu;
     const bool prof = a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     // every thread owns two positions of the window: t and t + 256
@@ -189,7 +167,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
             in_range[j] = p < n;
             can_match[j] = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
             v[j] = 0;
-            if (can_match[j]) v[j] = ld64(src + p);
+            if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
+            else if (can_match[j]) v[j] = ld64(src + p);
             else if (in_range[j]) v[j] = src[p];
             hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
             word_l[j] = word_s[j] = 0;
@@ -226,6 +205,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
         for (int j = 0; j < PPT; j++) {
             if (can_match[j] && search) { w_r[j] = ld64(src + q_r[j]); w_l[j] = ld64(src + q_l[j]); w_s[j] = ld64(src + q_s[j]); }
             else { w_r[j] = w_l[j] = w_s[j] = 0; }
+        }
+        {   // the next window's own bytes travel together with this window's candidates
+            const u32 pn = ip + WIN + t;
+            pref_ip = ip + WIN;
+            v_pref = 0;
+            if (pn + 8 <= n) v_pref = ld64(src + pn);
+            else if (pn < n) v_pref = src[pn];
         }
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
@@ -293,31 +279,44 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
             }
         }
         const u32 next_carry = enter - WIN;  // uniform: where the path enters the next window
-        volatile u8* mk = S.mark;
-        mk[t] = (t == my_entry) ? 1 : 0;
+        // (marks stay inside the wave's 64 bytes: LDS executes a wave's accesses in program order, the
+        // asm statements only keep the compiler from caching or reordering them)
+        S.mark[t] = (t == my_entry) ? 1 : 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            __builtin_amdgcn_wave_barrier();
-            if (mk[t] && jr[r] < wbase + 64) mk[jr[r]] = 1;
+            asm volatile("" ::: "memory");
+            if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
         }
-        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
         const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
         bool is_seq[PPT], is_lit[PPT], on_path[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-            on_path[j] = mk[t + ENC_THREADS * j] != 0;
+            on_path[j] = S.mark[t + ENC_THREADS * j] != 0;
             is_seq[j] = on_path[j] && has_match[j];
             is_lit[j] = on_path[j] && !has_match[j] && in_range[j];
         }
-        // positions t (j = 0) precede positions t + 256 (j = 1): two counts per scan lane, 16 bits each
-        u32 ex0, ex1, tot0, tot1;
-        match_scan2(S.scan_a, S.scan_b, (is_seq[0] ? 1u : 0u) | ((is_lit[0] ? 1u : 0u) << 16),
-                    (is_seq[PPT - 1] && PPT > 1 ? 1u : 0u) | ((is_lit[PPT - 1] && PPT > 1 ? 1u : 0u) << 16), ex0, ex1, tot0, tot1);
-        u32 ex_s[PPT], ex_l[PPT];
-        ex_s[0] = ex0 & 0xFFFF;
-        ex_l[0] = ex0 >> 16;
-        if (PPT > 1) { ex_s[PPT - 1] = (tot0 & 0xFFFF) + (ex1 & 0xFFFF); ex_l[PPT - 1] = (tot0 >> 16) + (ex1 >> 16); }
-        const u32 tot_s = (tot0 & 0xFFFF) + (tot1 & 0xFFFF), tot_l = (tot0 >> 16) + (tot1 >> 16);
+        // compaction ranks: the flags are single bits, so a wave ranks its lanes with two ballots and
+        // the four waves exchange their totals through LDS
+        u32 ex_s[PPT], ex_l[PPT], tot_s, tot_l;
+        {
+            const u64 ms = __ballot(is_seq[0]), ml = __ballot(is_lit[0]);
+            const u64 below = (1ull << (t & 63)) - 1;
+            const u32 ws = (u32)__popcll(ms), wl = (u32)__popcll(ml);
+            if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16);
+            lds_barrier();
+            u32 pre = 0, tot = 0;
+#pragma unroll
+            for (u32 w = 0; w < 4; w++) {
+                const u32 x = S.scan_a[w];
+                if (w < wave) pre += x;
+                tot += x;
+            }
+            ex_s[0] = (pre & 0xFFFF) + (u32)__popcll(ms & below);
+            ex_l[0] = (pre >> 16) + (u32)__popcll(ml & below);
+            tot_s = tot & 0xFFFF;
+            tot_l = tot >> 16;
+        }
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
             const u32 p = ip + t + ENC_THREADS * j;
