@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the bench line, a rocprofv3 kernel trace + stats of the same
+# command, and the two PMC passes (FETCH_SIZE, WRITE_SIZE -- each in its own run, never combined with
+# other trace domains).  Outputs land in gpurun_out/; scripts/summarize_profiles.py <round> turns
+# them into the summaries kept under profiles/.
+set -u
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write
+python3 bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full_err.log
+tail -c 600 gpurun_out/bench_full_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-c2 > gpurun_out/prof_bench_line.json 2> gpurun_out/prof_bench_err.log
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-c2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-c2 > /dev/null 2>&1
+# keep what travels back small: csv summaries only
+find gpurun_out -name "*.db" -delete 2>/dev/null
+du -sh gpurun_out

@@ -24,6 +24,8 @@
 #include "zl_device.h"
 #include "zl_format.h"
 #include "zl_kernels.h"
+// Every workgroup barrier in this file is zl_sync_global(): this kernel hands literals, sequences and
+// output between waves through global memory all over the place and is not the fast path.
 
 #define DEC_THREADS 256
 #define SEQ_BATCH 256
@@ -435,7 +437,7 @@ __device__ __forceinline__ void block_scan2(DecShared& S, u32 a, u32 b, u32& ex_
         if ((int)lane >= d) { ia += ta; ib += tb; }
     }
     if (lane == 63) { S.scan_a[wave] = ia; S.scan_b[wave] = ib; }
-    __syncthreads();
+    zl_sync_global();
     u32 pa = 0, pb = 0, ta = 0, tb = 0;
 #pragma unroll
     for (u32 w = 0; w < 4; w++) {
@@ -447,7 +449,7 @@ __device__ __forceinline__ void block_scan2(DecShared& S, u32 a, u32 b, u32& ex_
     ex_b = pb + ib - b;
     tot_a = ta;
     tot_b = tb;
-    __syncthreads();
+    zl_sync_global();
 }
 
 struct LitSrc {
@@ -635,7 +637,7 @@ __device__ u32 execute_block(DecShared& S, u8* blk_out, u64 cap_left, i64 blk_ab
         if ((u64)batch_end > cap_left || batch_end > ZL_BLOCK_MAX) {
             if (t == 0) S.err = (batch_end > ZL_BLOCK_MAX) ? ZL_E_CORRUPTION : ZL_E_DSTSIZE_TOO_SMALL;
         }
-        __syncthreads();
+        zl_sync_global();
         if (S.err) return 0;
         // 4-byte output words aligned on the destination address
         const u32 mis = (u32)((uintptr_t)(blk_out + batch_start) & 3);
@@ -663,16 +665,16 @@ __device__ u32 execute_block(DecShared& S, u8* blk_out, u64 cap_left, i64 blk_ab
         }
         lit_pos += tot_l;
         out_pos += tot_o;
-        __syncthreads();  // batch output visible to the next batch's match reads
+        zl_sync_global();  // batch output visible to the next batch's match reads
     }
     // trailing literals (zstd.c:44693-44700)
     const u32 rest = lit_size - lit_pos;
     if ((u64)out_pos + rest > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
     else if (out_pos + rest > ZL_BLOCK_MAX) { if (t == 0) S.err = ZL_E_CORRUPTION; }
-    __syncthreads();
+    zl_sync_global();
     if (S.err) return 0;
     for (u32 i = t; i < rest; i += DEC_THREADS) blk_out[out_pos + i] = lit_byte(L, lit_pos + i);
-    __syncthreads();
+    zl_sync_global();
     return out_pos + rest;
 }
 
@@ -688,9 +690,9 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
     const u8* dict_end = a.dict_content ? a.dict_content + a.dict_len : nullptr;
 
     for (;;) {
-        __syncthreads();
+        zl_sync_global();
         if (t == 0) S.frame = atomicAdd(a.counter, 1u);
-        __syncthreads();
+        zl_sync_global();
         const u32 f = S.frame;
         if (f >= a.nframes) break;
         if (a.plan && a.plan[f].route != 0 && a.frec[f].err != ZL_E_FALLBACK) continue;  // decoded by zl_decode2.hip
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                 S.tables_valid = 1; S.huf_valid = 1;
             }
         }
-        __syncthreads();
+        zl_sync_global();
         if (S.err || S.skippable) {
             if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : 0;
             continue;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
             for (u32 i = t; i < 512; i += DEC_THREADS) { S.fse_ll[i] = DT->fse_ll[i]; S.fse_ml[i] = DT->fse_ml[i]; }
             for (u32 i = t; i < 256; i += DEC_THREADS) S.fse_of[i] = DT->fse_of[i];
             for (u32 i = t; i < 4096; i += DEC_THREADS) S.huf[i] = DT->huf[i];
-            __syncthreads();
+            zl_sync_global();
         }
         u64 pos = S.hdr_size, op = 0;
         bool done = false;
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                     else if (S.blk_type == 2 && S.blk_size > ZL_BLOCK_MAX) S.err = ZL_E_SRCSIZE_WRONG;
                 }
             }
-            __syncthreads();
+            zl_sync_global();
             if (S.err) break;
             pos += 3;
             const u32 btype = S.blk_type, bsize = S.blk_size;
@@ -757,12 +759,12 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                     if (!S.err) parse_seq_header(S, blk + lsec, bsize - lsec);
                     if (!S.err) S.seq_off += lsec;
                 }
-                __syncthreads();
+                zl_sync_global();
                 if (S.err) break;
                 if (S.lit_mode == 2) {
                     fill_huf_table(S);
                     if (t == 0) S.huf_valid = 1;
-                    __syncthreads();
+                    zl_sync_global();
                 }
                 // ---- stages A + B, concurrently on different waves
                 LitSrc L;
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                     }
                 }
                 if (a.stats && S.lit_mode >= 2 && t >= 64 && t < 68) atomicMax((unsigned long long*)&S.stamp_a, (unsigned long long)(__builtin_amdgcn_s_memtime() - ta0));
-                __syncthreads();
+                zl_sync_global();
                 if (S.err) break;
                 if (a.stats && t == 0) ts3 = __builtin_amdgcn_s_memtime();
                 // ---- stage C
@@ -818,20 +820,20 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                 op += produced; pos += bsize;
             }
             done = S.blk_last != 0;
-            __syncthreads();
+            zl_sync_global();
         }
-        __syncthreads();
+        zl_sync_global();
         if (!S.err) {
             if (t == 0) {
                 if (S.fcs != ZL_CONTENTSIZE_UNKNOWN && S.fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
                 else if (S.has_checksum && n - pos < 4) S.err = ZL_E_CHECKSUM_WRONG;
             }
-            __syncthreads();
+            zl_sync_global();
             if (!S.err && S.has_checksum && !a.ignore_checksum) {
                 const u32 got = zl_xxh64_low32((u8*)S.huf, S.xxh_acc, S.scan_a, out, op);
                 if (t == 0 && got != zl_rd_le(src + pos, 4)) S.err = ZL_E_CHECKSUM_WRONG;  // zstd.c:41655
             }
-            __syncthreads();
+            zl_sync_global();
         }
         if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : op;
     }
@@ -853,9 +855,9 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_digest_dict_kernel(const u8* d
         pos += used;
         S.hdr_size = pos;
     }
-    __syncthreads();
+    zl_sync_global();
     if (!S.err) fill_huf_table(S);
-    __syncthreads();
+    zl_sync_global();
     if (t == 0 && !S.err) {
         u32 pos = S.hdr_size;
         const int kinds[3] = {K_OF, K_ML, K_LL};
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_digest_dict_kernel(const u8* d
         }
         out->status = (u32)S.err;
     }
-    __syncthreads();
+    zl_sync_global();
     if (!S.err) {
         for (u32 i = t; i < 512; i += DEC_THREADS) { out->fse_ll[i] = S.fse_ll[i]; out->fse_ml[i] = S.fse_ml[i]; }
         for (u32 i = t; i < 256; i += DEC_THREADS) out->fse_of[i] = S.fse_of[i];

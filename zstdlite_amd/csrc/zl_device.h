@@ -256,3 +256,39 @@ __device__ inline u32 zl_xxh64_low32(u8* tile /* 8 KiB LDS */, u64* acc4 /* LDS 
     return out;
 }
 
+// Workgroup w works on item zl_spread(w, n): pseudo-random order inside windows of 256 items, input
+// order across windows.  Measured on the 1 GiB mix (match kernel): input order is best when similar
+// items sit together (9.1 ms; a fully pseudo-random order lets expensive stragglers start late:
+// 10.6 ms), but costs 50 % when the cost alternates with a small period (four kinds of data
+// alternating chunk by chunk: 15.2 ms; windows of 64 do not cure it, windows of 256 give 10.4).
+__device__ __forceinline__ u32 zl_spread(u32 w, u32 n) {
+#ifndef ZL_SPREAD_LOG
+#define ZL_SPREAD_LOG 8
+#endif
+    const u32 mask = (1u << ZL_SPREAD_LOG) - 1;
+    if ((w | mask) >= n) return w;  // the ragged last window stays as it is
+    u32 x = w & mask;               // pseudo-random order inside a window, input order across windows
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> (ZL_SPREAD_LOG / 2);
+    x = (x * 0x85EBCA77u) & mask;
+    x ^= x >> (ZL_SPREAD_LOG / 2);
+    return (w & ~mask) | x;
+}
+
+// Debug aid (-DZL_POISON_LDS=<mask of kernels: 1 entropy decode, 2 exec, 4 match, 8 entropy encode>): kernels fill their LDS with a pattern before use, which turns a read of
+// never-written LDS -- normally whatever the previous workgroup left there -- into a reproducible failure.
+#ifdef ZL_POISON_LDS
+#define ZL_POISON(obj_, bit_) do { if (!((ZL_POISON_LDS) & (bit_))) break; u32* p__ = (u32*)&(obj_); for (u32 i__ = threadIdx.x; i__ < sizeof(obj_) / 4; i__ += blockDim.x) p__[i__] = 0xEEEEEEEEu; __syncthreads(); } while (0)
+#else
+#define ZL_POISON(obj_, bit_) do { } while (0)
+#endif
+
+// Workgroup barrier for data handed from one wave to another THROUGH GLOBAL MEMORY inside a kernel.
+// On gfx950 __syncthreads() waits for LDS traffic only (the compiler's memory model counts on the
+// CU's L1 seeing the workgroup's own stores in order); a wave that stored and then passed the barrier
+// may still have those stores in flight.  Draining them first costs one wait per hand-off and removed
+// a rare (about 1 in 15 fresh-box runs) wrong byte in the 1 GiB round trip.
+__device__ __forceinline__ void zl_sync_global() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}

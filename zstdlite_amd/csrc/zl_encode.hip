@@ -131,10 +131,11 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 //   seqs[c*seq_stride ...]   {lit_cum, match_len, offset} per sequence
 //   meta[c]                  {nseq, nlit}
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) {
+__global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a, u32 nchunks) {
     __shared__ MatchShared S;
+    ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
-    const u32 c = blockIdx.x;
+    const u32 c = zl_spread(blockIdx.x, nchunks);
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a) 
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_match_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
+    hipLaunchKernelGGL(zl_match_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -858,10 +859,11 @@ __device__ __forceinline__ void seq_fields(const zl_seq* seqs, u32 i, u32 blk_fi
     ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
 }
 
-__global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a) {
+__global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ EntShared S;
+    ZL_POISON(S, 8);
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const u32 c = blockIdx.x;
+    const u32 c = zl_spread(blockIdx.x, nchunks);
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 sst[i] = make_ushort4((unsigned short)(cl | (cm << 8)), (unsigned short)co, 0, 0);
             }
         }
-        __syncthreads();
+        zl_sync_global();  // the codes travel to the chain lanes through memory
         // table choice + construction: one lane per table, three waves in parallel
         // (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059)
         if (lane == 0 && wave < 3) {
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             }
             if (on) S.final_state[j][k] = st;
         }
-        __syncthreads();
+        zl_sync_global();  // the saved states travel to the assembling threads through memory
         ENT_STAMP(2)
     }
 
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     bool fail = false;        // uniform: the frame outgrew its staging slot -> raw block
     bool tree_out = false;    // uniform: a block has carried the Huffman tree
     bool tables_out = false;  // uniform: a block has carried the sequence tables
-    u32 last_hdr = 0;         // where the last block header went (for the Last_Block bit)
+    u32 last_hdr = 0, last_hdr_val = 0;  // where the last block header went and what it holds (for the Last_Block bit)
     const u32 tree_sz = S.tree_size;
     for (u32 j = 0; j < nbk && !fail; j++) {
         const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
@@ -1286,6 +1288,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         const u32 bsize = lit_sec + seq_sec;
         if (t == 0) wr_le(out + cur, (2u << 1) | (bsize << 3), 3);
         last_hdr = cur;
+        last_hdr_val = (2u << 1) | (bsize << 3);
         cur += 3 + bsize;
         __syncthreads();
         ENT_STAMP(4)
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         if (t == 0) wr_le(out + fh, 1u | (0u << 1) | (n << 3), 3);
         fsize = fh + 3 + n;
     } else {
-        if (t == 0) out[last_hdr] |= 1;  // Last_Block
+        if (t == 0) wr_le(out + last_hdr, last_hdr_val | 1u, 3);  // Last_Block
         fsize = cur;
     }
     if (a.checksum) {
@@ -1348,7 +1351,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_gather_kernel(zl_gather_args a
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_entropy_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
+    hipLaunchKernelGGL(zl_entropy_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream) {

@@ -29,6 +29,11 @@ struct DevBuf {
         size_t want = n + (n >> 3) + 256;
         if (!zl_hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
         cap = want;
+        // ZL_POISON_MEM=1 in the environment fills every new device buffer with a pattern: a kernel that
+        // reads scratch it has not written then fails reproducibly instead of depending on what the
+        // allocation held before (debug aid)
+        static const bool poison = getenv("ZL_POISON_MEM") != nullptr;
+        if (poison) { (void)hipMemset(p, 0xEE, want); (void)hipDeviceSynchronize(); }  // (the contexts' streams do not wait for the null stream)
         return true;
     }
     void release() {
