@@ -28,7 +28,7 @@ for kind in kinds:
     ct = (C.c_ulonglong * 16)()
     if hasattr(codec.L, "zl_cctx_phase_stats") and codec.L.zl_cctx_phase_stats(C.c_void_p(codec.cctx), ct) == 0 and ct[4]:
         it = ct[4]
-        print(f"        match phases, cycles/iteration: find {ct[0]/it:.0f}  parse {ct[1]/it:.0f}  emit {ct[2]/it:.0f}  insert {ct[3]/it:.0f}")
+        print(f"        match phases, cycles/iteration: find {ct[0]/it:.0f}  parse {ct[1]/it:.0f}  emit {ct[2]/it:.0f}  insert {ct[3]/it:.0f}   sequences/iteration {ct[5]/it:.1f}")
     if ct[14]:
         nc = ct[14]
         print(f"        entropy phases, kcycles/chunk: huffman {ct[8]/nc/1e3:.0f}  seq tables {ct[9]/nc/1e3:.0f}  chains {ct[10]/nc/1e3:.0f}  blk literals {ct[11]/nc/1e3:.0f}  blk sequences {ct[12]/nc/1e3:.0f}  rest {ct[13]/nc/1e3:.0f}")
