@@ -150,7 +150,8 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  * zl_CCtx_setParameter(cctx, ZL_c_profile, 1) / zl_DCtx_setParameter(dctx, ZL_d_profile, 1).
  * zl_cctx_kernel_ms fills ms[0..3] = {match, entropy, size-scan, gather}; zl_dctx_kernel_ms
  * fills ms[0..4] = {whole decode, frame/block index, literal+sequence lanes, execution, general
- * kernel}.  Return 0, or an error code when profiling was not enabled. */
+ * kernel}.  Return 0, or an error code when profiling was not enabled.  A value of 2 additionally makes
+ * the kernels count shader cycles per phase (global atomics: slows them down; development only). */
 #define ZL_c_profile 9001
 #define ZL_d_profile 9002
 size_t zl_cctx_kernel_ms(const zl_cctx *cctx, double *ms);

@@ -6,7 +6,7 @@ from zstdlite_amd.device import DeviceCodec, gen_device
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (256 << 20)
 kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rand", "iid10", "text", "int20"]
-codec = DeviceCodec(profile=True)
+codec = DeviceCodec(profile=2)
 for kind in kinds:
     src = gen_device(kind, n, dev)
     comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=dev)

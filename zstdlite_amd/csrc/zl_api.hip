@@ -286,7 +286,7 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     switch (param) {
     case ZL_d_forceIgnoreChecksum: d->ignore_checksum = value ? 1 : 0; return 0;
     case ZL_d_stableOutBuffer: return 0;
-    case ZL_d_profile: d->profile = value ? 1 : 0; return 0;
+    case ZL_d_profile: d->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -418,7 +418,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.seq_scratch = (u32*)d->d_seq2.p;
     f2.ignore_checksum = (u32)d->ignore_checksum;
     f2.stats = nullptr;
-    if (d->profile && d->d_stats.ensure(128)) {
+    if (d->profile >= 2 && d->d_stats.ensure(128)) {
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;
     }
@@ -444,7 +444,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     a.ignore_checksum = (u32)d->ignore_checksum;
     a.plan = f2.plan;
     a.frec = f2.frec;
-    a.stats = (d->profile && d->d_stats.p) ? (u64*)d->d_stats.p : nullptr;
+    a.stats = (d->profile >= 2 && d->d_stats.p) ? (u64*)d->d_stats.p : nullptr;
     if (zl_launch_decode(&a, slots, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (d->profile) { (void)hipEventRecord(d->ev[4], st); d->ev_valid = true; }
     return 0;

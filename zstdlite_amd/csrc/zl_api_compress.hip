@@ -75,7 +75,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.lit_stride = ZL_LIT_STRIDE_ENC;
         m.seq_stride = ZL_SEQ_STRIDE;
         m.stats = nullptr;
-        if (prof && c->d_stats.ensure(128)) {
+        if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
             (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
             m.stats = (u64*)c->d_stats.p;
         }
@@ -174,7 +174,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
     case ZL_c_stableInBuffer:
     case ZL_c_stableOutBuffer: return 0;
-    case ZL_c_profile: c->profile = value ? 1 : 0; return 0;
+    case ZL_c_profile: c->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }

@@ -965,6 +965,7 @@ struct ExecShared {
     u16 own[(EX_CAP >> EX_GRAN_LOG) + 8];
     u64 xxh_acc[4];
     u32 bcast[8];  // [0] xxh result, [1] batch size, [4..6] rotating "still pending" flags
+    u32 brec[ZL2_MAXB * 16];  // the frame's block records, fetched once
     int err;
 };
 
@@ -990,6 +991,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
     __shared__ __align__(16) ExecShared S;
     ZL_POISON(S, 2);
     const u32 t = threadIdx.x;
+    const u64 wg_t0 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
     const u32 f = zl_spread(blockIdx.x, a.nframes);
     zl2_frame_rec* fr = a.frec + f;
     const u32 ferr = fr->err;
@@ -1006,12 +1008,18 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
     const u8* lit_base = a.lit_scratch + a.plan[f].lit_off;
     const uint4* q_seq = (const uint4*)a.seq_scratch + a.plan[f].seq_off;
     if (t == 0) S.err = 0;
+    const u32 nblocks = fr->nblocks;
+    static_assert(sizeof(zl2_blk_rec) == 64, "block records are staged as 16 dwords each");
+    if (t < nblocks * 16) S.brec[t] = ((const u32*)br)[t];
     __syncthreads();
     u64 op = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
-    const u32 nblocks = fr->nblocks;
+    const u64 wg_t1 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    // Output goes to memory with plain stores and is read back (by other waves) only in pass 2a of a
+    // later batch, so the one place that drains the stores is the barrier in front of pass 2a:
+    // literal-only and raw blocks never wait for their stores.
     for (u32 b = 0; b < nblocks; b++) {
-        const zl2_blk_rec r = br[b];
+        const zl2_blk_rec r = *(const zl2_blk_rec*)&S.brec[b * 16];
         const u8* blk = src + r.src_off;
         u8* bdst = dst + op;
         if (r.type != 2) {
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                 for (u32 i = t * 16; i < body; i += EX_THREADS * 16) __builtin_memcpy(bdst + i, &v, 16);
                 if (t < r.size - body) bdst[body + t] = (u8)v4;
             }
-            zl_sync_global();
+            __syncthreads();
             if (S.err) break;
             op += r.size;
             continue;
@@ -1119,7 +1127,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                     }
                 }
             }
-            if (linked) __syncthreads(); else zl_sync_global();  // (the long-sequence path put its literals straight into memory)
+            zl_sync_global();  // everything this workgroup has written so far is in memory before pass 2a reads it back
             const u64 st2 = prof ? __builtin_amdgcn_s_memtime() : 0;
             if (linked) {
                 // ---- pass 2a: one hop for every match byte
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
             lit_pos += tot_l;
             out_pos += tot_o;
             b0 += nb;
-            zl_sync_global();  // the batch is in memory (and visible to this workgroup) before the next one reads it
+            __syncthreads();  // (LDS reuse; the flush is drained in front of the next pass 2a)
             if (prof) {
                 const u64 st3 = __builtin_amdgcn_s_memtime();
                 c_scan += st1 - st0; c_lit += st2 - st1; c_match += st3 - st2; c_batches++;
@@ -1241,7 +1249,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
             rep0 = n0; rep1 = n1; rep2 = n2;
         }
 #undef ZL2_RESOLVE
-        zl_sync_global();
+        __syncthreads();
         const u32 produced = out_pos + rest;
         if (prof) {
             const u64 st5 = __builtin_amdgcn_s_memtime();
@@ -1254,7 +1262,12 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
         }
         op += produced;
     }
+    const u64 wg_t2 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
     zl_sync_global();
+    if (a.stats != nullptr && t == 0) {  // profile: prologue, and the final drain of this frame's stores
+        atomicAdd((unsigned long long*)&a.stats[-2], (unsigned long long)(wg_t1 - wg_t0));
+        atomicAdd((unsigned long long*)&a.stats[-1], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t2));
+    }
     if (!S.err) {
         if (t == 0 && fr->fcs != ZL_CONTENTSIZE_UNKNOWN && fr->fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
         __syncthreads();
@@ -1265,6 +1278,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
         __syncthreads();
     }
     if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : op;
+    if (a.stats != nullptr && t == 0) atomicAdd((unsigned long long*)&a.stats[-3], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t0));  // profile: workgroup lifetime
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1281,4 +1295,12 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent
     hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
+}
+
+// debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
+extern "C" int zl2_debug_occupancy(int which) {
+    int n = -1;
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel, EX_THREADS, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_entropy_kernel, LIT_THREADS, 0);
+    return n;
 }

@@ -2066,3 +2066,11 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
     hipLaunchKernelGGL(zl_gather_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a);
     return hipGetLastError();
 }
+
+// debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
+extern "C" int zl_debug_occupancy(int which) {
+    int n = -1;
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel, ENC_THREADS, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
+    return n;
+}

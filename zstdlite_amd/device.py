@@ -27,9 +27,9 @@ class DeviceCodec:
             self.L.zl_CCtx_setParameter(self.cctx, ZL_c_checksumFlag, 1)
         if not validate_checksum:
             self.L.zl_DCtx_setParameter(self.dctx, ZL_d_forceIgnoreChecksum, 1)
-        if profile:
-            self.L.zl_CCtx_setParameter(self.cctx, ZL_c_profile, 1)
-            self.L.zl_DCtx_setParameter(self.dctx, ZL_d_profile, 1)
+        if profile:  # True / 1: per-kernel HIP events; 2: also in-kernel phase stamps (slows the kernels down)
+            self.L.zl_CCtx_setParameter(self.cctx, ZL_c_profile, int(profile))
+            self.L.zl_DCtx_setParameter(self.dctx, ZL_d_profile, int(profile))
 
     def close(self):
         if self.cctx:
