@@ -111,6 +111,16 @@ __device__ __forceinline__ void insert16_retry(u32* w, u32 old, u32 sh, u32 val,
         old = prev;
     }
 }
+// Ordered insert: the four waves of the workgroup write their 16-bit entries one wave after the
+// other (plain stores, a barrier between the waves), so a later wave -- later positions -- overwrites
+// an earlier one.  Two lanes of ONE wave that hit the same bucket in the same store instruction are
+// arbitrated by the LDS hardware, a fixed function of the lane numbers: whichever it picks, the table
+// content is the same on every run (what the format needs is determinism; "most recent wins" is only
+// a preference).  Costs four barriers instead of a compare-and-swap per entry with retries, which
+// measured 1400-1900 cycles per window (stride 1) and 2800-4000 (stride 2).
+#ifndef ZL_INSERT_CAS
+#define ZL_INSERT_CAS 0
+#endif
 __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* ts, u32 bs, u32 old_s, u32 p, u32 ip, u32 win) {
     const u32 val = (p + 1) & 0xFFFF;
     if (val == 0) return;
@@ -339,7 +349,17 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a, 
         for (int j = 0; j < PPT; j++) {
             if (can_match[j]) {
                 const u32 p = ip + t + ENC_THREADS * j;
-                insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip, WIN);
+                if (ZL_INSERT_CAS) insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip, WIN);
+            }
+        }
+        if (!ZL_INSERT_CAS) {
+            for (u32 ph = 0; ph < 4; ph++) {
+                if (ph == (t >> 6) && can_match[0]) {
+                    const unsigned short val = (unsigned short)(ip + t + 1);
+                    ((unsigned short*)S.tbl_long)[hl[0]] = val;
+                    ((unsigned short*)S.tbl_short)[hs[0]] = val;
+                }
+                if (ph < 3) lds_barrier();
             }
         }
         nseq += tot_s;
@@ -582,8 +602,18 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match2_kernel(zl_match_args a,
         carry = next_carry;
         const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
         // ---- insert both positions of every lane (most recent position wins)
-        if (can0) insert16_pair(S.tbl_long, hl0, wl0, S.tbl_short, hs0, ws0, p, ip, WIN2);
-        if (can1) insert16_pair(S.tbl_long, hl1, wl1, S.tbl_short, hs1, ws1, p + 1, ip, WIN2);
+        if (ZL_INSERT_CAS) {
+            if (can0) insert16_pair(S.tbl_long, hl0, wl0, S.tbl_short, hs0, ws0, p, ip, WIN2);
+            if (can1) insert16_pair(S.tbl_long, hl1, wl1, S.tbl_short, hs1, ws1, p + 1, ip, WIN2);
+        } else {
+            for (u32 ph = 0; ph < 4; ph++) {
+                if (ph == wave) {
+                    if (can0) { ((unsigned short*)S.tbl_long)[hl0] = (unsigned short)(p + 1); ((unsigned short*)S.tbl_short)[hs0] = (unsigned short)(p + 1); }
+                    if (can1) { ((unsigned short*)S.tbl_long)[hl1] = (unsigned short)(p + 2); ((unsigned short*)S.tbl_short)[hs1] = (unsigned short)(p + 2); }
+                }
+                if (ph < 3) lds_barrier();
+            }
+        }
         nseq += tot_s;
         nlit += tot_l;
         lds_barrier();
@@ -844,7 +874,17 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             for (int j = 0; j < PPT; j++) {
                 if (can_match[j]) {
                     const u32 p = ip + t + ENC_THREADS * j;
-                    insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip, WIN);
+                    if (ZL_INSERT_CAS) insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip, WIN);
+                }
+            }
+            if (!ZL_INSERT_CAS) {
+                for (u32 ph = 0; ph < 4; ph++) {
+                    if (ph == (t >> 6) && can_match[0]) {
+                        const unsigned short val = (unsigned short)(ip + t + 1);
+                        ((unsigned short*)S.tbl_long)[hl[0]] = val;
+                        ((unsigned short*)S.tbl_short)[hs[0]] = val;
+                    }
+                    if (ph < 3) lds_barrier();
                 }
             }
             nseq += tot_s;
@@ -1035,8 +1075,18 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             carry = covered ? carry - WIN2 : 2 * next_carry;
             const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- insert both positions of every lane (most recent position wins)
-            if (can0) insert16_pair(S.tbl_long, hl0, wl0, S.tbl_short, hs0, ws0, p, ip, WIN2);
-            if (can1) insert16_pair(S.tbl_long, hl1, wl1, S.tbl_short, hs1, ws1, p + 1, ip, WIN2);
+            if (ZL_INSERT_CAS) {
+                if (can0) insert16_pair(S.tbl_long, hl0, wl0, S.tbl_short, hs0, ws0, p, ip, WIN2);
+                if (can1) insert16_pair(S.tbl_long, hl1, wl1, S.tbl_short, hs1, ws1, p + 1, ip, WIN2);
+            } else {
+                for (u32 ph = 0; ph < 4; ph++) {
+                    if (ph == wave) {
+                        if (can0) { ((unsigned short*)S.tbl_long)[hl0] = (unsigned short)(p + 1); ((unsigned short*)S.tbl_short)[hs0] = (unsigned short)(p + 1); }
+                        if (can1) { ((unsigned short*)S.tbl_long)[hl1] = (unsigned short)(p + 2); ((unsigned short*)S.tbl_short)[hs1] = (unsigned short)(p + 2); }
+                    }
+                    if (ph < 3) lds_barrier();
+                }
+            }
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
