@@ -31,7 +31,7 @@ for kind in kinds:
         print(f"        match phases, cycles/iteration: find {ct[0]/it:.0f}  parse {ct[1]/it:.0f}  emit {ct[2]/it:.0f}  insert {ct[3]/it:.0f}   sequences/iteration {ct[5]/it:.1f}")
     if ct[14]:
         nc = ct[14]
-        print(f"        entropy phases, kcycles/chunk: huffman {ct[8]/nc/1e3:.0f}  seq tables {ct[9]/nc/1e3:.0f}  chains {ct[10]/nc/1e3:.0f}  blk literals {ct[11]/nc/1e3:.0f}  blk sequences {ct[12]/nc/1e3:.0f}  rest {ct[13]/nc/1e3:.0f}")
+        print(f"        entropy phases, kcycles/chunk: statistics {ct[8]/nc/1e3:.0f}  tree|tables {ct[9]/nc/1e3:.0f}  codes+bits {ct[10]/nc/1e3:.0f}  chains|tree description (+tail) {ct[13]/nc/1e3:.0f}  blk literals {ct[11]/nc/1e3:.0f}  blk sequences {ct[12]/nc/1e3:.0f}")
     if st[13]:
         nb = st[13]
         print(f"        exec phases, kcycles/block: scan {st[8]/nb/1e3:.0f}  lit {st[9]/nb/1e3:.0f}  match {st[10]/nb/1e3:.0f}  flush {st[11]/nb/1e3:.0f}  batches/block {st[12]/nb:.1f}")

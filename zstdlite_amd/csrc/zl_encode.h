@@ -55,7 +55,7 @@ struct zl_entropy_args {
     u32 out_stride;
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
-    u64* stats;        // optional (profiling): cycles {huffman build, sequence tables, chains, block literals, block sequences, rest, chunks}
+    u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
 
 struct zl_gather_args {

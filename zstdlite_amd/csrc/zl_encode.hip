@@ -1497,14 +1497,23 @@ __device__ u32 huf_write_tree(EntShared& S, u8* dst) {
 __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed */, const u8* lit, u32 cnt, u8* out) {
     const u32 lane = threadIdx.x & 63;
     u32 written = 0, carry_bits = 0;
+    // the 8 symbols of a lane are 8 consecutive bytes (read back to front): one load, fetched a tile ahead
+    u64 nextv = 0;
+    if (cnt >= 8 * (lane + 1)) nextv = ld64(lit + cnt - 8 * (lane + 1));
     for (u32 e0 = 0; e0 < cnt; e0 += 512) {
+        const u32 first = e0 + lane * 8;  // emission index of this lane's first symbol
+        u64 v = nextv;
+        if (first < cnt && first + 8 > cnt) {  // the ragged front of the stream: byte by byte
+            v = 0;
+            for (u32 j = 0; first + j < cnt; j++) v |= (u64)lit[cnt - 1 - first - j] << (56 - 8 * j);
+        }
+        if (first + 512 + 8 <= cnt) nextv = ld64(lit + cnt - (first + 512) - 8);
         u64 lo = 0, hi = 0;
         u32 nlo = 0, nhi = 0;
 #pragma unroll
         for (u32 j = 0; j < 8; j++) {
-            const u32 e = e0 + lane * 8 + j;
-            if (e < cnt) {
-                const u32 sym = lit[cnt - 1 - e];
+            if (first + j < cnt) {
+                const u32 sym = (u32)(v >> (56 - 8 * j)) & 0xFF;  // byte cnt-1-(first+j)
                 const u32 len = S.hlen[sym];
                 const u64 code = S.hcode[sym];
                 if (j < 4) { lo |= code << nlo; nlo += len; }
@@ -1515,8 +1524,8 @@ __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed *
         u32 inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const u32 v = __shfl_up(inc, d, 64);
-            if ((int)lane >= d) inc += v;
+            const u32 x = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += x;
         }
         const u32 tile_bits = __shfl(inc, 63, 64);
         const u32 pos = carry_bits + inc - mine;
@@ -1526,7 +1535,11 @@ __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed *
         const u32 total = carry_bits + tile_bits;
         const u32 nbytes = total >> 3;
         const u8* sb = (const u8*)stage;
-        for (u32 i = lane; i < nbytes; i += 64) out[written + i] = sb[i];
+        {   // whole dwords first (global memory takes unaligned dword stores), then the odd bytes
+            const u32 nd = nbytes >> 2;
+            for (u32 i = lane; i < nd; i += 64) { const u32 x = stage[i]; __builtin_memcpy(out + written + 4 * i, &x, 4); }
+            if (lane < (nbytes & 3)) out[written + 4 * nd + lane] = sb[4 * nd + lane];
+        }
         __builtin_amdgcn_wave_barrier();
         // keep the partial byte, clear the rest
         const u32 keep = (total & 7) ? sb[nbytes] : 0;
@@ -1645,7 +1658,10 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
     __syncthreads();
 
-    // =========================== literals: one Huffman table per chunk (zstd.c:20692 ZSTD_compressLiterals)
+    // =========================== statistics of the whole chunk: literal histogram, sequence codes and their histograms
+    // (zstd.c:20692 ZSTD_compressLiterals, zstd.c:25265 ZSTD_buildSequencesStatistics).  The serial
+    // pieces that follow run side by side on different waves: the Huffman tree next to the three FSE
+    // tables, the tree description next to the FSE state chains.
     {   // 16 literals per thread and trip (one byte per trip leaves a single load in flight per thread);
         // four histogram copies, one per wave, keep the atomics apart
         const u32 body = nlit & ~15u;
@@ -1662,7 +1678,22 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         }
         if (t < nlit - body) atomicAdd(&S.hist[wave][lit[body + t]], 1u);
     }
-    __syncthreads();
+    if (nseq) {
+        for (u32 j = 0; j < nbk; j++) {
+            const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
+            for (u32 i = f_seq + t; i < e_seq; i += ENC_THREADS) {
+                const zl_seq s = seqs[i];
+                u32 ll, ob;
+                seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
+                const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(s.match_len);
+                atomicAdd(&S.seq_hist[T_LL][cl], 1u);
+                atomicAdd(&S.seq_hist[T_OF][co], 1u);
+                atomicAdd(&S.seq_hist[T_ML][cm], 1u);
+                sst[i] = make_ushort4((unsigned short)(cl | (cm << 8)), (unsigned short)co, 0, 0);
+            }
+        }
+    }
+    zl_sync_global();  // (the codes travel to the chain lanes through memory)
     const u32 cnt_t = S.hist[0][t] + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
     __syncthreads();
     S.hist[0][t] = cnt_t;
@@ -1678,28 +1709,71 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             }
         }
         if (cnt_t) S.sorted[rank] = (u16)t;
-        if (t == 0) S.huf_present = present;
+        if (t == 0) {
+            S.huf_present = present;
+            u32 mode = 0;
+            if (nlit > 63 && present == 1) mode = 1;   // zstd.c:20725 minLitSize, :20750 RLE
+            else if (nlit > 63 && present >= 2) mode = 2;
+            S.lit_mode = mode;
+            S.tree_size = 0;
+        }
     }
     S.hlen[t] = 0;
     __syncthreads();
-    if (t == 0) {
-        u32 mode = 0;
-        const u32 m = S.huf_present;
-        if (nlit > 63 && m == 1) mode = 1;   // zstd.c:20725 minLitSize, :20750 RLE
-        else if (nlit > 63 && m >= 2) mode = 2;
-        S.lit_mode = mode;
-        S.tree_size = 0;
+    ENT_STAMP(0)
+    // ---- wave 3: the Huffman tree  |  waves 0..2: one FSE table each
+    if (t == 3 * 64 && S.lit_mode == 2) {
+        // zstd.c:18076 (HUF_compress_internal): "heuristic: probably not compressible enough"
+        if (S.hist[0][S.sorted[S.huf_present - 1]] <= (nlit >> 7) + 4) S.lit_mode = 0;
+    }
+    if (t == 3 * 64 && S.lit_mode == 2) {
+        S.huf_log = huf_build_lengths(S, S.huf_present);
+        u32 maxsym = 255;
+        while (S.hist[0][maxsym] == 0) maxsym--;
+        S.huf_maxsym = maxsym;
+    }
+    // table choice + construction (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059)
+    if (nseq && lane == 0 && wave < 3) {
+        const int k = (int)wave;
+        const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
+        const int def_log = k == T_OF ? 5 : 6, max_log = k == T_OF ? 8 : 9;
+        const u32* h = S.seq_hist[k];
+        int max_sym = 0;
+        u32 most = 0;
+        for (int s = 0; s <= max_code; s++) if (h[s]) { max_sym = s; if (h[s] > most) most = h[s]; }
+        FseCTable& ct = S.ct[k];
+        short* norm = S.tnorm[k];
+        u8* tsym = S.ttsym[k];
+        u32 mode;
+        if (most == nseq) mode = (nseq <= 2) ? 0 : 1;
+        else if (nseq < ((1u << def_log) * 8u >> 3) || most < (nseq >> (def_log - 1))) mode = 0;
+        else mode = 2;
+        if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
+        S.seq_mode[k] = mode;
+        ct.max_sym = max_sym;
+        if (mode == 0) {
+            const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
+            const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
+            for (int s = 0; s <= dmax; s++) norm[s] = def[s];
+            fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, dmax, def_log);
+            ct.log = (u32)def_log;
+        } else if (mode == 1) {
+            ct.log = 0;
+        } else {
+            int log = (int)hb32(nseq - 1) - 2;  // zstd.c:16220 FSE_optimalTableLog idea
+            if (log > max_log) log = max_log;
+            const int min_log = (int)hb32((u32)max_sym) + 2;
+            if (log < min_log) log = min_log;
+            if (log < 5) log = 5;
+            if (log > max_log) log = max_log;
+            fse_normalize(norm, h, nseq, max_sym, log);
+            fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, max_sym, log);
+            ct.log = (u32)log;
+        }
     }
     __syncthreads();
+    ENT_STAMP(1)
     if (S.lit_mode == 2) {
-        // tree (one thread)
-        if (t == 0) {
-            S.huf_log = huf_build_lengths(S, S.huf_present);
-            u32 maxsym = 255;
-            while (S.hist[0][maxsym] == 0) maxsym--;
-            S.huf_maxsym = maxsym;
-        }
-        __syncthreads();
         // codes: same cell order as the decoder's table (ascending weight, ascending symbol)
         {
             const u32 len = S.hlen[t];
@@ -1737,128 +1811,68 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d, 64);
             if (lane == 0) S.sbits[j][k] = bits;
         }
-        __syncthreads();
-        if (t == 0) {
-            u32 total = 0;
-            for (u32 j = 0; j < nbk; j++) {
-                const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
-                for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
-                total += four ? 6 : 0;
-            }
-            const u32 tree = huf_write_tree(S, S.tree_buf);
-            S.tree_size = tree;
-            if (tree == 0 || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
-        }
-        __syncthreads();
     }
+    __syncthreads();
+    ENT_STAMP(2)
+    // ---- wave 3: the tree description and the literal decision  |  wave 0: the FSE state chains
+    if (t == 3 * 64 && S.lit_mode == 2) {
+        u32 total = 0;
+        for (u32 j = 0; j < nbk; j++) {
+            const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
+            for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
+            total += four ? 6 : 0;
+        }
+        const u32 tree = huf_write_tree(S, S.tree_buf);
+        S.tree_size = tree;
+        if (tree == 0 || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
+    }
+    // The FSE state chains (zstd.c:21163-21222) are serial per table and per block -- and the blocks
+    // are independent, so the 3 x nbk chains run side by side on the lanes of one wave.  Each lane
+    // leaves the state *before* every sequence in the scratch record; the bits that state emits are
+    // cut from it when the bitstream is assembled.
+    if (nseq && wave == 0) {
+        const u32 j = lane / 3, k = lane % 3;
+        const bool on = lane < 3 * nbk;
+        const u32 e_seq = on ? S.blk_seq[j + 1] : 0u, ns = on ? e_seq - S.blk_seq[j] : 0u;
+        u32 max_ns = ns;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(max_ns, d, 64); max_ns = o > max_ns ? o : max_ns; }
+        const FseCTable& ct = S.ct[k];
+        const u32 log = ct.log;
+        unsigned short* slot = (unsigned short*)sst + (k == T_LL ? 2 : (k == T_ML ? 3 : 1));
+        u32 st = 0;
+        // Eight records are fetched while the previous eight are being coded: the chain itself only
+        // touches LDS, and a load that is needed right away would cost a memory round trip per step.
+        ushort4 cur[8], nxt[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { nxt[q] = make_ushort4(0, 0, 0, 0); if ((u32)q < ns) nxt[q] = sst[e_seq - 1 - q]; }
+        for (u32 e0 = 0; e0 < max_ns; e0 += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) cur[q] = nxt[q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (e0 + 8 + q < ns) nxt[q] = sst[e_seq - 1 - (e0 + 8 + q)];
+            u32 before[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const u32 e = e0 + q;
+                before[q] = 0;
+                if (e < ns && log) {
+                    const ushort4 rec = cur[q];
+                    const u32 sym = k == T_LL ? (rec.x & 0xFFu) : (k == T_ML ? (u32)(rec.x >> 8) : (u32)rec.y);
+                    if (e == 0) st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]);
+                    else { before[q] = st; (void)fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st); }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (e0 + q < ns) slot[4 * (size_t)(e_seq - 1 - (e0 + q))] = (unsigned short)before[q];
+        }
+        if (on) S.final_state[j][k] = st;
+    }
+    zl_sync_global();  // the saved states travel to the assembling threads through memory
     // the tree nodes shared this region: staging words must be zero before bits are OR-ed in
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     __syncthreads();
-
-    ENT_STAMP(0)
-    // =========================== sequences: one table set per chunk (zstd.c:25265 ZSTD_buildSequencesStatistics)
-    if (nseq) {
-        for (u32 j = 0; j < nbk; j++) {
-            const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
-            for (u32 i = f_seq + t; i < e_seq; i += ENC_THREADS) {
-                const zl_seq s = seqs[i];
-                u32 ll, ob;
-                seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
-                const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(s.match_len);
-                atomicAdd(&S.seq_hist[T_LL][cl], 1u);
-                atomicAdd(&S.seq_hist[T_OF][co], 1u);
-                atomicAdd(&S.seq_hist[T_ML][cm], 1u);
-                sst[i] = make_ushort4((unsigned short)(cl | (cm << 8)), (unsigned short)co, 0, 0);
-            }
-        }
-        zl_sync_global();  // the codes travel to the chain lanes through memory
-        // table choice + construction: one lane per table, three waves in parallel
-        // (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059)
-        if (lane == 0 && wave < 3) {
-            const int k = (int)wave;
-            const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
-            const int def_log = k == T_OF ? 5 : 6, max_log = k == T_OF ? 8 : 9;
-            const u32* h = S.seq_hist[k];
-            int max_sym = 0;
-            u32 most = 0;
-            for (int s = 0; s <= max_code; s++) if (h[s]) { max_sym = s; if (h[s] > most) most = h[s]; }
-            FseCTable& ct = S.ct[k];
-            short* norm = S.tnorm[k];
-            u8* tsym = S.ttsym[k];
-            u32 mode;
-            if (most == nseq) mode = (nseq <= 2) ? 0 : 1;
-            else if (nseq < ((1u << def_log) * 8u >> 3) || most < (nseq >> (def_log - 1))) mode = 0;
-            else mode = 2;
-            if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
-            S.seq_mode[k] = mode;
-            ct.max_sym = max_sym;
-            if (mode == 0) {
-                const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
-                const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
-                for (int s = 0; s <= dmax; s++) norm[s] = def[s];
-                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, dmax, def_log);
-                ct.log = (u32)def_log;
-            } else if (mode == 1) {
-                ct.log = 0;
-            } else {
-                int log = (int)hb32(nseq - 1) - 2;  // zstd.c:16220 FSE_optimalTableLog idea
-                if (log > max_log) log = max_log;
-                const int min_log = (int)hb32((u32)max_sym) + 2;
-                if (log < min_log) log = min_log;
-                if (log < 5) log = 5;
-                if (log > max_log) log = max_log;
-                fse_normalize(norm, h, nseq, max_sym, log);
-                fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, max_sym, log);
-                ct.log = (u32)log;
-            }
-        }
-        __syncthreads();
-        ENT_STAMP(1)
-        // The FSE state chains (zstd.c:21163-21222) are serial per table and per block -- and the blocks
-        // are independent, so the 3 x nbk chains run side by side on the lanes of one wave.  Each lane
-        // leaves the state *before* every sequence in the scratch record; the bits that state emits are
-        // cut from it when the bitstream is assembled.
-        if (wave == 0) {
-            const u32 j = lane / 3, k = lane % 3;
-            const bool on = lane < 3 * nbk;
-            const u32 e_seq = on ? S.blk_seq[j + 1] : 0u, ns = on ? e_seq - S.blk_seq[j] : 0u;
-            u32 max_ns = ns;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(max_ns, d, 64); max_ns = o > max_ns ? o : max_ns; }
-            const FseCTable& ct = S.ct[k];
-            const u32 log = ct.log;
-            unsigned short* slot = (unsigned short*)sst + (k == T_LL ? 2 : (k == T_ML ? 3 : 1));
-            u32 st = 0;
-            // Eight records are fetched while the previous eight are being coded: the chain itself only
-            // touches LDS, and a load that is needed right away would cost a memory round trip per step.
-            ushort4 cur[8], nxt[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) { nxt[q] = make_ushort4(0, 0, 0, 0); if ((u32)q < ns) nxt[q] = sst[e_seq - 1 - q]; }
-            for (u32 e0 = 0; e0 < max_ns; e0 += 8) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) cur[q] = nxt[q];
-#pragma unroll
-                for (int q = 0; q < 8; q++) if (e0 + 8 + q < ns) nxt[q] = sst[e_seq - 1 - (e0 + 8 + q)];
-                u32 before[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const u32 e = e0 + q;
-                    before[q] = 0;
-                    if (e < ns && log) {
-                        const ushort4 rec = cur[q];
-                        const u32 sym = k == T_LL ? (rec.x & 0xFFu) : (k == T_ML ? (u32)(rec.x >> 8) : (u32)rec.y);
-                        if (e == 0) st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]);
-                        else { before[q] = st; (void)fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st); }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) if (e0 + q < ns) slot[4 * (size_t)(e_seq - 1 - (e0 + q))] = (unsigned short)before[q];
-            }
-            if (on) S.final_state[j][k] = st;
-        }
-        zl_sync_global();  // the saved states travel to the assembling threads through memory
-        ENT_STAMP(2)
-    }
+    ENT_STAMP(5)
 
     // =========================== the blocks, one after the other (zstd.c:26833 ZSTD_compressBlock_internal)
     u32 cur = fh;             // write cursor inside the frame
