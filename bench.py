@@ -132,9 +132,10 @@ def c2_decode(codec, device, log, nframes=10000):
         if it:
             best = min(best, dt)
     assert total == nframes * fsz and torch.equal(d_dst, want), "C2 decode mismatch"
-    kms = codec.kernel_ms().get("decode")
+    km = codec.kernel_ms()
     return {"frames": nframes, "frame_bytes": fsz, "decompress_GBps": nframes * fsz / best / 1e9,
-            "decode_kernel_ms": kms, "compressed_bytes": int(blob.size), "bit_exact": True}
+            "decode_kernel_ms": km.get("decode"), "kernel_ms": {k: km[k] for k in ("d_index", "d_entropy", "d_exec", "d_general") if k in km},
+            "compressed_bytes": int(blob.size), "bit_exact": True}
 
 
 def main():
@@ -239,7 +240,7 @@ def main():
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_kernel", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
+            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
                                                            "gather": "zl_gather_kernel", "d_index": "zl2_index_kernel", "d_entropy": "zl2_entropy_kernel",
                                                            "d_exec": "zl2_exec_kernel", "d_general": "zl_decode_kernel"}[dom],
                                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,

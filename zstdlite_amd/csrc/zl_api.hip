@@ -135,6 +135,7 @@ struct zl_dctx_s {
     // diagnostics
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // start, after index, after entropy lanes, after exec, end
+    zl2_side side = {nullptr, nullptr, nullptr};
     bool ev_valid = false;
     double kernel_ms = 0;
     double stage_ms[4] = {0, 0, 0, 0};
@@ -277,6 +278,9 @@ size_t zl_freeDCtx(zl_dctx* d) {
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+    if (d->side.fork) (void)hipEventDestroy(d->side.fork);
+    if (d->side.join) (void)hipEventDestroy(d->side.join);
+    if (d->side.stream) (void)hipStreamDestroy(d->side.stream);
     delete d;
     return 0;
 }
@@ -422,7 +426,13 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;
     }
-    if (zl2_launch(&f2, st, d->profile ? d->ev + 1 : nullptr) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (!d->side.stream) {
+        if (hipStreamCreateWithFlags(&d->side.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d->side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->side.join, hipEventDisableTiming) != hipSuccess)
+            return kGpuUnavailable;
+    }
+    if (zl2_launch(&f2, st, &d->side, d->profile ? d->ev + 1 : nullptr) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     zl_decode_args a;
     a.frames = f2.frames;
     a.nframes = (u32)n;

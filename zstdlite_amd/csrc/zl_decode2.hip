@@ -950,25 +950,36 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
     }
 }
 
-// Literal lanes and sequence lanes are independent and each under-fills the chip (512 waves per
-// GiB), so both run in ONE launch: even workgroups decode literals, odd ones sequences.
-static_assert(LIT_FRAMES == SEQ_FRAMES, "the fused launch pairs one literal and one sequence workgroup per group of frames");
-union EntropyShared {
-    LitGroup G[LIT_FRAMES];
-    SeqShared S;
-};
-__global__ __launch_bounds__(LIT_THREADS, 2) void zl2_entropy_kernel(zl2_args a, u32 ngroups) {
-    __shared__ EntropyShared U;
-    ZL_POISON(U, 1);
+// Literal lanes and sequence lanes are independent, want different shapes (256 threads and 69 KiB
+// of LDS against one wave and 50 KiB) and each under-fills the chip on its own, so they are two
+// kernels launched side by side on two streams.  Measured on 10 000 reference-made 64 KiB frames,
+// whose single long sequence chain per frame is the critical resource: fused into one launch (one
+// workgroup shape for both roles) the two roles took 22.6 ms, side by side 8-9 ms.
+static_assert(LIT_FRAMES == SEQ_FRAMES, "both roles walk the frames in the same groups");
+#ifndef ZL_LIT_PAD_BYTES
+#define ZL_LIT_PAD_BYTES (38 << 10)
+#endif
+__global__ __launch_bounds__(LIT_THREADS, 2) void zl2_lit_kernel(zl2_args a) {
+    __shared__ LitGroup G[LIT_FRAMES];
     __shared__ u32 rounds;  // bit r: some lane of this workgroup has block r as its leader
-    const u32 wg = blockIdx.x >> 1;  // (input order: a workgroup's eight frames share lanes, and measured 2.6 vs 3.0 ms against the spread order)
-    (void)ngroups;
+    // Resource shaping: with this much LDS a CU takes ONE literal workgroup plus one sequence workgroup
+    // (or three sequence workgroups where no literal workgroup is left) instead of two literal
+    // workgroups that would keep the sequence chains -- the longer pole -- waiting.
+    // (the extra LDS is requested as dynamic shared memory by the launcher and never touched)
+    ZL_POISON(G, 1);
     const bool prof = a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
-    if (blockIdx.x & 1) seq_role(a, U.S, &rounds, wg);
-    else lit_role(a, U.G, &rounds, wg);
-    // profile: cycles spent in each role (stats[6] literal workgroups, stats[7] sequence workgroups)
-    if (prof) atomicAdd((unsigned long long*)&a.stats[6 + (blockIdx.x & 1)], (unsigned long long)(clock64() - t0));
+    lit_role(a, G, &rounds, blockIdx.x);
+    if (prof) atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(clock64() - t0));  // profile: cycles per literal workgroup
+}
+__global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
+    __shared__ SeqShared S;
+    __shared__ u32 rounds;
+    ZL_POISON(S, 1);
+    const bool prof = a.stats != nullptr && threadIdx.x == 0;
+    const long long t0 = prof ? clock64() : 0;
+    seq_role(a, S, &rounds, blockIdx.x);
+    if (prof) atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(clock64() - t0));  // profile: cycles per sequence workgroup
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1324,13 +1335,22 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
+extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
     if (a->nframes == 0) return hipSuccess;
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
     const u32 ngroups = (n + LIT_FRAMES - 1) / LIT_FRAMES;
-    hipLaunchKernelGGL(zl2_entropy_kernel, dim3(2 * ngroups), dim3(LIT_THREADS), 0, stream, *a, ngroups);
+    // fork: the sequence lanes run on the side stream next to the literal lanes, join before the exec kernel
+    if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, side->stream, *a);
+    static bool shaped = false;
+    if (!shaped) {
+        if (hipFuncSetAttribute((const void*)zl2_lit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
+        shaped = true;
+    }
+    hipLaunchKernelGGL(zl2_lit_kernel, dim3(ngroups), dim3(LIT_THREADS), ZL_LIT_PAD_BYTES, stream, *a);
+    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);
@@ -1341,6 +1361,7 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent
 extern "C" int zl2_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel, EX_THREADS, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_entropy_kernel, LIT_THREADS, 0);
+    else if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_lit_kernel, LIT_THREADS, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_seq_kernel, 64, 0);
     return n;
 }

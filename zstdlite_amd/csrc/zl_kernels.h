@@ -83,7 +83,11 @@ struct zl2_args {
     u32 ignore_checksum;
     u64* stats;  // optional (profiling): exec-kernel phase cycles {scan, literals, matches, flush, batches, blocks}
 };
-extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, hipEvent_t* ev);
+struct zl2_side {           // owned by the decompression context: lets the two entropy kernels run side by side
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev);
 
 extern "C" hipError_t zl_launch_decode(const zl_decode_args* a, u32 nslots, hipStream_t stream);
 extern "C" hipError_t zl_launch_digest_dict(const u8* d_dict, u32 n, void* d_tables, hipStream_t stream);
