@@ -46,8 +46,14 @@ __device__ __forceinline__ u64 ld64(const u8* p) {
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-__device__ __forceinline__ u32 hash8(u64 v) { return (u32)((v * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
-__device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << 24) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
+#ifndef ZL_LONG_BYTES
+#define ZL_LONG_BYTES 8
+#endif
+#ifndef ZL_SHORT_BYTES
+#define ZL_SHORT_BYTES 6
+#endif
+__device__ __forceinline__ u32 hash8(u64 v) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
+__device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_SHORT_BYTES)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
 __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
     const u64 x = a ^ b;
     return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
