@@ -376,17 +376,24 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_kernel(zl_match_args a, 
             c_find += s1 - s0; c_parse += s2 - s1; c_emit += s3 - s2; c_ins += s4 - s3; c_it++;
         }
         // ---- search acceleration on data without matches (cf. the growing step of zstd.c:30018-30023):
-        // after 4 / 8 / 12 consecutive windows that produced no sequence, the next 1 / 2 / 3 windows are
+        // after 4 / 8 / 12 ... consecutive windows that produced no sequence, the next 1 / 2 / 3 ... (at most 7) windows are
         // emitted as literals without searching or inserting.  A pure function of the data, so the
         // output stays deterministic.  Any sequence resets it.
         miss = (tot_s == 0 && carry == 0) ? miss + 1 : 0;
         u32 skip = miss >> 2;
-        if (skip > 3) skip = 3;
+#ifndef ZL_SKIP_MAX
+#define ZL_SKIP_MAX 7
+#endif
+        if (skip > ZL_SKIP_MAX) skip = ZL_SKIP_MAX;
         if (skip) {
             const u32 from = ip + WIN;
             const u32 to = (from + skip * WIN < n) ? from + skip * WIN : n;
             if (to > from) {
-                for (u32 q = from + t; q < to; q += ENC_THREADS) lits[nlit + (q - from)] = src[q];
+                {   // 16 bytes per thread and trip (global memory takes unaligned vectors)
+                    const u32 cnt = to - from, body = cnt & ~15u;
+                    for (u32 q = t * 16; q < body; q += ENC_THREADS * 16) { uint4 x; __builtin_memcpy(&x, src + from + q, 16); __builtin_memcpy(lits + nlit + q, &x, 16); }
+                    if (t < cnt - body) lits[nlit + body + t] = src[from + body + t];
+                }
                 nlit += to - from;
                 ip += to - from;  // the loop increment adds the window just processed
             }
@@ -506,7 +513,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match2_kernel(zl_match_args a,
         u32 cand_before = 0x100;
         if (has_match && p >= 1 && q_best >= 1) cand_before = src[q_best - 1];
         const bool back_ok = cand_before == byte_before;
-        if (has_match && best_len == MIN_MATCH && best_off != rep && !back_ok) has_match = false;
+#ifndef ZL_SPARSE_MIN
+#define ZL_SPARSE_MIN 5
+#endif
+        if (has_match && best_off != rep && best_len + (back_ok ? 1u : 0u) < ZL_SPARSE_MIN) has_match = false;
         S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
         const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
         lds_barrier();
@@ -630,12 +640,19 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match2_kernel(zl_match_args a,
         // ---- search acceleration on data without matches (cf. the growing step of zstd.c:30018-30023)
         miss = (tot_s == 0 && carry == 0) ? miss + 1 : 0;
         u32 skip = miss >> 2;
-        if (skip > 3) skip = 3;
+#ifndef ZL_SKIP_MAX
+#define ZL_SKIP_MAX 7
+#endif
+        if (skip > ZL_SKIP_MAX) skip = ZL_SKIP_MAX;
         if (skip) {
             const u32 from = ip + WIN2;
             const u32 to = (from + skip * WIN2 < n) ? from + skip * WIN2 : n;
             if (to > from) {
-                for (u32 q = from + t; q < to; q += ENC_THREADS) lits[nlit + (q - from)] = src[q];
+                {   // 16 bytes per thread and trip (global memory takes unaligned vectors)
+                    const u32 cnt = to - from, body = cnt & ~15u;
+                    for (u32 q = t * 16; q < body; q += ENC_THREADS * 16) { uint4 x; __builtin_memcpy(&x, src + from + q, 16); __builtin_memcpy(lits + nlit + q, &x, 16); }
+                    if (t < cnt - body) lits[nlit + body + t] = src[from + body + t];
+                }
                 nlit += to - from;
                 ip += to - from;  // the loop increment adds the window just processed
             }
@@ -979,7 +996,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 cand_before = 0x100;
             if (has_match && p >= 1 && q_best >= 1) cand_before = src[q_best - 1];
             const bool back_ok = cand_before == byte_before;
-            if (has_match && best_len == MIN_MATCH && best_off != rep && !back_ok) has_match = false;
+    #ifndef ZL_SPARSE_MIN
+#define ZL_SPARSE_MIN 5
+#endif
+        if (has_match && best_off != rep && best_len + (back_ok ? 1u : 0u) < ZL_SPARSE_MIN) has_match = false;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
             const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             lds_barrier();
@@ -1104,16 +1124,23 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
 
         }
         // ---- search acceleration on data without matches (cf. the growing step of zstd.c:30018-30023):
-        // after 4 / 8 / 12 consecutive windows that produced no sequence, the next 1 / 2 / 3 windows are
+        // after 4 / 8 / 12 ... consecutive windows that produced no sequence, the next 1 / 2 / 3 ... (at most 7) windows are
         // emitted as literals without searching or inserting.  A pure function of the data, so the
         // output stays deterministic.  Any sequence resets it.
         miss = (win_seqs == 0 && carry == 0) ? miss + 1 : 0;
         u32 skip = miss >> 2;
-        if (skip > 3) skip = 3;
+#ifndef ZL_SKIP_MAX
+#define ZL_SKIP_MAX 7
+#endif
+        if (skip > ZL_SKIP_MAX) skip = ZL_SKIP_MAX;
         ip += win;
         if (skip && ip < n) {
             const u32 to = (ip + skip * win < n) ? ip + skip * win : n;
-            for (u32 q = ip + t; q < to; q += ENC_THREADS) lits[nlit + (q - ip)] = src[q];
+            {   // 16 bytes per thread and trip (global memory takes unaligned vectors)
+                const u32 cnt = to - ip, body = cnt & ~15u;
+                for (u32 q = t * 16; q < body; q += ENC_THREADS * 16) { uint4 x; __builtin_memcpy(&x, src + ip + q, 16); __builtin_memcpy(lits + nlit + q, &x, 16); }
+                if (t < cnt - body) lits[nlit + body + t] = src[ip + body + t];
+            }
             nlit += to - ip;
             ip = to;
         }
