@@ -378,12 +378,15 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     if (!d->h_plan.ensure(n * sizeof(zl2_frame_plan))) return kGpuUnavailable;
     zl2_frame_plan* plan = (zl2_frame_plan*)d->h_plan.p;
     const bool has_dict = !d->dict.empty();
+    // ZL_PIPELINE_MAX=<bytes> in the environment lowers the routing limit (experiments: 0 sends everything to the general kernel)
+    static const u64 route_max = getenv("ZL_PIPELINE_MAX") ? std::min<u64>(strtoull(getenv("ZL_PIPELINE_MAX"), nullptr, 10), (u64)ZL2_MAXB * ZL_BLOCK_MAX) : (u64)ZL2_MAXB * ZL_BLOCK_MAX;
     u64 lit_total = 0, seq_total = 0;
     size_t nslow = 0;
     for (size_t i = 0; i < n; i++) {
         zl2_frame_plan& p = plan[i];
         p.pad = 0;
-        const bool fast = !has_dict && tbl[i].dst_cap <= ZL_BLOCK_MAX && tbl[i].src_size < (1u << 30);
+        // the lane pipeline takes frames of up to ZL2_MAXB blocks (it hands back on the device what has more)
+        const bool fast = !has_dict && tbl[i].dst_cap <= route_max && tbl[i].src_size < (1u << 30);
         p.route = fast ? 1u : 0u;
         p.lit_off = lit_total;
         p.seq_off = seq_total;
