@@ -189,3 +189,46 @@ def test_multiblock_frames_with_repeated_tables(ref, oracle):
     r = L.zl_decompressDCtx(dctx._ptr, dst.ctypes.data_as(C.c_void_p), dst.size, a + b, len(a) + len(b))
     assert not is_error(r), _lib.error_name(r)
     assert dst[:r].tobytes() == want
+
+
+def test_damaged_frames_agree_with_the_oracle(oracle):
+    """Frames of the HIP encoder (8 blocks sharing tables: symbolic repcodes, leader rounds) and of the
+    reference library with 1-3 flipped bits, decoded 1000+ at a time: the GPU must accept exactly the
+    frames the oracle accepts and produce the same bytes (scripts/fuzz_decode.py is the long version)."""
+    import ctypes as C
+    from zstdlite_amd import _lib
+    from zl_testlib import GENERATORS, Ref, have_ref, is_error
+    rng = np.random.default_rng(11)
+    base = []
+    for gen in ("text", "iid10", "int20"):
+        for n in (300, 20000, 131072):
+            base.append((z.zstd_compress(GENERATORS[gen](n, seed=n)), n))
+    if have_ref():
+        ref = Ref()
+        for gen in ("text", "iid10"):
+            for n in (65536, 300000):
+                base.append((ref.compress(GENERATORS[gen](n, seed=n + 1), level=3), n))
+    frames = []
+    for f, n in base:
+        for _ in range(80):
+            b = bytearray(f)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(4, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append((bytes(b), n))
+    m = len(frames)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _, n in frames]
+    srcs = [np.frombuffer(f, dtype=np.uint8) for f, _ in frames]
+    res = (C.c_size_t * m)()
+    dctx = z.zstd_dctx()
+    r = _lib.lib().zl_decompress_batch(dctx._ptr, m, (C.c_void_p * m)(*[x.ctypes.data for x in outs]), (C.c_size_t * m)(*[n for _, n in frames]),
+                                       (C.c_void_p * m)(*[x.ctypes.data for x in srcs]), (C.c_size_t * m)(*[len(f) for f, _ in frames]), res)
+    assert not is_error(r)
+    accepted = 0
+    for i, (f, n) in enumerate(frames):
+        code, out = oracle.decompress_code(f, n)
+        if is_error(res[i]):
+            assert is_error(code), (i, _lib.error_name(res[i]), code)
+        else:
+            accepted += 1
+            assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
+    assert 0 < accepted < m
