@@ -130,3 +130,20 @@ def test_ratio_within_five_percent_of_reference(gen, slack, ref):
     ours = len(z.zstd_compress(data))
     theirs = len(ref.compress(data, level=3))
     assert ours <= theirs * slack, (gen, ours, theirs, ours / theirs)
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_lower_levels_track_the_reference_at_the_same_level(level, ref, oracle):
+    """Levels below 3 select the faster operating point of the encoder (every other position probed);
+    the ratio must stay within 5 % of the reference library at that level, and frames must round-trip."""
+    n = 8 << 20
+    for gen in ("text", "iid10", "int20"):
+        data = GENERATORS[gen](n)
+        comp = z.zstd_compress(data, level=level)
+        theirs = len(ref.compress(data, level=level))
+        assert len(comp) <= theirs * 1.05, (gen, level, len(comp), theirs)
+        assert z.zstd_decompress(comp) == data
+        if gen == "text":
+            assert comp != z.zstd_compress(data, level=3)
+    small = GENERATORS["text"](70000, seed=3)
+    assert oracle.decompress(z.zstd_compress(small, level=level), cap=len(small)) == small

@@ -39,6 +39,8 @@ struct zl_match_args {
     u32 lit_stride;
     u32 seq_stride;
     u64* stats;  // optional (profiling): cycles {find, parse, emit, insert, iterations}
+    u32 sparse_only;  // levels below 3: the stride-2 body throughout (faster, lower ratio on match-dense data)
+    u32 pad;
 };
 
 struct zl_entropy_args {

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
     u32 carry = 0;           // where the parse enters the next window, in bytes (uniform)
-    bool dense = true;       // which body the next window gets (uniform)
+    bool dense = !a.sparse_only;  // which body the next window gets (uniform)
     u64 v_pref = 0;          // stride 1: prefetched bytes of position pref_ip + t
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nlit += to - ip;
             ip = to;
         }
-        dense = win_seqs * (WIN2 / win) >= ZL_DENSE_SEQS;
+        dense = !a.sparse_only && win_seqs * (WIN2 / win) >= ZL_DENSE_SEQS;
     }
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
