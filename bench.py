@@ -179,11 +179,15 @@ def main():
     def step():
         nonlocal gathered
         _, total, fsizes = codec.compress(src, comp)
+        works = []
         if world > 1:
-            # the path's one exchange step: compressed shard sizes, then payloads to rank 0
-            gathered, _ = gather_compressed(comp, total, root=0, out=gathered)
+            # the path's one exchange step: compressed shard sizes, then payloads to rank 0 -- started
+            # here, overlapped with the decompression of the local shard, completed before the step ends
+            gathered, _, works = gather_compressed(comp, total, root=0, out=gathered, wait=False)
         tbl = codec.frame_table(fsizes, content)
         out_total, _ = codec.decompress(comp, tbl, back)
+        for w in works:
+            w.wait()
         assert out_total == n
         return total
 

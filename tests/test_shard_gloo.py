@@ -55,6 +55,10 @@ def _worker(rank, world, port, out_dir):
         out = None
         for _ in range(2):  # second call reuses the root buffer
             out, sizes = gather_compressed(buf, len(payload), root=0, out=out)
+        # the overlapped form used by bench.py: start, do something else, then wait
+        out, sizes, works = gather_compressed(buf, len(payload), root=0, out=out, wait=False)
+        for w in works:
+            w.wait()
         assert sizes[rank] == len(payload)
         if rank == 0:
             want = b"".join(b"".join(c["comp"] for c in picks[r::world]) for r in range(world))

@@ -27,10 +27,12 @@ def plan_shards(nbytes, world):
     return out
 
 
-def gather_compressed(payload, total, root=0, group=None, out=None):
+def gather_compressed(payload, total, root=0, group=None, out=None, wait=True):
     """Collect every rank's compressed shard (payload[:total], uint8 tensor) on `root`, in rank
     order.  Returns (buffer, sizes) on root and (None, sizes) elsewhere.  `out` may be a
-    preallocated root buffer that is reused when large enough."""
+    preallocated root buffer that is reused when large enough.  With wait=False the transfers are
+    only started: a third return value holds the work handles, and the caller overlaps them with
+    compute (the payload must stay untouched until they have been waited for)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
@@ -51,7 +53,9 @@ def gather_compressed(payload, total, root=0, group=None, out=None):
             off += hs[r]
     else:
         ops = [dist.P2POp(dist.isend, payload[:int(total)], root, group=group)] if total else []
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if not wait:
+        return (out if rank == root else None), hs, works
+    for w in works:
+        w.wait()
     return (out if rank == root else None), hs
