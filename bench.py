@@ -170,29 +170,41 @@ def main():
     n = args.size
     src, kinds, quarter = gen_mixed(n, device)
     codec = DeviceCodec(level=3, profile=True)
-    comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
+    # two compressed buffers (and two gather buffers on rank 0): the gather of one step's shard runs
+    # while the next step computes; every gather is waited for inside the timed region
+    comps = [torch.empty(codec.bound(n), dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
+    comp = comps[0]
     back = torch.empty(n, dtype=torch.uint8, device=device)
     content = codec.chunk_content_sizes(n)
-    gathered = None
+    gathered = [None, None]
+    pending = [[], []]
+    step_no = 0
     kms_sum = {}
 
-    def step():
-        nonlocal gathered
-        _, total, fsizes = codec.compress(src, comp)
-        works = []
-        if world > 1:
-            # the path's one exchange step: compressed shard sizes, then payloads to rank 0 -- started
-            # here, overlapped with the decompression of the local shard, completed before the step ends
-            gathered, _, works = gather_compressed(comp, total, root=0, out=gathered, wait=False)
-        tbl = codec.frame_table(fsizes, content)
-        out_total, _ = codec.decompress(comp, tbl, back)
-        for w in works:
+    def drain(slot):
+        for w in pending[slot]:
             w.wait()
+        pending[slot] = []
+
+    def step():
+        nonlocal step_no
+        slot = step_no % len(comps)
+        step_no += 1
+        drain(slot)  # this buffer's previous shard has left (no-op on one GPU)
+        buf = comps[slot]
+        _, total, fsizes = codec.compress(src, buf)
+        if world > 1:
+            # the path's one exchange step: compressed shard sizes, then payloads to rank 0 over xGMI
+            gathered[slot], _, pending[slot] = gather_compressed(buf, total, root=0, out=gathered[slot], wait=False)
+        tbl = codec.frame_table(fsizes, content)
+        out_total, _ = codec.decompress(buf, tbl, back)
         assert out_total == n
         return total
 
     for _ in range(args.warmup):
         step()
+    drain(0)
+    drain(1)
     kms_sum = {}
     if world > 1:
         dist.barrier()
@@ -202,6 +214,8 @@ def main():
         csize = step()
         for k, v in codec.kernel_ms().items():
             kms_sum[k] = kms_sum.get(k, 0.0) + v
+    drain(0)
+    drain(1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
