@@ -124,7 +124,7 @@ struct zl_dctx_s {
     bool dict_uploaded = false;
     u32 dict_content_off = 0;
     hipStream_t own_stream = nullptr;
-    DevBuf d_src, d_dst, d_frames, d_results, d_counter, d_lit, d_seq, d_dict, d_dict_tables;
+    DevBuf d_src, d_dst, d_frames, d_results, d_counter, d_lit, d_seq, d_dict, d_dict_tables, d_order;
     DevBuf d_plan, d_frec, d_brec, d_lit2, d_seq2;  // lane-parallel pipeline (zl_decode2.hip)
     PinBuf h_frames, h_results, h_stage_in, h_stage_out, h_plan;
     // pending device-resident call
@@ -271,7 +271,7 @@ zl_dctx* zl_createDCtx(void) { return new (std::nothrow) zl_dctx_s(); }
 size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
-    DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_stats,
+    DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
                       &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
@@ -398,7 +398,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     }
     const u32 max_slots = (u32)g_num_cu * 4;
     const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 256), max_slots);  // >= 256 so that skipping routed frames is quick
-    if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) ||
+    if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) || !d->d_order.ensure(2 * n * sizeof(u32) + 64) ||
         !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)) ||
         !d->d_plan.ensure(n * sizeof(zl2_frame_plan)) || !d->d_frec.ensure(n * sizeof(zl2_frame_rec)) ||
         !d->d_brec.ensure(n * (size_t)ZL2_MAXB * sizeof(zl2_blk_rec)) || !d->d_lit2.ensure(lit_total + 64) ||
@@ -425,6 +425,8 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.seq_scratch = (u32*)d->d_seq2.p;
     f2.ignore_checksum = (u32)d->ignore_checksum;
     f2.stats = nullptr;
+    f2.max_blocks = (u32*)d->d_counter.p + 8;
+    f2.order = (u32*)d->d_order.p;  // (the 64-byte counter block is zeroed above; word 0 is the general kernel's queue head)
     if (d->profile >= 2 && d->d_stats.ensure(128)) {
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;

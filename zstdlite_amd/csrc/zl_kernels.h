@@ -36,7 +36,10 @@ struct zl2_blk_rec {        // per (frame, block), written by zl2_index_kernel
 struct zl2_frame_rec {
     u32 err, nblocks, has_checksum, skippable;
     u64 fcs;
-    u32 end_pos, pad;
+    u32 end_pos;
+    u32 cost;               // sequences in all blocks: the sequence lanes' scheduling key (zl2_order_kernel)
+    u32 lit_cost;           // Huffman-coded literal bytes in all blocks: the literal lanes' scheduling key
+    u32 pad2;
 };
 
 struct zl_decode_args {
@@ -82,6 +85,8 @@ struct zl2_args {
     u32* seq_scratch;
     u32 ignore_checksum;
     u64* stats;  // optional (profiling): exec-kernel phase cycles {scan, literals, matches, flush, batches, blocks}
+    u32* max_blocks;  // device word, zeroed before the launch: the largest block count of a frame on the pipeline (set by zl2_index_kernel)
+    u32* order;       // 2 x nframes entries: the frames sorted by decreasing sequence count, then by decreasing literal bytes (zl2_order_kernel)
 };
 struct zl2_side {           // owned by the decompression context: lets the two entropy kernels run side by side
     hipStream_t stream;
