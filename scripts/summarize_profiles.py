@@ -40,11 +40,11 @@ if trace:
         r["Grid_Size"] = r.get("Grid_Size") or r["Grid_Size_X"]
     big = collections.defaultdict(int)
     for r in rows:
-        if r["Kernel_Name"].startswith("zl"):
+        if ("zl_" in r["Kernel_Name"] or "zl2_" in r["Kernel_Name"]):
             big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
     for r in rows:
         k = r["Kernel_Name"]
-        if k.startswith("zl") and int(r["Grid_Size"]) == big[k]:
+        if ("zl_" in k or "zl2_" in k) and int(r["Grid_Size"]) == big[k]:
             dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 
 
@@ -55,11 +55,11 @@ def pmc(path):
     rows = list(csv.DictReader(open(path)))
     big = collections.defaultdict(int)
     for r in rows:
-        if r["Kernel_Name"].startswith("zl"):
+        if ("zl_" in r["Kernel_Name"] or "zl2_" in r["Kernel_Name"]):
             big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
     for r in rows:
         k = r["Kernel_Name"]
-        if k.startswith("zl") and int(r["Grid_Size"]) == big[k]:
+        if ("zl_" in k or "zl2_" in k) and int(r["Grid_Size"]) == big[k]:
             d[k].append(float(r["Counter_Value"]))
     return d
 
@@ -68,9 +68,9 @@ fetch = pmc(one("pmc_fetch/*/*counter_collection.csv"))
 write = pmc(one("pmc_write/*/*counter_collection.csv"))
 summary, short = {}, {}
 names = {"zl_match_kernel": "match", "zl_match_auto_kernel": "match", "zl_match2_kernel": "match", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
-         "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_lit_kernel": "d_entropy_lit", "zl2_exec_kernel": "d_exec"}
+         "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_lit_kernel": "d_entropy_lit", "zl2_lit_kernel<8>": "d_entropy_lit", "zl2_lit_kernel<1>": "d_entropy_lit1", "zl2_order_kernel": "d_order", "zl2_exec_kernel": "d_exec"}
 for k in sorted(set(dur) | set(fetch) | set(write)):
-    base = k.split("(")[0]
+    base = k.split("(")[0].replace("void ", "")
     f_kb = sum(fetch[k]) / len(fetch[k]) if fetch[k] else None
     w_kb = sum(write[k]) / len(write[k]) if write[k] else None
     e = {"full_grid_launches": len(dur[k]), "avg_ms": sum(dur[k]) / len(dur[k]) if dur[k] else None,
