@@ -147,3 +147,47 @@ def test_lower_levels_track_the_reference_at_the_same_level(level, ref, oracle):
             assert comp != z.zstd_compress(data, level=3)
     small = GENERATORS["text"](70000, seed=3)
     assert oracle.decompress(z.zstd_compress(small, level=level), cap=len(small)) == small
+
+
+def test_dictionary_compression_of_small_objects(ref, oracle):
+    """BASELINE config C4's shape (vignettes/dictionaries.Rmd:95-141): many small objects, one trained
+    dictionary.  The dictionary's content is history in front of every frame: frames name its id,
+    decode with the reference library, the oracle and the GPU decoder given the dictionary, fail
+    without it, and are clearly smaller than without a dictionary.  (The dictionary's entropy tables
+    are not reused yet, which is what separates the ratio from the reference's.)"""
+    import pickle
+    rng = np.random.default_rng(3)
+    names = [f"name_{i:02d}_{'x' * (i % 7)}" for i in range(50)]
+
+    def obj():
+        perm = rng.permutation(50)[: int(rng.integers(10, 40))]
+        return pickle.dumps({names[j]: int(rng.integers(0, 1000)) for j in perm}, protocol=4)
+    items = [obj() for _ in range(3000)]
+    d = ref.train_dict(items[:1500], 5000)
+    cctx = z.zstd_cctx(dict=d)
+    plain = z.zstd_compress_batch(items)
+    withd = z.zstd_compress_batch(items, cctx=cctx)
+    assert withd == z.zstd_compress_batch(items, cctx=cctx)  # deterministic, context reusable
+    assert [z.zstd_compress(x, cctx=cctx) for x in items[:20]] == withd[:20]
+    raw = sum(map(len, items))
+    assert sum(map(len, withd)) < 0.7 * sum(map(len, plain))
+    cpu = sum(len(ref.compress(x, level=3, dict=d)) for x in items[:500])
+    ours = sum(map(len, withd[:500]))
+    assert ours <= cpu * 1.15, (ours, cpu)
+    assert z.zstd_info(withd[0])["dict_id"] == z.zstd_dict_id(d) != 0
+    for i in range(0, len(items), 37):
+        assert ref.decompress(withd[i], len(items[i]), dict=d) == items[i]
+        assert oracle.decompress(withd[i], cap=len(items[i]), dict=d) == items[i]
+    assert z.zstd_decompress_batch(withd, dict=d) == items
+    with pytest.raises(z.ZstdError):
+        z.zstd_decompress(withd[0])
+    # a large input with a dictionary: every 128 KiB frame sees the dictionary
+    big = b"".join(items)
+    comp = z.zstd_compress(big, cctx=cctx)
+    assert z.zstd_decompress(comp, dctx=z.zstd_dctx(dict=d)) == big
+    assert ref.decompress(comp[: z.zstd_info(comp)["compressed_size"]], 131072, dict=d) == big[:131072]
+    # a raw-content dictionary (no magic): no id in the frame, still history
+    rawd = b"".join(items[:10])
+    c2 = z.zstd_compress(items[20], cctx=z.zstd_cctx(dict=rawd))
+    assert z.zstd_info(c2)["dict_id"] == 0
+    assert ref.decompress(c2, len(items[20]), dict=rawd) == items[20]

@@ -12,6 +12,7 @@
 #include "zl_encode.h"
 #include "zl_format.h"
 #include "zl_host.h"
+#include "zl_kernels.h"
 
 #define ZL_GROUP_CHUNKS 8192u  // chunks encoded per launch group (1 GiB of input); bounds the scratch
 
@@ -20,6 +21,9 @@ struct zl_cctx_s {
     int checksum = 0;
     int nb_workers = 0;
     std::vector<u8> dict;
+    bool dict_uploaded = false, dict_formatted = false;
+    u32 dict_id = 0, dict_content_off = 0, dict_use = 0;  // dict_use: trailing content bytes the matcher can reach
+    DevBuf d_dict, d_dict_tables, d_dict_hash;
     hipStream_t own_stream = nullptr;
     DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals;
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
@@ -46,10 +50,43 @@ hipStream_t cctx_stream(zl_cctx* c, void* user) {
 
 inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_CHUNK; }
 
+inline u32 zl_rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+
+// upload + digest the dictionary once per context: where its content starts (device parse of the
+// entropy section, shared with the decoder) and the match tables as they look after its last byte
+size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
+    if (c->dict.empty() || c->dict_uploaded) return 0;
+    if (!c->d_dict.ensure(c->dict.size() + 16)) return kGpuUnavailable;
+    if (hipMemcpyAsync(c->d_dict.p, c->dict.data(), c->dict.size(), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    c->dict_content_off = 0;
+    if (c->dict_formatted) {
+        if (!c->d_dict_tables.ensure(sizeof(zl_dict_tables))) return kGpuUnavailable;
+        if (zl_launch_digest_dict((const u8*)c->d_dict.p, (u32)c->dict.size(), c->d_dict_tables.p, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        zl_dict_tables hdr;
+        if (hipMemcpyAsync(&hdr, c->d_dict_tables.p, sizeof(hdr), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hdr.status) return ZL_ERR(hdr.status);
+        c->dict_content_off = hdr.content_off;
+    }
+    const size_t content = c->dict.size() - c->dict_content_off;
+    c->dict_use = (u32)std::min<size_t>(content, ZL_DICT_REACH);
+    if (c->dict_use >= 8) {
+        if (!c->d_dict_hash.ensure(ZL_MATCH_TABLE_BYTES)) return kGpuUnavailable;
+        const u8* tail = (const u8*)c->d_dict.p + c->dict.size() - c->dict_use;
+        if (zl_launch_dict_hash(tail, c->dict_use, (u32*)c->d_dict_hash.p, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    } else {
+        c->dict_use = 0;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    c->dict_uploaded = true;
+    return 0;
+}
+
 // Enqueue the whole encoder over a chunk table already written to c->h_chunks (nchunks entries):
 // E1 -> E2 -> size scan -> gather, in groups that reuse the scratch.  Frames end up back to
 // back in d_dst; per-chunk sizes in d_fsize, per-group running totals in d_totals[g+1].
 size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st) {
+    { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
     const size_t group = std::min<size_t>(nchunks, ZL_GROUP_CHUNKS);
     const size_t ngroups = (nchunks + ZL_GROUP_CHUNKS - 1) / ZL_GROUP_CHUNKS;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
@@ -76,7 +113,9 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.seq_stride = ZL_SEQ_STRIDE;
         m.stats = nullptr;
         m.sparse_only = c->level < 3 ? 1u : 0u;
-        m.pad = 0;
+        m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
+        m.dict_len = c->dict_use;
+        m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
         if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
             (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
             m.stats = (u64*)c->d_stats.p;
@@ -97,7 +136,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.seq_stride = ZL_SEQ_STRIDE;
         e.out_stride = ZL_OUT_STRIDE;
         e.checksum = (u32)c->checksum;
-        e.dict_id = 0;
+        e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
         e.stats = m.stats ? m.stats + 8 : nullptr;
         if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (prof) (void)hipEventRecord(c->ev[2], st);
@@ -152,7 +191,7 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
-    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
@@ -193,12 +232,26 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     }
 }
 
-// zstd.c:23826 ZSTD_CCtx_loadDictionary: copied.  The encoder does not use dictionaries yet:
-// frames are produced without a dictionary id and decode with or without one loaded.
+// zstd.c:23826 ZSTD_CCtx_loadDictionary: copied, digested on the device at first use.  The encoder
+// uses the dictionary's CONTENT as history in front of every frame (zstd.c:27550
+// ZSTD_loadZstdDictionary / the dfast dictionary variant zstd.c:30120): the match tables start out
+// filled with its positions, offsets may reach into it, and the frame header names its id.  The
+// dictionary's entropy tables are not reused yet (frames describe their own or use the predefined
+// ones), so the ratio gain is the content's.
 size_t zl_CCtx_loadDictionary(zl_cctx* c, const void* dict, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     c->dict.clear();
-    if (dict && n) c->dict.assign((const u8*)dict, (const u8*)dict + n);
+    c->dict_uploaded = false;
+    c->dict_formatted = false;
+    c->dict_id = 0;
+    c->dict_use = 0;
+    if (dict && n) {
+        c->dict.assign((const u8*)dict, (const u8*)dict + n);
+        if (n >= 8 && zl_rd32((const u8*)dict) == ZL_MAGIC_DICT) {
+            c->dict_formatted = true;
+            c->dict_id = zl_rd32((const u8*)dict + 4);
+        }
+    }
     return 0;
 }
 

@@ -6,6 +6,8 @@
 #include "zl_format.h"
 
 #define ZL_CHUNK ZL_BLOCK_MAX                    // one frame per 128 KiB of input
+#define ZL_MATCH_TABLE_BYTES (((1 << 13) + (1 << 12)) * 2)  // 16-bit entries of the long and the short table
+#define ZL_DICT_REACH 65000                       // trailing dictionary bytes the 16-bit entries can address
 #define ZL_ENC_BLOCKS 8                          // blocks per frame (they share one set of entropy tables)
 #define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
 #define ZL_LIT_STRIDE_ENC (ZL_CHUNK + 64)
@@ -40,7 +42,9 @@ struct zl_match_args {
     u32 seq_stride;
     u64* stats;  // optional (profiling): cycles {find, parse, emit, insert, iterations}
     u32 sparse_only;  // levels below 3: the stride-2 body throughout (faster, lower ratio on match-dense data)
-    u32 pad;
+    u32 dict_len;     // dictionary content bytes that sit, as history, in front of every chunk (0: none)
+    const u8* dict;   // those bytes
+    const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)
 };
 
 struct zl_entropy_args {
@@ -69,6 +73,7 @@ struct zl_gather_args {
 };
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream);
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hipStream_t stream);

@@ -695,15 +695,21 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     u8* lits = a.lits + (size_t)c * a.lit_stride;
     zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
 
-    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = 0;
-    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = 0;
+    // With a dictionary, its last D content bytes sit in front of the chunk as history: positions are
+    // counted from the start of that content (chunk position p is "virtual" position D + p), the match
+    // tables start out as they look after the dictionary's last byte, and a candidate below D is read
+    // from the dictionary (zstd.c:30120, the dictionary variant of the double-hash parse).
+    const u32 D = a.dict_len;
+    const u8* const dict = a.dict;
+    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
+    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
     lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
     u32 carry = 0;           // where the parse enters the next window, in bytes (uniform)
-    bool dense = !a.sparse_only;  // which body the next window gets (uniform)
+    bool dense = !a.sparse_only || D != 0;  // which body the next window gets (uniform); dictionary frames use the stride-1 body throughout
     u64 v_pref = 0;          // stride 1: prefetched bytes of position pref_ip + t
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
@@ -742,7 +748,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             for (int j = 0; j < PPT; j++) {
                 const u32 p = ip + t + ENC_THREADS * j;
                 have_r[j] = have_l[j] = have_s[j] = false;
-                q_r[j] = q_l[j] = q_s[j] = p;
+                const u32 V = D + p;  // virtual position
+                q_r[j] = q_l[j] = q_s[j] = V;
                 if (can_match[j]) {
                     hl[j] = hash8(v[j]);
                     hs[j] = hash5(v[j]);
@@ -750,19 +757,27 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     word_s[j] = S.tbl_short[hs[j] >> 1];
                     if (search) {
                         const u32 el = (word_l[j] >> ((hl[j] & 1) * 16)) & 0xFFFF, es = (word_s[j] >> ((hs[j] & 1) * 16)) & 0xFFFF;
-                        const u32 dl = (p + 1 - el) & 0xFFFF, ds = (p + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
-                        have_r[j] = rep && p >= rep;
-                        have_l[j] = el != 0 && dl != 0 && dl <= p;
-                        have_s[j] = es != 0 && ds != 0 && ds <= p;
-                        if (have_r[j]) q_r[j] = p - rep;
-                        if (have_l[j]) q_l[j] = p - dl;
-                        if (have_s[j]) q_s[j] = p - ds;
+                        const u32 dl = (V + 1 - el) & 0xFFFF, ds = (V + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
+                        have_r[j] = rep && V >= rep;
+                        have_l[j] = el != 0 && dl != 0 && dl <= V;
+                        have_s[j] = es != 0 && ds != 0 && ds <= V;
+                        if (have_r[j]) q_r[j] = V - rep;
+                        if (have_l[j]) q_l[j] = V - dl;
+                        if (have_s[j]) q_s[j] = V - ds;
+                        // (a candidate whose 8 bytes would straddle the end of the dictionary is dropped)
+                        if (q_r[j] < D && q_r[j] + 8 > D) { have_r[j] = false; q_r[j] = V; }
+                        if (q_l[j] < D && q_l[j] + 8 > D) { have_l[j] = false; q_l[j] = V; }
+                        if (q_s[j] < D && q_s[j] + 8 > D) { have_s[j] = false; q_s[j] = V; }
                     }
                 }
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
-                if (can_match[j] && search) { w_r[j] = ld64(src + q_r[j]); w_l[j] = ld64(src + q_l[j]); w_s[j] = ld64(src + q_s[j]); }
+                if (can_match[j] && search) {
+                    w_r[j] = ld64(q_r[j] >= D ? src + (q_r[j] - D) : dict + q_r[j]);
+                    w_l[j] = ld64(q_l[j] >= D ? src + (q_l[j] - D) : dict + q_l[j]);
+                    w_s[j] = ld64(q_s[j] >= D ? src + (q_s[j] - D) : dict + q_s[j]);
+                }
                 else { w_r[j] = w_l[j] = w_s[j] = 0; }
             }
             {   // the next window's own bytes travel together with this window's candidates
@@ -778,11 +793,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (can_match[j] && search) {
                     const u32 l_r = common_bytes(v[j], w_r[j]), l_l = common_bytes(v[j], w_l[j]), l_s = common_bytes(v[j], w_s[j]);
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
-                    if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = p - q_l[j]; q_best[j] = q_l[j]; }
-                    if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = p - q_s[j]; q_best[j] = q_s[j]; }
+                    if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
+                    if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
                     // extend while whole 8-byte words keep matching
                     while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < LANE_MATCH_CAP && p + best_len[j] + 8 <= n) {
-                        const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(src + q_best[j] + best_len[j]));
+                        const u32 qv = q_best[j] + best_len[j];
+                        if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
+                        const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(qv >= D ? src + (qv - D) : dict + qv));
                         best_len[j] += l;
                         if (l < 8) break;
                     }
@@ -897,13 +914,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             for (int j = 0; j < PPT; j++) {
                 if (can_match[j]) {
                     const u32 p = ip + t + ENC_THREADS * j;
-                    if (ZL_INSERT_CAS) insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], p, ip, WIN);
+                    if (ZL_INSERT_CAS) insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], D + p, D + ip, WIN);
                 }
             }
             if (!ZL_INSERT_CAS) {
                 for (u32 ph = 0; ph < 4; ph++) {
                     if (ph == (t >> 6) && can_match[0]) {
-                        const unsigned short val = (unsigned short)(ip + t + 1);
+                        const unsigned short val = (unsigned short)(D + ip + t + 1);
                         ((unsigned short*)S.tbl_long)[hl[0]] = val;
                         ((unsigned short*)S.tbl_short)[hs[0]] = val;
                     }
@@ -1144,7 +1161,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nlit += to - ip;
             ip = to;
         }
-        dense = !a.sparse_only && win_seqs * (WIN2 / win) >= ZL_DENSE_SEQS;
+        dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= ZL_DENSE_SEQS);
     }
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
@@ -1158,6 +1175,32 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
         a.meta[c].nseq = nseq;
         a.meta[c].nlit = nlit;
     }
+}
+
+// The match tables as they look after the last byte of a dictionary's content: one workgroup walks the
+// content window by window with the same ordered insert as the encoder (run once per loaded dictionary).
+__global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* content, u32 n, u32* out) {
+    __shared__ MatchShared S;
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = 0;
+    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = 0;
+    lds_barrier();
+    for (u32 ip = 0; ip + 8 <= n; ip += ENC_THREADS) {
+        const u32 v_pos = ip + t;
+        const bool can = v_pos + 8 <= n;
+        u32 hl = 0, hs = 0;
+        if (can) { const u64 v = ld64(content + v_pos); hl = hash8(v); hs = hash5(v); }
+        for (u32 ph = 0; ph < 4; ph++) {
+            if (ph == (t >> 6) && can) {
+                const unsigned short val = (unsigned short)(v_pos + 1);
+                ((unsigned short*)S.tbl_long)[hl] = val;
+                ((unsigned short*)S.tbl_short)[hs] = val;
+            }
+            lds_barrier();
+        }
+    }
+    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) out[i] = S.tbl_long[i];
+    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) out[(1u << LONG_LOG) / 2 + i] = S.tbl_short[i];
 }
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
@@ -2170,4 +2213,9 @@ extern "C" int zl_debug_occupancy(int which) {
     if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel, ENC_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
     return n;
+}
+
+extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream) {
+    hipLaunchKernelGGL(zl_dict_hash_kernel, dim3(1), dim3(ENC_THREADS), 0, stream, d_content, n, d_tables);
+    return hipGetLastError();
 }
