@@ -23,7 +23,7 @@ struct zl_cctx_s {
     std::vector<u8> dict;
     bool dict_uploaded = false, dict_formatted = false;
     u32 dict_id = 0, dict_content_off = 0, dict_use = 0;  // dict_use: trailing content bytes the matcher can reach
-    DevBuf d_dict, d_dict_tables, d_dict_hash;
+    DevBuf d_dict, d_dict_tables, d_dict_hash, d_cdict;
     hipStream_t own_stream = nullptr;
     DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals;
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
@@ -67,6 +67,8 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hdr.status) return ZL_ERR(hdr.status);
         c->dict_content_off = hdr.content_off;
+        if (!c->d_cdict.ensure(ZL_CDICT_BYTES)) return kGpuUnavailable;
+        if (zl_launch_cdict_build(c->d_dict_tables.p, c->d_cdict.p, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     const size_t content = c->dict.size() - c->dict_content_off;
     c->dict_use = (u32)std::min<size_t>(content, ZL_DICT_REACH);
@@ -137,6 +139,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.out_stride = ZL_OUT_STRIDE;
         e.checksum = (u32)c->checksum;
         e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
+        e.cdict = (c->dict_use && c->dict_formatted) ? c->d_cdict.p : nullptr;
         e.stats = m.stats ? m.stats + 8 : nullptr;
         if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (prof) (void)hipEventRecord(c->ev[2], st);
@@ -191,7 +194,7 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
-    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();

@@ -7,6 +7,7 @@
 
 #define ZL_CHUNK ZL_BLOCK_MAX                    // one frame per 128 KiB of input
 #define ZL_MATCH_TABLE_BYTES (((1 << 13) + (1 << 12)) * 2)  // 16-bit entries of the long and the short table
+#define ZL_CDICT_BYTES 8192                      // device-side encoder tables of a dictionary (struct zl_cdict, zl_encode.hip)
 #define ZL_DICT_REACH 65000                       // trailing dictionary bytes the 16-bit entries can address
 #define ZL_ENC_BLOCKS 8                          // blocks per frame (they share one set of entropy tables)
 #define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
@@ -61,6 +62,7 @@ struct zl_entropy_args {
     u32 out_stride;
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
+    const void* cdict; // zl_cdict* (device) or null: the dictionary's entropy tables, offered to frames of a single block
     u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
 
@@ -74,6 +76,7 @@ struct zl_gather_args {
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream);
+extern "C" hipError_t zl_launch_cdict_build(const void* d_dict_tables, void* d_cdict, hipStream_t stream);
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hipStream_t stream);

@@ -31,6 +31,7 @@
 #include "zl_device.h"
 #include "zl_encode.h"
 #include "zl_format.h"
+#include "zl_kernels.h"
 
 #define ENC_THREADS 256
 #define PPT 1              // positions per thread and iteration (2 was measured: same speed, 0.8 % worse ratio)
@@ -1270,6 +1271,21 @@ struct FseCTable {   // encoding side of one FSE table (zstd.c:15917 FSE_buildCT
     int max_sym;     // last symbol described by the table header
 };
 
+// Encoding side of a dictionary's entropy section (zstd.c:27450 ZSTD_loadCEntropy), derived on the
+// device from the decoder's digest of the same dictionary (zl_dict_tables): Huffman code lengths and
+// codes, the three FSE encoding tables, and which symbols each of them can encode.
+struct zl_cdict {
+    u8 hlen[256];
+    u16 hcode[256];
+    u32 huf_log;
+    u32 huf_ok;
+    FseCTable ct[3];     // T_LL, T_OF, T_ML order
+    u64 sym_mask[3];     // bit s: symbol s has a non-zero probability
+    u32 ok;
+    u32 pad;
+};
+static_assert(sizeof(zl_cdict) <= ZL_CDICT_BYTES, "ZL_CDICT_BYTES (zl_encode.h) must cover zl_cdict");
+
 struct EntShared {
     // Two 4 KiB regions are shared by arrays with disjoint lifetimes (LDS per workgroup decides how
     // many chunks a CU works on at once): the literal histograms die when the Huffman decision is
@@ -1307,6 +1323,7 @@ struct EntShared {
     u32 small[16];     // short serial counters (code-length / weight histograms)
     u32 final_state[ZL_ENC_BLOCKS][3];  // FSE states after the last (= first in order) sequence of each block
     // control
+    u32 lit_from_dict;  // the literals are coded with the dictionary's Huffman table (treeless from the first block)
     u32 lit_mode;  // 0 raw, 1 rle, 2 huffman
     u32 huf_log, huf_present, huf_maxsym, tree_size;
     u32 lit_sec_size;
@@ -1672,6 +1689,91 @@ __device__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
     return pos;
 }
 
+// Bits (x256) a symbol costs in an FSE table, read off its encoding transform: between min and min + 1
+// bits, by the share of its states that take the larger count (the estimate zstd.c:15560 FSE_bitCost makes)
+__device__ __forceinline__ u32 fse_bit_cost(int dnb, u32 log) {
+    const u32 min_nb = (u32)dnb >> 16;
+    const u32 threshold = (min_nb + 1) << 16;
+    const u32 delta = threshold - ((u32)dnb + (1u << log));
+    return ((min_nb + 1) << 8) - ((delta << 8) >> log);
+}
+
+// Dictionary entropy for the encoder: one workgroup turns the decoder's digest into encoding tables.
+__global__ __launch_bounds__(ENC_THREADS) void zl_cdict_build_kernel(const zl_dict_tables* dt, zl_cdict* out) {
+    __shared__ u8 hlen[256];
+    __shared__ u8 tsym[512];
+    __shared__ u16 cumul[64];
+    const u32 t = threadIdx.x;
+    hlen[t] = 0;
+    __syncthreads();
+    const u32 hlog = dt->huf_log;
+    if (t == 0) { out->ok = (dt->status == 0 && hlog >= 1 && hlog <= 12) ? 1u : 0u; out->huf_log = hlog; out->huf_ok = 1; }
+    // Huffman: code length per symbol from the decode table, codes in the decoder's cell order
+    for (u32 i = t; i < (1u << hlog) && hlog <= 12; i += ENC_THREADS) { const u32 e = dt->huf[i]; hlen[e & 0xFF] = (u8)(e >> 8); }
+    __syncthreads();
+    {
+        const u32 len = hlen[t];
+        u32 code = 0;
+        if (len) {
+            const u32 w = hlog + 1 - len;
+            u32 start = 0;
+            for (u32 q = 0; q < 256; q++) {
+                const u32 lq = hlen[q];
+                if (!lq) continue;
+                const u32 wq = hlog + 1 - lq;
+                if (wq < w || (wq == w && q < t)) start += 1u << (wq - 1);
+            }
+            code = start >> (w - 1);
+        }
+        out->hlen[t] = (u8)len;
+        out->hcode[t] = (u16)code;
+    }
+    // FSE: symbol of every cell from the decode cell, then the encoder's view of the same table
+    for (int k = 0; k < 3; k++) {
+        __syncthreads();
+        const u32 log = k == T_LL ? dt->ll_log : (k == T_ML ? dt->ml_log : dt->of_log);
+        const u32 size = 1u << log;
+        const u64* cells = k == T_LL ? dt->fse_ll : (k == T_ML ? dt->fse_ml : dt->fse_of);
+        const int nsym = k == T_LL ? 36 : (k == T_ML ? 53 : 32);
+        for (u32 u = t; u < size; u += ENC_THREADS) {
+            const u64 cell = cells[u];
+            const u32 base = (u32)cell, bits = (u32)(cell >> 48) & 0xFF;
+            u32 sym = 0;
+            if (k == T_OF) sym = bits;
+            else for (int q = 0; q < nsym; q++) { const u32 b = k == T_LL ? e_LL_base[q] : e_ML_base[q]; if (b == base) sym = (u32)q; }
+            tsym[u] = (u8)sym;
+        }
+        __syncthreads();
+        if (t == 0) {
+            FseCTable& ct = out->ct[k];
+            u32 cnt[64];
+            for (int q = 0; q < 64; q++) cnt[q] = 0;
+            for (u32 u = 0; u < size; u++) cnt[tsym[u]]++;
+            u64 mask = 0;
+            int max_sym = 0;
+            u32 run = 0;
+            for (int q = 0; q < nsym; q++) { cumul[q] = (u16)run; run += cnt[q]; if (cnt[q]) { mask |= 1ull << q; max_sym = q; } }
+            for (u32 u = 0; u < size; u++) { const u32 q = tsym[u]; ct.state[cumul[q]++] = (u16)(size + u); }
+            int total = 0;
+            for (int q = 0; q < nsym; q++) {
+                const int n = (int)cnt[q];
+                if (n == 0) { ct.dnb[q] = (int)((log + 1) << 16) - (int)size; ct.dfs[q] = 0; }
+                else if (n == 1) { ct.dnb[q] = (int)(log << 16) - (int)size; ct.dfs[q] = total - 1; total++; }
+                else {
+                    const int max_bits_out = (int)log - (int)hb32((u32)(n - 1));
+                    const int min_state_plus = n << max_bits_out;
+                    ct.dnb[q] = (max_bits_out << 16) - min_state_plus;
+                    ct.dfs[q] = total - n;
+                    total += n;
+                }
+            }
+            ct.log = log;
+            ct.max_sym = max_sym;
+            out->sym_mask[k] = mask;
+        }
+    }
+}
+
 // position of block boundary `j` of `nbk`: the byte target j*n/nbk moved to the end of the match
 // that covers it, if one does.  Returns {first sequence, first literal} of the block behind it.
 __device__ void block_boundary(const zl_seq* seqs, u32 nseq, u32 nlit, u32 n, u32 j, u32 nbk, u32* first_seq, u32* first_lit) {
@@ -1796,6 +1898,13 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     }
     S.hlen[t] = 0;
     __syncthreads();
+    // With a dictionary, a frame of a single block may take its entropy tables from it: treeless
+    // literals (zstd.c:20745: minLitSize drops to 6 when a table can be repeated) and FSE repeat
+    // modes, both from the very first block -- no table descriptions at all, which is where small
+    // inputs spend their bytes.
+    const zl_cdict* dtab = (const zl_cdict*)a.cdict;
+    const bool dict_tables = dtab != nullptr && nbk == 1 && dtab->ok;
+    if (t == 0) S.lit_from_dict = 0;
     ENT_STAMP(0)
     // ---- wave 3: the Huffman tree  |  waves 0..2: one FSE table each
     if (t == 3 * 64 && S.lit_mode == 2) {
@@ -1825,7 +1934,6 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         else if (nseq < ((1u << def_log) * 8u >> 3) || most < (nseq >> (def_log - 1))) mode = 0;
         else mode = 2;
         if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
-        S.seq_mode[k] = mode;
         ct.max_sym = max_sym;
         if (mode == 0) {
             const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
@@ -1846,12 +1954,53 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, max_sym, log);
             ct.log = (u32)log;
         }
+        if (dict_tables && mode != 1) {
+            // Repeat_Mode against the table just built (zstd.c:21060-21110 weighs the same three costs):
+            // every code that occurs must have a cell in the dictionary's table, and the bits it
+            // spends there must not exceed ours plus our table's description
+            u64 need = 0;
+            for (int s = 0; s <= max_code; s++) if (h[s]) need |= 1ull << s;
+            const FseCTable& dct = dtab->ct[k];
+            if ((need & ~dtab->sym_mask[k]) == 0) {
+                u32 cost_dict = 0, cost_own = 0;
+                for (int s = 0; s <= max_sym; s++) if (h[s]) { cost_dict += h[s] * fse_bit_cost(dct.dnb[s], dct.log); cost_own += h[s] * fse_bit_cost(ct.dnb[s], ct.log); }
+                if (mode == 2) cost_own += 256u * 8u * (((u32)max_sym + 1) * 5 / 8 + 1);
+                if (cost_dict <= cost_own) {
+                    mode = 3;
+                    for (u32 q = 0; q < (1u << dct.log); q++) ct.state[q] = dct.state[q];
+                    for (int q = 0; q < 56; q++) { ct.dnb[q] = dct.dnb[q]; ct.dfs[q] = dct.dfs[q]; }
+                    ct.log = dct.log;
+                    ct.max_sym = dct.max_sym;
+                }
+            }
+        }
+        S.seq_mode[k] = mode;
     }
     __syncthreads();
     ENT_STAMP(1)
+    if (dict_tables && nlit >= 6) {
+        // bits with the dictionary's codes against bits with our own codes plus our tree description
+        const u32 h = S.hist[0][t], dl = dtab->hlen[t];
+        u32 v_dict = h * dl, v_own = h * S.hlen[t], bad = (h && !dl) ? 1u : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { v_dict += __shfl_xor(v_dict, d, 64); v_own += __shfl_xor(v_own, d, 64); bad += __shfl_xor(bad, d, 64); }
+        if (lane == 0) { S.scan_a[wave] = v_dict; S.scan_b[wave] = v_own | (bad ? 0x80000000u : 0u); }
+        __syncthreads();
+        if (t == 0) {
+            const u32 bits_dict = S.scan_a[0] + S.scan_a[1] + S.scan_a[2] + S.scan_a[3];
+            const u32 own_raw = (S.scan_b[0] & 0x7FFFFFFFu) + (S.scan_b[1] & 0x7FFFFFFFu) + (S.scan_b[2] & 0x7FFFFFFFu) + (S.scan_b[3] & 0x7FFFFFFFu);
+            const bool invalid = ((S.scan_b[0] | S.scan_b[1] | S.scan_b[2] | S.scan_b[3]) & 0x80000000u) != 0;
+            // our own table costs its description: about half a byte per symbol up to the largest one present
+            const u32 bits_own = S.lit_mode == 2 ? own_raw + 8 * (S.huf_maxsym / 2 + 2) : 8 * nlit;
+            if (!invalid && S.lit_mode != 1 && bits_dict < bits_own) { S.lit_from_dict = 1; S.lit_mode = 2; S.huf_log = dtab->huf_log; }
+        }
+        __syncthreads();
+        if (S.lit_from_dict) { S.hlen[t] = dtab->hlen[t]; S.hcode[t] = dtab->hcode[t]; }
+        __syncthreads();
+    }
     if (S.lit_mode == 2) {
         // codes: same cell order as the decoder's table (ascending weight, ascending symbol)
-        {
+        if (!S.lit_from_dict) {
             const u32 len = S.hlen[t];
             if (len) {
                 const u32 log = S.huf_log, w = log + 1 - len;
@@ -1892,15 +2041,16 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     ENT_STAMP(2)
     // ---- wave 3: the tree description and the literal decision  |  wave 0: the FSE state chains
     if (t == 3 * 64 && S.lit_mode == 2) {
+        const bool from_dict = S.lit_from_dict != 0;
         u32 total = 0;
         for (u32 j = 0; j < nbk; j++) {
             const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
             for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
             total += four ? 6 : 0;
         }
-        const u32 tree = huf_write_tree(S, S.tree_buf);
+        const u32 tree = from_dict ? 0u : huf_write_tree(S, S.tree_buf);
         S.tree_size = tree;
-        if (tree == 0 || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
+        if ((!from_dict && tree == 0) || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
     }
     // The FSE state chains (zstd.c:21163-21222) are serial per table and per block -- and the blocks
     // are independent, so the 3 x nbk chains run side by side on the lanes of one wave.  Each lane
@@ -1953,7 +2103,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     // =========================== the blocks, one after the other (zstd.c:26833 ZSTD_compressBlock_internal)
     u32 cur = fh;             // write cursor inside the frame
     bool fail = false;        // uniform: the frame outgrew its staging slot -> raw block
-    bool tree_out = false;    // uniform: a block has carried the Huffman tree
+    bool tree_out = S.lit_from_dict != 0;  // uniform: a block has carried the Huffman tree (or the dictionary supplies the table)
     bool tables_out = false;  // uniform: a block has carried the sequence tables
     u32 last_hdr = 0, last_hdr_val = 0;  // where the last block header went and what it holds (for the Last_Block bit)
     const u32 tree_sz = S.tree_size;
@@ -2217,5 +2367,10 @@ extern "C" int zl_debug_occupancy(int which) {
 
 extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream) {
     hipLaunchKernelGGL(zl_dict_hash_kernel, dim3(1), dim3(ENC_THREADS), 0, stream, d_content, n, d_tables);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t zl_launch_cdict_build(const void* d_dict_tables, void* d_cdict, hipStream_t stream) {
+    hipLaunchKernelGGL(zl_cdict_build_kernel, dim3(1), dim3(ENC_THREADS), 0, stream, (const zl_dict_tables*)d_dict_tables, (zl_cdict*)d_cdict);
     return hipGetLastError();
 }
