@@ -182,8 +182,12 @@ def main():
     kms_sum = {}
 
     def drain(slot):
-        for w in pending[slot]:
-            w.wait()
+        if pending[slot]:
+            for w in pending[slot]:
+                w.wait()  # (RCCL: orders torch's current stream behind the transfer, does not block the host)
+            # the codec launches on its own streams, so the host itself must see the transfer finished
+            # before the next compression may overwrite this buffer
+            torch.cuda.current_stream().synchronize()
         pending[slot] = []
 
     def step():
