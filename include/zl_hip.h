@@ -156,6 +156,10 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
 #define ZL_d_profile 9002
 size_t zl_cctx_kernel_ms(const zl_cctx *cctx, double *ms);
 size_t zl_dctx_kernel_ms(const zl_dctx *dctx, double *ms);
+/* Frames this context has decoded with the large-frame pipeline (one frame of many blocks spread over
+ * the whole device: what ZSTD_compress2 writes for inputs above 128 KiB, src/raw-file.c:74) rather
+ * than with one workgroup.  Lets tests and benchmarks assert which path ran. */
+size_t zl_dctx_large_frames(const zl_dctx *dctx);
 
 /* library / device info */
 const char *zl_versionString(void); /* ZSTD_versionString twin for src/serialize.c:26 */

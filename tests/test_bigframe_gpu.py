@@ -1,0 +1,136 @@
+"""Large single frames: what the reference's zstd_compress() writes for any input above 128 KiB
+(src/raw-file.c:74 ZSTD_compress2: ONE frame, 128 KiB blocks, treeless literals and Repeat_Mode tables
+across blocks, matches across blocks up to the window) must decode bit-exact through the large-frame
+pipeline (zl_decode3.hip) -- not through the one-workgroup general kernel.  The frames are made by the
+reference library (oracle/_ref) at test time; the oracle restatement is the second opinion on errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import zstdlite_amd as z
+from zstdlite_amd import _lib
+from zl_testlib import GENERATORS, have_ref
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")]
+
+
+def large_frames(dctx):
+    return int(_lib.lib().zl_dctx_large_frames(dctx._ptr))
+
+
+@pytest.mark.parametrize("gen", ["text", "iid10", "int20", "rand"])
+def test_reference_made_large_frames(gen, ref):
+    dctx = z.zstd_dctx()
+    took = 0
+    for n, level in [(8 * 131072 + 1, 3), (3 << 20, 1), ((5 << 20) + 12345, 3), (2 << 20, 9)]:
+        data = GENERATORS[gen](n, seed=n & 0xFFFF)
+        comp = ref.compress(data, level=level)
+        assert z.zstd_info(comp)["compressed_size"] == len(comp)  # one frame
+        assert z.zstd_decompress(comp, dctx=dctx) == data, (gen, n, level)
+        took += 1
+        assert large_frames(dctx) == took, (gen, n, level)
+
+
+def test_high_levels_and_long_windows(ref):
+    """Levels 16-19 use larger windows, the block splitter and the optimal parser (more repcodes,
+    shorter blocks); multithreaded compression cuts the input into overlapping jobs."""
+    dctx = z.zstd_dctx()
+    data = GENERATORS["text"](3 << 20, seed=9) + GENERATORS["int20"](1 << 20, seed=9) + GENERATORS["text"](2 << 20, seed=9)
+    for kw in ({"level": 19}, {"level": 16}, {"level": 3, "nb_workers": 2}, {"level": -5}):
+        comp = ref.compress(data, **kw)
+        assert z.zstd_decompress(comp, dctx=dctx) == data, kw
+    assert large_frames(dctx) == 4
+
+
+def test_checksummed_large_frame(ref):
+    data = GENERATORS["text"](2 << 20, seed=3) + bytes(300000) + GENERATORS["rand"](400000, seed=3)
+    comp = ref.compress(data, level=3, checksum=True)
+    dctx = z.zstd_dctx()
+    assert z.zstd_decompress(comp, dctx=dctx) == data
+    assert large_frames(dctx) == 1
+    bad = bytearray(comp)
+    bad[-2] ^= 0x40  # the stored checksum
+    with pytest.raises(z.ZstdError, match="doesn't match checksum"):
+        z.zstd_decompress(bytes(bad), dctx=dctx)
+    assert z.zstd_decompress(bytes(bad), dctx=z.zstd_dctx(validate_checksum=False)) == data
+
+
+def test_runs_and_incompressible_stretches(ref):
+    """RLE blocks (a run longer than a block), raw blocks, blocks without sequences, and one match far longer than a batch."""
+    rng = np.random.default_rng(11)
+    parts = [bytes(700000), GENERATORS["rand"](300000, seed=1), b"ab" * 400000, GENERATORS["text"](500000, seed=2),
+             bytes(rng.integers(0, 256, 1000, dtype=np.uint8)) * 900, bytes([7]) * 140000, GENERATORS["iid10"](200000, seed=4)]
+    data = b"".join(parts)
+    dctx = z.zstd_dctx()
+    for level in (1, 3, 12):
+        assert z.zstd_decompress(ref.compress(data, level=level), dctx=dctx) == data, level
+    assert large_frames(dctx) == 3
+
+
+def test_large_and_small_frames_in_one_call(ref):
+    """zstd.c:41671 ZSTD_decompressMultiFrame: concatenated frames come back concatenated; large ones
+    take the large-frame pipeline, the small ones the lane pipeline, in the same call."""
+    a = GENERATORS["text"](2 << 20, seed=5)
+    b = GENERATORS["iid10"](50000, seed=5)
+    c = GENERATORS["int20"]((1 << 20) + 77, seed=5)
+    d = b""
+    e = GENERATORS["text"](131072, seed=6)
+    frames = [ref.compress(x, level=3) for x in (a, b, c, d, e)]
+    dctx = z.zstd_dctx()
+    assert z.zstd_decompress(b"".join(frames), dctx=dctx) == a + b + c + d + e
+    assert large_frames(dctx) == 2
+    # our own encoder's output for the same inputs (one frame per 128 KiB) next to a reference frame
+    mixed = z.zstd_compress(a) + frames[2]
+    assert z.zstd_decompress(mixed, dctx=dctx) == a + c
+
+
+def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
+    """Flipped bytes and truncation anywhere in a large frame: same verdict (error or not) as the oracle,
+    same bytes when both decode, and never a hang."""
+    data = GENERATORS["text"](1 << 20, seed=8) + GENERATORS["iid10"](600000, seed=8)
+    comp = ref.compress(data, level=3, checksum=True)
+    rng = np.random.default_rng(21)
+    dctx = z.zstd_dctx()
+    cases = [comp[:len(comp) - 1], comp[:len(comp) // 2], comp[:20]]
+    for _ in range(40):
+        bad = bytearray(comp)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(4, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(bad))
+    agree_err = agree_ok = 0
+    for bad in cases:
+        try:
+            want = oracle.decompress(bad, cap=len(data))
+        except Exception:
+            want = None
+        try:
+            got = z.zstd_decompress(bad, dctx=dctx)
+        except z.ZstdError:
+            got = None
+        assert (got is None) == (want is None), "verdicts differ"
+        if got is not None:
+            assert got == want
+            agree_ok += 1
+        else:
+            agree_err += 1
+    assert agree_err >= 10
+    assert z.zstd_decompress(comp, dctx=dctx) == data  # the context survives the errors
+
+
+def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
+    """A frame that does not record its size cannot be planned: it stays on the general kernel and still decodes."""
+    data = GENERATORS["text"](400000, seed=12)
+    comp = bytearray(ref.compress(data, level=3))
+    # rewrite the header: Single_Segment off, no Frame_Content_Size, explicit window descriptor (zstd.c:41050)
+    fhd = comp[4]
+    fcs_bytes = {0: 1 if (fhd >> 5) & 1 else 0, 1: 2, 2: 4, 3: 8}[fhd >> 6]
+    assert (fhd >> 5) & 1 == 1 or fcs_bytes  # the reference records the size
+    body = bytes(comp[5 + (0 if (fhd >> 5) & 1 else 1) + fcs_bytes:])
+    new = bytes(comp[:4]) + bytes([fhd & 0x1F & ~0x20]) + bytes([(19 - 10) << 3]) + body  # windowLog 19 >= the data
+    assert oracle.decompress(new, cap=len(data)) == data
+    dctx = z.zstd_dctx()
+    out = (C.c_char * len(data))()
+    r = _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data), new, len(new))
+    assert r == len(data) and bytes(out) == data
+    assert large_frames(dctx) == 0

@@ -54,6 +54,7 @@ SYMBOLS = [
     ("zl_index_frames", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(FrameT), C.c_size_t]),
     ("zl_cctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("zl_dctx_large_frames", C.c_size_t, [C.c_void_p]),
     ("zl_versionString", C.c_char_p, []),
     ("zl_deviceCount", C.c_int, []),
 ]

@@ -15,6 +15,7 @@
 #include "zl_format.h"
 #include "zl_host.h"
 #include "zl_kernels.h"
+#include "zl_decode3.h"
 
 static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
 
@@ -136,6 +137,8 @@ struct zl_dctx_s {
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // start, after index, after entropy lanes, after exec, end
     zl2_side side = {nullptr, nullptr, nullptr};
+    zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
+    size_t large_frames = 0;
     bool ev_valid = false;
     double kernel_ms = 0;
     double stage_ms[4] = {0, 0, 0, 0};
@@ -274,6 +277,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
                       &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2};
     for (DevBuf* b : bufs) b->release();
+    zl3_free(d->big);
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -301,6 +305,8 @@ size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
     for (int k = 0; k < 4; k++) ms[1 + k] = d->stage_ms[k];
     return 0;
 }
+
+size_t zl_dctx_large_frames(const zl_dctx* d) { return d ? d->large_frames : 0; }
 
 // not part of the public header: phase cycle sums.  [0..7] general kernel {H, B, A, A||B wall, C, blocks,
 // sequences, huffman literals}; [8..13] lane-parallel exec kernel {scan, literals, matches, flush, batches, blocks}
@@ -404,6 +410,23 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         !d->d_brec.ensure(n * (size_t)ZL2_MAXB * sizeof(zl2_blk_rec)) || !d->d_lit2.ensure(lit_total + 64) ||
         !d->d_seq2.ensure(seq_total * 16 + 64))
         return kGpuUnavailable;
+    if (!d->side.stream) {
+        if (hipStreamCreateWithFlags(&d->side.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&d->side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->side.join, hipEventDisableTiming) != hipSuccess)
+            return kGpuUnavailable;
+    }
+    // Frames of more blocks than the lane pipeline takes, with a recorded content size and no dictionary
+    // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
+    // first, one after the other; it leaves each frame's result word on the device.
+    static const bool no_big = getenv("ZL_NO_BIG") != nullptr;  // (experiments: the general kernel takes them instead)
+    for (size_t i = 0; i < n && !no_big; i++) {
+        if (has_dict || tbl[i].dst_cap <= route_max || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;
+        if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
+        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side);
+        if (e3 == 0) { plan[i].route = 3; d->large_frames++; }
+        else if (e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
+    }
     if (hipMemcpyAsync(d->d_frames.p, d->h_frames.p, n * sizeof(zl_frame_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemcpyAsync(d->d_plan.p, d->h_plan.p, n * sizeof(zl2_frame_plan), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(d->d_counter.p, 0, 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -427,15 +450,11 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.stats = nullptr;
     f2.max_blocks = (u32*)d->d_counter.p + 8;
     f2.order = (u32*)d->d_order.p;  // (the 64-byte counter block is zeroed above; word 0 is the general kernel's queue head)
+    f2.ext = nullptr;
+    f2.big = nullptr;
     if (d->profile >= 2 && d->d_stats.ensure(128)) {
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;
-    }
-    if (!d->side.stream) {
-        if (hipStreamCreateWithFlags(&d->side.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&d->side.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->side.join, hipEventDisableTiming) != hipSuccess)
-            return kGpuUnavailable;
     }
     if (zl2_launch(&f2, st, &d->side, d->profile ? d->ev + 1 : nullptr) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     zl_decode_args a;

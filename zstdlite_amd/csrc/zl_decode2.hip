@@ -27,6 +27,7 @@
 #include "zl_device.h"
 #include "zl_format.h"
 #include "zl_kernels.h"
+#include "zl_blocks.h"
 
 // ---------------------------------------------------------------------------------------
 // tables (zstd.c:15462-15512)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
     fr->skippable = 0;
     fr->cost = 0;
     fr->lit_cost = 0;
-    if (a.plan[f].route == 0) { fr->err = ZL_E_FALLBACK; return; }
+    if (a.plan[f].route != 1) { fr->err = a.plan[f].route == 3 ? ZL_E_DONE : ZL_E_FALLBACK; return; }
     const zl_frame_desc fd = a.frames[f];
     const u8* src = a.src + fd.src_off;
     const u64 n = fd.src_size;
@@ -115,53 +116,11 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
         r.lit_mode = 0; r.lit_size = 0; r.lit_a = 0; r.lit_b = 0; r.seq_off = 0; r.seq_len = 0;
         r.lit_dst = lit_total; r.seq_dst = seq_total; r.nseq = 0; r.streams = 0; r.seq_modes = 0; r.pad[0] = 0; r.pad[1] = 0;
         if (type == 2) {
-            if (bsize > ZL_BLOCK_MAX) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
-            const u8* blk = src + pos;
-            // literals section header (zstd.c:43146-43230)
-            if (bsize < 1) { fr->err = ZL_E_CORRUPTION; return; }
-            const u32 lt = blk[0] & 3, sf = (blk[0] >> 2) & 3;
-            u32 lsec;
-            if (lt < 2) {
-                u32 lh, regen;
-                if (sf == 0 || sf == 2) { lh = 1; regen = blk[0] >> 3; }
-                else if (sf == 1) { if (bsize < 2) { fr->err = ZL_E_CORRUPTION; return; } lh = 2; regen = zl_rd_le(blk, 2) >> 4; }
-                else { if (bsize < 3) { fr->err = ZL_E_CORRUPTION; return; } lh = 3; regen = zl_rd_le(blk, 3) >> 4; }
-                if (regen > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
-                r.lit_size = regen;
-                if (lt == 0) {
-                    if (lh + regen > bsize) { fr->err = ZL_E_CORRUPTION; return; }
-                    r.lit_mode = 0; r.lit_a = lh; lsec = lh + regen;
-                } else {
-                    if (lh + 1 > bsize) { fr->err = ZL_E_CORRUPTION; return; }
-                    r.lit_mode = 1; r.lit_a = blk[lh]; lsec = lh + 1;
-                }
-            } else {
-                if (bsize < 5) { fr->err = ZL_E_CORRUPTION; return; }
-                const u32 h4 = zl_rd_le(blk, 4);
-                u32 lh, regen, cs, streams = 4;
-                if (sf == 0 || sf == 1) { streams = sf == 0 ? 1 : 4; lh = 3; regen = (h4 >> 4) & 0x3FF; cs = (h4 >> 14) & 0x3FF; }
-                else if (sf == 2) { lh = 4; regen = (h4 >> 4) & 0x3FFF; cs = h4 >> 18; }
-                else { lh = 5; regen = (h4 >> 4) & 0x3FFFF; cs = (h4 >> 22) + ((u32)blk[4] << 10); }
-                if (regen > ZL_BLOCK_MAX) { fr->err = ZL_E_CORRUPTION; return; }
-                if (streams == 4 && regen < 6) { fr->err = ZL_E_LITERALS_HEADER; return; }
-                if (lh + cs > bsize) { fr->err = ZL_E_CORRUPTION; return; }
-                r.lit_mode = lt; r.lit_size = regen; r.lit_a = lh; r.lit_b = cs; r.streams = streams;
-                lsec = lh + cs;
-                lit_total += (regen + 3) & ~3u;
-            }
-            // sequences section header (zstd.c:43707-43735)
-            const u8* sp = blk + lsec;
-            const u32 sn = bsize - lsec;
-            if (sn < 1) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
-            u32 nseq = sp[0], sh = 1;
-            if (nseq > 0x7F) {
-                if (nseq == 0xFF) { if (sn < 3) { fr->err = ZL_E_SRCSIZE_WRONG; return; } nseq = zl_rd_le(sp + 1, 2) + 0x7F00; sh = 3; }
-                else { if (sn < 2) { fr->err = ZL_E_SRCSIZE_WRONG; return; } nseq = ((nseq - 0x80) << 8) + sp[1]; sh = 2; }
-            }
-            if (nseq == 0 && sh != sn) { fr->err = ZL_E_CORRUPTION; return; }
-            r.nseq = nseq; r.seq_off = lsec + sh; r.seq_len = sn - sh;
-            r.seq_modes = (nseq && sn > sh) ? sp[sh] : 0x100u;
-            seq_total += nseq + 2;  // + the totals and final-repcode records the sequence lanes append
+            u32 lit_bytes;
+            const u32 perr = parse_block_sections(src + pos, bsize, r, lit_bytes);
+            if (perr) { fr->err = perr; return; }
+            lit_total += lit_bytes;
+            seq_total += r.nseq + 2;  // + the totals and final-repcode records the sequence lanes append
         } else {
             if ((u64)bsize > fd.dst_cap) { fr->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
         }
@@ -537,9 +496,14 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
     const u8* src = nullptr;
     u8* lit = nullptr;
     zl2_frame_rec* fr = nullptr;
+    // large-frame pipeline: the tree a segment inherits from an earlier block of the frame is built in a round of its own
+    // (round index 0; block k of the segment leads round k + 1)
+    bool ext_leader = false;
     if (f < a.nframes) {
         fr = a.frec + f;
         const u32 nblocks = (fr->err == 0 && !fr->skippable) ? fr->nblocks : 0;
+        const bool have_ext = a.ext != nullptr && nblocks != 0 && a.ext[(size_t)f * 4].type == 2;
+        ext_leader = have_ext && b == 0 && sub == 0;
         if (b < nblocks) {
             const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
             src = a.src + a.frames[f].src_off;
@@ -548,18 +512,23 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
                 if (br[k].type == 2 && br[k].lit_mode == 2) lb = (int)k;
             r = br[b];
             active = (r.type == 2 && r.lit_mode >= 2);
-            if (active && lb < 0) { set_err(fr, ZL_E_DICT_CORRUPTED); active = false; }  // treeless block without a previous table (zstd.c:43171)
+            if (active && lb < 0 && !have_ext) { set_err(fr, ZL_E_DICT_CORRUPTED); active = false; }  // treeless block without a previous table (zstd.c:43171)
+        } else if (ext_leader) {
+            src = a.src + a.frames[f].src_off;
         }
     }
-    if (active) atomicOr(rounds, 1u << lb);
+    if (active) atomicOr(rounds, 1u << (lb + 1));
     __syncthreads();
     const u32 mask = *rounds;
-    for (u32 round = 0; round < MB; round++) {
-        if (!((mask >> round) & 1)) continue;
-        const bool mine = active && lb == (int)round;
-        if (mine && b == round && sub == 0) {
-            const u8* blk = src + r.src_off;
-            u32 tree = build_huf_table(g, blk + r.lit_a, r.lit_b);
+    for (u32 ri = 0; ri <= MB; ri++) {
+        if (!((mask >> ri) & 1)) continue;
+        const int round = (int)ri - 1;
+        const bool mine = active && lb == round;
+        if (ri == 0 ? ext_leader : (mine && (int)b == round && sub == 0)) {
+            zl2_blk_rec lr = r;
+            if (ri == 0) lr = a.ext[(size_t)f * 4];
+            const u8* blk = src + lr.src_off;
+            u32 tree = build_huf_table(g, blk + lr.lit_a, lr.lit_b);
             if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); tree = 0; g.ok = 0; }
             else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
             else g.ok = 1;
@@ -567,7 +536,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
         }
         __syncthreads();
         if (mine && g.ok && fr->err == 0) {
-            const u32 tree = (b == round) ? g.tree : 0u;
+            const u32 tree = ((int)b == round) ? g.tree : 0u;
             const u8* blk = src + r.src_off;
             const u8* hs = blk + r.lit_a + tree;
             const u32 cs = r.lit_b - tree, regen = r.lit_size;
@@ -932,27 +901,39 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
             r = br[b];
             active = (r.type == 2 && r.nseq > 0);
             if (active && r.seq_modes == 0x100u) { set_err(fr, ZL_E_SRCSIZE_WRONG); active = false; }
-            else if (active && lb < 0) { set_err(fr, ZL_E_CORRUPTION); active = false; }  // repeat mode with nothing to repeat (zstd.c:43666)
+            else if (active && lb < 0 && !(a.ext != nullptr && a.ext[(size_t)f * 4 + 1].type == 2)) { set_err(fr, ZL_E_CORRUPTION); active = false; }  // repeat mode with nothing to repeat (zstd.c:43666)
         }
     }
-    if (active) atomicOr(rounds, 1u << lb);
+    // Rounds: 0..2 build the tables a segment of a large frame inherits from earlier blocks (large-frame
+    // pipeline only; no chains), 3 runs the chains of blocks that repeat exactly those, 4 + k is led by
+    // block k of the frame (segment).
+    u32 ext_n = 0;  // inherited table descriptions of this lane's segment (block 0's lane reads them)
+    if (a.ext != nullptr && f < a.nframes && b == 0 && fr->err == 0 && !fr->skippable && fr->nblocks != 0)
+        for (u32 k = 1; k < 4; k++) if (a.ext[(size_t)f * 4 + k].type == 2) ext_n = k;
+    if (f < a.nframes && src == nullptr) src = a.src + a.frames[f].src_off;
+    if (active) atomicOr(rounds, 1u << (lb + 4));
+    if (ext_n) atomicOr(rounds, (1u << ext_n) - 1);
     wave_sync();
     const u32 mask = *rounds;
     SeqLane& L = S.L[fi];
     const bool prof = a.stats != nullptr && lane == 0;
     u64 p_build = 0, p_chain = 0, p_parse = 0, p_tab = 0;
-    for (u32 round = 0; round < ZL2_MAXB; round++) {
-        if (!((mask >> round) & 1)) continue;
+    for (u32 ri = 0; ri < 4 + ZL2_MAXB; ri++) {
+        if (!((mask >> ri) & 1)) continue;
+        const u32 round = ri;  // (stamps the parsed header)
         const u64 q0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        const bool mine = active && lb == (int)round;
+        const bool mine = active && lb + 4 == (int)ri;
+        const bool ext_lead = ri < 3 && ri < ext_n;  // block 0's lane stands in for the earlier block
         u32 pos = 1;  // a block that repeats all tables: the chain starts right after the mode byte
         SeqBuild& B = *(SeqBuild*)((u8*)S.ring + fi * 1024);
         // the scratch shares LDS with the record ring: whatever the last chains left there must not look like a parsed header
         if (b == 0) B.stamp = 0;
         wave_sync();
-        if (mine && b == round) {  // leader: copy the table descriptions out of the frame, then parse them
-            const u8* sp = src + r.src_off + r.seq_off;
-            const u32 sn = r.seq_len, hn = sn < sizeof(B.hdr) ? sn : (u32)sizeof(B.hdr);
+        if (ext_lead || (mine && b + 4 == ri)) {  // leader: copy the table descriptions out of the frame, then parse them
+            zl2_blk_rec lr = r;
+            if (ext_lead) lr = a.ext[(size_t)f * 4 + 1 + ri];
+            const u8* sp = src + lr.src_off + lr.seq_off;
+            const u32 sn = lr.seq_len, hn = sn < sizeof(B.hdr) ? sn : (u32)sizeof(B.hdr);
             {   // whole 16-byte pieces in one round trip, the last few bytes one by one
                 const u32 full = hn >> 4;
                 uint4 v[sizeof(B.hdr) / 16];
@@ -963,7 +944,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
                 for (u32 x = full * 16; x < hn; x++) B.hdr[x] = sp[x];
             }
             const u32 modes = B.hdr[0];
-            const bool have_tables = S.logs[fi][3] == 1;
+            const bool have_tables = S.logs[fi][3] == 1 || ext_lead;  // (an inherited description may itself repeat a table: the block that defines that one is another of the three)
             bool ok = (modes & 3) == 0;
             if (ok) {
                 u32 used = parse_seq_table(B, 0, modes >> 6, B.hdr + pos, hn - pos, have_tables);
@@ -990,7 +971,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         wave_sync();
         const u64 q1 = prof ? __builtin_amdgcn_s_memtime() : 0;
         if (mine && S.logs[fi][3] == 1 && fr->err == 0) {
-            const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0,
+            const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0 || (a.ext != nullptr && f != 0),
                                       q_seq + r.seq_dst);
             if (err) set_err(fr, err);
         }
@@ -1067,7 +1048,9 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
 #define EX_CAP 8192u     // output bytes per batch (links are 16-bit, relative to the batch start)
 #define EX_MAXSEQ 1023u  // sequences per batch (+1 look-ahead entry)
 #define EX_FINAL 0xFFFFu
-struct ExecShared {
+#define EX_DEFER 0xFFFEu  // large-frame pipeline: the byte's source lies in another segment (or is itself waiting); S.far holds where
+template <bool BIG>
+struct ExecSharedT {
     u8 img[EX_CAP + 16];  // byte d of the block sits at img[d + ibase]; (img + d + ibase) and (destination + d) agree modulo 16
     u16 link[EX_CAP];
     u32 b_out[EX_MAXSEQ + 1];
@@ -1078,10 +1061,13 @@ struct ExecShared {
     u32 bcast[8];  // [0] xxh result, [1] batch size, [4..6] rotating "still pending" flags
     u32 brec[ZL2_MAXB * 16];  // the frame's block records, fetched once
     int err;
+    u32 pad3;
+    u32 far[BIG ? EX_CAP : 4];  // frame position a deferred byte of the batch copies
 };
 
 // sequence of the current batch that owns block-relative output position p
-__device__ __forceinline__ u32 owner_of(const ExecShared& S, u32 p, u32 gbase) {
+template <class Shared>
+__device__ __forceinline__ u32 owner_of(const Shared& S, u32 p, u32 gbase) {
     u32 k = S.own[(p - gbase) >> EX_GRAN_LOG];
     while (p >= S.b_out[k + 1]) k++;
     return k;
@@ -1098,19 +1084,27 @@ __device__ __forceinline__ void ex_copy(u8* dst, const u8* src, u32 n) {
     if (t < n - body) dst[body + t] = src[body + t];
 }
 
-__global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
-    __shared__ __align__(16) ExecShared S;
+// Large-frame pipeline (BIG): the workgroup executes one SEGMENT (ZL3_SEG_BLOCKS blocks) of a frame whose
+// other segments run at the same time.  A match that reaches in front of the segment cannot be copied
+// yet: the byte is left "deferred" with the frame position it copies in a.big->link, everything that
+// depends on it inherits that position, and zl3_resolve_kernel fills the bytes in afterwards.
+__device__ __forceinline__ u32 ex_link_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool BIG>
+__global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_args a) {
+    __shared__ __align__(16) ExecSharedT<BIG> S;
     ZL_POISON(S, 2);
     const u32 t = threadIdx.x;
     const u64 wg_t0 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
     const u32 f = a.order[blockIdx.x];  // long frames first
     zl2_frame_rec* fr = a.frec + f;
     const u32 ferr = fr->err;
-    if (ferr == ZL_E_FALLBACK) return;  // the general kernel owns this frame
+    if (!BIG && (ferr == ZL_E_FALLBACK || ferr == ZL_E_DONE)) return;  // the general kernel (or the large-frame pipeline) owns this frame
+    if (BIG && (ferr || a.big->info->err)) return;  // (zl3_offsets_kernel has collected the segments' errors)
     if (ferr || fr->skippable) {
         if (t == 0) a.results[f] = ferr ? ZL_ERR(ferr) : 0;
         return;
     }
+    u32* const glink = BIG ? a.big->link : nullptr;
     const zl_frame_desc fd = a.frames[f];
     const u8* src = a.src + fd.src_off;
     u8* dst = a.dst + fd.dst_off;
@@ -1123,7 +1117,8 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
     static_assert(sizeof(zl2_blk_rec) == 64, "block records are staged as 16 dwords each");
     if (t < nblocks * 16) S.brec[t] = ((const u32*)br)[t];
     __syncthreads();
-    u64 op = 0;
+    u64 op = BIG ? (u64)a.big->blk_dst[(size_t)f * ZL3_SEG_BLOCKS] : 0;
+    const u64 seg_start = op;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
     const u64 wg_t1 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
     // Output goes to memory with plain stores and is read back (by other waves) only in pass 2a of a
@@ -1133,6 +1128,10 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
         const zl2_blk_rec r = *(const zl2_blk_rec*)&S.brec[b * 16];
         const u8* blk = src + r.src_off;
         u8* bdst = dst + op;
+        if (BIG) {  // the history this block starts with was worked out by zl3_offsets_kernel
+            const u32* rs = a.big->rep_start + ((size_t)f * ZL3_SEG_BLOCKS + b) * 3;
+            rep0 = rs[0]; rep1 = rs[1]; rep2 = rs[2];
+        }
         if (r.type != 2) {
             if (r.size > cap - op) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
             else if (r.type == 0) ex_copy(bdst, blk, r.size);
@@ -1143,6 +1142,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                 for (u32 i = t * 16; i < body; i += EX_THREADS * 16) __builtin_memcpy(bdst + i, &v, 16);
                 if (t < r.size - body) bdst[body + t] = (u8)v4;
             }
+            if (BIG && r.size <= cap - op) for (u32 i = t; i < r.size; i += EX_THREADS) glink[op + i] = ZL3_ROOT;
             __syncthreads();
             if (S.err) break;
             op += r.size;
@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                             const u32 d = S.b_out[k] + (j - S.b_lit[k]);
                             const u8 v = (u8)(word >> (8 * (j - (u32)jj)));
                             if (linked) { S.img[d + ibase] = v; S.link[d - batch_start] = EX_FINAL; }
-                            else bdst[d] = v;
+                            else { bdst[d] = v; if (BIG) glink[op + d] = ZL3_ROOT; }
                         }
                     }
                 }
@@ -1257,8 +1257,18 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                         const u32 m = p - mstart, o = S.b_off[k];
                         const i64 q = (m < o) ? (i64)p - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
                         if (q < (i64)batch_start) {
-                            S.img[p + ibase] = bdst[q];  // an earlier batch or an earlier block: already in memory
-                            S.link[p - batch_start] = EX_FINAL;
+                            u32 defer = ZL3_ROOT;
+                            if (BIG) {
+                                const u64 fp = (u64)((i64)op + q);  // frame position of the source
+                                defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);  // (another segment | this segment: final, or waiting itself)
+                            }
+                            if (defer == ZL3_ROOT) {
+                                S.img[p + ibase] = bdst[q];  // an earlier batch or an earlier block: already in memory
+                                S.link[p - batch_start] = EX_FINAL;
+                            } else {
+                                S.far[p - batch_start] = defer;
+                                S.link[p - batch_start] = EX_DEFER;
+                            }
                         } else {
                             const u32 qq = (u32)q;
                             const u32 k2 = owner_of(S, qq, gbase);
@@ -1281,9 +1291,14 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                     u32 pending = 0;
                     for (u32 i = t; i < tot_o; i += EX_THREADS) {
                         const u32 l1 = S.link[i];
-                        if (l1 == EX_FINAL) continue;
+                        if (l1 >= EX_DEFER) continue;
                         const u32 l2 = S.link[l1];
-                        if (l2 == EX_FINAL) {
+                        if (BIG && l2 == EX_DEFER) {  // (same order rules as for the bytes)
+                            asm volatile("" ::: "memory");
+                            S.far[i] = S.far[l1];
+                            asm volatile("" ::: "memory");
+                            S.link[i] = EX_DEFER;
+                        } else if (l2 == EX_FINAL) {
                             // (order matters against the other waves of this round: read the link before the byte, write the byte before the link)
                             asm volatile("" ::: "memory");
                             S.img[ib + i] = S.img[ib + l1];
@@ -1311,6 +1326,14 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                     }
                     const u32 tail0 = h + (body << 4);
                     if (tail0 + t < tot_o) g[tail0 + t] = S.img[ib + tail0 + t];
+                    if (BIG) {  // what each byte of the batch is: final, or waiting for a frame position
+                        u32* gl = glink + op + batch_start;
+                        for (u32 i = t; i < tot_o; i += EX_THREADS) {
+                            const bool fin = S.link[i] == EX_FINAL;
+                            gl[i] = fin ? ZL3_ROOT : S.far[i];
+                            if (!fin) a.big->tile_flag[(op + batch_start + i) >> ZL3_TILE_LOG] = 1;
+                        }
+                    }
                 }
             } else {
                 // one sequence longer than the image: its literals are in memory (pass 1); every match
@@ -1319,7 +1342,17 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
                 const u32 mstart = S.b_out[0] + ll, ml = batch_end - mstart, o = S.b_off[0];
                 const u8* from = bdst + mstart - o;
                 u8* to = bdst + mstart;
-                if (o >= 16) {
+                if (BIG) {
+                    // byte by byte: a source in front of the segment, or one that is itself waiting, defers the byte
+                    const u64 fm = op + mstart;  // frame position of the match
+                    for (u32 m = t; m < ml; m += EX_THREADS) {
+                        const u64 fp = fm - o + (m % o);
+                        const u32 defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);
+                        if (defer == ZL3_ROOT) to[m] = dst[fp];
+                        else a.big->tile_flag[(fm + m) >> ZL3_TILE_LOG] = 1;
+                        glink[fm + m] = defer;
+                    }
+                } else if (o >= 16) {
                     // whole 16-byte pieces while they do not wrap around the period
                     for (u32 m = t * 16; m < ml; m += EX_THREADS * 16) {
                         const u32 s = m % o;
@@ -1354,6 +1387,7 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
         if (S.err) break;
         if (lit_rle) { for (u32 i = t; i < rest; i += EX_THREADS) bdst[out_pos + i] = (u8)rle_byte; }
         else ex_copy(bdst + out_pos, lit + lit_pos, rest);
+        if (BIG) for (u32 i = t; i < rest; i += EX_THREADS) glink[op + out_pos + i] = ZL3_ROOT;
         if (nseq) {  // history after this block (zstd.c:44686)
             const uint4 e = sq[nseq + 1];
             const u32 n0 = ZL2_RESOLVE(e.x), n1 = ZL2_RESOLVE(e.y), n2 = ZL2_RESOLVE(e.z);
@@ -1378,6 +1412,10 @@ __global__ __launch_bounds__(EX_THREADS, 8) void zl2_exec_kernel(zl2_args a) {
     if (a.stats != nullptr && t == 0) {  // profile: prologue, and the final drain of this frame's stores
         atomicAdd((unsigned long long*)&a.stats[-2], (unsigned long long)(wg_t1 - wg_t0));
         atomicAdd((unsigned long long*)&a.stats[-1], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t2));
+    }
+    if (BIG) {  // content size and checksum belong to the whole frame: zl3_finish_kernel
+        if (t == 0 && S.err) atomicCAS(&a.big->info->err, 0u, (u32)S.err);
+        return;
     }
     if (!S.err) {
         if (t == 0 && fr->fcs != ZL_CONTENTSIZE_UNKNOWN && fr->fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
@@ -1414,15 +1452,34 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(zl2_exec_kernel, dim3(n), dim3(EX_THREADS), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_exec_kernel<false>, dim3(n), dim3(EX_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);
+    return hipGetLastError();
+}
+
+// Large-frame pipeline (zl_decode3.hip): the same kernels over the segments of one frame.  The caller has
+// filled frec / brec / plan / ext on the device.
+extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t stream, const zl2_side* side) {
+    const u32 n = a->nframes;
+    hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
+    const u32 ngroups = (n + LIT_FRAMES - 1) / LIT_FRAMES;
+    if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, side->stream, *a);
+    if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
+    hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ngroups), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, *a);
+    hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
+    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
+    return hipGetLastError();
+}
+extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, hipStream_t stream) {
+    hipLaunchKernelGGL(zl2_exec_kernel<true>, dim3(a->nframes), dim3(EX_THREADS), 0, stream, *a);
     return hipGetLastError();
 }
 
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl2_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel, EX_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel<false>, EX_THREADS, 0);
     else if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_lit_kernel<ZL2_MAXB>, LIT_FRAMES * ZL2_MAXB * 4, ZL_LIT_PAD_BYTES);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_seq_kernel, 64, 0);
     return n;
