@@ -87,7 +87,36 @@ def cpu_baseline(host_bytes, log):
         "sample": f"the full {n >> 20} MiB bench vector, one pass: ZSTD_compress2(level 3) + ZSTD_decompressDCtx, bundled libzstd 1.5.6 built -O2 from the reference source (oracle/_ref), 1 thread",
         "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / csize, "compressed_bytes": int(csize),
         "compress_GBps_nbWorkers": n / res["mt"][0] / 1e9, "nbWorkers": ncores, "host_cores": ncores,
+        "_frame": comp[:csize],  # (the reference's single frame of the whole vector: input of the N1 leg, removed before printing)
     }
+
+
+def n1_decode(codec, device, frame, src, log):
+    """zstd_decompress() of ONE reference-made frame of the whole bench vector (what the
+    reference's zstd_compress() writes: 8192 blocks, one window), through the large-frame pipeline,
+    device-resident, checked against the plaintext."""
+    import torch
+    from zstdlite_amd import _lib
+    n = int(src.numel())
+    d_src = torch.from_numpy(np.ascontiguousarray(frame)).to(device)
+    d_dst = torch.empty(n, dtype=torch.uint8, device=device)
+    tbl = codec.frame_table([int(frame.size)], [n])
+    before = int(_lib.lib().zl_dctx_large_frames(codec.dctx))
+    best = 1e9
+    for it in range(3):
+        d_dst.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, _ = codec.decompress(d_src, tbl, d_dst)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if it:
+            best = min(best, dt)
+    took = int(_lib.lib().zl_dctx_large_frames(codec.dctx)) - before
+    assert total == n and torch.equal(d_dst, src), "N1 decode mismatch"
+    log(f"N1: one reference frame of {n >> 20} MiB decoded at {n / best / 1e9:.2f} GB/s (large-frame pipeline: {took == 3})")
+    return {"frame_content_bytes": n, "compressed_bytes": int(frame.size), "decompress_GBps": n / best / 1e9, "ms": best * 1e3,
+            "large_frame_pipeline": took == 3, "bit_exact": True}
 
 
 def c2_decode(codec, device, log, nframes=10000):
@@ -281,6 +310,7 @@ def main():
             host = src.cpu().numpy()
             cb = cpu_baseline(host, log)
             if cb is not None:
+                ref_frame = cb.pop("_frame")
                 out["cpu_baseline"] = cb
                 out["ratio_vs_cpu"] = {"speedup_roundtrip": value / cb["value"], "compressed_size_ours_over_cpu": csize / cb["compressed_bytes"]}
                 if not args.no_c2:
@@ -288,6 +318,11 @@ def main():
                         out["c2_frames64k"] = c2_decode(codec, device, log)
                     except Exception as e:  # informative leg; never lose the headline line to it
                         out["c2_frames64k"] = {"error": repr(e)}
+                    try:
+                        out["n1_large_frame"] = n1_decode(codec, device, ref_frame, src, log)
+                        out["n1_large_frame"]["cpu_decompress_GBps"] = cb["decompress_GBps"]
+                    except Exception as e:
+                        out["n1_large_frame"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

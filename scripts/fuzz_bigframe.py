@@ -1,0 +1,60 @@
+"""Fuzz the large-frame pipeline against the oracle: reference-made frames of 9..20 blocks get a few
+damaged bytes (or are cut short); batches of them are decoded in one call.  Rules as in
+fuzz_decode.py: never a hang or crash, accepted frames equal the oracle's bytes, nothing the oracle
+accepts is rejected.  usage: fuzz_bigframe.py [rounds] [seed]"""
+import sys, time, ctypes as C
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import zstdlite_amd as z
+from zstdlite_amd import _lib
+from zl_testlib import GENERATORS, Oracle, Ref, is_error
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+o = Oracle(); L = _lib.lib(); ref = Ref()
+base = []
+for gen, n, kw in (("text", 1200000, {"level": 3}), ("iid10", 1300000, {"level": 3, "checksum": True}), ("int20", 1500000, {"level": 1}),
+                   ("text", 2500000, {"level": 9}), ("iid10", 1100000, {"level": 19})):
+    d = GENERATORS[gen](n, seed=n) + (bytes(200000) if gen == "int20" else b"")
+    base.append((ref.compress(d, **kw), len(d)))
+print(len(base), "base frames;", sum(len(f) for f, _ in base), "compressed bytes")
+dctx = z.zstd_dctx()
+bad_accept = bad_reject = accepted = rejected = 0
+t0 = time.time()
+for rd in range(rounds):
+    frames = []
+    for f, n in base:
+        for k in range(6):
+            b = bytearray(f)
+            if k == 5:
+                b = b[: int(rng.integers(8, len(b)))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    pos = int(rng.integers(4, len(b)))  # keep the magic number
+                    b[pos] ^= 1 << int(rng.integers(0, 8))
+            frames.append((bytes(b), n))
+    m = len(frames)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _, n in frames]
+    srcs = [np.frombuffer(f, dtype=np.uint8) for f, _ in frames]
+    dsts = (C.c_void_p * m)(*[x.ctypes.data for x in outs])
+    caps = (C.c_size_t * m)(*[n for _, n in frames])
+    ptrs = (C.c_void_p * m)(*[x.ctypes.data for x in srcs])
+    sizes = (C.c_size_t * m)(*[len(f) for f, _ in frames])
+    res = (C.c_size_t * m)()
+    r = L.zl_decompress_batch(dctx._ptr, m, dsts, caps, ptrs, sizes, res)
+    assert not is_error(r), _lib.error_name(r)
+    for i, (f, n) in enumerate(frames):
+        code, out = o.decompress_code(f, n)
+        g_ok = not is_error(res[i])
+        if g_ok:
+            accepted += 1
+            if is_error(code) or res[i] != code or outs[i][: res[i]].tobytes() != out:
+                bad_accept += 1
+                print("GPU accepted, oracle disagrees: frame", i, "gpu", res[i], "oracle", code if not is_error(code) else o.error_name(code))
+        else:
+            rejected += 1
+            if not is_error(code):
+                bad_reject += 1
+                print("GPU rejected a frame the oracle accepts: frame", i, _lib.error_name(res[i]), "oracle size", code)
+    print(f"round {rd}: {accepted} accepted, {rejected} rejected, {bad_accept} wrong accepts, {bad_reject} wrong rejects, large frames so far {L.zl_dctx_large_frames(dctx._ptr)}, {time.time() - t0:.0f}s", flush=True)
+assert bad_accept == 0 and bad_reject == 0
+print("ok")
