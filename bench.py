@@ -318,11 +318,11 @@ def main():
                         out["c2_frames64k"] = c2_decode(codec, device, log)
                     except Exception as e:  # informative leg; never lose the headline line to it
                         out["c2_frames64k"] = {"error": repr(e)}
-                    try:
-                        out["n1_large_frame"] = n1_decode(codec, device, ref_frame, src, log)
-                        out["n1_large_frame"]["cpu_decompress_GBps"] = cb["decompress_GBps"]
-                    except Exception as e:
-                        out["n1_large_frame"] = {"error": repr(e)}
+                try:
+                    out["n1_large_frame"] = n1_decode(codec, device, ref_frame, src, log)
+                    out["n1_large_frame"]["cpu_decompress_GBps"] = cb["decompress_GBps"]
+                except Exception as e:
+                    out["n1_large_frame"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

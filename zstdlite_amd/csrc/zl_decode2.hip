@@ -1089,20 +1089,19 @@ __device__ __forceinline__ void ex_copy(u8* dst, const u8* src, u32 n) {
 // yet: the byte is left "deferred" with the frame position it copies in a.big->link, everything that
 // depends on it inherits that position, and zl3_resolve_kernel fills the bytes in afterwards.
 __device__ __forceinline__ u32 ex_link_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// One frame (BIG: one segment; `seg_start` is the first output position of the workgroup's run of
+// segments: what lies in front of it belongs to other workgroups).  Returns false when the run must stop.
 template <bool BIG>
-__global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_args a) {
-    __shared__ __align__(16) ExecSharedT<BIG> S;
-    ZL_POISON(S, 2);
+__device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& S, const u32 f, u64& seg_start, const bool first) {
     const u32 t = threadIdx.x;
     const u64 wg_t0 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
-    const u32 f = a.order[blockIdx.x];  // long frames first
     zl2_frame_rec* fr = a.frec + f;
     const u32 ferr = fr->err;
-    if (!BIG && (ferr == ZL_E_FALLBACK || ferr == ZL_E_DONE)) return;  // the general kernel (or the large-frame pipeline) owns this frame
-    if (BIG && (ferr || a.big->info->err)) return;  // (zl3_offsets_kernel has collected the segments' errors)
+    if (!BIG && (ferr == ZL_E_FALLBACK || ferr == ZL_E_DONE)) return false;  // the general kernel (or the large-frame pipeline) owns this frame
+    if (BIG && (ferr || a.big->info->err)) return false;  // (zl3_offsets_kernel has collected the segments' errors)
     if (ferr || fr->skippable) {
         if (t == 0) a.results[f] = ferr ? ZL_ERR(ferr) : 0;
-        return;
+        return false;
     }
     u32* const glink = BIG ? a.big->link : nullptr;
     const zl_frame_desc fd = a.frames[f];
@@ -1118,7 +1117,7 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
     if (t < nblocks * 16) S.brec[t] = ((const u32*)br)[t];
     __syncthreads();
     u64 op = BIG ? (u64)a.big->blk_dst[(size_t)f * ZL3_SEG_BLOCKS] : 0;
-    const u64 seg_start = op;
+    if (first) seg_start = op;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
     const u64 wg_t1 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
     // Output goes to memory with plain stores and is read back (by other waves) only in pass 2a of a
@@ -1415,7 +1414,7 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
     }
     if (BIG) {  // content size and checksum belong to the whole frame: zl3_finish_kernel
         if (t == 0 && S.err) atomicCAS(&a.big->info->err, 0u, (u32)S.err);
-        return;
+        return S.err == 0;
     }
     if (!S.err) {
         if (t == 0 && fr->fcs != ZL_CONTENTSIZE_UNKNOWN && fr->fcs != op) S.err = ZL_E_CORRUPTION;  // zstd.c:41646
@@ -1428,6 +1427,25 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
     }
     if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : op;
     if (a.stats != nullptr && t == 0) atomicAdd((unsigned long long*)&a.stats[-3], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t0));  // profile: workgroup lifetime
+    return true;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_args a) {
+    __shared__ __align__(16) ExecSharedT<BIG> S;
+    ZL_POISON(S, 2);
+    u64 seg_start = 0;
+    if (!BIG) {
+        (void)exec_frame<BIG>(a, S, a.order[blockIdx.x], seg_start, true);  // long frames first
+    } else {
+        // a run of consecutive segments per workgroup: matches that stay inside the run are copied here
+        // and now, only what reaches in front of it is left to the resolve rounds
+        const u32 f0 = blockIdx.x * ZL3_EXEC_RUN, f1 = f0 + ZL3_EXEC_RUN < a.nframes ? f0 + ZL3_EXEC_RUN : a.nframes;
+        for (u32 f = f0; f < f1; f++) {
+            if (!exec_frame<BIG>(a, S, f, seg_start, f == f0)) break;
+            __syncthreads();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1472,7 +1490,7 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     return hipGetLastError();
 }
 extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, hipStream_t stream) {
-    hipLaunchKernelGGL(zl2_exec_kernel<true>, dim3(a->nframes), dim3(EX_THREADS), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_exec_kernel<true>, dim3((a->nframes + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN), dim3(EX_THREADS), 0, stream, *a);
     return hipGetLastError();
 }
 

@@ -95,6 +95,9 @@ struct zl2_args {
 // Large-frame pipeline: what the segment workgroups of zl2_exec_kernel<true> share.
 #define ZL3_ROOT 0xFFFFFFFFu      // link value of a byte that is final in the output (marks of later rounds: ZL3_ROOT - 1, - 2)
 #define ZL3_SEG_BLOCKS 1          // blocks per segment: reference-made blocks bring their own tables, so more blocks per segment would only queue up behind one another in the entropy lanes
+#ifndef ZL3_EXEC_RUN
+#define ZL3_EXEC_RUN 8            // consecutive segments one exec workgroup works through
+#endif
 #define ZL3_TILE_LOG 14           // resolve rounds skip 16 KiB tiles without pending bytes
 struct zl3_info {                 // one per large frame, device memory
     u32 err;                      // first error of any stage (0: none)
