@@ -24,6 +24,8 @@
 // All integer work; output must be bit-exact with the reference decoder.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "zl_device.h"
 #include "zl_format.h"
 #include "zl_kernels.h"
@@ -1481,6 +1483,12 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
     const u32 ngroups = (n + LIT_FRAMES - 1) / LIT_FRAMES;
+    static const bool serial = getenv("ZL_BIG_SERIAL") != nullptr;  // (experiments: the two kernels one after the other)
+    if (serial) {
+        hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, stream, *a);
+        hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
+        return hipGetLastError();
+    }
     if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, side->stream, *a);
     if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;

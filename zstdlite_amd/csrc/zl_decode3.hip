@@ -17,7 +17,8 @@
 //   zl3_offsets_kernel  one wave: output position and starting repcode history of every block
 //   zl2_exec_kernel<true>  workgroup per segment, all segments at once: bytes whose source lies in
 //                       another segment are left as links (frame positions)
-//   zl3_resolve_kernel  pointer jumping over those links, one launch per round, until none is pending
+//   zl3_copy_kernel     the deferred bytes, in order: one tiny launch per run of segments, so that every
+//                       source is final when it is read (zl3_resolve_kernel: the pointer-jumping variant)
 //   zl3_finish_kernel   content size, XXH64 (zstd.c:41646-41660), the frame's result word
 //
 // All integer work; output must be bit-exact with the reference decoder.
@@ -369,6 +370,39 @@ __global__ __launch_bounds__(256) void zl3_resolve_kernel(u8* dst, u32* link, u3
 }
 
 // ---------------------------------------------------------------------------------------
+// resolve, in order: one launch per run of segments (the unit an exec workgroup worked through).  A
+// deferred byte of run R copies a byte of an earlier run, and all of those are final once the
+// launches of the runs in front of R have ended -- so every deferred byte is visited exactly once and
+// no link is ever followed twice.  The launches are tiny (<= 1 MiB of output each); what they cost is
+// their number, not their work.
+// ---------------------------------------------------------------------------------------
+#define ZL3_COPY_THREADS 256
+#define ZL3_COPY_SLICE 4096u  // output bytes per workgroup
+__global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_copy_kernel(u8* dst, const u32* link, const u32* tile_flag, const u32* blk_dst, u32 run, zl3_info* info) {
+    const u32 nb = info->nblocks;
+    const u32 b0 = run * ZL3_EXEC_RUN * ZL3_SEG_BLOCKS, b1 = b0 + ZL3_EXEC_RUN * ZL3_SEG_BLOCKS < nb ? b0 + ZL3_EXEC_RUN * ZL3_SEG_BLOCKS : nb;
+    const u32 p0 = blk_dst[b0], p1 = blk_dst[b1];
+    const u32 s0 = (p0 & ~3u) + blockIdx.x * ZL3_COPY_SLICE;
+    if (s0 >= p1) return;
+    for (u32 q = s0 + threadIdx.x * 4; q < s0 + ZL3_COPY_SLICE && q < p1; q += ZL3_COPY_THREADS * 4) {
+        if (!tile_flag[q >> ZL3_TILE_LOG]) continue;
+        const uint4 v = *(const uint4*)(link + q);  // (the link buffer is padded: reading a few entries past the end is fine)
+        const u32 lk[4] = {v.x, v.y, v.z, v.w};
+        u32 word = 0;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 pos = q + j;
+            if (pos < p0 || pos >= p1 || lk[j] >= ZL3_MARK_MIN) continue;
+            if (!any) { __builtin_memcpy(&word, dst + q, 4); any = true; }  // (the frame may start at any address)
+            if (lk[j] >= pos) { info_err(info, ZL_E_CORRUPTION); continue; }  // (links only ever point backwards; a guard against garbage)
+            word = (word & ~(0xFFu << (8 * j))) | ((u32)dst[lk[j]] << (8 * j));
+        }
+        if (any) __builtin_memcpy(dst + q, &word, 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // the frame's result: checksum and size (zstd.c:41646-41660)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_frame_desc fd, const u8* src_base, const u8* dst_base, u64* result, u32 ignore_checksum) {
@@ -448,7 +482,14 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (zl2_launch_segments_exec(&a, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("exec");
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        for (u32 round = 0; !info.err; round++) {
+        static const bool jumping = getenv("ZL_BIG_JUMPING") != nullptr;  // (experiments: the pointer-jumping rounds instead of the in-order launches)
+        if (!info.err && !jumping) {
+            const u32 nruns = (info.nsegs + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN;
+            for (u32 run = 1; run < nruns; run++)
+                hipLaunchKernelGGL(zl3_copy_kernel, dim3((ZL3_EXEC_RUN * ZL3_SEG_BLOCKS * ZL_BLOCK_MAX + 4) / ZL3_COPY_SLICE + 1), dim3(ZL3_COPY_THREADS), 0, st,
+                                   d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, (const u32*)d.blk_dst, run, d.info);
+        }
+        for (u32 round = 0; !info.err && jumping; round++) {
             if (hipMemsetAsync(&d.info->pending, 0, 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             hipLaunchKernelGGL(zl3_resolve_kernel, dim3((u32)ntiles), dim3(256), 0, st, d_dst + fd.dst_off, (u32*)s->link.p, (u32*)s->tile_flag.p, (u64)info.fcs, round, d.info);
             if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
