@@ -29,3 +29,9 @@ def ref():
 def golden():
     from zl_testlib import load_golden
     return load_golden()
+
+
+@pytest.fixture(scope="session")
+def golden_large():
+    from zl_testlib import load_golden_large
+    return load_golden_large()

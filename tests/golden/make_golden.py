@@ -55,5 +55,32 @@ def main():
     print(len(meta), "frames,", sum(m["csize"] for m in meta), "compressed bytes")
 
 
+# Large frames: ONE reference-made frame of more than eight blocks each -- treeless literals and
+# Repeat_Mode tables across blocks, matches across blocks, a checksum, runs (RLE blocks) and raw blocks.
+LARGE = [  # (name, [(generator, n, seed)...] concatenated, level, checksum)
+    ("text_l3", [("text", 1200000, 31)], 3, False),
+    ("iid10_l3_ck", [("iid10", 1190000, 32)], 3, True),
+    ("mixed_l19", [("text", 500000, 33), ("zeros", 300000, 0), ("rand", 150000, 34), ("int20", 300000, 35), ("text", 200000, 33)], 19, False),
+]
+
+
+def large_plain(parts):
+    return b"".join(bytes(n) if g == "zeros" else GENERATORS[g](n, seed=seed) for g, n, seed in parts)
+
+
+def main_large():
+    ref = Ref()
+    blobs, meta = {}, []
+    for name, parts, level, checksum in LARGE:
+        data = large_plain(parts)
+        comp = ref.compress(data, level=level, checksum=checksum)
+        blobs[name] = np.frombuffer(comp, dtype=np.uint8)
+        meta.append({"key": name, "parts": parts, "n": len(data), "level": level, "checksum": checksum, "csize": len(comp), "sha256": sha256(data)})
+    blobs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLDEN, "large_frames.npz"), **blobs)
+    print(len(meta), "large frames,", sum(m["csize"] for m in meta), "compressed bytes")
+
+
 if __name__ == "__main__":
     main()
+    main_large()

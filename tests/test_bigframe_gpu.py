@@ -12,13 +12,35 @@ import zstdlite_amd as z
 from zstdlite_amd import _lib
 from zl_testlib import GENERATORS, have_ref
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")]
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")
 
 
 def large_frames(dctx):
     return int(_lib.lib().zl_dctx_large_frames(dctx._ptr))
 
 
+def test_golden_large_frames_bit_exact(golden_large):
+    """The committed reference-made frames (text level 3; iid10 level 3 with checksum; a level-19 mix with
+    runs and incompressible stretches): bit-exact, through the large-frame pipeline, one by one and in one call."""
+    dctx = z.zstd_dctx()
+    for c in golden_large:
+        assert z.zstd_decompress(c["comp"], dctx=dctx) == c["plain"], c["key"]
+    assert large_frames(dctx) == len(golden_large)
+    assert z.zstd_decompress(b"".join(c["comp"] for c in golden_large), dctx=dctx) == b"".join(c["plain"] for c in golden_large)
+    assert large_frames(dctx) == 2 * len(golden_large)
+    # the device-resident entry takes the same route
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    codec = DeviceCodec(level=3)
+    c = golden_large[0]
+    d_src = torch.frombuffer(bytearray(c["comp"]), dtype=torch.uint8).cuda()
+    d_dst = torch.empty(c["n"], dtype=torch.uint8, device="cuda")
+    total, _ = codec.decompress(d_src, codec.frame_table([len(c["comp"])], [c["n"]]), d_dst)
+    assert total == c["n"] and bytes(d_dst.cpu().numpy()) == c["plain"]
+
+
+@needs_ref
 @pytest.mark.parametrize("gen", ["text", "iid10", "int20", "rand"])
 def test_reference_made_large_frames(gen, ref):
     dctx = z.zstd_dctx()
@@ -32,6 +54,7 @@ def test_reference_made_large_frames(gen, ref):
         assert large_frames(dctx) == took, (gen, n, level)
 
 
+@needs_ref
 def test_high_levels_and_long_windows(ref):
     """Levels 16-19 use larger windows, the block splitter and the optimal parser (more repcodes,
     shorter blocks); multithreaded compression cuts the input into overlapping jobs."""
@@ -43,6 +66,7 @@ def test_high_levels_and_long_windows(ref):
     assert large_frames(dctx) == 4
 
 
+@needs_ref
 def test_checksummed_large_frame(ref):
     data = GENERATORS["text"](2 << 20, seed=3) + bytes(300000) + GENERATORS["rand"](400000, seed=3)
     comp = ref.compress(data, level=3, checksum=True)
@@ -56,6 +80,7 @@ def test_checksummed_large_frame(ref):
     assert z.zstd_decompress(bytes(bad), dctx=z.zstd_dctx(validate_checksum=False)) == data
 
 
+@needs_ref
 def test_runs_and_incompressible_stretches(ref):
     """RLE blocks (a run longer than a block), raw blocks, blocks without sequences, and one match far longer than a batch."""
     rng = np.random.default_rng(11)
@@ -68,6 +93,7 @@ def test_runs_and_incompressible_stretches(ref):
     assert large_frames(dctx) == 3
 
 
+@needs_ref
 def test_large_and_small_frames_in_one_call(ref):
     """zstd.c:41671 ZSTD_decompressMultiFrame: concatenated frames come back concatenated; large ones
     take the large-frame pipeline, the small ones the lane pipeline, in the same call."""
@@ -85,6 +111,7 @@ def test_large_and_small_frames_in_one_call(ref):
     assert z.zstd_decompress(mixed, dctx=dctx) == a + c
 
 
+@needs_ref
 def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
     """Flipped bytes and truncation anywhere in a large frame: same verdict (error or not) as the oracle,
     same bytes when both decode, and never a hang."""
@@ -118,6 +145,7 @@ def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
     assert z.zstd_decompress(comp, dctx=dctx) == data  # the context survives the errors
 
 
+@needs_ref
 def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
     """A frame that does not record its size cannot be planned: it stays on the general kernel and still decodes."""
     data = GENERATORS["text"](400000, seed=12)

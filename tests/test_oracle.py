@@ -32,6 +32,16 @@ def test_golden_frames(oracle, golden):
         assert oracle.L.zlo_get_frame_content_size(c["comp"], len(c["comp"])) == c["n"]
 
 
+def test_golden_large_frames(oracle, golden_large):
+    """Reference-made single frames of more than eight blocks (tests/golden/large_frames.npz): the oracle
+    is pinned against them too -- they are what the large-frame pipeline is checked with on the GPU."""
+    assert len(golden_large) >= 3
+    for c in golden_large:
+        assert oracle.decompress(c["comp"]) == c["plain"], c["key"]
+        assert oracle.L.zlo_find_frame_compressed_size(c["comp"], len(c["comp"])) == c["csize"]
+        assert oracle.L.zlo_get_frame_content_size(c["comp"], len(c["comp"])) == c["n"] > 8 * 131072
+
+
 def test_pinned_facts(oracle, golden):
     # BASELINE.md section 2
     assert oracle.L.zlo_compress_bound(1 << 30) == 1077936128

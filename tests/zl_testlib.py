@@ -279,3 +279,18 @@ def load_golden():
         assert sha256(m["plain"]) == m["sha256"], "generator drifted from the committed golden hashes"
         cases.append(m)
     return cases, z["dict"].tobytes()
+
+
+def load_golden_large():
+    """tests/golden/large_frames.npz (make_golden.py main_large): reference-made single frames of more
+    than eight blocks.  Returns case dicts with 'comp' and the regenerated 'plain'."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "large_frames.npz"))
+    cases = []
+    for m in json.loads(z["meta"].tobytes().decode()):
+        m = dict(m)
+        m["comp"] = z[m["key"]].tobytes()
+        m["plain"] = b"".join(bytes(n) if g == "zeros" else GENERATORS[g](n, seed=seed) for g, n, seed in m["parts"])
+        assert sha256(m["plain"]) == m["sha256"], "generator drifted from the committed golden hashes"
+        cases.append(m)
+    return cases
