@@ -689,6 +689,8 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
     const zl_dict_tables* DT = (const zl_dict_tables*)a.dict_tables;
     const u8* dict_end = a.dict_content ? a.dict_content + a.dict_len : nullptr;
 
+    // behind the lane pipeline: nothing to do unless it has counted frames for this kernel (word 9 of the counter block)
+    if (a.plan && a.counter[9] == 0) return;
     for (;;) {
         zl_sync_global();
         if (t == 0) S.frame = atomicAdd(a.counter, 1u);

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
     fr->skippable = 0;
     fr->cost = 0;
     fr->lit_cost = 0;
-    if (a.plan[f].route != 1) { fr->err = a.plan[f].route == 3 ? ZL_E_DONE : ZL_E_FALLBACK; return; }
+    if (a.plan[f].route != 1) {
+        fr->err = a.plan[f].route == 3 ? ZL_E_DONE : ZL_E_FALLBACK;
+        if (a.plan[f].route == 0) atomicAdd(a.max_blocks + 1, 1u);  // (the word behind max_blocks: frames the general kernel has to take)
+        return;
+    }
     const zl_frame_desc fd = a.frames[f];
     const u8* src = a.src + fd.src_off;
     const u64 n = fd.src_size;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
         if (type == 3) { fr->err = ZL_E_CORRUPTION; return; }
         const u32 csize = (type == 1) ? 1 : bsize;
         if (n - pos < csize) { fr->err = ZL_E_SRCSIZE_WRONG; return; }
-        if (nb >= ZL2_MAXB) { fr->err = ZL_E_FALLBACK; return; }
+        if (nb >= ZL2_MAXB) { fr->err = ZL_E_FALLBACK; atomicAdd(a.max_blocks + 1, 1u); return; }
         zl2_blk_rec r;
         r.type = type; r.size = bsize; r.src_off = pos;
         r.lit_mode = 0; r.lit_size = 0; r.lit_a = 0; r.lit_b = 0; r.seq_off = 0; r.seq_len = 0;
@@ -531,7 +535,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
             if (ri == 0) lr = a.ext[(size_t)f * 4];
             const u8* blk = src + lr.src_off;
             u32 tree = build_huf_table(g, blk + lr.lit_a, lr.lit_b);
-            if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); tree = 0; g.ok = 0; }
+            if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); atomicAdd(a.max_blocks + 1, 1u); tree = 0; g.ok = 0; }
             else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
             else g.ok = 1;
             g.tree = tree;
@@ -956,7 +960,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
                 if (ok) pos += used;
             }
             // descriptions that may reach past the copy go to the general kernel, which reads them in place
-            if (hn < sn && (!ok || pos + 8 > hn)) { set_err(fr, ZL_E_FALLBACK); ok = false; S.logs[fi][3] = 2; }
+            if (hn < sn && (!ok || pos + 8 > hn)) { set_err(fr, ZL_E_FALLBACK); atomicAdd(a.max_blocks + 1, 1u); ok = false; S.logs[fi][3] = 2; }
             else if (!ok) { set_err(fr, ZL_E_CORRUPTION); S.logs[fi][3] = 2; }
             B.stamp = ok ? round + 1 : 0;
         }
