@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, (MB > 1 ? 2 : 1)) void zl2_lit
     __shared__ u32 rounds;  // bit r: some lane of this workgroup has block r as its leader
     // both instantiations are launched; the index kernel's verdict says which one works
     if ((*a.max_blocks > 1) != (MB > 1)) return;
+    if (MB == 1 && a.fuse1) return;  // (zl2_entropy1_kernel does the work)
     // Resource shaping (general instantiation): with 38 KiB of dynamic LDS it never touches a CU
     // takes ONE literal workgroup plus one sequence workgroup (or three sequence workgroups where no
     // literal workgroup is left) instead of two literal workgroups that would keep the sequence
@@ -1022,11 +1023,37 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, (MB > 1 ? 2 : 1)) void zl2_lit
 __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
     __shared__ SeqShared S;
     __shared__ u32 rounds;
+    if (a.fuse1 && *a.max_blocks <= 1) return;  // (zl2_entropy1_kernel does the work)
     ZL_POISON(S, 1);
     const bool prof = a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
     seq_role(a, S, &rounds, blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(clock64() - t0));  // profile: cycles per sequence workgroup
+}
+
+// Launches whose frames all have ONE block (config C2's 64 KiB frames, the segments of a large frame):
+// both roles then want nearly the same shape -- one wave with 50 KiB of LDS for eight sequence chains,
+// half a wave with 41 KiB for eight frames' Huffman streams -- and the only thing two kernels on two
+// streams add is a fight for the CUs' LDS (one 1 GiB reference frame: sequence kernel alone 15.2 ms,
+// literal kernel alone 11.0 ms, side by side 19.9 ms, because a CU that has taken two literal
+// workgroups has room for one sequence workgroup only, and the sequence chains are the longer pole).
+// Fused, the workgroups are dealt out in the pattern sequence, sequence, literal -- each list sorted
+// by decreasing cost -- which is what fits a CU: 2 x 50 + 41 KiB.
+__global__ __launch_bounds__(64) void zl2_entropy1_kernel(zl2_args a) {
+    __shared__ union U_ {
+        SeqShared s;
+        LitGroupT<1> g[LIT_FRAMES];
+        __device__ U_() {}
+    } U;
+    __shared__ u32 rounds;
+    if (!a.fuse1 || *a.max_blocks > 1) return;
+    const u32 ngroups = (a.nframes + LIT_FRAMES - 1) / LIT_FRAMES;
+    const u32 r = blockIdx.x % 3, g = blockIdx.x / 3;
+    if (r < 2) {
+        if (2 * g + r < ngroups) seq_role(a, U.s, &rounds, 2 * g + r);
+    } else {
+        lit_role<1>(a, U.g, &rounds, g);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1474,6 +1501,7 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     }
     hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ngroups), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, *a);
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ngroups), dim3(64), 0, stream, *a);
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(zl2_exec_kernel<false>, dim3(n), dim3(EX_THREADS), 0, stream, *a);
@@ -1498,6 +1526,7 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ngroups), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, *a);
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ngroups), dim3(64), 0, stream, *a);
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     return hipGetLastError();
 }
