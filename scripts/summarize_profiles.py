@@ -27,6 +27,13 @@ stats = one("prof_bench/*/*kernel_stats.csv")
 trace = one("prof_bench/*/*kernel_trace.csv")
 if stats:
     shutil.copy(stats, os.path.join(P, f"{rnd}_kernel_stats.csv"))
+n1 = os.path.join(G, "n1_kernel_stats.csv")
+if os.path.exists(n1):  # the large-frame pipeline's kernels (scripts/exp_n1.py 1024: three decodes of the 1 GiB single frame)
+    rows = [r for r in csv.DictReader(open(n1)) if "zl" in r["Name"]]
+    with open(os.path.join(P, f"{rnd}_n1_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["Name"])
+        w.writeheader()
+        w.writerows(rows)
 line = os.path.join(G, "prof_bench_line.json")
 if os.path.exists(line):
     shutil.copy(line, os.path.join(P, f"{rnd}_bench_under_rocprof.json"))
@@ -68,7 +75,7 @@ fetch = pmc(one("pmc_fetch/*/*counter_collection.csv"))
 write = pmc(one("pmc_write/*/*counter_collection.csv"))
 summary, short = {}, {}
 names = {"zl_match_auto_kernel": "match", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
-         "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_lit_kernel": "d_entropy_lit", "zl2_lit_kernel<8>": "d_entropy_lit", "zl2_lit_kernel<1>": "d_entropy_lit1", "zl2_order_kernel": "d_order", "zl2_exec_kernel": "d_exec", "zl2_exec_kernel<false>": "d_exec", "zl2_exec_kernel<true>": "d_exec_large"}
+         "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_entropy1_kernel": "d_entropy1", "zl2_lit_kernel": "d_entropy_lit", "zl2_lit_kernel<8>": "d_entropy_lit", "zl2_lit_kernel<1>": "d_entropy_lit1", "zl2_order_kernel": "d_order", "zl2_exec_kernel": "d_exec", "zl2_exec_kernel<false>": "d_exec", "zl2_exec_kernel<true>": "d_exec_large"}
 for k in sorted(set(dur) | set(fetch) | set(write)):
     base = k.split("(")[0].replace("void ", "")
     f_kb = sum(fetch[k]) / len(fetch[k]) if fetch[k] else None
