@@ -145,6 +145,38 @@ size_t zl_compress_device_finish(zl_cctx *cctx, size_t *frameSizes);
  * of data frames found or an error code.  dst offsets are assigned back to back. */
 size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size_t cap);
 
+/* ---- streaming entries: twins of ZSTD_compressStream2 / ZSTD_decompressStream and the
+ * session calls around them, as the reference's file / connection glue uses them
+ * (src/raw-file-out.c:74-113, src/raw-file-in.c:87-102, src/serialize-file-out.c:84-219,
+ * src/serialize-file-in.c:90, src/zstdfile.c:202-238,362,475-511; zstd.h:800-880, :930-960).
+ * The buffer structs and the directive values are libzstd's, so a binding only renames.
+ *
+ * Compression: input is collected on the host into jobs of 64 MiB (libzstd's own multi-threaded
+ * streaming cuts jobs the same way, zstd.c:36848); every full job -- and the rest at ZL_e_flush /
+ * ZL_e_end -- goes through the same kernels as zl_compress2, so the stream is a concatenation of
+ * frames of at most 128 KiB of content each: valid zstd that ZSTD_decompressStream / ZSTD_decompress
+ * read (and whose first frame records only its own content size: deviation H1 of INTEGRATION.md
+ * applies to a reader that sizes its buffer from the first 18 bytes, src/raw-file-in.c:66).
+ * Returns the bytes still waiting to be handed out (0 at ZL_e_end: the session is complete), or an
+ * error code.  Decompression: input is collected until it holds complete frames; those are decoded
+ * at once (all routes of zl_decompressDCtx, frames without a recorded size included) and handed out
+ * as the output buffer allows.  Returns 0 when everything received so far has been decoded and
+ * handed out, an error code, or a non-zero hint.  Sixteen calls in a row without progress return
+ * the no-forward-progress errors of zstd.c:42957-42960. */
+typedef struct { const void *src; size_t size; size_t pos; } zl_inBuffer;  /* ZSTD_inBuffer  (zstd.h:805) */
+typedef struct { void *dst; size_t size; size_t pos; } zl_outBuffer;       /* ZSTD_outBuffer (zstd.h:811) */
+typedef enum { ZL_e_continue = 0, ZL_e_flush = 1, ZL_e_end = 2 } zl_EndDirective;                 /* ZSTD_EndDirective (zstd.h:841) */
+typedef enum { ZL_reset_session_only = 1, ZL_reset_parameters = 2, ZL_reset_session_and_parameters = 3 } zl_ResetDirective; /* zstd.h:575 */
+size_t zl_compressStream2(zl_cctx *cctx, zl_outBuffer *output, zl_inBuffer *input, zl_EndDirective endOp);
+size_t zl_CCtx_setPledgedSrcSize(zl_cctx *cctx, unsigned long long pledgedSrcSize); /* checked at ZL_e_end (zstd.c:23793) */
+size_t zl_CCtx_reset(zl_cctx *cctx, zl_ResetDirective reset);
+size_t zl_CStreamInSize(void);  /* ZSTD_CStreamInSize: 128 KiB; any size works, jobs are cut inside */
+size_t zl_CStreamOutSize(void);
+size_t zl_decompressStream(zl_dctx *dctx, zl_outBuffer *output, zl_inBuffer *input);
+size_t zl_DCtx_reset(zl_dctx *dctx, zl_ResetDirective reset);
+size_t zl_DStreamInSize(void);
+size_t zl_DStreamOutSize(void);
+
 /* ---- diagnostics (new): per-kernel device time of the last device-resident call, measured with
  * HIP events recorded on the stream the kernels were launched on.  Enable with
  * zl_CCtx_setParameter(cctx, ZL_c_profile, 1) / zl_DCtx_setParameter(dctx, ZL_d_profile, 1).

@@ -1,0 +1,210 @@
+"""Streaming entries: the twins of ZSTD_compressStream2 / ZSTD_decompressStream and the
+file / connection glue on top of them.  Interop is the bar, as in the reference's own tests
+(tests/testthat/test-compress-raw.R:38-105, test-zstdfile.R): what the streaming compressor writes,
+the REFERENCE's ZSTD_decompressStream and one-shot decoder read; what the reference's streaming
+compressor writes (frames without a recorded size when nothing is pledged), the streaming decoder reads."""
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import zstdlite_amd as z
+from zstdlite_amd import _lib, stream
+from zl_testlib import GENERATORS, have_ref
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")
+
+
+def ref_stream_compress(ref, data, level=3, pledge=False, piece=100000, checksum=False):
+    """ZSTD_compressStream2 of the reference library, fed in pieces (src/raw-file-out.c:83-123)."""
+    L = ref.L
+    L.ZSTD_compressStream2.restype = C.c_size_t
+    L.ZSTD_compressStream2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.ZSTD_CCtx_setPledgedSrcSize.argtypes = [C.c_void_p, C.c_ulonglong]
+    cctx = L.ZSTD_createCCtx()
+    L.ZSTD_CCtx_setParameter(cctx, 100, level)
+    if checksum:
+        L.ZSTD_CCtx_setParameter(cctx, 201, 1)
+    if pledge:
+        L.ZSTD_CCtx_setPledgedSrcSize(cctx, len(data))
+    out = np.empty(1 << 20, dtype=np.uint8)
+    pieces = []
+    src = np.frombuffer(data, dtype=np.uint8) if data else np.empty(0, dtype=np.uint8)
+    offs = list(range(0, len(data), piece)) or [0]
+    for k, off in enumerate(offs):
+        part = src[off:off + piece]
+        inb = stream._InBuffer(part.ctypes.data if part.size else None, part.size, 0)
+        mode = 2 if k == len(offs) - 1 else 0
+        while True:
+            outb = stream._OutBuffer(out.ctypes.data, out.size, 0)
+            rem = L.ZSTD_compressStream2(cctx, C.byref(outb), C.byref(inb), mode)
+            assert not L.ZSTD_isError(rem)
+            pieces.append(out[:outb.pos].tobytes())
+            if inb.pos == inb.size and (mode == 0 or rem == 0):
+                break
+    L.ZSTD_freeCCtx(cctx)
+    return b"".join(pieces)
+
+
+def ref_stream_decompress(ref, comp, piece=131702):
+    """ZSTD_decompressStream of the reference library (src/raw-file-in.c:94-103)."""
+    L = ref.L
+    L.ZSTD_decompressStream.restype = C.c_size_t
+    L.ZSTD_decompressStream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    dctx = L.ZSTD_createDCtx()
+    out = np.empty(1 << 20, dtype=np.uint8)
+    src = np.frombuffer(comp, dtype=np.uint8)
+    pieces = []
+    for off in range(0, len(comp), piece):
+        part = src[off:off + piece]
+        inb = stream._InBuffer(part.ctypes.data, part.size, 0)
+        while True:
+            outb = stream._OutBuffer(out.ctypes.data, out.size, 0)
+            r = L.ZSTD_decompressStream(dctx, C.byref(outb), C.byref(inb))
+            assert not L.ZSTD_isError(r), L.ZSTD_getErrorName(r)
+            pieces.append(out[:outb.pos].tobytes())
+            if inb.pos == inb.size and outb.pos < outb.size:
+                break
+    L.ZSTD_freeDCtx(dctx)
+    return b"".join(pieces)
+
+
+@needs_ref
+@pytest.mark.parametrize("n", [0, 1, 1000, 131072, 131073, 1 << 20, (9 << 20) + 12345, (17 << 20) + 1])
+def test_stream_compress_is_read_by_the_reference(n, ref):
+    data = GENERATORS["text"](n, seed=n & 0xFFF) if n else b""
+    cctx = z.zstd_cctx()
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    parts = [comp.feed(data[off:off + 3000000]) for off in range(0, n, 3000000)]
+    parts.append(comp.finish())
+    blob = b"".join(parts)
+    assert ref_stream_decompress(ref, blob) == data
+    assert z.zstd_decompress(blob) == data
+    # same bytes as the one-shot entry as long as the jobs line up with it (a job is a whole number of chunks)
+    assert blob == z.zstd_compress(data)
+    # the context serves the next session
+    again = stream.Compressor(cctx._ptr).finish(data)
+    assert again == blob
+
+
+def test_stream_session_rules():
+    L = _lib.lib()
+    cctx = z.zstd_cctx(include_checksum=True)
+    data = GENERATORS["iid10"](300000, seed=4)
+    # a wrong pledge is an error at the end (zstd.c:24140)
+    comp = stream.Compressor(cctx._ptr, pledged=len(data) + 1)
+    comp.feed(data)
+    with pytest.raises(stream.ZstdStreamError, match="Src size is incorrect"):
+        comp.finish()
+    # flush hands out what has been taken so far as complete frames
+    comp = stream.Compressor(cctx._ptr)
+    assert comp.feed(data[:100000]) == b""
+    first = comp.flush()
+    assert z.zstd_decompress(first) == data[:100000]
+    rest = comp.finish(data[100000:])
+    assert z.zstd_decompress(first + rest) == data
+    # pledging in the middle of a session is refused (zstd.c:23795)
+    comp = stream.Compressor(cctx._ptr)
+    comp.feed(data[:10])
+    assert _lib.is_error(L.zl_CCtx_setPledgedSrcSize(cctx._ptr, 5))
+    L.zl_CCtx_reset(cctx._ptr, 1)
+    # a tiny output buffer: the bytes come out over many calls, the return value counts down to 0
+    src = np.frombuffer(data, dtype=np.uint8)
+    inb = stream._InBuffer(src.ctypes.data, src.size, 0)
+    small = np.empty(1000, dtype=np.uint8)
+    got = []
+    while True:
+        outb = stream._OutBuffer(small.ctypes.data, small.size, 0)
+        rem = L.zl_compressStream2(cctx._ptr, C.byref(outb), C.byref(inb), 2)
+        assert not _lib.is_error(rem)
+        got.append(small[:outb.pos].tobytes())
+        if rem == 0:
+            break
+    assert inb.pos == inb.size and z.zstd_decompress(b"".join(got)) == data
+
+
+@needs_ref
+def test_stream_decompress_reads_the_reference(ref):
+    dctx = z.zstd_dctx()
+    for gen, n, kw in (("text", 3000000, {}), ("iid10", 1500000, {"pledge": True, "checksum": True}), ("int20", 400000, {"level": 9}),
+                       ("text", 0, {}), ("rand", 200000, {"pledge": True})):
+        data = GENERATORS[gen](n, seed=n & 0xFF) if n else b""
+        comp = ref_stream_compress(ref, data, **kw)
+        if n and not kw.get("pledge"):  # nothing pledged: the frame does not record its size (Single_Segment off, FCS flag 0)
+            assert (comp[4] >> 6) == 0 and (comp[4] >> 5) & 1 == 0
+        for piece in (131702, 1000, len(comp) or 1):
+            dec = stream.Decompressor(dctx._ptr)
+            out = b"".join(dec.feed(comp[off:off + piece]) for off in range(0, len(comp), piece))
+            assert out == data, (gen, n, piece)
+            assert dec.at_frame_boundary
+    # concatenated streams, skippable frame in between, fed byte-odd pieces
+    a, b = GENERATORS["text"](500000, seed=1), GENERATORS["iid10"](300000, seed=2)
+    blob = ref_stream_compress(ref, a) + b"\x50\x2a\x4d\x18\x04\x00\x00\x00abcd" + z.zstd_compress(b) + ref.compress(a, level=1)
+    dec = stream.Decompressor(dctx._ptr)
+    out = b"".join(dec.feed(blob[off:off + 77777]) for off in range(0, len(blob), 77777))
+    assert out == a + b + a and dec.at_frame_boundary
+    # a stream that stops inside a frame is noticed; garbage is an error
+    dec = stream.Decompressor(dctx._ptr)
+    dec.feed(blob[:100000])
+    assert not dec.at_frame_boundary
+    with pytest.raises(stream.ZstdStreamError, match="Unknown frame descriptor"):
+        stream.Decompressor(dctx._ptr).feed(b"this is not zstd at all, not even close")
+
+
+def test_no_forward_progress_is_an_error():
+    """zstd.c:42955-42962: sixteen calls that neither take input nor give output."""
+    L = _lib.lib()
+    dctx = z.zstd_dctx()
+    comp = z.zstd_compress(GENERATORS["text"](100000, seed=1))
+    src = np.frombuffer(comp, dtype=np.uint8)
+    L.zl_DCtx_reset(dctx._ptr, 1)
+    inb = stream._InBuffer(src.ctypes.data, src.size, 0)
+    outb = stream._OutBuffer(None, 0, 0)  # no room at all
+    codes = [L.zl_decompressStream(dctx._ptr, C.byref(outb), C.byref(inb)) for _ in range(20)]
+    assert not _lib.is_error(codes[0]) and _lib.is_error(codes[-1])
+    assert "output buffer being full" in _lib.error_name(codes[-1])
+
+
+@needs_ref
+def test_file_streaming_and_zstdfile(tmp_path, ref):
+    """tests/testthat/test-compress-raw.R:38-105 and test-zstdfile.R: every writer's file is read by every reader."""
+    data = GENERATORS["text"](2500000, seed=7)
+    p1, p2, p3, p4 = (str(tmp_path / f"f{i}.zst") for i in range(4))
+    z.zstd_compress(data, dst=p1, use_file_streaming=True)
+    z.zstd_compress(data, dst=p2)
+    with open(p3, "wb") as f:
+        f.write(ref_stream_compress(ref, data, pledge=True))
+    for p in (p1, p2, p3):
+        assert z.zstd_decompress(p, use_file_streaming=True) == data
+        assert z.zstd_decompress(p) == data
+        with open(p, "rb") as f:
+            assert ref_stream_decompress(ref, f.read()) == data
+    obj = {"a": list(range(100000)), "b": "x" * 300000}
+    z.zstd_serialize(obj, dst=p4, use_file_streaming=True, level=5)
+    assert z.zstd_unserialize(p4, use_file_streaming=True) == obj
+    assert z.zstd_unserialize(p4) == obj
+    with pytest.raises(z.ZstdError, match="Couldn't open file"):
+        z.zstd_decompress(str(tmp_path / "missing.zst"), use_file_streaming=True)
+    # zstdfile: binary and text, written in pieces, read back whole, in pieces and by lines
+    pb, pt = str(tmp_path / "b.zst"), str(tmp_path / "t.zst")
+    with z.zstdfile(pb, "wb", level=1) as f:
+        for off in range(0, len(data), 70001):
+            f.write(data[off:off + 70001])
+    with z.zstdfile(pb) as f:
+        assert f.read(10) == data[:10]
+        assert f.read() == data[10:]
+        assert f.read() == b""
+    with open(pb, "rb") as f:
+        assert ref.decompress(f.read()[: z.zstd_info(open(pb, "rb").read())["compressed_size"]], 131072) == data[:131072]
+    lines = [f"line {i}: " + "é" * (i % 7) for i in range(50000)]
+    with z.zstdfile(pt, "w") as f:
+        f.writelines(lines)
+    with z.zstdfile(pt, "r") as f:
+        assert f.readlines() == lines
+    with open(pt, "rb") as f:
+        assert ref_stream_decompress(ref, f.read()).decode().splitlines() == lines
+    with pytest.raises(ValueError):
+        z.zstdfile(pt, "a")

@@ -26,7 +26,7 @@ from ._lib import FrameT, ZstdError, is_error
 __all__ = [
     "zstd_compress", "zstd_decompress", "zstd_serialize", "zstd_unserialize", "zstd_cctx", "zstd_dctx",
     "zstd_cctx_settings", "zstd_dctx_settings", "zstd_info", "zstd_dict_id", "zstd_version",
-    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "ZstdError",
+    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "zstdfile", "ZstdError",
 ]
 
 ZL_c_compressionLevel = 100
@@ -60,7 +60,7 @@ class _Ctx:
 
     def __del__(self):  # the reference attaches a C finalizer to the external pointer (src/cctx.c:191)
         ptr, self._ptr = getattr(self, "_ptr", None), None
-        if ptr:
+        if ptr and _lib is not None:  # (module globals are gone when the interpreter shuts down)
             getattr(_lib.lib(), self._free)(ptr)
 
 
@@ -187,6 +187,9 @@ def zstd_compress(x, *, dst=None, cctx=None, use_file_streaming=False, **opts):
     if not isinstance(x, (bytes, bytearray, memoryview, np.ndarray, str)):
         raise ZstdError("zstd_compress() only accepts raw vectors or strings")
     ptr, n, _keep = _as_buffer(x, "zstd_compress()")
+    if dst is not None and use_file_streaming:  # src/raw-file.c:41-43 -> zstd_compress_stream_file (src/raw-file-out.c:31)
+        _stream_write(dst, memoryview(_keep), cctx, opts, "zstd_compress_stream_file_")
+        return None
     out = _compress_bytes(ptr, n, cctx, opts, "zstd_compress")
     if dst is not None:
         try:
@@ -222,6 +225,9 @@ def _decompress_bytes(src, dctx, opts, who):
 
 def zstd_decompress(src, type="raw", *, dctx=None, use_file_streaming=False, **opts):
     """R/serialize.R:146-156 -> zstd_decompress_ (src/raw-file.c:125-210)."""
+    if isinstance(src, str) and use_file_streaming:  # src/raw-file.c:133-135 -> zstd_decompress_stream_file (src/raw-file-in.c:32)
+        out = _stream_read(src, dctx, opts, "zstd_decompress_stream_file_")
+        return out if type == "raw" else out.decode()
     if isinstance(src, str):  # filename (src/raw-file.c:133-138)
         with open(src, "rb") as f:
             src = f.read()
@@ -234,6 +240,9 @@ def zstd_decompress(src, type="raw", *, dctx=None, use_file_streaming=False, **o
 def zstd_serialize(robj, *, dst=None, cctx=None, use_file_streaming=False, **opts):
     """R/serialize.R:56-66 -> zstd_serialize_ (src/serialize.c:34-142)."""
     payload = pickle.dumps(robj, protocol=pickle.HIGHEST_PROTOCOL)
+    if dst is not None and use_file_streaming:  # src/serialize.c:44-48 -> zstd_serialize_stream_file (src/serialize-file-out.c:150)
+        _stream_write(dst, payload, cctx, opts, "zstd_serialize_stream_file_")
+        return None
     ptr, n, _keep = _as_buffer(payload, "zstd_serialize()")
     out = _compress_bytes(ptr, n, cctx, opts, "zstd_serialize")
     if dst is not None:
@@ -245,10 +254,36 @@ def zstd_serialize(robj, *, dst=None, cctx=None, use_file_streaming=False, **opt
 
 def zstd_unserialize(src, *, dctx=None, use_file_streaming=False, **opts):
     """R/serialize.R:74-84 -> zstd_unserialize_ (src/serialize.c:149-240)."""
+    if isinstance(src, str) and use_file_streaming:  # src/serialize.c:158-160 -> zstd_unserialize_stream_file (src/serialize-file-in.c:104)
+        return pickle.loads(_stream_read(src, dctx, opts, "zstd_unserialize_stream_file_"))
     if isinstance(src, str):
         with open(src, "rb") as f:
             src = f.read()
     return pickle.loads(_decompress_bytes(src, dctx, opts, "zstd_unserialize"))
+
+
+def _stream_write(dst, data, cctx, opts, who):
+    from . import stream
+    ctx = _init_cctx_with_opts(opts) if cctx is None else cctx
+    try:
+        stream.write_file(dst, data, ctx._ptr, who)
+    except stream.ZstdStreamError as e:
+        raise ZstdError(str(e))
+
+
+def _stream_read(src, dctx, opts, who):
+    from . import stream
+    ctx = _init_dctx_with_opts(opts) if dctx is None else dctx
+    try:
+        return stream.read_file(src, ctx._ptr, who)
+    except stream.ZstdStreamError as e:
+        raise ZstdError(str(e))
+
+
+def zstdfile(description, open="rb", *, cctx=None, dctx=None, **opts):
+    """R/zstdfile.R:41 -> src/zstdfile.c: a file connection whose bytes are zstd on disk."""
+    from . import stream
+    return stream.zstdfile(description, open, cctx=cctx, dctx=dctx, **opts)
 
 
 def zstd_dict_id(dict):

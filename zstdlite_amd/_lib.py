@@ -55,6 +55,15 @@ SYMBOLS = [
     ("zl_cctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_large_frames", C.c_size_t, [C.c_void_p]),
+    ("zl_compressStream2", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("zl_CCtx_setPledgedSrcSize", C.c_size_t, [C.c_void_p, C.c_ulonglong]),
+    ("zl_CCtx_reset", C.c_size_t, [C.c_void_p, C.c_int]),
+    ("zl_CStreamInSize", C.c_size_t, []),
+    ("zl_CStreamOutSize", C.c_size_t, []),
+    ("zl_decompressStream", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("zl_DCtx_reset", C.c_size_t, [C.c_void_p, C.c_int]),
+    ("zl_DStreamInSize", C.c_size_t, []),
+    ("zl_DStreamOutSize", C.c_size_t, []),
     ("zl_versionString", C.c_char_p, []),
     ("zl_deviceCount", C.c_int, []),
 ]

@@ -39,6 +39,7 @@ struct FrameHeader {
     bool skippable = false;
     u32 skippable_size = 0;
     size_t header_size = 0;
+    u32 nblocks = 0;  // filled by find_frame_size
 };
 
 size_t parse_frame_header(FrameHeader& h, const u8* src, size_t n) {
@@ -87,14 +88,15 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
     FrameHeader h;
     size_t e = parse_frame_header(h, src, n);
     if (ZL_IS_ERR(e)) return e;
-    if (out) *out = h;
     if (h.skippable) {
+        if (out) *out = h;
         const u64 total = 8ULL + h.skippable_size;
         if (total > n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
         return (size_t)total;
     }
     size_t pos = h.header_size;
     for (;;) {
+        h.nblocks++;
         if (n - pos < 3) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
         const u32 bh = rd_le(src + pos, 3);
         const u32 type = (bh >> 1) & 3, bsize = bh >> 3;
@@ -109,6 +111,7 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
         if (n - pos < 4) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
         pos += 4;
     }
+    if (out) *out = h;
     return pos;
 }
 
@@ -137,6 +140,13 @@ struct zl_dctx_s {
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // start, after index, after entropy lanes, after exec, end
     zl2_side side = {nullptr, nullptr, nullptr};
+    // streaming session (zl_decompressStream)
+    struct {
+        ByteBuf acc;  // compressed input not decoded yet (at most one incomplete frame once a call returns)
+        ByteBuf out;  // decoded bytes not handed out yet
+        size_t out_pos = 0;
+        int stalled = 0;      // calls in a row without progress
+    } ds;
     zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
     size_t large_frames = 0;
     bool ev_valid = false;
@@ -176,6 +186,8 @@ const char* zl_getErrorName(size_t code) {
     case ZL_E_DSTSIZE_TOO_SMALL: return "Destination buffer is too small";
     case ZL_E_SRCSIZE_WRONG: return "Src size is incorrect";
     case ZL_E_DSTBUFFER_NULL: return "Operation on NULL destination buffer";
+    case ZL_E_NOFORWARD_DESTFULL: return "Operation made no progress over multiple calls, due to output buffer being full";
+    case ZL_E_NOFORWARD_INPUTEMPTY: return "Operation made no progress over multiple calls, due to input being empty";
     default: return "Unspecified error code";
     }
 }
@@ -645,6 +657,80 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// streaming: ZSTD_decompressStream and the session reset (zstd.c:42700-42990, :42544), as a host-side
+// collector in front of zl_decompressDCtx: whatever complete frames the input holds are decoded at
+// once, by whichever route fits them
+// ---------------------------------------------------------------------------------------
+size_t zl_DStreamInSize(void) { return ZL_BLOCK_MAX + 3; }   // zstd.c:42297
+size_t zl_DStreamOutSize(void) { return ZL_BLOCK_MAX; }
+
+size_t zl_DCtx_reset(zl_dctx* d, zl_ResetDirective reset) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    if (reset == ZL_reset_session_only || reset == ZL_reset_session_and_parameters) {
+        d->ds.acc.clear();
+        d->ds.out.clear();
+        d->ds.out_pos = 0;
+        d->ds.stalled = 0;
+    }
+    if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
+        if (!d->ds.acc.empty() || !d->ds.out.empty()) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:42552
+        d->ignore_checksum = 0;
+        d->dict.clear();
+        d->dict_id = 0;
+        d->dict_formatted = d->dict_uploaded = false;
+    }
+    return 0;
+}
+
+size_t zl_decompressStream(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
+    if (!d || !output || !input) return ZL_ERR(ZL_E_GENERIC);
+    if (output->pos > output->size) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);  // zstd.c:42716-42723
+    if (input->pos > input->size) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    auto& S = d->ds;
+    const size_t in0 = input->pos, out0 = output->pos;
+    auto hand_out = [&]() {
+        const size_t k = std::min(output->size - output->pos, S.out.size() - S.out_pos);
+        if (k) memcpy((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
+        output->pos += k;
+        S.out_pos += k;
+        if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }
+    };
+    hand_out();
+    if (S.out.empty()) {
+        if (!S.acc.append((const u8*)input->src + input->pos, input->size - input->pos)) return ZL_ERR(ZL_E_MEMORY);
+        input->pos = input->size;
+        // the complete frames at the front of what has been collected
+        size_t pos = 0, cap = 0;
+        while (S.acc.size() - pos >= 4) {
+            FrameHeader h;
+            const size_t fs = find_frame_size(S.acc.p + pos, S.acc.size() - pos, &h);
+            if (fs == ZL_ERR(ZL_E_SRCSIZE_WRONG)) break;  // incomplete: more input needed
+            if (ZL_IS_ERR(fs)) return fs;
+            if (!h.skippable) cap += h.content_size != ZL_CONTENTSIZE_UNKNOWN ? (size_t)h.content_size : (size_t)h.nblocks * ZL_BLOCK_MAX;
+            pos += fs;
+        }
+        if (pos) {
+            if (!S.out.grow(cap + 1)) return ZL_ERR(ZL_E_MEMORY);
+            const size_t r = zl_decompressDCtx(d, S.out.p, cap, S.acc.p, pos);
+            S.out.n = ZL_IS_ERR(r) ? 0 : r;
+            if (ZL_IS_ERR(r)) return r;
+            S.acc.drop_front(pos);
+            hand_out();
+        }
+    }
+    if (input->pos == in0 && output->pos == out0) {  // zstd.c:42955-42962
+        if (++S.stalled >= 16) {
+            if (output->pos == output->size) return ZL_ERR(ZL_E_NOFORWARD_DESTFULL);
+            if (input->pos == input->size) return ZL_ERR(ZL_E_NOFORWARD_INPUTEMPTY);
+        }
+    } else {
+        S.stalled = 0;
+    }
+    if (!S.out.empty()) return S.out.size() - S.out_pos;
+    return S.acc.empty() ? 0 : 1;  // (a frame is under way: more input expected)
 }
 
 }  // extern "C"

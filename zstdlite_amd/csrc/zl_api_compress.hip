@@ -38,6 +38,16 @@ struct zl_cctx_s {
     double kernel_ms[4] = {0, 0, 0, 0};
     DevBuf d_stats;
     u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // streaming session (zl_compressStream2)
+    struct {
+        ByteBuf stage;  // input collected for the current job
+        ByteBuf out;    // compressed bytes not handed out yet
+        size_t out_pos = 0;
+        u64 pledged = ZL_CONTENTSIZE_UNKNOWN, consumed = 0;
+        bool started = false;   // input has been taken in this session
+        bool emitted = false;   // a frame has been written in this session
+        bool finishing = false; // ZL_e_end has compressed the rest; only handing out remains
+    } cs;
 };
 
 namespace {
@@ -377,6 +387,102 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         off += sz;
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// streaming: ZSTD_compressStream2 and the session calls (zstd.c:23793, :22775, :24835-24990), as a
+// host-side job queue in front of zl_compress2
+// ---------------------------------------------------------------------------------------
+#define ZL_STREAM_JOB ((size_t)64 << 20)  // bytes of input per launch: 512 chunks -- a launch lasts about as long as its slowest chunk, so small jobs waste the device (zstd.c:36848: the multi-threaded streaming path cuts jobs too)
+
+size_t zl_CStreamInSize(void) { return ZL_CHUNK; }
+size_t zl_CStreamOutSize(void) { return zl_compressBound(ZL_CHUNK); }
+
+size_t zl_CCtx_setPledgedSrcSize(zl_cctx* c, unsigned long long pledged) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:23795: only between sessions
+    c->cs.pledged = pledged;
+    return 0;
+}
+
+size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (reset == ZL_reset_session_only || reset == ZL_reset_session_and_parameters) {
+        c->cs.stage.clear();
+        c->cs.out.clear();
+        c->cs.out_pos = 0;
+        c->cs.pledged = ZL_CONTENTSIZE_UNKNOWN;
+        c->cs.consumed = 0;
+        c->cs.started = c->cs.emitted = c->cs.finishing = false;
+    }
+    if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
+        if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:22790
+        c->level = 3;
+        c->checksum = 0;
+        c->nb_workers = 0;
+        c->dict.clear();
+        c->dict_uploaded = c->dict_formatted = false;
+        c->dict_id = c->dict_content_off = c->dict_use = 0;
+    }
+    return 0;
+}
+
+size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, zl_EndDirective end_op) {
+    if (!c || !output || !input) return ZL_ERR(ZL_E_GENERIC);
+    if (output->pos > output->size) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);  // zstd.c:24848-24850
+    if (input->pos > input->size) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+    if ((unsigned)end_op > (unsigned)ZL_e_end) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+    auto& S = c->cs;
+    auto hand_out = [&]() {
+        const size_t k = std::min(output->size - output->pos, S.out.size() - S.out_pos);
+        if (k) memcpy((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
+        output->pos += k;
+        S.out_pos += k;
+        if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }
+    };
+    auto run_job = [&]() -> size_t {  // the collected input -> frames, appended to what waits to be handed out
+        const size_t n = S.stage.size(), bound = zl_compressBound(n), old = S.out.size();
+        u8* at = S.out.grow(bound);
+        if (!at) return ZL_ERR(ZL_E_MEMORY);
+        const size_t r = zl_compress2(c, at, bound, S.stage.p, n);
+        S.out.n = old + (ZL_IS_ERR(r) ? 0 : r);
+        if (ZL_IS_ERR(r)) return r;
+        S.stage.clear();
+        S.emitted = true;
+        return 0;
+    };
+    hand_out();
+    while (!S.finishing && input->pos < input->size && S.out.empty()) {
+        const size_t take = std::min(input->size - input->pos, ZL_STREAM_JOB - S.stage.size());
+        if (!S.stage.append((const u8*)input->src + input->pos, take)) return ZL_ERR(ZL_E_MEMORY);
+        input->pos += take;
+        S.consumed += take;
+        S.started = true;
+        if (S.stage.size() == ZL_STREAM_JOB) {
+            const size_t e = run_job();
+            if (ZL_IS_ERR(e)) return e;
+            hand_out();
+        }
+    }
+    if (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && !S.finishing) {
+        if (end_op == ZL_e_end && S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.pledged != S.consumed) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140
+        // the rest of the input; at the end of a session that has written nothing, the frame of an empty input
+        if (!S.stage.empty() || (end_op == ZL_e_end && !S.emitted)) {
+            const size_t e = run_job();
+            if (ZL_IS_ERR(e)) return e;
+        }
+        if (end_op == ZL_e_end) S.finishing = true;
+        hand_out();
+    } else if (S.finishing) {
+        hand_out();
+    }
+    if (S.finishing && S.out.empty()) {  // session complete: the next call starts a new one
+        S.pledged = ZL_CONTENTSIZE_UNKNOWN;
+        S.consumed = 0;
+        S.started = S.emitted = S.finishing = false;
+        return 0;
+    }
+    return S.out.size() - S.out_pos;
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "zl_format.h"
 
@@ -60,6 +61,46 @@ struct PinBuf {
         p = nullptr;
         cap = 0;
     }
+};
+
+// growable host byte buffer that does not zero what it grows by (a std::vector would: 64 MiB per streaming job)
+struct ByteBuf {
+    u8* p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf() { free(p); }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        size_t c = cap ? cap : 4096;
+        while (c < want) c += c >> 1;
+        u8* q = (u8*)realloc(p, c);
+        if (!q) return false;
+        p = q;
+        cap = c;
+        return true;
+    }
+    u8* grow(size_t k) {  // k uninitialised bytes at the end
+        if (!reserve(n + k)) return nullptr;
+        u8* at = p + n;
+        n += k;
+        return at;
+    }
+    bool append(const void* src, size_t k) {
+        u8* at = grow(k);
+        if (!at) return false;
+        if (k) memcpy(at, src, k);
+        return true;
+    }
+    void drop_front(size_t k) {
+        if (k >= n) { n = 0; return; }
+        memmove(p, p + k, n - k);
+        n -= k;
+    }
+    void clear() { n = 0; }
+    bool empty() const { return n == 0; }
+    size_t size() const { return n; }
 };
 
 static int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
