@@ -76,3 +76,24 @@ def test_context_options_mirror_reference_glue():
         z.zstd_compress(12345)
     info = z.zstd_info(open(os.path.join(GOLDEN, "data.json.zst"), "rb").read())
     assert info == {"compressed_size": 126, "uncompressed_size": 172, "dict_id": 0, "has_checksum": True}
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "consumer.c")
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.join(ROOT, "zstdlite_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lzl_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/zl_hip.h compiled as C99 (-pedantic -Werror) into a consumer written like the reference's
+    glue (tests/c/consumer.c); on a box without a HIP device its compute calls report an error."""
+    import subprocess
+    _lib.lib()  # make sure the library is built
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("ok")

@@ -208,3 +208,12 @@ def test_file_streaming_and_zstdfile(tmp_path, ref):
         assert ref_stream_decompress(ref, f.read()).decode().splitlines() == lines
     with pytest.raises(ValueError):
         z.zstdfile(pt, "a")
+
+
+def test_c_consumer_round_trips(tmp_path):
+    """The C99 consumer of the header (tests/c/consumer.c), on the GPU: one-shot and streaming round trips from C."""
+    import subprocess
+    from test_abi import _build_c_consumer
+    out = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "round trips ok" in out.stdout and out.stdout.strip().endswith("ok")
