@@ -140,6 +140,17 @@ def test_stream_decompress_reads_the_reference(ref):
             out = b"".join(dec.feed(comp[off:off + piece]) for off in range(0, len(comp), piece))
             assert out == data, (gen, n, piece)
             assert dec.at_frame_boundary
+    # a large frame that records no size still takes the large-frame pipeline (bounded by its block count)
+    data = GENERATORS["text"](4000000, seed=77)
+    comp = ref_stream_compress(ref, data)
+    assert (comp[4] >> 6) == 0 and (comp[4] >> 5) & 1 == 0
+    before = _lib.lib().zl_dctx_large_frames(dctx._ptr)
+    dec = stream.Decompressor(dctx._ptr)
+    assert b"".join(dec.feed(comp[off:off + 500000]) for off in range(0, len(comp), 500000)) == data
+    assert _lib.lib().zl_dctx_large_frames(dctx._ptr) == before + 1
+    out = (C.c_char * (len(data) + 100))()  # one-shot entry, more room than needed
+    assert _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data) + 100, comp, len(comp)) == len(data) and out.raw[:len(data)] == data
+    assert _lib.is_error(_lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data) - 1, comp, len(comp)))  # too little room
     # concatenated streams, skippable frame in between, fed byte-odd pieces
     a, b = GENERATORS["text"](500000, seed=1), GENERATORS["iid10"](300000, seed=2)
     blob = ref_stream_compress(ref, a) + b"\x50\x2a\x4d\x18\x04\x00\x00\x00abcd" + z.zstd_compress(b) + ref.compress(a, level=1)

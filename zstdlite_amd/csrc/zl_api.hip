@@ -433,7 +433,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // first, one after the other; it leaves each frame's result word on the device.
     static const bool no_big = getenv("ZL_NO_BIG") != nullptr;  // (experiments: the general kernel takes them instead)
     for (size_t i = 0; i < n && !no_big; i++) {
-        if (has_dict || tbl[i].dst_cap <= route_max || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;
+        if (has_dict || tbl[i].dst_cap <= route_max || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side);
         if (e3 == 0) { plan[i].route = 3; d->large_frames++; }

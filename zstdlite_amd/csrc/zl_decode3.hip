@@ -86,8 +86,9 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
     else if (fflag == 2) fcs = zl_rd_le(src + pos, 4);
     else fcs = (u64)zl_rd_le(src + pos, 4) | ((u64)zl_rd_le(src + pos + 4, 4) << 32);
     if (did) { info->err = ZL_E_DICT_WRONG; return; }  // this path never has a dictionary (zstd.c:41318)
-    if (fcs == ZL_CONTENTSIZE_UNKNOWN) { info->err = ZL_E_FALLBACK; return; }  // (the links are sized by the recorded size)
-    if (fcs > fd.dst_cap) { info->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
+    // (a frame that does not record its size -- what ZSTD_compressStream2 writes when nothing is pledged -- is
+    // bounded by its block count: the host sizes the links from that)
+    if (fcs != ZL_CONTENTSIZE_UNKNOWN && fcs > fd.dst_cap) { info->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
     info->fcs = fcs;
     info->has_checksum = (fhd >> 2) & 1;
     pos = hs;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
         info->produced = op;
         if (bad) info->err = bad;
         else if (op > fd.dst_cap) info->err = ZL_E_DSTSIZE_TOO_SMALL;
-        else if (op != info->fcs) info->err = ZL_E_CORRUPTION;  // zstd.c:41646
+        else if (info->fcs != ZL_CONTENTSIZE_UNKNOWN && op != info->fcs) info->err = ZL_E_CORRUPTION;  // zstd.c:41646
     }
 }
 
@@ -440,9 +441,11 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = dbg ? now() : 0;
     auto stamp = [&](const char* what) { if (dbg) { const double t1 = now(); fprintf(stderr, "[zl3] %-10s %8.3f ms\n", what, t1 - t0); t0 = t1; } };
-    if (fd.dst_cap >= 0xFFFFFF00ull || fd.src_size >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // links and block records are 32-bit
+    if (fd.src_size >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // block records are 32-bit
+    // (dst_cap may be the room left in the caller's buffer rather than the frame's size: what the frame can produce is bounded by its input too)
+    const u64 out_bound = std::min<u64>(fd.dst_cap, fd.src_size * 1024 + ((u64)1 << 20));
     // blocks planned for: full blocks plus a generous allowance for encoders that split blocks
-    const u32 cap_blocks = (u32)std::min<u64>((fd.dst_cap >> 14) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
+    const u32 cap_blocks = (u32)std::min<u64>((out_bound >> 14) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
     const u32 cap_segs = cap_blocks / ZL3_SEG_BLOCKS;
     if (!s->info.ensure(sizeof(zl3_info)) || !s->brec.ensure((size_t)cap_segs * ZL2_MAXB * sizeof(zl2_blk_rec)) || !s->frec.ensure((size_t)cap_segs * sizeof(zl2_frame_rec)) ||
         !s->plan.ensure((size_t)cap_segs * sizeof(zl2_frame_plan)) || !s->frames.ensure((size_t)cap_segs * sizeof(zl_frame_desc)) ||
@@ -462,9 +465,12 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     stamp("index");
     if (dbg) fprintf(stderr, "[zl3] blocks %u segments %u literals %llu sequences %llu err %u\n", info.nblocks, info.nsegs, (unsigned long long)info.lit_total, (unsigned long long)info.seq_total, info.err);
     if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
-    const u64 ntiles = (info.fcs >> ZL3_TILE_LOG) + 1;
+    // output positions the links must cover: the recorded size, else what the blocks can produce at most (and the caller has room for)
+    const u64 span = info.fcs != ZL_CONTENTSIZE_UNKNOWN ? info.fcs : std::min<u64>(fd.dst_cap, (u64)info.nblocks * ZL_BLOCK_MAX);
+    if (span >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // links are 32-bit
+    const u64 ntiles = (span >> ZL3_TILE_LOG) + 1;
     if (!info.err) {
-        if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(info.fcs * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
+        if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
             return kGpuUnavailable;
         zl3_big big;
         big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start;
@@ -493,7 +499,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         }
         for (u32 round = 0; !info.err && jumping; round++) {
             if (hipMemsetAsync(&d.info->pending, 0, 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-            hipLaunchKernelGGL(zl3_resolve_kernel, dim3((u32)ntiles), dim3(256), 0, st, d_dst + fd.dst_off, (u32*)s->link.p, (u32*)s->tile_flag.p, (u64)info.fcs, round, d.info);
+            hipLaunchKernelGGL(zl3_resolve_kernel, dim3((u32)ntiles), dim3(256), 0, st, d_dst + fd.dst_off, (u32*)s->link.p, (u32*)s->tile_flag.p, span, round, d.info);
             if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             if (dbg) fprintf(stderr, "[zl3] round %u pending %u\n", round, info.pending);
             if (info.err || info.pending == 0 || round >= 80) break;
