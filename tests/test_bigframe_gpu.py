@@ -106,6 +106,11 @@ def test_large_and_small_frames_in_one_call(ref):
     dctx = z.zstd_dctx()
     assert z.zstd_decompress(b"".join(frames), dctx=dctx) == a + b + c + d + e
     assert large_frames(dctx) == 2
+    # large frames that start at odd output addresses (every alignment of the 16-byte flush and of the 4-byte copy words)
+    for odd in (1, 2, 3, 5, 13, 12345):
+        head = GENERATORS["iid10"](odd, seed=odd)
+        blob = ref.compress(head, level=3) + frames[0] + frames[2]
+        assert z.zstd_decompress(blob, dctx=dctx) == head + a + c, odd
     # our own encoder's output for the same inputs (one frame per 128 KiB) next to a reference frame
     mixed = z.zstd_compress(a) + frames[2]
     assert z.zstd_decompress(mixed, dctx=dctx) == a + c
