@@ -1,25 +1,31 @@
-// zl_decode2.hip -- lane-parallel decode pipeline for frames of at most one block size
-// (<= 128 KiB of content): the shape of BASELINE config C2 (10k independent 64 KiB frames) and of
-// everything the HIP encoder emits.  zl_decode.hip's one-workgroup-per-frame kernel stays as the
-// general path (dictionaries, larger frames, unusual tables); frames are routed per frame.
+// zl_decode2.hip -- lane-parallel decode pipeline for frames of up to eight blocks (<= 1 MiB of
+// content): the shape of BASELINE config C2 (10k independent 64 KiB frames) and of everything the
+// HIP encoder emits.  The same kernels decode the SEGMENTS of one large frame for the large-frame
+// pipeline (zl_decode3.hip).  zl_decode.hip's one-workgroup-per-frame kernel stays as the general
+// path (dictionaries, unusual tables); frames are routed per frame.
 //
 // The reference decodes a block with three serial loops (zstd.c:45084 ZSTD_decompressBlock_internal:
 // Huffman literals zstd.c:38653, FSE sequences zstd.c:44241, sequence execution zstd.c:44013).
 // Measured on MI355X, running those chains on one lane of a wavefront costs ~500 cycles per
 // literal and ~2200 cycles per sequence while the other 63 lanes idle.  Here every lane of a
-// wavefront runs its own chain, so a wave instruction advances 64 Huffman streams (or 16 FSE
+// wavefront runs its own chain, so a wave instruction advances many Huffman streams (or FSE
 // chains) at once:
 //
 //   zl2_index_kernel  lane per frame: frame header, block walk, literal/sequence section headers
 //                     (zstd.c:41050, :43075, :43146, :43707) -> block records
-//   zl2_lit_kernel    lane per Huffman stream (16 frames x 4 streams per wave); single-symbol
-//                     decode tables of the 16 frames side by side in LDS (zstd.c:38436)
-//   zl2_seq_kernel    lane per frame: FSE table build + the 3-state sequence chain with repcode
-//                     resolution (zstd.c:43497, :44241); compact LDS cells (3 bytes per state)
-//   zl2_exec_kernel   1024-thread workgroup per frame: the block's output is assembled in LDS
-//                     (128 KiB), every 4-byte word produced independently by chasing its source
-//                     through the batch's sequence table, then flushed with 16-byte coalesced
-//                     stores (replaces zstd.c:44013 ZSTD_execSequence); XXH64 check.
+//   zl2_order_kernel  the frames sorted by decreasing sequence count / literal bytes: the schedule
+//   zl2_lit_kernel    lane per (frame, block, Huffman stream): 8 frames x 8 blocks x 4 streams per
+//                     workgroup; a block that brings a tree leads the treeless blocks behind it
+//                     (zstd.c:38436); LDS rings keep memory off the decode chain
+//   zl2_seq_kernel    lane per (frame, block): FSE table build + the 3-state sequence chain with
+//                     branch-free repcode rules (zstd.c:43497, :44241); a block decoded before its
+//                     predecessor carries its starting repcodes as symbols
+//   zl2_entropy1_kernel  both roles in one launch when every frame has one block
+//   zl2_exec_kernel   512-thread workgroup per frame; only the 8 KiB batch being built lives in LDS:
+//                     literals scattered, every match byte one hop through the batch's sequence
+//                     table, 16-bit links shortened by pointer jumping, 16-byte coalesced flush
+//                     (replaces zstd.c:44013 ZSTD_execSequence); XXH64 check.  <true>: one run of
+//                     segments of a large frame, bytes whose source lies in front of the run deferred
 //
 // All integer work; output must be bit-exact with the reference decoder.
 #include <hip/hip_runtime.h>
