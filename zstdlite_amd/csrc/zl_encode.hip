@@ -833,7 +833,7 @@ __device__ __forceinline__ u32 bw_finish(BitW& w) {
 // Normalise counts to sum 2^log (own rounding scheme; any distribution that sums to the
 // table size is valid -- cf. zstd.c:16314 FSE_normalizeCount).  Symbols rarer than one slot
 // get the "less than one" marker -1.  Requires >= 2 present symbols.  One thread.
-__device__ void fse_normalize(short* norm, const u32* count, u32 total, int max_sym, int log) {
+__device__ __noinline__ void fse_normalize(short* norm, const u32* count, u32 total, int max_sym, int log) {
     const u32 size = 1u << log;
     int largest = 0;
     u32 largest_c = 0, used = 0;
@@ -870,7 +870,7 @@ __device__ void fse_normalize(short* norm, const u32* count, u32 total, int max_
 }
 
 // zstd.c:16179 FSE_writeNCount: exact inverse of read_ncount in zl_decode.hip.  One thread.
-__device__ u32 fse_write_ncount(u8* dst, const short* norm, int max_sym, int log) {
+__device__ __noinline__ u32 fse_write_ncount(u8* dst, const short* norm, int max_sym, int log) {
     BitW w;
     bw_init(w, dst);
     bw_add(w, (u32)(log - 5), 4);
@@ -900,7 +900,7 @@ __device__ u32 fse_write_ncount(u8* dst, const short* norm, int max_sym, int log
 
 // zstd.c:15917 FSE_buildCTable_wksp: same spread as the decoder, then rank the cells of each
 // symbol.  One thread.  tsym: LDS scratch of table size.
-__device__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8* tsym, u16* cumul /* 64 entries of LDS */, const short* norm, int max_sym, int log) {
+__device__ __noinline__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8* tsym, u16* cumul /* 64 entries of LDS */, const short* norm, int max_sym, int log) {
     const int size = 1 << log;
     int high = size - 1;
     cumul[0] = 0;
@@ -965,7 +965,7 @@ __device__ __forceinline__ void stage_or(u32* stage, u32 pos, u64 v, u32 n) {
 // Optimal tree by the two-queue method, depths limited to HUF_MAX_BITS by moving leaves down
 // until the Kraft sum is exactly one (cf. zstd.c:17200 HUF_buildCTable_wksp / HUF_setMaxHeight
 // which reach the same goal differently).  Returns table log (max length used).
-__device__ u32 huf_build_lengths(EntShared& S, u32 m) {
+__device__ __noinline__ u32 huf_build_lengths(EntShared& S, u32 m) {
     for (u32 i = 0; i < m; i++) S.node_w[i] = S.hist[0][S.sorted[i]];
     u32 q1 = 0, q2 = m, next = m;
     for (u32 k = 0; k + 1 < m; k++) {
@@ -1008,7 +1008,7 @@ __device__ u32 huf_build_lengths(EntShared& S, u32 m) {
 // Huffman tree description (zstd.c:16907 HUF_writeCTable_wksp): weights of symbols
 // 0..maxsym-1, FSE-compressed when that is smaller (zstd.c:16840 HUF_compressWeights),
 // else 4 bits each.  One thread.  Returns bytes written, 0 if the table cannot be described.
-__device__ u32 huf_write_tree(EntShared& S, u8* dst) {
+__device__ __noinline__ u32 huf_write_tree(EntShared& S, u8* dst) {
     const u32 maxsym = S.huf_maxsym, log = S.huf_log;
     for (u32 s = 0; s < maxsym; s++) S.weights[s] = S.hlen[s] ? (u8)(log + 1 - S.hlen[s]) : 0;
     // ---- try FSE
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void wr_le(u8* p, u64 v, u32 nbytes) {
 }
 
 // zstd.c:27089 ZSTD_writeFrameHeader for a single-segment frame of n bytes.
-__device__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
+__device__ __noinline__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 dict_id) {
     wr_le(p, ZL_MAGIC, 4);
     const u32 fcs_flag = n < 256 ? 0 : (n < 65536 + 256 ? 1 : 2);
     const u32 dflag = dict_id == 0 ? 0 : (dict_id < 256 ? 1 : (dict_id < 65536 ? 2 : 3));
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_cdict_build_kernel(const zl_di
 
 // position of block boundary `j` of `nbk`: the byte target j*n/nbk moved to the end of the match
 // that covers it, if one does.  Returns {first sequence, first literal} of the block behind it.
-__device__ void block_boundary(const zl_seq* seqs, u32 nseq, u32 nlit, u32 n, u32 j, u32 nbk, u32* first_seq, u32* first_lit) {
+__device__ __noinline__ void block_boundary(const zl_seq* seqs, u32 nseq, u32 nlit, u32 n, u32 j, u32 nbk, u32* first_seq, u32* first_lit) {
     if (j == 0) { *first_seq = 0; *first_lit = 0; return; }
     if (j >= nbk) { *first_seq = nseq; *first_lit = nlit; return; }
     const u32 target = (u32)(((u64)j * n) / nbk);
@@ -1280,6 +1280,9 @@ __device__ __forceinline__ void seq_fields(const zl_seq* seqs, u32 i, u32 blk_fi
     ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
 }
 
+// (The serial helpers above are __noinline__: inlined, their registers weigh on a kernel that is held to 64
+// of them -- measured 2.51 -> 2.39 ms.  Taking the phase stamps out at compile time as well removed most of
+// the remaining spills and was SLOWER, 2.56 ms: the allocator's choices matter more than the spill count.)
 __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ EntShared S;
     ZL_POISON(S, 8);
@@ -1790,6 +1793,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         atomicAdd((unsigned long long*)&a.stats[6], 1ull);
     }
 }
+
 
 // exclusive scan of frame sizes (one workgroup; chunk counts are small: 8192 per GiB)
 __global__ __launch_bounds__(ENC_THREADS) void zl_scan_sizes_kernel(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 n) {
