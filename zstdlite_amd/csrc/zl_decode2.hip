@@ -37,6 +37,12 @@
 #include "zl_kernels.h"
 #include "zl_blocks.h"
 
+// -DZL_ROLE_STAMPS=1: cycle stamps inside the literal and sequence roles (the "entropy roles" line of
+// scripts/kernel_bench.py).  Compiled out by default: even unused they cost the roles 1-2 %.
+#ifndef ZL_ROLE_STAMPS
+#define ZL_ROLE_STAMPS 0
+#endif
+
 // ---------------------------------------------------------------------------------------
 // tables (zstd.c:15462-15512)
 // ---------------------------------------------------------------------------------------
@@ -928,7 +934,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
     wave_sync();
     const u32 mask = *rounds;
     SeqLane& L = S.L[fi];
-    const bool prof = a.stats != nullptr && lane == 0;
+    const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && lane == 0;
     u64 p_build = 0, p_chain = 0, p_parse = 0, p_tab = 0;
     for (u32 ri = 0; ri < 4 + ZL2_MAXB; ri++) {
         if (!((mask >> ri) & 1)) continue;
@@ -1021,7 +1027,7 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, (MB > 1 ? 2 : 1)) void zl2_lit
     // literal workgroup is left) instead of two literal workgroups that would keep the sequence
     // chains -- the longer pole -- waiting.
     ZL_POISON(G, 1);
-    const bool prof = a.stats != nullptr && threadIdx.x == 0;
+    const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
     lit_role<MB>(a, G, &rounds, blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(clock64() - t0));  // profile: cycles per literal workgroup
@@ -1031,7 +1037,7 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
     __shared__ u32 rounds;
     if (a.fuse1 && *a.max_blocks <= 1) return;  // (zl2_entropy1_kernel does the work)
     ZL_POISON(S, 1);
-    const bool prof = a.stats != nullptr && threadIdx.x == 0;
+    const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
     seq_role(a, S, &rounds, blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(clock64() - t0));  // profile: cycles per sequence workgroup
@@ -1130,10 +1136,13 @@ __device__ __forceinline__ void ex_copy(u8* dst, const u8* src, u32 n) {
 __device__ __forceinline__ u32 ex_link_load(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // One frame (BIG: one segment; `seg_start` is the first output position of the workgroup's run of
 // segments: what lies in front of it belongs to other workgroups).  Returns false when the run must stop.
-template <bool BIG>
+// (PROF: the in-kernel phase stamps of ZL_d_profile = 2, a template parameter: kept as a run-time test their
+// accumulators cost registers in a kernel that is held to 64 of them -- 2.07 -> 1.92 ms without)
+template <bool BIG, bool PROF>
 __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& S, const u32 f, u64& seg_start, const bool first) {
     const u32 t = threadIdx.x;
-    const u64 wg_t0 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    const bool wg_prof = PROF && a.stats != nullptr && t == 0;
+    const u64 wg_t0 = wg_prof ? __builtin_amdgcn_s_memtime() : 0;
     zl2_frame_rec* fr = a.frec + f;
     const u32 ferr = fr->err;
     if (!BIG && (ferr == ZL_E_FALLBACK || ferr == ZL_E_DONE)) return false;  // the general kernel (or the large-frame pipeline) owns this frame
@@ -1158,7 +1167,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
     u64 op = BIG ? (u64)a.big->blk_dst[(size_t)f * ZL3_SEG_BLOCKS] : 0;
     if (first) seg_start = op;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
-    const u64 wg_t1 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    const u64 wg_t1 = wg_prof ? __builtin_amdgcn_s_memtime() : 0;
     // Output goes to memory with plain stores and is read back (by other waves) only in pass 2a of a
     // later batch, so the one place that drains the stores is the barrier in front of pass 2a:
     // literal-only and raw blocks never wait for their stores.
@@ -1194,7 +1203,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         const u64 cap_left = cap - op;
         u32 lit_pos = 0, out_pos = 0;
         u64 c_scan = 0, c_lit = 0, c_match = 0, c_batches = 0;
-        const bool prof = a.stats != nullptr && t == 0;
+        const bool prof = PROF && a.stats != nullptr && t == 0;
         // offsets that name the history the block started with (ZL2_REP_SYM, see the sequence lanes) get their numbers here
 #define ZL2_RESOLVE(v_) (((v_) >> 31) ? (((v_) & 3u) == 0 ? rep0 : (((v_) & 3u) == 1 ? rep1 : rep2)) - (((v_) & 0x7FFFFFFFu) >> 2) : (v_))
         for (u32 b0 = 0; b0 < nseq;) {
@@ -1445,9 +1454,9 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         }
         op += produced;
     }
-    const u64 wg_t2 = (a.stats != nullptr && t == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    const u64 wg_t2 = wg_prof ? __builtin_amdgcn_s_memtime() : 0;
     zl_sync_global();
-    if (a.stats != nullptr && t == 0) {  // profile: prologue, and the final drain of this frame's stores
+    if (wg_prof) {  // profile: prologue, and the final drain of this frame's stores
         atomicAdd((unsigned long long*)&a.stats[-2], (unsigned long long)(wg_t1 - wg_t0));
         atomicAdd((unsigned long long*)&a.stats[-1], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t2));
     }
@@ -1465,23 +1474,23 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         __syncthreads();
     }
     if (t == 0) a.results[f] = S.err ? ZL_ERR(S.err) : op;
-    if (a.stats != nullptr && t == 0) atomicAdd((unsigned long long*)&a.stats[-3], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t0));  // profile: workgroup lifetime
+    if (wg_prof) atomicAdd((unsigned long long*)&a.stats[-3], (unsigned long long)(__builtin_amdgcn_s_memtime() - wg_t0));  // profile: workgroup lifetime
     return true;
 }
 
-template <bool BIG>
+template <bool BIG, bool PROF>
 __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_args a) {
     __shared__ __align__(16) ExecSharedT<BIG> S;
     ZL_POISON(S, 2);
     u64 seg_start = 0;
     if (!BIG) {
-        (void)exec_frame<BIG>(a, S, a.order[blockIdx.x], seg_start, true);  // long frames first
+        (void)exec_frame<BIG, PROF>(a, S, a.order[blockIdx.x], seg_start, true);  // long frames first
     } else {
         // a run of consecutive segments per workgroup: matches that stay inside the run are copied here
         // and now, only what reaches in front of it is left to the resolve rounds
         const u32 f0 = blockIdx.x * ZL3_EXEC_RUN, f1 = f0 + ZL3_EXEC_RUN < a.nframes ? f0 + ZL3_EXEC_RUN : a.nframes;
         for (u32 f = f0; f < f1; f++) {
-            if (!exec_frame<BIG>(a, S, f, seg_start, f == f0)) break;
+            if (!exec_frame<BIG, PROF>(a, S, f, seg_start, f == f0)) break;
             __syncthreads();
         }
     }
@@ -1510,7 +1519,8 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ngroups), dim3(64), 0, stream, *a);
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(zl2_exec_kernel<false>, dim3(n), dim3(EX_THREADS), 0, stream, *a);
+    if (a->stats) hipLaunchKernelGGL((zl2_exec_kernel<false, true>), dim3(n), dim3(EX_THREADS), 0, stream, *a);
+    else hipLaunchKernelGGL((zl2_exec_kernel<false, false>), dim3(n), dim3(EX_THREADS), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }
@@ -1537,14 +1547,14 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     return hipGetLastError();
 }
 extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, hipStream_t stream) {
-    hipLaunchKernelGGL(zl2_exec_kernel<true>, dim3((a->nframes + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN), dim3(EX_THREADS), 0, stream, *a);
+    hipLaunchKernelGGL((zl2_exec_kernel<true, false>), dim3((a->nframes + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN), dim3(EX_THREADS), 0, stream, *a);
     return hipGetLastError();
 }
 
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl2_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel<false>, EX_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_exec_kernel<false, false>, EX_THREADS, 0);
     else if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_lit_kernel<ZL2_MAXB>, LIT_FRAMES * ZL2_MAXB * 4, ZL_LIT_PAD_BYTES);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl2_seq_kernel, 64, 0);
     return n;

@@ -15,7 +15,7 @@
 //                       kernels as if they were frames; inherited tables are rebuilt in extra rounds;
 //                       repcodes stay symbolic for every block but the first
 //   zl3_offsets_kernel  one wave: output position and starting repcode history of every block
-//   zl2_exec_kernel<true>  workgroup per segment, all segments at once: bytes whose source lies in
+//   zl2_exec_kernel<true, false>  workgroup per run of 8 segments, all runs at once: bytes whose source lies in
 //                       another segment are left as links (frame positions)
 //   zl3_copy_kernel     the deferred bytes, in order: one tiny launch per run of segments, so that every
 //                       source is final when it is read (zl3_resolve_kernel: the pointer-jumping variant)
