@@ -256,12 +256,20 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
+                w_r[j] = w_l[j] = w_s[j] = 0;
                 if (can_match[j] && search) {
-                    w_r[j] = ld64(q_r[j] >= D ? src + (q_r[j] - D) : dict + q_r[j]);
-                    w_l[j] = ld64(q_l[j] >= D ? src + (q_l[j] - D) : dict + q_l[j]);
-                    w_s[j] = ld64(q_s[j] >= D ? src + (q_s[j] - D) : dict + q_s[j]);
+                    // only lanes that have a candidate fetch it, and a position named twice is fetched once: the
+                    // gathers are what this kernel waits for (one line request per active lane)
+                    const bool same_lr = have_l[j] && have_r[j] && q_l[j] == q_r[j];
+                    const bool same_sr = have_s[j] && have_r[j] && q_s[j] == q_r[j];
+                    const bool same_sl = have_s[j] && have_l[j] && q_s[j] == q_l[j];
+                    if (have_r[j]) w_r[j] = ld64(q_r[j] >= D ? src + (q_r[j] - D) : dict + q_r[j]);
+                    if (have_l[j] && !same_lr) w_l[j] = ld64(q_l[j] >= D ? src + (q_l[j] - D) : dict + q_l[j]);
+                    if (have_s[j] && !same_sr && !same_sl) w_s[j] = ld64(q_s[j] >= D ? src + (q_s[j] - D) : dict + q_s[j]);
+                    if (same_lr) w_l[j] = w_r[j];
+                    if (same_sr) w_s[j] = w_r[j];
+                    else if (same_sl) w_s[j] = w_l[j];
                 }
-                else { w_r[j] = w_l[j] = w_s[j] = 0; }
             }
             {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN + t;
@@ -468,7 +476,15 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
             u64 w_r = 0, w_l = 0, w_s = 0;
-            if (can0 && search) { w_r = ld64(src + q_r); w_l = ld64(src + q_l); w_s = ld64(src + q_s); }
+            if (can0 && search) {  // (as in the stride-1 body: candidates are fetched by the lanes that have one, each position once)
+                const bool same_lr = have_l && have_r && q_l == q_r, same_sr = have_s && have_r && q_s == q_r, same_sl = have_s && have_l && q_s == q_l;
+                if (have_r) w_r = ld64(src + q_r);
+                if (have_l && !same_lr) w_l = ld64(src + q_l);
+                if (have_s && !same_sr && !same_sl) w_s = ld64(src + q_s);
+                if (same_lr) w_l = w_r;
+                if (same_sr) w_s = w_r;
+                else if (same_sl) w_s = w_l;
+            }
             {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN2 + 2 * t;
                 pref_ip2 = ip + WIN2;
