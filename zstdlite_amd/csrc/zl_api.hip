@@ -463,7 +463,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.max_blocks = (u32*)d->d_counter.p + 8;
     f2.order = (u32*)d->d_order.p;  // (the 64-byte counter block is zeroed above; word 0 is the general kernel's queue head)
     f2.ext = nullptr;
-    static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : 1u;  // (experiments: literal and sequence lanes of single-block launches as two kernels)
+    static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : (getenv("ZL_NO_QUAD") ? 1u : 3u);  // bit 1: the sequence chains of single-block launches on quads of lanes  // (experiments: literal and sequence lanes of single-block launches as two kernels)
     f2.fuse1 = fuse1;
     f2.big = nullptr;
     if (d->profile >= 2 && d->d_stats.ensure(128)) {

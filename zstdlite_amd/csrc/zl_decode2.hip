@@ -610,6 +610,8 @@ struct SeqShared {
     u32 ll_tab[36];  // [23:0] baseline, [31:24] extra bits
     u32 ml_tab[53];
     short defn[3][64];  // predefined distributions (kind 0 LL, 1 OF, 2 ML), zstd.c:15480-15512
+    u32 val_tab[3][64];  // quad chains: baseline of symbol s, one table per role (0 LL, 1 OF: 1 << s, 2 ML)
+    u32 qpos[SEQ_FRAMES];  // quad chains: where the frame's bitstream starts this round (0xFFFFFFFF: no chain to run)
 };
 // Repcode history of a block that is decoded before its predecessor has finished: the three
 // unknown start values travel as symbols, 0x80000000 | k + 4 * (times "minus one" was applied)
@@ -707,6 +709,62 @@ __device__ __forceinline__ u32 make_seq_table(SeqLane& L, SeqBuild& B, const sho
         norm = defn + 64 * kind;  // the predefined distributions, staged in LDS once per workgroup
     }
     return build_seq_table(L, base, norm, B.next[kind], max_sym, log) ? (u32)log : 0xFFFFFFFFu;
+}
+
+// The chain from sequence i on, one field at a time with every bound checked: the end of every chain, and the
+// whole chain of short streams.  Writes the block's totals and final history behind the records.
+__device__ __forceinline__ u32 seq_tail(SeqShared& S, const SeqLane& L, const zl2_blk_rec& r, const u8* bs, u32 bn, i32 bp, u32 i, u32 sl, u32 so, u32 sm,
+                                        u32 r0, u32 r1, u32 r2, u32 lit_used, u32 out_used, uint4* oseq) {
+    const u32 nseq = r.nseq;
+    // generic tail (also the whole chain of short streams)
+    for (; i < nseq; i++) {
+        const u32 cl = L.ent[sl], cm = L.ent[512 + sm], co = L.ent[1024 + so];
+        const u32 yl = (cl >> 16) & 0xFF, ym = (cm >> 16) & 0xFF, yo = (co >> 16) & 0xFF;
+        if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) return ZL_E_CORRUPTION;
+        const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
+        const u32 nl = tl >> 24, nm = tm >> 24;
+        bp -= (i32)yo;
+        const u32 ofv = (1u << yo) + zl_bits_bwd(bs, bn, bp, yo);
+        bp -= (i32)nm;
+        const u32 ml = (tm & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nm);
+        bp -= (i32)nl;
+        const u32 ll = (tl & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nl);
+        if (bp < 0) return ZL_E_CORRUPTION;
+        u32 off;
+        if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
+        else {
+            const u32 idx = ofv - 1 + (ll == 0);
+            if (idx == 0) off = r0;
+            else {
+                off = (idx == 3) ? rep_minus1(r0) : (idx == 1 ? r1 : r2);
+                if (off == 0) return ZL_E_CORRUPTION;
+                if (idx != 1) r2 = r1;
+                r1 = r0;
+                r0 = off;
+            }
+        }
+        oseq[i] = make_uint4(lit_used, out_used, off, 0u);
+        lit_used += ll;
+        out_used += ll + ml;
+        if (out_used > ZL_BLOCK_MAX) return ZL_E_CORRUPTION;
+        if (i + 1 < nseq) {
+            u32 nb = (cl >> 10) & 0xF;
+            bp -= (i32)nb;
+            sl = (cl & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            nb = (cm >> 10) & 0xF;
+            bp -= (i32)nb;
+            sm = (cm & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            nb = (co >> 10) & 0xF;
+            bp -= (i32)nb;
+            so = (co & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
+            if (bp < 0) return ZL_E_CORRUPTION;
+        }
+    }
+    if (bp != 0) return ZL_E_CORRUPTION;  // zstd.c:44690
+    if (lit_used > r.lit_size) return ZL_E_CORRUPTION;
+    oseq[nseq] = make_uint4(lit_used, out_used, 1u, 0u);  // totals of the block
+    oseq[nseq + 1] = make_uint4(r0, r1, r2, 0u);          // history handed to the next block
+    return 0;
 }
 
 // The 3-state chain of one block on one lane (zstd.c:44241-44356).  Returns 0 or an error code.
@@ -825,55 +883,125 @@ __device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lan
         sm = zl_bits_bwd(bs, bn, bp, ml_log);
         if (bp < 0) return ZL_E_CORRUPTION;
     }
-    // generic tail (also the whole chain of short streams)
-    for (; i < nseq; i++) {
-        const u32 cl = L.ent[sl], cm = L.ent[512 + sm], co = L.ent[1024 + so];
-        const u32 yl = (cl >> 16) & 0xFF, ym = (cm >> 16) & 0xFF, yo = (co >> 16) & 0xFF;
-        if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) return ZL_E_CORRUPTION;
-        const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
-        const u32 nl = tl >> 24, nm = tm >> 24;
-        bp -= (i32)yo;
-        const u32 ofv = (1u << yo) + zl_bits_bwd(bs, bn, bp, yo);
-        bp -= (i32)nm;
-        const u32 ml = (tm & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nm);
-        bp -= (i32)nl;
-        const u32 ll = (tl & 0xFFFFFF) + zl_bits_bwd(bs, bn, bp, nl);
-        if (bp < 0) return ZL_E_CORRUPTION;
-        u32 off;
-        if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
-        else {
-            const u32 idx = ofv - 1 + (ll == 0);
-            if (idx == 0) off = r0;
-            else {
-                off = (idx == 3) ? rep_minus1(r0) : (idx == 1 ? r1 : r2);
-                if (off == 0) return ZL_E_CORRUPTION;
-                if (idx != 1) r2 = r1;
-                r1 = r0;
-                r0 = off;
+    return seq_tail(S, L, r, bs, bn, bp, i, sl, so, sm, r0, r1, r2, lit_used, out_used, oseq);
+}
+
+
+// ---- the same chain on a QUAD of lanes (launches of single-block frames, where a wave has lanes to spare):
+// lane 0 of the quad owns the literal-length state, lane 1 the offset state, lane 2 the match-length
+// state.  Per sequence every lane does the same table-driven work for its own state -- one table
+// entry, its extra bits and its state bits cut out of a 128-bit window of the stream that all four
+// lanes hold -- after the three (extra bits, state bits) pairs have gone round the quad with
+// quad-permute DPP moves (register moves, not LDS traffic), so that every lane knows where its
+// fields sit.  The three values go round the same way; the repcode rules then run identically in
+// all four lanes and lane 3 writes the record.  About half the instructions per sequence of the
+// one-lane chain, whose cost is its length.
+template <int K>
+__device__ __forceinline__ u32 quad_get(u32 v) {  // v of lane K of this lane's quad
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xF, 0xF, true);
+}
+// n bits (0..32) whose lowest sits at bit `at` of the 128-bit window x (dwords x.x .. x.w, ascending)
+typedef u32 zl_v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32 window_bits(const zl_v4u32 x, u32 at, u32 n) {
+    // (plain arithmetic: written with ?: on the dword index the compiler builds a tree of exec-masked branches)
+    const u64 lo64 = ((u64)x.y << 32) | x.x, hi64 = ((u64)x.w << 32) | x.z;
+    const u32 sh = at & 63;
+    const u64 low = (lo64 >> sh) | ((hi64 << 1) << (63 - sh));  // bits from `at` on when at < 64
+    const u64 high = hi64 >> sh;                                  // ... when at >= 64
+    const u64 pick = 0ull - (u64)(at >> 6);                       // all ones when at >= 64
+    const u32 v = (u32)((high & pick) | (low & ~pick));
+    const u32 mask = (u32)((1ull << n) - 1);
+    return v & mask;
+}
+__device__ __forceinline__ u32 seq_chain_quad(SeqShared& S, const SeqLane& L, u32 lane, const zl2_blk_rec& r, const u8* sp, u32 pos,
+                                              u32 ll_log, u32 of_log, u32 ml_log, bool symbolic, uint4* oseq) {
+    const u32 role = lane & 3;
+    u32 r0 = symbolic ? ZL2_REP_SYM : 1u, r1 = symbolic ? (ZL2_REP_SYM | 1u) : 4u, r2 = symbolic ? (ZL2_REP_SYM | 2u) : 8u;
+    const u8* bs = sp + pos;
+    const u32 bn = r.seq_len - pos;
+    i32 bp = zl_bwd_init(bs, bn);
+    if (bp < 0) return ZL_E_CORRUPTION;
+    const u32 nseq = r.nseq;
+    u32 lit_used = 0, out_used = 0, i = 0;
+    bp -= (i32)ll_log;
+    u32 sl = zl_bits_bwd(bs, bn, bp, ll_log);
+    bp -= (i32)of_log;
+    u32 so = zl_bits_bwd(bs, bn, bp, of_log);
+    bp -= (i32)ml_log;
+    u32 sm = zl_bits_bwd(bs, bn, bp, ml_log);
+    if (bp < 0) return ZL_E_CORRUPTION;
+    u32 bad = 0;
+    if (bp >= 160) {
+        const u32 mis = (u32)((uintptr_t)bs & 3);
+        const u32* w = (const u32*)(bs - mis);     // aligned dwords; the cursor c counts bits from w[0]: unread bits are [mis * 8, c)
+        u32 c = mis * 8 + (u32)bp;
+        u32 s = role == 0 ? sl : (role == 1 ? so : sm);
+        const u32 ebase = role == 0 ? 0u : (role == 1 ? 1024u : 512u);
+        const u32* vtab = &S.val_tab[role == 3 ? 2 : role][0];
+        u32 Dw = (c - 1) >> 5;                      // dword that holds the top unread bit; the window is w[Dw - 3 .. Dw]
+        zl_v4u32 x = *(const zl_v4u32*)(w + Dw - 3);
+        zl_v4u32* ring = (zl_v4u32*)&S.ring[0][lane];
+        while (i < nseq && Dw >= 4) {
+            const u32 ce = L.ent[ebase + s];
+            const u32 sym = (ce >> 16) & 0xFF, e = ce >> 24, b = (ce >> 10) & 0xF;
+            const u32 pk = e | (b << 8);
+            const u32 p0 = quad_get<0>(pk), p1 = quad_get<1>(pk), p2 = quad_get<2>(pk);
+            const u32 e_ll = p0 & 0xFF, b_ll = p0 >> 8, e_of = p1 & 0xFF, b_of = p1 >> 8, e_ml = p2 & 0xFF, b_ml = p2 >> 8;
+            const u32 keep = (i + 1 == nseq) ? 0u : 0xFFFFFFFFu;  // the last sequence reads no state bits
+            // stream order below the cursor: offset bits, match-length bits, literal-length bits, then the state bits LL, ML, OF
+            const u32 e_all = e_of + e_ml + e_ll;
+            const u32 T = e_all + ((b_ll + b_ml + b_of) & keep);
+            const u32 above_e = role == 1 ? 0u : (role == 2 ? e_of : e_of + e_ml);
+            const u32 above_s = e_all + (role == 0 ? 0u : (role == 2 ? b_ll : b_ll + b_ml));
+            const u32 top = c - ((Dw - 3) << 5);  // the cursor inside the window: 97..128
+            const u32 extra = window_bits(x, top - above_e - e, e);
+            const u32 u = window_bits(x, top - above_s - (b & keep), b & keep);
+            s = (ce & 0x3FF) + u;
+            c -= T;
+            const u32 Dn = (c - 1) >> 5;
+            // (the same address in all four lanes, asked for before the values are needed.  Dn >= 1 here, so the load may
+            // start up to 8 bytes in front of the stream: inside the block, whose headers and literals precede it)
+            const zl_v4u32 xn = *(const zl_v4u32*)(w + (i32)Dn - 3);
+            const u32 val = vtab[sym] + extra;
+            const u32 ll = quad_get<0>(val), ofv = quad_get<1>(val), ml = quad_get<2>(val);
+            // repcode rules (zstd.c:44291-44327), the same in every lane; masks instead of ?: (see window_bits)
+            const u32 m_real = 0u - (u32)(ofv > 3);
+            const u32 ri = ofv - 1 + (u32)(ll == 0);  // meaningful when not real: 0..3
+            const u32 m1 = 0u - (u32)(ri == 1), m2 = 0u - (u32)(ri == 2), m3 = 0u - (u32)(ri == 3);
+            const u32 r0m = r0 + 5 * (r0 >> 31) - 1;  // rep_minus1: a symbolic history entry counts the decrements in its upper bits
+            const u32 cand = (r1 & m1) | (r2 & m2) | (r0m & m3) | (r0 & ~(m1 | m2 | m3));
+            const u32 off = ((ofv - 3) & m_real) | (cand & ~m_real);
+            const u32 m_sh2 = m_real | m2 | m3, m_sh1 = m_sh2 | m1;
+            r2 = (r1 & m_sh2) | (r2 & ~m_sh2);
+            r1 = (r0 & m_sh1) | (r1 & ~m_sh1);
+            r0 = off;
+            bad |= (u32)(off == 0);
+            const zl_v4u32 rec = {lit_used, out_used, off, 0u};
+            lit_used += ll;
+            out_used += ll + ml;
+            bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
+            if (role == 3) {
+                ring[(i & 7) * 64] = rec;
+                if ((i & 7) == 7) {
+                    zl_v4u32* o = (zl_v4u32*)(oseq + (i - 7));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o[q] = ring[q * 64];
+                }
             }
+            x = xn;
+            Dw = Dn;
+            i++;
         }
-        oseq[i] = make_uint4(lit_used, out_used, off, 0u);
-        lit_used += ll;
-        out_used += ll + ml;
-        if (out_used > ZL_BLOCK_MAX) return ZL_E_CORRUPTION;
-        if (i + 1 < nseq) {
-            u32 nb = (cl >> 10) & 0xF;
-            bp -= (i32)nb;
-            sl = (cl & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-            nb = (cm >> 10) & 0xF;
-            bp -= (i32)nb;
-            sm = (cm & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-            nb = (co >> 10) & 0xF;
-            bp -= (i32)nb;
-            so = (co & 0x3FF) + zl_bits_bwd(bs, bn, bp, nb);
-            if (bp < 0) return ZL_E_CORRUPTION;
-        }
+        if (role == 3) for (u32 k = i & ~7u; k < i; k++) { const zl_v4u32 v = ring[(k & 7) * 64]; oseq[k] = make_uint4(v.x, v.y, v.z, v.w); }
+        bp = (i32)c - (i32)(mis * 8);
+        sl = quad_get<0>(s);
+        so = quad_get<1>(s);
+        sm = quad_get<2>(s);
     }
-    if (bp != 0) return ZL_E_CORRUPTION;  // zstd.c:44690
-    if (lit_used > r.lit_size) return ZL_E_CORRUPTION;
-    oseq[nseq] = make_uint4(lit_used, out_used, 1u, 0u);  // totals of the block
-    oseq[nseq + 1] = make_uint4(r0, r1, r2, 0u);          // history handed to the next block
-    return 0;
+    if (bad) return ZL_E_CORRUPTION;
+    if (bp < 0) return ZL_E_CORRUPTION;
+    if (role != 3) return 0;  // the rest of the chain, the checks at its end and the totals: one lane
+    return seq_tail(S, L, r, bs, bn, bp, i, sl, so, sm, r0, r1, r2, lit_used, out_used, oseq);
 }
 
 __device__ __forceinline__ void wave_sync() {  // the sequence role runs on one wave: LDS order is program order
@@ -886,9 +1014,16 @@ __device__ __forceinline__ void wave_sync() {  // the sequence role runs on one 
 // one table is the "leader" of the blocks behind it that repeat all three (mode byte 0xFC);
 // round r builds block r's tables, then every lane whose leader is r runs its chain.  Frames from
 // the HIP encoder share one table set per frame and finish in one round with all lanes busy.
+// QUAD (launches of single-block frames): the chain of a frame runs on four lanes, seq_chain_quad.
+template <bool QUAD>
 __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* rounds, u32 wg) {
     const u32 lane = threadIdx.x;
     if (lane >= 64) return;
+    if (QUAD) {
+        if (lane < 36) S.val_tab[0][lane] = k_LL_base[lane];
+        if (lane < 32) S.val_tab[1][lane] = 1u << lane;
+        if (lane < 53) S.val_tab[2][lane] = k_ML_base[lane];
+    }
     if (lane < 36) S.ll_tab[lane] = k_LL_base[lane] | ((u32)k_LL_bits[lane] << 24);
     if (lane < 53) S.ml_tab[lane] = k_ML_base[lane] | ((u32)k_ML_bits[lane] << 24);
     if (lane < 36) S.defn[0][lane] = k_LL_default[lane];
@@ -988,7 +1123,20 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         if (b == 0 && f < a.nframes && B.stamp == round + 1) { if (S.logs[fi][3] != 2) S.logs[fi][3] = 1; B.stamp = 0; }
         wave_sync();
         const u64 q1 = prof ? __builtin_amdgcn_s_memtime() : 0;
-        if (mine && S.logs[fi][3] == 1 && fr->err == 0) {
+        if (QUAD) {
+            // the frame's own lane says where its bitstream starts; the quad lanes 4 * slot .. 4 * slot + 3 run the chain
+            if (b == 0) S.qpos[fi] = (mine && S.logs[fi][3] == 1 && fr->err == 0) ? pos : 0xFFFFFFFFu;
+            wave_sync();
+            const u32 fq = lane >> 2;
+            if (lane < 4 * SEQ_FRAMES && S.qpos[fq] != 0xFFFFFFFFu) {
+                const u32 f4 = a.order[wg * SEQ_FRAMES + fq];
+                const zl2_blk_rec r4 = a.brec[(size_t)f4 * ZL2_MAXB];
+                const u8* sp4 = a.src + a.frames[f4].src_off + r4.src_off + r4.seq_off;
+                uint4* o4 = (uint4*)a.seq_scratch + a.plan[f4].seq_off + r4.seq_dst;
+                const u32 err = seq_chain_quad(S, S.L[fq], lane, r4, sp4, S.qpos[fq], S.logs[fq][0], S.logs[fq][1], S.logs[fq][2], a.ext != nullptr && f4 != 0, o4);
+                if (err) set_err(a.frec + f4, err);
+            }
+        } else if (mine && S.logs[fi][3] == 1 && fr->err == 0) {
             const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0 || (a.ext != nullptr && f != 0),
                                       q_seq + r.seq_dst);
             if (err) set_err(fr, err);
@@ -1039,7 +1187,7 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
     ZL_POISON(S, 1);
     const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
-    seq_role(a, S, &rounds, blockIdx.x);
+    seq_role<false>(a, S, &rounds, blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(clock64() - t0));  // profile: cycles per sequence workgroup
 }
 
@@ -1062,7 +1210,7 @@ __global__ __launch_bounds__(64) void zl2_entropy1_kernel(zl2_args a) {
     const u32 ngroups = (a.nframes + LIT_FRAMES - 1) / LIT_FRAMES;
     const u32 r = blockIdx.x % 3, g = blockIdx.x / 3;
     if (r < 2) {
-        if (2 * g + r < ngroups) seq_role(a, U.s, &rounds, 2 * g + r);
+        if (2 * g + r < ngroups) { if (a.fuse1 & 2) seq_role<true>(a, U.s, &rounds, 2 * g + r); else seq_role<false>(a, U.s, &rounds, 2 * g + r); }
     } else {
         lit_role<1>(a, U.g, &rounds, g);
     }

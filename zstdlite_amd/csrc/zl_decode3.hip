@@ -480,7 +480,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
         a.ext = d.ext; a.big = (const zl3_big*)s->big.p;
-        static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : 1u;
+        static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : (getenv("ZL_NO_QUAD") ? 1u : 3u);
         a.fuse1 = fuse1;
         stamp("alloc");
         if (zl2_launch_segments_entropy(&a, st, side) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
