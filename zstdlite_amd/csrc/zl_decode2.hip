@@ -841,16 +841,18 @@ __device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lan
             const u32 ofv = (1u << yo) + ofx;
             const u32 ml = (tm & 0xFFFFFF) + (x >> nl);  // match-length bits above literal-length bits
             const u32 ll = (tl & 0xFFFFFF) + (x & ((1u << nl) - 1));
-            // repcode rules (zstd.c:44291-44327), branch-free
-            const bool real = ofv > 3;
-            const u32 ri = ofv - 1 + (ll == 0 ? 1u : 0u);  // meaningful when !real: 0..3
-            const u32 cand = ri == 1 ? r1 : (ri == 2 ? r2 : (ri == 3 ? rep_minus1(r0) : r0));
-            const u32 off = real ? ofv - 3 : cand;
-            const bool sh2 = real || ri >= 2, sh1 = real || ri >= 1;
-            r2 = sh2 ? r1 : r2;
-            r1 = sh1 ? r0 : r1;
+            // repcode rules (zstd.c:44291-44327) as mask arithmetic: written with ?: the compiler builds exec-masked branches
+            const u32 m_real = 0u - (u32)(ofv > 3);
+            const u32 ri = ofv - 1 + (u32)(ll == 0);  // meaningful when not real: 0..3
+            const u32 m1 = 0u - (u32)(ri == 1), m2 = 0u - (u32)(ri == 2), m3 = 0u - (u32)(ri == 3);
+            const u32 r0m = r0 + 5 * (r0 >> 31) - 1;  // rep_minus1
+            const u32 cand = (r1 & m1) | (r2 & m2) | (r0m & m3) | (r0 & ~(m1 | m2 | m3));
+            const u32 off = ((ofv - 3) & m_real) | (cand & ~m_real);
+            const u32 m_sh2 = m_real | m2 | m3, m_sh1 = m_sh2 | m1;
+            r2 = (r1 & m_sh2) | (r2 & ~m_sh2);
+            r1 = (r0 & m_sh1) | (r1 & ~m_sh1);
             r0 = off;
-            bad |= (off == 0) ? 1u : 0u;
+            bad |= (u32)(off == 0);
             zl_v4u rec = {lit_used, out_used, off, 0u};
             lit_used += ll;
             out_used += ll + ml;
