@@ -1563,6 +1563,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         const u32 log = ct.log;
         unsigned short* slot = (unsigned short*)sst + (k == T_LL ? 2 : (k == T_ML ? 3 : 1));
         u32 st = 0;
+        const u32 sym_shift = k == T_LL ? 0u : (k == T_ML ? 8u : 16u);  // where this lane's code sits in {LL | ML << 8, OF}
         // Eight records are fetched while the previous eight are being coded: the chain itself only
         // touches LDS, and a load that is needed right away would cost a memory round trip per step.
         ushort4 cur[8], nxt[8];
@@ -1580,7 +1581,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 before[q] = 0;
                 if (e < ns && log) {
                     const ushort4 rec = cur[q];
-                    const u32 sym = k == T_LL ? (rec.x & 0xFFu) : (k == T_ML ? (u32)(rec.x >> 8) : (u32)rec.y);
+                    const u32 sym = (((u32)rec.x | ((u32)rec.y << 16)) >> sym_shift) & 0xFFu;  // (a shift per lane, not a ?: per table: no branches)
                     if (e == 0) st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]);
                     else { before[q] = st; (void)fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st); }
                 }
