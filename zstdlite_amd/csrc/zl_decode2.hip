@@ -259,7 +259,7 @@ struct LitGroupT {
     static constexpr int LANES = MB * 4;  // stream lanes per frame
     u16 tab[2048];   // [7:0] symbol, [15:8] code length
     u32 ring[16 * LANES];  // 16 output dwords per stream lane, slot-major; the first 256 bytes hold the weights while a table is built
-    u32 rin[16 * LANES];   // 16 input dwords per stream lane, slot-major: the compressed stream runs up to 15 dwords ahead of the decoder
+    u32 rin[32 * LANES];   // 32 input dwords per stream lane, slot-major: the compressed stream runs up to 31 dwords ahead of the decoder
     u32 wfse[64];    // weight FSE cells: [15:0] base, [23:16] nbits, [31:24] symbol
     short norm[16];
     u16 next[16];
@@ -419,20 +419,20 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
                 for (int k = 0; k < 4; k++) __builtin_memcpy(&q[k], w + low + 4 * k, 16);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    rin[((low + 4 * k + 0) & 15) * LIT_LANES] = q[k].x;
-                    rin[((low + 4 * k + 1) & 15) * LIT_LANES] = q[k].y;
-                    rin[((low + 4 * k + 2) & 15) * LIT_LANES] = q[k].z;
-                    rin[((low + 4 * k + 3) & 15) * LIT_LANES] = q[k].w;
+                    rin[((low + 4 * k + 0) & 31) * LIT_LANES] = q[k].x;
+                    rin[((low + 4 * k + 1) & 31) * LIT_LANES] = q[k].y;
+                    rin[((low + 4 * k + 2) & 31) * LIT_LANES] = q[k].z;
+                    rin[((low + 4 * k + 3) & 31) * LIT_LANES] = q[k].w;
                 }
             } else {
-                for (i32 k = 0; k <= idx; k++) rin[(k & 15) * LIT_LANES] = w[k];
+                for (i32 k = 0; k <= idx; k++) rin[(k & 31) * LIT_LANES] = w[k];
             }
             uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = pv0;  // eight dwords on their way from memory
             u32 pend = 0;                                    // iterations until they are written into the ring
             u32 it = 0;
             u8* const out0 = dst + i;
             while (i + 4 <= nout && idx >= 3) {
-                const u32 wa = rin[((u32)idx & 15) * LIT_LANES], wb = rin[((u32)(idx - 1) & 15) * LIT_LANES];
+                const u32 wa = rin[((u32)idx & 31) * LIT_LANES], wb = rin[((u32)(idx - 1) & 31) * LIT_LANES];
                 const u32 e0 = tab[(u32)(acc >> 32) >> sh];
                 acc <<= (e0 >> 8);
                 const u32 e1 = tab[(u32)(acc >> 32) >> sh];
@@ -454,21 +454,27 @@ __device__ __forceinline__ bool huf_stream2(const u16* tab, u32 log, u8* dst, u3
                 ring[(it & 15) * LIT_LANES] = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
                 if (pend && --pend == 0) {  // the dwords asked for two iterations ago go below the ones still unread
                     low -= 8;
-                    rin[((u32)(low + 0) & 15) * LIT_LANES] = pv0.x;
-                    rin[((u32)(low + 1) & 15) * LIT_LANES] = pv0.y;
-                    rin[((u32)(low + 2) & 15) * LIT_LANES] = pv0.z;
-                    rin[((u32)(low + 3) & 15) * LIT_LANES] = pv0.w;
-                    rin[((u32)(low + 4) & 15) * LIT_LANES] = pv1.x;
-                    rin[((u32)(low + 5) & 15) * LIT_LANES] = pv1.y;
-                    rin[((u32)(low + 6) & 15) * LIT_LANES] = pv1.z;
-                    rin[((u32)(low + 7) & 15) * LIT_LANES] = pv1.w;
-                } else if (!pend && low > 0 && idx - low < 8) {  // fewer than eight unread dwords: ask for eight more
+                    rin[((u32)(low + 0) & 31) * LIT_LANES] = pv0.x;
+                    rin[((u32)(low + 1) & 31) * LIT_LANES] = pv0.y;
+                    rin[((u32)(low + 2) & 31) * LIT_LANES] = pv0.z;
+                    rin[((u32)(low + 3) & 31) * LIT_LANES] = pv0.w;
+                    rin[((u32)(low + 4) & 31) * LIT_LANES] = pv1.x;
+                    rin[((u32)(low + 5) & 31) * LIT_LANES] = pv1.y;
+                    rin[((u32)(low + 6) & 31) * LIT_LANES] = pv1.z;
+                    rin[((u32)(low + 7) & 31) * LIT_LANES] = pv1.w;
+                }
+                // Fewer than eight unread dwords: ask for eight more -- and with this lane every lane of the wave
+                // that has room for them (the ring holds 32), so that the lanes refill in the same iterations:
+                // decided lane by lane, some lane of the wave was refilling in nearly every iteration and the whole
+                // wave walked through the refill code each time.
+                const bool want = !pend && low > 0 && idx - low < 8;
+                if (__ballot(want) != 0 && !pend && low > 0 && idx - low < 24) {
                     if (low >= 8) {
                         __builtin_memcpy(&pv0, w + low - 8, 16);
                         __builtin_memcpy(&pv1, w + low - 4, 16);
                         pend = 2;
                     } else {  // the last few dwords of the stream
-                        for (i32 k = 0; k < low; k++) rin[((u32)k & 15) * LIT_LANES] = w[k];
+                        for (i32 k = 0; k < low; k++) rin[((u32)k & 31) * LIT_LANES] = w[k];
                         low = 0;
                     }
                 }
@@ -1163,10 +1169,10 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
 // workgroup shape for both roles) the two roles took 22.6 ms, side by side 8-9 ms.
 static_assert(LIT_FRAMES == SEQ_FRAMES, "both roles walk the frames in the same groups");
 #ifndef ZL_LIT_PAD_BYTES
-#define ZL_LIT_PAD_BYTES (38 << 10)
+#define ZL_LIT_PAD_BYTES (22 << 10)
 #endif
 template <int MB>
-__global__ __launch_bounds__(LIT_FRAMES * MB * 4, (MB > 1 ? 2 : 1)) void zl2_lit_kernel(zl2_args a) {
+__global__ __launch_bounds__(LIT_FRAMES * MB * 4, 1) void zl2_lit_kernel(zl2_args a) {
     __shared__ LitGroupT<MB> G[LIT_FRAMES];
     __shared__ u32 rounds;  // bit r: some lane of this workgroup has block r as its leader
     // both instantiations are launched; the index kernel's verdict says which one works
