@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, 1) void zl2_lit_kernel(zl2_arg
     // both instantiations are launched; the index kernel's verdict says which one works
     if ((*a.max_blocks > 1) != (MB > 1)) return;
     if (MB == 1 && a.fuse1) return;  // (zl2_entropy1_kernel does the work)
-    // Resource shaping (general instantiation): with 38 KiB of dynamic LDS it never touches a CU
+    // Resource shaping (general instantiation): with 22 KiB of dynamic LDS it never touches a CU
     // takes ONE literal workgroup plus one sequence workgroup (or three sequence workgroups where no
     // literal workgroup is left) instead of two literal workgroups that would keep the sequence
     // chains -- the longer pole -- waiting.
