@@ -10,16 +10,17 @@ from zstdlite_amd import _lib
 from zl_testlib import GENERATORS, Oracle, Ref, have_ref, is_error
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+single = len(sys.argv) > 3 and sys.argv[3] == "single"  # only single-block reference frames: the fused entropy kernel with its quad chains
 o = Oracle(); L = _lib.lib()
 base = []
 for gen in ("text", "iid10", "int20"):
     for n in (300, 5000, 20000, 70000, 131072):
         d = GENERATORS[gen](n, seed=n)
-        base.append((z.zstd_compress(d), n))
+        if not single: base.append((z.zstd_compress(d), n))
 if have_ref():
     ref = Ref()
     for gen in ("text", "iid10"):
-        for n in (5000, 65536, 131072, 300000):
+        for n in ((5000, 30000, 65536, 100000, 131072) if single else (5000, 65536, 131072, 300000)):
             d = GENERATORS[gen](n, seed=n + 1)
             base.append((ref.compress(d, level=3), n))
 print(len(base), "base frames;", sum(len(f) for f, _ in base), "compressed bytes")
