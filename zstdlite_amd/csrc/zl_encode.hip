@@ -169,7 +169,8 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #endif
 // DICT: a dictionary's content sits in front of every chunk.  A template parameter: without it the
 // position arithmetic, the pointer selects and the straddle tests of the dictionary fold away (5.93 -> 5.80 ms).
-template <bool DICT>
+// PROF: the in-kernel phase stamps of ZL_c_profile = 2 (compiled out otherwise: 0.7 %).
+template <bool DICT, bool PROF>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     __shared__ MatchShared S;
     ZL_POISON(S, 4);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
     u32 pref_ip2 = 0xFFFFFFFFu;
-    const bool prof = a.stats != nullptr && t == 0;
+    const bool prof = PROF && a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     for (u32 ip = 0; ip < n;) {
         u32 win, win_seqs = 0;
@@ -707,8 +708,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* con
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    if (a->dict_len) hipLaunchKernelGGL(zl_match_auto_kernel<true>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else hipLaunchKernelGGL(zl_match_auto_kernel<false>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -1862,7 +1864,7 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false>, ENC_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false>, ENC_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
     return n;
 }
