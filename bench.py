@@ -167,6 +167,49 @@ def c2_decode(codec, device, log, nframes=10000):
             "compressed_bytes": int(blob.size), "bit_exact": True}
 
 
+class _DryCodec:
+    """--dry only: stands in for the HIP codec so that the multi-rank CONTROL FLOW of a step (shard
+    buffers, size all-gather, payload gather to rank 0, drains, max-over-ranks timing) can run on CPU
+    ranks under gloo in the tests.  "Compression" is a copy; nothing it prints is a measurement."""
+
+    def __init__(self):
+        from zstdlite_amd.shard import CHUNK
+        self.chunk = CHUNK
+
+    def bound(self, n):
+        return n + 64
+
+    def chunk_content_sizes(self, n):
+        k = max(1, -(-n // self.chunk))
+        cs = np.full(k, self.chunk, dtype=np.uint64)
+        cs[-1] = n - (k - 1) * self.chunk
+        return cs
+
+    def compress(self, src, dst):
+        dst[:src.numel()].copy_(src)
+        return dst, int(src.numel()), self.chunk_content_sizes(int(src.numel()))
+
+    @staticmethod
+    def frame_table(fs, cs):
+        return None
+
+    def decompress(self, src, table, dst):
+        dst.copy_(src[:dst.numel()])
+        return int(dst.numel()), None
+
+    def kernel_ms(self):
+        return {}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,22 +218,51 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 30, help="raw bytes per GPU (default 1 GiB)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-c2", action="store_true", help="skip the 10k x 64 KiB frame decode leg")
+    ap.add_argument("--dry", action="store_true", help="control flow only, CPU ranks over gloo (tests); prints no measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched without torchrun: start the N ranks ourselves.  This parent has not touched the GPU
+        # (no torch import yet), so it only waits for the child launcher and passes its exit code on.
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
-    from zstdlite_amd.device import DeviceCodec, gen_mixed
+    from zstdlite_amd.device import gen_mixed
     from zstdlite_amd.shard import gather_compressed
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry:
+        device = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible device(s)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
+        sync = torch.cuda.synchronize
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        # every rank on its own device, and the communicator as large as the flag says
+        ids = [None] * world
+        dist.all_gather_object(ids, (local_rank, "cpu" if args.dry else str(torch.cuda.get_device_properties(local_rank).uuid)
+                                     if hasattr(torch.cuda.get_device_properties(local_rank), "uuid") else local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert len({i[0] for i in ids}) == world, f"ranks share a device: {ids}"
+        if not args.dry:
+            assert len({i[1] for i in ids}) == world, f"ranks share a device: {ids}"
 
     def log(msg):
         if rank == 0:
@@ -198,7 +270,11 @@ def main():
 
     n = args.size
     src, kinds, quarter = gen_mixed(n, device)
-    codec = DeviceCodec(level=3, profile=True)
+    if args.dry:
+        codec = _DryCodec()
+    else:
+        from zstdlite_amd.device import DeviceCodec
+        codec = DeviceCodec(level=3, profile=True)
     # two compressed buffers (and two gather buffers on rank 0): the gather of one step's shard runs
     # while the next step computes; every gather is waited for inside the timed region
     comps = [torch.empty(codec.bound(n), dtype=torch.uint8, device=device) for _ in range(2 if world > 1 else 1)]
@@ -216,7 +292,8 @@ def main():
                 w.wait()  # (RCCL: orders torch's current stream behind the transfer, does not block the host)
             # the codec launches on its own streams, so the host itself must see the transfer finished
             # before the next compression may overwrite this buffer
-            torch.cuda.current_stream().synchronize()
+            if not args.dry:
+                torch.cuda.current_stream().synchronize()
         pending[slot] = []
 
     def step():
@@ -241,7 +318,7 @@ def main():
     kms_sum = {}
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         csize = step()
@@ -249,19 +326,38 @@ def main():
             kms_sum[k] = kms_sum.get(k, 0.0) + v
     drain(0)
     drain(1)
-    torch.cuda.synchronize()
+    sync()
+    own = time.perf_counter() - t0  # this rank's own time, before waiting for the others
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_gbps = [n * args.steps / own / 1e9]
+    gather_ms = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine = torch.tensor([per_rank_gbps[0]], dtype=torch.float64, device=device)
+        allr = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank_gbps = [float(x) for x in allr.cpu().tolist()]
+        # the exchange step on its own (not overlapped): sizes + payloads of one step to rank 0
+        dist.barrier()
+        sync()
+        tg = time.perf_counter()
+        gathered[0], _ = gather_compressed(comps[0], csize, root=0, out=gathered[0])
+        sync()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
     assert torch.equal(back, src), "round trip is not bit-exact"
     ms_per_step = elapsed / args.steps * 1e3
     kms = {k: v / args.steps for k, v in kms_sum.items()}
 
-    if rank == 0:
+    if rank == 0 and args.dry:
+        print(json.dumps({"dry": True, "metric": "control flow only (no measurement)", "value": None, "n_gpus": world,
+                          "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+                          "bytes_per_rank": n, "per_rank_ok": len(per_rank_gbps) == world}), flush=True)
+    elif rank == 0:
         value = world * n / (ms_per_step / 1e3) / 1e9
         t_comp = sum(kms.get(k, 0.0) for k in ("match", "entropy", "scan", "gather"))
         out = {
@@ -276,6 +372,7 @@ def main():
             "compress_GBps_kernels": (n / (t_comp / 1e3) / 1e9) if t_comp else None,
             "decompress_GBps_kernel": (n / (kms["decode"] / 1e3) / 1e9) if kms.get("decode") else None,
             "kernel_ms": kms,
+            "per_rank_GBps": per_rank_gbps, "gather_ms_standalone": gather_ms,
         }
         # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the timed steps)
         if kms:

@@ -258,6 +258,46 @@ def gen_text(n, seed=SEED):
 GENERATORS = {"rand": gen_rand, "iid10": gen_iid10, "text": gen_text, "int20": gen_int20}
 
 
+# ---- inputs with LONG-RANGE redundancy (repeats further back than one 128 KiB chunk): what the
+# reference's level 3 sees through its 2 MiB window (zstd.c:29529) and chunk-local matching cannot
+def gen_records(n, seed=SEED):
+    """A 1 MiB pseudo-random block repeated, every copy after the first with 1 % of its bytes replaced."""
+    rng = np.random.default_rng(seed + 4)
+    blk = 1 << 20
+    base = rng.integers(0, 256, size=blk, dtype=np.uint8)
+    parts = []
+    for i in range((n + blk - 1) // blk):
+        b = base.copy()
+        if i:
+            idx = rng.integers(0, blk, size=blk // 100)
+            b[idx] = rng.integers(0, 256, size=idx.size, dtype=np.uint8)
+        parts.append(b)
+    return np.concatenate(parts).tobytes()[:n] if parts else b""
+
+
+_CORPUS_ROOT = "/usr/lib/python3.10"
+
+
+def gen_corpus(n=None, seed=None):
+    """The .py files of the Python standard library of this image (identical here and on the GPU box),
+    sorted by path and concatenated (about 10.7 MB); n = None gives all of it, a larger n repeats it."""
+    import glob
+    key = "_corpus_cache"
+    blob = globals().get(key)
+    if blob is None:
+        files = sorted(f for f in glob.glob(os.path.join(_CORPUS_ROOT, "**", "*.py"), recursive=True)
+                       if "site-packages" not in f and "dist-packages" not in f)
+        blob = b"".join(open(f, "rb").read() for f in files)
+        globals()[key] = blob
+    if n is None:
+        return blob
+    reps = -(-n // max(len(blob), 1))
+    return (blob * reps)[:n]
+
+
+LONG_RANGE = {"records": gen_records, "corpus": gen_corpus}
+
+
 def sha256(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 

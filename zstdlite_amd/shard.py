@@ -36,6 +36,8 @@ def gather_compressed(payload, total, root=0, group=None, out=None, wait=True):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = payload.device
+    # P2POp peers are GLOBAL ranks; inside a sub-group the group-relative numbers must be translated
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([int(total)], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
@@ -49,10 +51,10 @@ def gather_compressed(payload, total, root=0, group=None, out=None, wait=True):
             if r == root:
                 out[off:off + hs[r]].copy_(payload[:hs[r]])
             elif hs[r]:
-                ops.append(dist.P2POp(dist.irecv, out[off:off + hs[r]], r, group=group))
+                ops.append(dist.P2POp(dist.irecv, out[off:off + hs[r]], peer(r), group=group))
             off += hs[r]
     else:
-        ops = [dist.P2POp(dist.isend, payload[:int(total)], root, group=group)] if total else []
+        ops = [dist.P2POp(dist.isend, payload[:int(total)], peer(root), group=group)] if total else []
     works = dist.batch_isend_irecv(ops) if ops else []
     if not wait:
         return (out if rank == root else None), hs, works
