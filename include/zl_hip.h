@@ -43,6 +43,20 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 #define ZL_c_nbWorkers 400        /* zstd.h:449  ZSTD_c_nbWorkers (accepted, ignored: the GPU path is always parallel) */
 #define ZL_c_stableInBuffer 1006  /* zstd.h:2083 ZSTD_c_stableInBuffer  (accepted, no-op) */
 #define ZL_c_stableOutBuffer 1007 /* zstd.h:2103 ZSTD_c_stableOutBuffer (accepted, no-op) */
+/* Frame layout of inputs larger than one 128 KiB chunk (new; no libzstd twin).
+ *   ZL_layout_one_frame (2): ONE zstd frame, like ZSTD_compress2 writes (src/raw-file.c:74): the chunks become
+ *     consecutive runs of blocks of that frame, matches reach up to 2 MiB back across chunks (window log 21 as the
+ *     reference's level 3, zstd.c:29529), zl_findFrameCompressedSize(out) == bytes written, and a reader that takes
+ *     the first frame only (src/raw-file.c:150-155, src/raw-file-in.c:66) gets everything.
+ *   ZL_layout_frames (1): one independent frame per chunk, concatenated: decodes fastest (no chunk depends on
+ *     another), but a first-frame reader sees 128 KiB, and nothing further back than the chunk is matched.
+ *   ZL_layout_auto (0, default): one frame for zl_compress2 / zl_compressStream2, independent frames for the
+ *     device-resident and batch entries.  A context with a dictionary or with ZL_c_checksumFlag always writes
+ *     independent frames (a dictionary frame is small by nature; XXH64 over one huge frame is a serial chain). */
+#define ZL_c_frameLayout 9003
+#define ZL_layout_auto 0
+#define ZL_layout_frames 1
+#define ZL_layout_one_frame 2
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
 #define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
 
@@ -187,6 +201,7 @@ size_t zl_DStreamOutSize(void);
 #define ZL_c_profile 9001
 #define ZL_d_profile 9002
 size_t zl_cctx_kernel_ms(const zl_cctx *cctx, double *ms);
+size_t zl_cctx_far_ms(const zl_cctx *cctx, double *ms); /* the far-table passes in front of the match kernel (one-frame layout; 0 otherwise) */
 size_t zl_dctx_kernel_ms(const zl_dctx *dctx, double *ms);
 /* Frames this context has decoded with the large-frame pipeline (one frame of many blocks spread over
  * the whole device: what ZSTD_compress2 writes for inputs above 128 KiB, src/raw-file.c:74) rather

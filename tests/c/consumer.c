@@ -31,8 +31,6 @@ int main(void) {
     dctx = zl_createDCtx();                                              /* dctx.c:119 */
     CHECK(cctx && dctx, "contexts");
     CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 100 /* ZSTD_c_compressionLevel */, 3)), "level");
-    CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 201 /* ZSTD_c_checksumFlag */, 1)), "checksum flag");
-    CHECK(!zl_isError(zl_CCtx_getParameter(cctx, 201, &value)) && value == 1, "get parameter");
     CHECK(zl_isError(zl_CCtx_setParameter(cctx, 100, 1000)), "level out of range is an error");
     CHECK(strcmp(zl_getErrorName((size_t)0 - 20), "Data corruption detected") == 0, "error string");
 
@@ -44,15 +42,30 @@ int main(void) {
     } else {
         zl_inBuffer in;
         zl_outBuffer out;
-        size_t rem, spos = 0;
-        unsigned char *stream = (unsigned char *)malloc(bound);
+        size_t rem, spos = 0, csize2;
+        unsigned long long fcs;
+        unsigned char *stream = (unsigned char *)malloc(bound), *dst2 = (unsigned char *)malloc(bound);
+        CHECK(stream && dst2, "malloc");
         CHECK(!zl_isError(csize), zl_getErrorName(csize));
-        fsize = zl_findFrameCompressedSize(dst, csize);                  /* raw-file.c:150: first frame only */
-        CHECK(!zl_isError(fsize) && fsize <= csize, "frame size");
-        CHECK(zl_getFrameContentSize(dst, csize) == 131072, "one frame per 128 KiB chunk");   /* raw-file.c:155 */
-        CHECK(zl_findDecompressedSize(dst, csize) == n, "whole-buffer size twin");
-        total = zl_decompressDCtx(dctx, back, n, dst, csize);            /* raw-file.c:189 */
-        CHECK(total == n && memcmp(src, back, n) == 0, "one-shot round trip");
+        /* exactly the reference glue's read side, first-frame helpers only (raw-file.c:150-189): ONE frame holds all 3 MiB */
+        fsize = zl_findFrameCompressedSize(dst, csize);                  /* raw-file.c:150 */
+        CHECK(!zl_isError(fsize) && fsize == csize, "zl_compress2 writes one frame");
+        fcs = zl_getFrameContentSize(dst, fsize);                        /* raw-file.c:155 */
+        CHECK(fcs == n, "the frame records the whole content size");
+        total = zl_decompressDCtx(dctx, back, (size_t)fcs, dst, fsize);  /* raw-file.c:189 */
+        CHECK(total == n && memcmp(src, back, n) == 0, "one-shot round trip through the first-frame helpers");
+        /* a checksum context writes one independent frame per 128 KiB chunk: the whole-buffer twins size those */
+        CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 201 /* ZSTD_c_checksumFlag */, 1)), "checksum flag");
+        CHECK(!zl_isError(zl_CCtx_getParameter(cctx, 201, &value)) && value == 1, "get parameter");
+        csize2 = zl_compress2(cctx, dst2, bound, src, n);
+        CHECK(!zl_isError(csize2), zl_getErrorName(csize2));
+        CHECK(zl_getFrameContentSize(dst2, csize2) == 131072, "checksum: one frame per 128 KiB chunk");
+        CHECK(zl_findDecompressedSize(dst2, csize2) == n && zl_findAllFramesCompressedSize(dst2, csize2) == csize2, "whole-buffer size twins");
+        memset(back, 0, n);
+        total = zl_decompressDCtx(dctx, back, n, dst2, csize2);
+        CHECK(total == n && memcmp(src, back, n) == 0, "round trip of concatenated checksummed frames");
+        CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 201, 0)), "checksum flag off");
+        free(dst2);
         /* streaming out (raw-file-out.c:74-123): pledge, whole buffer as input, output in pieces */
         CHECK(!zl_isError(zl_CCtx_setPledgedSrcSize(cctx, n)), "pledge");
         in.src = src; in.size = n; in.pos = 0;

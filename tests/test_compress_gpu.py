@@ -100,8 +100,10 @@ def test_checksum_adds_four_bytes_per_frame():
     with pytest.raises(z.ZstdError, match="doesn't match checksum"):
         z.zstd_unserialize(bytes(bad))
     assert z.zstd_unserialize(bytes(bad), dctx=z.zstd_dctx(validate_checksum=False)) == dat
+    # a checksum context writes one independent frame per 128 KiB chunk (XXH64 over one huge frame would be one
+    # serial chain): four frames here, each four bytes longer than without
     big = GENERATORS["text"](400000)
-    assert len(z.zstd_compress(big, include_checksum=True)) == len(z.zstd_compress(big)) + 4 * 4
+    assert len(z.zstd_compress(big, include_checksum=True)) == len(z.zstd_compress(big, frame_layout="frames")) + 4 * 4
 
 
 def test_serialize_roundtrip():
@@ -115,8 +117,9 @@ def test_batch_compress(oracle):
     items = [GENERATORS[g](n, seed=i) for i, (g, n) in enumerate(
         [("text", 0), ("text", 300), ("iid10", 5000), ("rand", 777), ("int20", 70000), ("text", 200000), ("text", 131072)])]
     comps = z.zstd_compress_batch(items)
-    singles = [z.zstd_compress(x) for x in items]
+    singles = [z.zstd_compress(x, frame_layout="frames") for x in items]  # batch items are independent frames per chunk
     assert comps == singles
+    assert [z.zstd_compress(x) for x in items if len(x) <= 131072] == [c for x, c in zip(items, comps) if len(x) <= 131072]
     for x, c in zip(items, comps):
         assert oracle.decompress(c, cap=len(x)) == x
     assert z.zstd_decompress_batch([c for x, c in zip(items, comps) if len(x) <= 131072]) == [x for x in items if len(x) <= 131072]

@@ -32,6 +32,7 @@ __all__ = [
 ZL_c_compressionLevel = 100
 ZL_c_checksumFlag = 201
 ZL_c_nbWorkers = 400
+ZL_c_frameLayout = 9003  # include/zl_hip.h: 0 auto, 1 independent frames, 2 one frame
 ZL_d_forceIgnoreChecksum = 1002
 _UNKNOWN = (1 << 64) - 1
 _ERROR = (1 << 64) - 2
@@ -100,6 +101,10 @@ def _init_cctx_with_opts(opts, quiet=False):
                     raise ZstdError("init_cctx(): Couldn't set checksum flag")
         elif name == "dict":
             dict_ = val
+        elif name == "frame_layout":  # (not in the reference: include/zl_hip.h ZL_c_frameLayout)
+            code = {"auto": 0, "frames": 1, "one_frame": 2}.get(val)
+            if code is None or is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_frameLayout, code)):
+                raise ZstdError("init_cctx(): 'frame_layout' must be 'auto', 'frames' or 'one_frame'")
         elif not quiet:
             warnings.warn(f"init_cctx(): Unknown option '{name}'")
     if dict_ is not None:
@@ -132,10 +137,13 @@ def _init_dctx_with_opts(opts, quiet=False):
     return dctx
 
 
-def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None):
-    """R/cctx.R:38-48 -> init_cctx_ (src/cctx.c:323)."""
+def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None, frame_layout="auto"):
+    """R/cctx.R:38-48 -> init_cctx_ (src/cctx.c:323).  frame_layout is this library's own knob (the reference
+    always writes one frame): "auto" = one frame from zstd_compress / zstd_serialize, "frames" = one
+    independent frame per 128 KiB (fastest to decode; first-frame readers see the first chunk only)."""
     return _init_cctx_with_opts({"level": level, "num_threads": num_threads, "include_checksum": include_checksum,
-                                 **({"dict": dict} if dict is not None else {})})
+                                 **({"dict": dict} if dict is not None else {}),
+                                 **({"frame_layout": frame_layout} if frame_layout != "auto" else {})})
 
 
 def zstd_dctx(validate_checksum=True, dict=None):

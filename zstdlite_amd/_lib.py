@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libzl_hip.so")
+# ZL_HIP_LIB names another build of the SAME library (an A/B variant made by `python -m zstdlite_amd.build --variant`,
+# development only); whatever it names must export every symbol below or the import fails.
+LIB_PATH = os.environ.get("ZL_HIP_LIB") or os.path.join(HERE, "libzl_hip.so")
 
 _ERR_FLOOR = (1 << 64) - 120
 
@@ -53,6 +55,7 @@ SYMBOLS = [
     ("zl_compress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
     ("zl_index_frames", C.c_size_t, [C.c_void_p, C.c_size_t, C.POINTER(FrameT), C.c_size_t]),
     ("zl_cctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
+    ("zl_cctx_far_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_large_frames", C.c_size_t, [C.c_void_p]),
     ("zl_compressStream2", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -21,6 +21,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines, verbose=False):
+    """A/B builds for kernel experiments: the whole library compiled with extra -D flags into
+    zstdlite_amd/build/variants/libzl_hip.<name>.so (select it with ZL_HIP_LIB=...)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    vdir = os.path.join(HERE, "build", "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, f"libzl_hip.{name}.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + list(defines) + ["-shared", "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -47,4 +62,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

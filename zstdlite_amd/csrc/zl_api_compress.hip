@@ -20,12 +20,13 @@ struct zl_cctx_s {
     int level = 3;
     int checksum = 0;
     int nb_workers = 0;
+    int layout = 0;  // ZL_c_frameLayout: 0 auto, 1 independent frames, 2 one frame
     std::vector<u8> dict;
     bool dict_uploaded = false, dict_formatted = false;
     u32 dict_id = 0, dict_content_off = 0, dict_use = 0;  // dict_use: trailing content bytes the matcher can reach
     DevBuf d_dict, d_dict_tables, d_dict_hash, d_cdict;
     hipStream_t own_stream = nullptr;
-    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals;
+    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals, d_far_table, d_far_hints;
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
     // pending device-resident call
     bool pending = false;
@@ -34,6 +35,9 @@ struct zl_cctx_s {
     // diagnostics
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_far = nullptr;   // start of the far-table passes (windowed layout)
+    bool far_valid = false;
+    double far_ms = 0;
     bool ev_valid = false;
     double kernel_ms[4] = {0, 0, 0, 0};
     DevBuf d_stats;
@@ -97,8 +101,11 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
 // Enqueue the whole encoder over a chunk table already written to c->h_chunks (nchunks entries):
 // E1 -> E2 -> size scan -> gather, in groups that reuse the scratch.  Frames end up back to
 // back in d_dst; per-chunk sizes in d_fsize, per-group running totals in d_totals[g+1].
-size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st) {
+// joined_total != 0: the chunks are the consecutive pieces of ONE input of that many bytes and become one frame
+// (windowed layout: far matches, one header, one Last_Block).
+size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st, u64 joined_total = 0) {
     { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
+    const bool joined = joined_total != 0;
     const size_t group = std::min<size_t>(nchunks, ZL_GROUP_CHUNKS);
     const size_t ngroups = (nchunks + ZL_GROUP_CHUNKS - 1) / ZL_GROUP_CHUNKS;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
@@ -107,14 +114,29 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         !c->d_seqs.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(zl_seq)) || !c->d_sst.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(ushort4)) ||
         !c->d_staged.ensure(group * (size_t)ZL_OUT_STRIDE))
         return kGpuUnavailable;
+    if (joined && (!c->d_far_table.ensure(ZL_FAR_TABLE_BYTES(group)) || !c->d_far_hints.ensure(group * (size_t)ZL_FAR_HINT_WORDS * 4))) return kGpuUnavailable;
     if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const bool prof = c->profile && ngroups == 1;
     if (prof && !c->ev[0]) for (auto& e : c->ev) (void)hipEventCreate(&e);
+    if (prof && joined && !c->ev_far) (void)hipEventCreate(&c->ev_far);
     c->ev_valid = false;
     for (size_t g = 0; g < ngroups; g++) {
         const size_t first = g * ZL_GROUP_CHUNKS;
         const u32 cnt = (u32)std::min<size_t>(ZL_GROUP_CHUNKS, nchunks - first);
+        c->far_valid = false;
+        if (joined) {
+            if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
+            // the far table over this launch group's input, then the hint words the match kernel reads
+            zl_far_args f;
+            f.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
+            f.src = d_src;
+            f.total = joined_total;
+            f.table = (u32*)c->d_far_table.p;
+            f.hints = (u32*)c->d_far_hints.p;
+            if (hipMemsetAsync(f.table, 0, ZL_FAR_TABLE_BYTES(cnt), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            if (zl_launch_far_build(&f, cnt, st) != hipSuccess || zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        }
         zl_match_args m;
         m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
         m.src = d_src;
@@ -128,6 +150,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
         m.dict_len = c->dict_use;
         m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
+        m.far_hints = joined ? (const u32*)c->d_far_hints.p : nullptr;
         if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
             (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
             m.stats = (u64*)c->d_stats.p;
@@ -149,6 +172,11 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         e.out_stride = ZL_OUT_STRIDE;
         e.checksum = (u32)c->checksum;
         e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
+        e.joined = joined ? 1u : 0u;
+        e.chunk_base = (u32)first;
+        e.total_chunks = (u32)nchunks;
+        e.wlog = ZL_FAR_WLOG;
+        e.total_size = joined_total;
         e.cdict = (c->dict_use && c->dict_formatted) ? c->d_cdict.p : nullptr;
         e.stats = m.stats ? m.stats + 8 : nullptr;
         if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -171,6 +199,18 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     c->pending_chunks = nchunks;
     c->pending_groups = ngroups;
     return 0;
+}
+
+// Which layout a call over n bytes of ONE input takes.  One frame (windowed) needs what only it can have: no
+// dictionary (dictionary frames are small and their own), no checksum (XXH64 over the whole content is one
+// serial chain, zstd.c:11708; per-chunk frames check their 128 KiB each in parallel), more than one chunk, and
+// 32-bit positions per launch group.  host_entry: the calls that stand in for ZSTD_compress2 / ZSTD_compressStream2,
+// whose readers take the FIRST frame only (src/raw-file.c:150-155) -- there one frame is the default.
+bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
+    if (n <= ZL_CHUNK || !c->dict.empty() || c->checksum) return false;
+    if (c->layout == 1) return false;
+    if (c->layout == 2) return true;
+    return host_entry;
 }
 
 size_t fill_chunk_table(zl_cctx* c, size_t n) {
@@ -204,7 +244,8 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
-    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
+    if (c->ev_far) (void)hipEventDestroy(c->ev_far);
+    DevBuf* bufs[] = {&c->d_far_table, &c->d_far_hints, &c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
@@ -231,6 +272,10 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     case ZL_c_stableInBuffer:
     case ZL_c_stableOutBuffer: return 0;
     case ZL_c_profile: c->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
+    case ZL_c_frameLayout:
+        if (value < 0 || value > 2) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        c->layout = value;
+        return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -241,6 +286,7 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     case ZL_c_compressionLevel: *value = c->level; return 0;
     case ZL_c_checksumFlag: *value = c->checksum; return 0;
     case ZL_c_nbWorkers: *value = c->nb_workers; return 0;
+    case ZL_c_frameLayout: *value = c->layout; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -276,7 +322,7 @@ size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void*
     hipStream_t st = cctx_stream(c, stream);
     const size_t nchunks = fill_chunk_table(c, n);
     if (ZL_IS_ERR(nchunks)) return nchunks;
-    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st);
+    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, use_one_frame(c, n, false) ? (u64)n : 0);
     if (ZL_IS_ERR(e)) return e;
     c->pending = true;
     c->pending_stream = st;
@@ -293,6 +339,8 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
             (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
             c->kernel_ms[k] = ms;
         }
+        c->far_ms = 0;
+        if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->far_ms = ms; }
         if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
     if (frame_sizes) {
@@ -305,6 +353,11 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
 size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
     if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     for (int k = 0; k < 4; k++) ms[k] = c->kernel_ms[k];
+    return 0;
+}
+size_t zl_cctx_far_ms(const zl_cctx* c, double* ms) {
+    if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
+    *ms = c->far_ms;
     return 0;
 }
 
@@ -327,7 +380,7 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
     if (n && hipMemcpyAsync(c->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const size_t nchunks = fill_chunk_table(c, n);
     if (ZL_IS_ERR(nchunks)) return nchunks;
-    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
+    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st, use_one_frame(c, n, true) ? (u64)n : 0);
     if (ZL_IS_ERR(e)) return e;
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];

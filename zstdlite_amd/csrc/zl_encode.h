@@ -15,6 +15,17 @@
 #define ZL_FRAME_OVERHEAD 24                     // magic 4 + FHD 1 + dictID 4 + FCS 4 + block header 3 + checksum 4 (+ slack)
 #define ZL_OUT_STRIDE (ZL_CHUNK + ZL_FRAME_OVERHEAD + 8)
 
+// ---- far matches (single-frame "windowed" layout): a hash table in HBM over SAMPLED positions of the whole input,
+// built before the match kernel runs, gives every 32-byte neighbourhood at most one offset worth trying
+// that reaches further back than the chunk's own LDS tables (up to ZL_FAR_GROUP - 1 chunks = the frame's window).
+#define ZL_FAR_SAMPLE_LOG 4                      // one position in 16 is inserted / probed (content-defined: top hash bits zero)
+#define ZL_FAR_BUCKET_LOG 13                     // buckets per group of chunks
+#define ZL_FAR_GROUP 16                          // chunks per table group = slots per bucket: one 64-byte line
+#define ZL_FAR_WLOG 21                           // window the frame header declares: ZL_FAR_GROUP chunks of 128 KiB (the reference's level 3 uses the same, zstd.c:29529)
+#define ZL_FAR_HINT_LOG 5                        // one hint word per 32 input bytes
+#define ZL_FAR_TABLE_BYTES(nchunks) ((((size_t)(nchunks) + ZL_FAR_GROUP - 1) / ZL_FAR_GROUP) * ((size_t)ZL_FAR_GROUP << ZL_FAR_BUCKET_LOG) * 4)
+#define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
+
 struct zl_chunk_desc {
     u64 src_off;   // first byte of the chunk inside the source buffer
     u32 src_size;  // <= ZL_CHUNK
@@ -46,6 +57,15 @@ struct zl_match_args {
     u32 dict_len;     // dictionary content bytes that sit, as history, in front of every chunk (0: none)
     const u8* dict;   // those bytes
     const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)
+    const u32* far_hints;  // windowed layout only: per chunk ZL_FAR_HINT_WORDS words, [25:0] an offset worth trying around these 32 bytes (0: none)
+};
+
+struct zl_far_args {
+    const zl_chunk_desc* chunks;  // the chunks of ONE contiguous input, in order
+    const u8* src;
+    u64 total;             // bytes of that input (positions whose 8 bytes would run past it are not hashed)
+    u32* table;            // ZL_FAR_TABLE_BYTES(nchunks), zeroed before zl_launch_far_build
+    u32* hints;            // per chunk ZL_FAR_HINT_WORDS words, written by zl_launch_far_probe
 };
 
 struct zl_entropy_args {
@@ -62,6 +82,12 @@ struct zl_entropy_args {
     u32 out_stride;
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
+    // single-frame layout: the chunks of this launch are consecutive runs of blocks of ONE frame
+    u32 joined;        // 1: chunk 0 of the frame carries the frame header, only the frame's last chunk sets Last_Block, no per-chunk checksum
+    u32 chunk_base;    // index, inside the frame, of this launch's first chunk
+    u32 total_chunks;  // chunks of the whole frame
+    u32 wlog;          // window the header declares when the content is larger than it
+    u64 total_size;    // content size of the whole frame
     const void* cdict; // zl_cdict* (device) or null: the dictionary's entropy tables, offered to frames of a single block
     u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
@@ -75,6 +101,8 @@ struct zl_gather_args {
 };
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream);
+extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream);
 extern "C" hipError_t zl_launch_cdict_build(const void* d_dict_tables, void* d_cdict, hipStream_t stream);
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream);

@@ -170,7 +170,11 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 // DICT: a dictionary's content sits in front of every chunk.  A template parameter: without it the
 // position arithmetic, the pointer selects and the straddle tests of the dictionary fold away (5.93 -> 5.80 ms).
 // PROF: the in-kernel phase stamps of ZL_c_profile = 2 (compiled out otherwise: 0.7 %).
-template <bool DICT, bool PROF>
+// FAR: the windowed (single-frame) layout.  The chunk is one run of blocks of a larger frame, so offsets may reach in
+// front of it: every 32-byte neighbourhood brings at most one offset found by the far table (zl_far_*_kernel below),
+// tried as a fourth candidate by every lane of the neighbourhood -- the lane the table hit extends it forwards, the
+// lanes in front of it backwards -- and a repeat offset may point in front of the chunk as well.
+template <bool DICT, bool PROF, bool FAR>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     __shared__ MatchShared S;
     ZL_POISON(S, 4);
@@ -188,6 +192,14 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // from the dictionary (zstd.c:30120, the dictionary variant of the double-hash parse).
     const u32 D = DICT ? a.dict_len : 0u;
     const u8* const dict = a.dict;
+    static_assert(!(DICT && FAR), "a dictionary frame is a frame of its own");
+    // bytes of the frame in front of this chunk (clamped); a source position is a chunk position that may be "negative"
+    const u32 reach = FAR ? (u32)(cd.src_off < 0x7F000000ull ? cd.src_off : 0x7F000000ull) : 0u;
+    const u32* const hints = FAR ? a.far_hints + (size_t)c * ZL_FAR_HINT_WORDS : nullptr;
+    auto at = [&](u32 q) -> const u8* {  // where (virtual) position q lives
+        if (FAR) return src + (ptrdiff_t)(i32)q;
+        return q >= D ? src + (q - D) : dict + q;
+    };
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
     u32 pref_ip2 = 0xFFFFFFFFu;
+    u32 hint_pref = 0;       // FAR: the hint word of the prefetched position
     const bool prof = PROF && a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     for (u32 ip = 0; ip < n;) {
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             const u32 rep = S.rep;
             u64 v[PPT];
+            u32 far_off[PPT];
             u32 hl[PPT], hs[PPT], best_len[PPT], best_off[PPT], q_best[PPT];
             u32 word_l[PPT], word_s[PPT];  // the table words as read by the lookup (reused by the insert)
             bool in_range[PPT], can_match[PPT];
@@ -222,19 +236,21 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
                 else if (can_match[j]) v[j] = ld64(src + p);
                 else if (in_range[j]) v[j] = src[p];
+                if (FAR) far_off[j] = ((pref_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
                 hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
                 word_l[j] = word_s[j] = 0;
             }
             const bool search = carry < WIN;  // otherwise the whole window lies inside an earlier match
             // candidates of both positions are fetched together: one memory round trip.  A lane without
             // a candidate reads its own position and is masked out afterwards.
-            u64 w_r[PPT], w_l[PPT], w_s[PPT];
+            u64 w_r[PPT], w_l[PPT], w_s[PPT], w_f[PPT];
             u32 q_r[PPT], q_l[PPT], q_s[PPT];
-            bool have_r[PPT], have_l[PPT], have_s[PPT];
+            bool have_r[PPT], have_l[PPT], have_s[PPT], have_f[PPT];
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
                 const u32 p = ip + t + ENC_THREADS * j;
-                have_r[j] = have_l[j] = have_s[j] = false;
+                have_r[j] = have_l[j] = have_s[j] = have_f[j] = false;
+                w_f[j] = 0;
                 const u32 V = D + p;  // virtual position
                 q_r[j] = q_l[j] = q_s[j] = V;
                 if (can_match[j]) {
@@ -245,7 +261,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (search) {
                         const u32 el = (word_l[j] >> ((hl[j] & 1) * 16)) & 0xFFFF, es = (word_s[j] >> ((hs[j] & 1) * 16)) & 0xFFFF;
                         const u32 dl = (V + 1 - el) & 0xFFFF, ds = (V + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
-                        have_r[j] = rep && V >= rep;
+                        have_r[j] = rep && V + reach >= rep;
+                        have_f[j] = FAR && far_off[j] != 0 && far_off[j] != rep && p + reach >= far_off[j];
                         have_l[j] = el != 0 && dl != 0 && dl <= V;
                         have_s[j] = es != 0 && ds != 0 && ds <= V;
                         if (have_r[j]) q_r[j] = V - rep;
@@ -267,9 +284,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     const bool same_lr = have_l[j] && have_r[j] && q_l[j] == q_r[j];
                     const bool same_sr = have_s[j] && have_r[j] && q_s[j] == q_r[j];
                     const bool same_sl = have_s[j] && have_l[j] && q_s[j] == q_l[j];
-                    if (have_r[j]) w_r[j] = ld64(q_r[j] >= D ? src + (q_r[j] - D) : dict + q_r[j]);
-                    if (have_l[j] && !same_lr) w_l[j] = ld64(q_l[j] >= D ? src + (q_l[j] - D) : dict + q_l[j]);
-                    if (have_s[j] && !same_sr && !same_sl) w_s[j] = ld64(q_s[j] >= D ? src + (q_s[j] - D) : dict + q_s[j]);
+                    if (have_r[j]) w_r[j] = ld64(at(q_r[j]));
+                    if (have_l[j] && !same_lr) w_l[j] = ld64(at(q_l[j]));
+                    if (have_s[j] && !same_sr && !same_sl) w_s[j] = ld64(at(q_s[j]));
+                    if (FAR && have_f[j]) w_f[j] = ld64(at(ip + t + ENC_THREADS * j - far_off[j]));
                     if (same_lr) w_l[j] = w_r[j];
                     if (same_sr) w_s[j] = w_r[j];
                     else if (same_sl) w_s[j] = w_l[j];
@@ -281,6 +299,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 v_pref = 0;
                 if (pn + 8 <= n) v_pref = ld64(src + pn);
                 else if (pn < n) v_pref = src[pn];
+                if (FAR) hint_pref = pn < n ? hints[pn >> ZL_FAR_HINT_LOG] : 0u;
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
@@ -290,11 +309,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
                     if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
                     if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
+                    // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
+                    if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
                     while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < LANE_MATCH_CAP && p + best_len[j] + 8 <= n) {
                         const u32 qv = q_best[j] + best_len[j];
                         if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
-                        const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(qv >= D ? src + (qv - D) : dict + qv));
+                        const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(at(qv)));
                         best_len[j] += l;
                         if (l < 8) break;
                     }
@@ -459,15 +480,18 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             const bool search = carry_n < ENC_THREADS;  // otherwise the whole window lies inside an earlier match
             u32 hl0 = 0, hs0 = 0, hl1 = 0, hs1 = 0, wl0 = 0, ws0 = 0, wl1 = 0, ws1 = 0;
             u32 best_len = 0, best_off = 0, q_best = p;
-            bool have_r = false, have_l = false, have_s = false;
+            bool have_r = false, have_l = false, have_s = false, have_f = false;
             u32 q_r = p, q_l = p, q_s = p;
+            u32 far_off2 = 0;
+            if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
             if (can0) {
                 hl0 = hash8(v0); hs0 = hash5(v0);
                 wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1];
                 if (search) {
                     const u32 el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF, es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF;
                     const u32 dl = (p + 1 - el) & 0xFFFF, ds = (p + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
-                    have_r = rep && p >= rep;
+                    have_r = rep && p + reach >= rep;
+                    have_f = FAR && far_off2 != 0 && far_off2 != rep && p + reach >= far_off2;
                     have_l = el != 0 && dl != 0 && dl <= p;
                     have_s = es != 0 && ds != 0 && ds <= p;
                     if (have_r) q_r = p - rep;
@@ -479,12 +503,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 hl1 = hash8(v1); hs1 = hash5(v1);
                 wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
-            u64 w_r = 0, w_l = 0, w_s = 0;
+            u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
             if (can0 && search) {  // (as in the stride-1 body: candidates are fetched by the lanes that have one, each position once)
                 const bool same_lr = have_l && have_r && q_l == q_r, same_sr = have_s && have_r && q_s == q_r, same_sl = have_s && have_l && q_s == q_l;
-                if (have_r) w_r = ld64(src + q_r);
+                if (have_r) w_r = ld64(at(q_r));
                 if (have_l && !same_lr) w_l = ld64(src + q_l);
                 if (have_s && !same_sr && !same_sl) w_s = ld64(src + q_s);
+                if (FAR && have_f) w_f = ld64(at(p - far_off2));
                 if (same_lr) w_l = w_r;
                 if (same_sr) w_s = w_r;
                 else if (same_sl) w_s = w_l;
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 const u32 pn = ip + WIN2 + 2 * t;
                 pref_ip2 = ip + WIN2;
                 pref0 = 0; pref1 = 0;
-                if (pn + 15 <= n) { pref0 = ld64(src + pn - 1); pref1 = ld64(src + pn + 7); }
+                if (pn + 15 <= n) { pref0 = ld64(src + pn - 1); pref1 = ld64(src + pn + 7); if (FAR) hint_pref = hints[pn >> ZL_FAR_HINT_LOG]; }
                 else pref_ip2 = 0xFFFFFFFFu;  // the ragged end is read byte by byte when it is reached
             }
             if (can0 && search) {
@@ -502,9 +527,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 // (a 4-byte hit is kept for now: it is worth a new offset only if the byte in front matches too, see below)
                 if (have_l && l_l >= MIN_MATCH && l_l > best_len) { best_len = l_l; best_off = p - q_l; q_best = q_l; }
                 if (have_s && best_len < 8 && l_s >= MIN_MATCH && l_s > best_len) { best_len = l_s; best_off = p - q_s; q_best = q_s; }
+                if (FAR && have_f && best_len < 8 && common_bytes(v0, w_f) == 8) { best_len = 8; best_off = far_off2; q_best = p - far_off2; }
                 // extend while whole 8-byte words keep matching
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < LANE_MATCH_CAP && p + best_len + 8 <= n) {
-                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + q_best + best_len));
+                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(at(q_best + best_len)));
                     best_len += l;
                     if (l < 8) break;
                 }
@@ -514,7 +540,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             // front of the candidate is fetched now (it is needed when the sequence is written): if it
             // equals the byte in front of p and that byte is still a free literal, the match starts there.
             u32 cand_before = 0x100;
-            if (has_match && p >= 1 && q_best >= 1) cand_before = src[q_best - 1];
+            if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);
             const bool back_ok = cand_before == byte_before;
     #ifndef ZL_SPARSE_MIN
 #define ZL_SPARSE_MIN 5
@@ -674,8 +700,53 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
         atomicAdd((unsigned long long*)&a.stats[4], (unsigned long long)c_it);
         atomicAdd((unsigned long long*)&a.stats[5], (unsigned long long)nseq);
     }
+    // ---- merge continuation pieces.  A lane verifies at most LANE_MATCH_CAP bytes, so a longer match arrives as
+    // several sequences: one starts where the last one ends, with the same offset and no literal between them.
+    // Coded as they are, every piece after the first would spell its offset out (a repeat offset needs a literal in
+    // front of it, zstd.c:19680); joined, they are the one sequence the reference would have found.  One pass over
+    // the chunk's sequences, 256 at a time, compacting in place: heads move down, pieces add their length to
+    // their head.  (The match tables are dead by now: their LDS holds the tile's ends and offsets.)
+    u32 out_n = nseq;
+    if (nseq > 1) {
+        zl_sync_global();  // the sequences were written by other lanes
+        u32* const t_end = S.tbl_long;        // [256] where the sequence of lane t ends
+        u32* const t_off = S.tbl_long + 256;  // [256] its offset
+        u32 carried_end = 0xFFFFFFFFu, carried_off = 0;  // of the last sequence of the tile before (uniform)
+        out_n = 0;
+        for (u32 base = 0; base < nseq; base += ENC_THREADS) {
+            const u32 i = base + t;
+            const bool on = i < nseq;
+            zl_seq sq;
+            sq.lit_cum = sq.match_len = sq.offset = sq.pos = 0;
+            if (on) sq = seqs[i];
+            t_end[t] = on ? sq.pos + sq.match_len : 0xFFFFFFFFu;
+            t_off[t] = sq.offset;
+            zl_sync_global();  // every lane holds its sequence before any slot of the array is rewritten
+            const u32 pe = t ? t_end[t - 1] : carried_end, po = t ? t_off[t - 1] : carried_off;
+            const bool cont = on && sq.pos == pe && sq.offset == po;
+            const bool head = on && !cont;
+            const u64 mh = __ballot(head);
+            const u32 wave = t >> 6, wh = (u32)__popcll(mh);
+            if ((t & 63) == 0) S.scan_a[wave] = wh;
+            const u32 last = (nseq - base < ENC_THREADS ? nseq - base : ENC_THREADS) - 1;
+            const u32 next_end = t_end[last], next_off = t_off[last];
+            lds_barrier();
+            u32 pre = 0, tot = 0;
+#pragma unroll
+            for (u32 w = 0; w < 4; w++) { const u32 x = S.scan_a[w]; if (w < wave) pre += x; tot += x; }
+            // heads up to and including this lane: the head's new slot is that count minus one
+            const u32 dest = out_n + pre + (u32)__popcll(mh & ((2ull << (t & 63)) - 1)) - 1;
+            if (head) seqs[dest] = sq;
+            zl_sync_global();  // heads are in place before their pieces add to them
+            if (cont) atomicAdd(&seqs[dest].match_len, sq.match_len);
+            carried_end = next_end;
+            carried_off = next_off;
+            out_n += tot;
+            lds_barrier();
+        }
+    }
     if (t == 0) {
-        a.meta[c].nseq = nseq;
+        a.meta[c].nseq = out_n;
         a.meta[c].nlit = nlit;
     }
 }
@@ -706,11 +777,122 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* con
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) out[(1u << LONG_LOG) / 2 + i] = S.tbl_short[i];
 }
 
+// ---------------------------------------------------------------------------------------
+// Far matches (windowed layout).  The chunk-local tables see 64 KiB at most and nothing in front of the
+// chunk; the reference's level 3 sees 2 MiB (zstd.c:29529).  What lies further back is found through a
+// hash table in HBM over SAMPLED positions: a position takes part when the top bits of the hash of its
+// 8 bytes are zero -- a property of the content, so the two occurrences of a repeat are sampled alike
+// (the idea of the reference's long-distance matcher, zstd.c:33790 ZSTD_ldm_*, restated for a machine
+// that cannot walk the input in order).  Two passes over the input, both one workgroup per chunk:
+//   zl_far_build_kernel  table[group of 16 chunks][bucket][chunk mod 16] = max (position in chunk << 15 | tag);
+//                        "max" makes the content independent of scheduling (determinism), one slot per
+//                        chunk keeps a later chunk from hiding an earlier one from the chunks in between
+//   zl_far_probe_kernel  every sampled position reads the slots of the 15 chunks in front of its own
+//                        (the two 64-byte lines of its bucket), checks the nearest one whose tag agrees
+//                        against the bytes, and the longest hit of every 32-byte neighbourhood becomes
+//                        that neighbourhood's hint word: the offset the match kernel tries there.
+// All chunks but the last are ZL_CHUNK bytes and contiguous, so chunk k steps back are k * ZL_CHUNK bytes.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 far_hash(u64 v) { return v * 0x9E3779B185EBCA87ULL; }
+__device__ __forceinline__ bool far_sampled(u64 h) { return (h >> (64 - ZL_FAR_SAMPLE_LOG)) == 0; }
+__device__ __forceinline__ u32 far_bucket(u64 h) { return (u32)(h >> (64 - ZL_FAR_SAMPLE_LOG - ZL_FAR_BUCKET_LOG)) & ((1u << ZL_FAR_BUCKET_LOG) - 1); }
+__device__ __forceinline__ u32 far_tag(u64 h) { return (u32)(h >> (64 - ZL_FAR_SAMPLE_LOG - ZL_FAR_BUCKET_LOG - 15)) & 0x7FFFu; }
+__device__ __forceinline__ size_t far_slot(u32 chunk, u32 bucket) {
+    return ((((size_t)(chunk / ZL_FAR_GROUP)) << ZL_FAR_BUCKET_LOG) + bucket) * ZL_FAR_GROUP + (chunk % ZL_FAR_GROUP);
+}
+// positions p < far_limit have their 8 bytes inside the input
+__device__ __forceinline__ u32 far_limit(const zl_far_args& a, const zl_chunk_desc& cd) {
+    const u64 left = a.total - cd.src_off;
+    return left >= (u64)cd.src_size + 8 ? cd.src_size : (left >= 8 ? (u32)(left - 7) : 0u);
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
+    const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const zl_chunk_desc cd = a.chunks[c];
+    const u8* src = a.src + cd.src_off;
+    const u32 lim = far_limit(a, cd);
+    for (u32 ip = 0; ip < lim; ip += ENC_THREADS) {
+        const u32 p = ip + t;
+        bool on = false;
+        u32 bucket = 0, val = 0;
+        if (p < lim) {
+            const u64 h = far_hash(ld64(src + p));
+            on = far_sampled(h);
+            bucket = far_bucket(h);
+            val = (p << 15) | far_tag(h);
+        }
+        // one insert per bucket and wave -- the wave's highest position wins anyway, and a run of equal
+        // bytes would otherwise send 64 atomics to one word
+        u64 m = __ballot(on);
+        while (m) {
+            const int first = __ffsll((unsigned long long)m) - 1;
+            const u32 b = __shfl(bucket, first, 64);
+            const u64 same = __ballot(on && bucket == b);
+            if (lane == 63u - (u32)__clzll((long long)same)) atomicMax(a.table + far_slot(c, b), val);
+            m &= ~same;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
+    const u32 c = blockIdx.x, t = threadIdx.x;
+    const zl_chunk_desc cd = a.chunks[c];
+    const u8* src = a.src + cd.src_off;
+    const u32 n = cd.src_size, lim = far_limit(a, cd);
+    u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
+    for (u32 ip = 0; ip < n; ip += ENC_THREADS) {
+        const u32 p = ip + t;
+        u32 best = 0;
+        u64 v = 0, h = 1ull << 63;
+        if (p < lim) { v = ld64(src + p); h = far_hash(v); }
+        if (far_sampled(h) && c > 0) {
+            const u32 bucket = far_bucket(h), tag = far_tag(h);
+            u32 e[ZL_FAR_GROUP - 1];  // the 15 slots travel together: one round trip
+#pragma unroll
+            for (u32 k = 1; k < ZL_FAR_GROUP; k++) e[k - 1] = k <= c ? a.table[far_slot(c - k, bucket)] : 0u;
+            u32 off = 0;  // of the nearest chunk whose slot carries our tag
+#pragma unroll
+            for (u32 k = ZL_FAR_GROUP - 1; k >= 1; k--) {
+                const u32 x = e[k - 1];
+                if (x != 0 && (x & 0x7FFFu) == tag) off = k * ZL_CHUNK + p - (x >> 15);
+            }
+            if (off) {
+                const u8* q = src + p - off;
+                if (ld64(q) == v) {
+                    u32 len = 8;
+                    while (len < 32 && p + len < lim) {
+                        const u32 l = common_bytes(ld64(src + p + len), ld64(q + len));
+                        len += l;
+                        if (l < 8) break;
+                    }
+                    best = (len << 26) | off;
+                }
+            }
+        }
+        // the longest hit of each 32-byte neighbourhood (ties: the larger offset -- any fixed rule will do)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+        if ((t & 31) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best;
+    }
+}
+
+extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_far_build_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    return hipGetLastError();
+}
+extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_far_probe_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -1188,6 +1370,25 @@ __device__ __noinline__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 d
     return pos;
 }
 
+// zstd.c:27089 ZSTD_writeFrameHeader for the single-frame layout: a frame of `total` bytes whose blocks are written by
+// many chunks.  Single_Segment when the content fits the window (zstd.c:27100), else a Window_Descriptor of 2^wlog.
+__device__ __forceinline__ u32 joined_header_size(u64 total, u32 wlog) {
+    const bool single = total <= (1ull << wlog);
+    const u32 fcs = total < 256 ? (single ? 1u : 2u) : (total < 65536 + 256 ? 2u : (total < 0xFFFFFFFFull ? 4u : 8u));
+    return 5 + (single ? 0u : 1u) + fcs;
+}
+__device__ __noinline__ u32 write_frame_header_joined(u8* p, u64 total, u32 wlog) {
+    wr_le(p, ZL_MAGIC, 4);
+    const bool single = total <= (1ull << wlog);
+    const u32 fcs = joined_header_size(total, wlog) - 5 - (single ? 0u : 1u);
+    const u32 fcs_flag = fcs == 1 ? 0u : (fcs == 2 ? 1u : (fcs == 4 ? 2u : 3u));
+    p[4] = (u8)((fcs_flag << 6) | (single ? (1u << 5) : 0u));
+    u32 pos = 5;
+    if (!single) p[pos++] = (u8)((wlog - 10) << 3);
+    wr_le(p + pos, fcs == 2 ? total - 256 : total, fcs);
+    return pos + fcs;
+}
+
 // Bits (x256) a symbol costs in an FSE table, read off its encoding transform: between min and min + 1
 // bits, by the share of its states that take the larger count (the estimate zstd.c:15560 FSE_bitCost makes)
 __device__ __forceinline__ u32 fse_bit_cost(int dnb, u32 log) {
@@ -1325,11 +1526,19 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
 #define ENT_STAMP(k_) if (prof) { const u64 now__ = __builtin_amdgcn_s_memtime(); pt[k_] += now__ - p_last; p_last = now__; }
 
     // ---- frame header; the blocks follow
-    const u32 fh = (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
+    // (single-frame layout: only the frame's first chunk carries a header, only its last one ends the frame)
+    const bool joined = a.joined != 0;
+    const bool frame_first = !joined || a.chunk_base + c == 0, frame_last = !joined || a.chunk_base + c + 1 == a.total_chunks;
+    const u32 fh = joined ? (frame_first ? joined_header_size(a.total_size, a.wlog) : 0u)
+                          : (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
     for (u32 i = t; i < 4 * 256; i += ENC_THREADS) (&S.hist[0][0])[i] = 0;
     for (u32 i = t; i < 3 * 64; i += ENC_THREADS) (&S.seq_hist[0][0])[i] = 0;
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
-    if (t == 0) { S.fail = 0; write_frame_header(out, n, a.checksum, a.dict_id); }
+    if (t == 0) {
+        S.fail = 0;
+        if (!joined) write_frame_header(out, n, a.checksum, a.dict_id);
+        else if (frame_first) write_frame_header_joined(out, a.total_size, a.wlog);
+    }
     // ---- blocks: up to ZL_ENC_BLOCKS per chunk, cut at sequence boundaries near equal byte counts.
     // They share one set of entropy tables (the first block describes them, the others use the
     // repeat modes, zstd.c:20745 / :21059), which keeps the format overhead at ~12 bytes per block
@@ -1796,13 +2005,13 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     if (raw) {
         u8* blk = out + fh + 3;
         copy_wg(blk, src, n);
-        if (t == 0) wr_le(out + fh, 1u | (0u << 1) | (n << 3), 3);
+        if (t == 0) wr_le(out + fh, (frame_last ? 1u : 0u) | (0u << 1) | (n << 3), 3);
         fsize = fh + 3 + n;
     } else {
-        if (t == 0) wr_le(out + last_hdr, last_hdr_val | 1u, 3);  // Last_Block
+        if (t == 0 && frame_last) wr_le(out + last_hdr, last_hdr_val | 1u, 3);  // Last_Block
         fsize = cur;
     }
-    if (a.checksum) {
+    if (a.checksum && !joined) {
         __syncthreads();
         const u32 x = zl_xxh64_low32((u8*)&S, S.xxh_acc, S.scan_a, src, n);  // first 8 KiB of S are dead by now
         if (t == 0) wr_le(out + fsize, x, 4);
@@ -1864,7 +2073,7 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false>, ENC_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false>, ENC_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
     return n;
 }
