@@ -144,6 +144,12 @@ size_t zl_decompress_device_async(zl_dctx *dctx, void *d_dst, const void *d_src,
                                   size_t nframes, void *stream);
 /* results (host, may be NULL) receives the per-frame regenerated sizes / error codes. */
 size_t zl_decompress_device_finish(zl_dctx *dctx, size_t *results);
+/* Optional, before zl_decompress_device_async: frames[0] of the next call is ONE frame written by
+ * zl_compress_device_async in the one-frame layout, and chunkSizes (nchunks entries, as zl_compress_device_finish
+ * reported them) say where each 128 KiB chunk's run of blocks starts.  The decoder then finds the frame's blocks with a
+ * lane per chunk instead of following 3-byte headers through the whole frame on one lane (zstd.c:43075).  Only a hint:
+ * it is checked against the frame and ignored when it does not fit; it is forgotten after one call. */
+size_t zl_decompress_device_hint(zl_dctx *dctx, const size_t *chunkSizes, size_t nchunks);
 
 /* Compress d_src[0..srcSize) into d_dst as concatenated frames (one per 128 KiB chunk).
  * d_dst must hold zl_compressBound(srcSize) bytes.  After _finish, frameSizes (host, may

@@ -7,7 +7,7 @@
 #include <stdint.h>
 typedef uint8_t u8; typedef uint32_t u32; typedef uint64_t u64;
 static int LONG_LOG = 13, SHORT_LOG = 12, SHORT_BYTES = 6, CAP = 40, WIN = 256, INTRA = 0, BACK = 0, LAZY = 1, CHUNK = 131072, REP23 = 0, FARLOG = 0, INSERT_ALL = 1;
-static double BL = 5.4, BS = 20.0;
+static double BL = 5.49, BS = 20.56;
 static int REACH = 65535; static int FAR = 0, FSAMP = 5, FBUCK = 13, FGRP = 16, FMIN = 8, FHINT = 5; static int MERGE = 0; static int IW = 512, IB = 5, WAVE = 64, BACKMAX = 1000, INSFILT = 0, IMIN = 4;
 static u64 ld64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 static u32 h8(u64 v) { return (u32)((v * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "fbuck")) FBUCK = v; else if (!strcmp(argv[i], "fgrp")) FGRP = v; else if (!strcmp(argv[i], "fmin")) FMIN = v; else if (!strcmp(argv[i], "fhint")) FHINT = v; else if (!strcmp(argv[i], "ib")) IB = v; else if (!strcmp(argv[i], "wave")) WAVE = v;
         else if (!strcmp(argv[i], "backmax")) BACKMAX = v; else if (!strcmp(argv[i], "insfilt")) INSFILT = v; else if (!strcmp(argv[i], "imin")) IMIN = v; else if (!strcmp(argv[i], "insall")) INSERT_ALL = v;
     }
-    u64 tot_lit = 0, tot_seq = 0, tot_rep = 0;
+    u64 tot_lit = 0, tot_seq = 0, tot_rep = 0, r1 = 0, r2 = 0, r3 = 0, r1m = 0, offbits = 0; u32 R[3] = {1,4,8};
     int32_t* tl = malloc(sizeof(int32_t) << LONG_LOG); int32_t* ts = malloc(sizeof(int32_t) << SHORT_LOG);
     u32* blen = malloc(4 * WIN); u32* boff = malloc(4 * WIN);
     long nch = (N + CHUNK - 1) / CHUNK;
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
         const u8* s = data + c0; u32 n = (u32)((N - c0 < CHUNK) ? N - c0 : CHUNK);
         for (u32 i = 0; i < (1u << LONG_LOG); i++) tl[i] = -1;
         for (u32 i = 0; i < (1u << SHORT_LOG); i++) ts[i] = -1;
-        u32 rep = 0, rep2 = 0, carry = 0, anchor = 0, prev_off_m = 0, prev_end_m = 0;
+        u32 rep = 0, rep2 = 0, carry = 0, anchor = 0, prev_off_m = 0, prev_end_m = 0; if (!FAR) { R[0] = 1; R[1] = 4; R[2] = 8; }
         int32_t* ti = malloc(4 * IW); u8* inmatch = calloc(WIN, 1);
         for (u32 ip = 0; ip < n; ip += WIN) {
             u32 wend = ip + WIN < n ? ip + WIN : n;
@@ -104,6 +104,15 @@ int main(int argc, char** argv) {
                     u32 ps = p, o = boff[w];
                     if (BACK) while (ps > anchor && (u64)c0 + ps > o && p - ps < (u32)BACKMAX && s[ps - 1] == s[(long)ps - 1 - (long)o]) { ps--; bl++; }
                     tot_lit += ps - anchor; tot_seq++;
+                    {   // zstd.c:19680 repcode rules, for counting only
+                        u32 ll = ps - anchor; int hit = 0;
+                        if (MERGE && ps == anchor && o == prev_off_m && anchor == prev_end_m && anchor > 0) hit = -1;  // merged away
+                        if (hit == 0) {
+                            if (ll > 0) { if (o == R[0]) { r1++; hit = 1; } else if (o == R[1]) { r2++; hit = 1; u32 t = R[1]; R[1] = R[0]; R[0] = t; } else if (o == R[2]) { r3++; hit = 1; u32 t = R[2]; R[2] = R[1]; R[1] = R[0]; R[0] = t; } }
+                            else { if (o == R[1]) { r2++; hit = 1; u32 t = R[1]; R[1] = R[0]; R[0] = t; } else if (o == R[2]) { r3++; hit = 1; u32 t = R[2]; R[2] = R[1]; R[1] = R[0]; R[0] = t; } else if (o == R[0] - 1 && o) { r1m++; hit = 1; R[2] = R[1]; R[1] = R[0]; R[0] = o; } }
+                            if (!hit) { offbits += 32 - __builtin_clz(o + 3); R[2] = R[1]; R[1] = R[0]; R[0] = o; }
+                        }
+                    }
                     if (MERGE && ps == anchor && o == prev_off_m && anchor == prev_end_m && anchor > 0) tot_seq--;
                     if (o == last_off || o == rep) tot_rep++;
                     if (o != last_off && last_off) rep2 = last_off;
@@ -120,6 +129,7 @@ int main(int argc, char** argv) {
         }
         tot_lit += n - (anchor < n ? anchor : n);
     }
+    printf("rep1 %llu rep2 %llu rep3 %llu rep1-1 %llu explicit-offset extra bits %llu\n", (unsigned long long)r1, (unsigned long long)r2, (unsigned long long)r3, (unsigned long long)r1m, (unsigned long long)offbits);
     double bits = BL * tot_lit + BS * tot_seq;
     printf("lits %llu seqs %llu (rep-ish %llu) est bytes %.0f ratio %.3f\n", (unsigned long long)tot_lit, (unsigned long long)tot_seq, (unsigned long long)tot_rep, bits / 8, N / (bits / 8));
     return 0;

@@ -50,6 +50,7 @@ SYMBOLS = [
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     ("zl_decompress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameT), C.c_size_t, C.c_void_p]),
     ("zl_decompress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("zl_decompress_device_hint", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t]),
     ("zl_compress_device_nframes", C.c_size_t, [C.c_size_t]),
     ("zl_compress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("zl_compress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),

@@ -84,7 +84,8 @@ size_t parse_frame_header(FrameHeader& h, const u8* src, size_t n) {
     return 0;
 }
 
-size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
+// blocks: optionally, the block table of the frame as this walk sees it (what the large-frame pipeline needs first)
+size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr, std::vector<zl3_hblk>* blocks = nullptr, u32* end_pos = nullptr) {
     FrameHeader h;
     size_t e = parse_frame_header(h, src, n);
     if (ZL_IS_ERR(e)) return e;
@@ -104,9 +105,11 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr) {
         const size_t csize = (type == 1) ? 1 : bsize;
         pos += 3;
         if (n - pos < csize) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+        if (blocks && pos < 0xFFFFFF00ull) { zl3_hblk hb; hb.src_off = (u32)pos; hb.hdr = bh; blocks->push_back(hb); }
         pos += csize;
         if (bh & 1) break;
     }
+    if (end_pos) *end_pos = (u32)pos;
     if (h.has_checksum) {
         if (n - pos < 4) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
         pos += 4;
@@ -148,6 +151,11 @@ struct zl_dctx_s {
         int stalled = 0;      // calls in a row without progress
     } ds;
     zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
+    // what is known about the large frames of the call being enqueued (either, or neither):
+    struct HostWalk { std::vector<zl3_hblk> blocks; u32 end_pos = 0; };
+    std::vector<HostWalk> host_walk;   // host entries: per frame of the current launch group, the blocks the host walked (empty: none)
+    std::vector<u64> chunk_off;        // device entries: zl_decompress_device_hint, consumed by the next call
+    DevBuf d_chunk_off;
     size_t large_frames = 0;
     bool ev_valid = false;
     double kernel_ms = 0;
@@ -287,7 +295,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
-                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2};
+                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off};
     for (DevBuf* b : bufs) b->release();
     zl3_free(d->big);
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
@@ -396,8 +404,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     if (!d->h_plan.ensure(n * sizeof(zl2_frame_plan))) return kGpuUnavailable;
     zl2_frame_plan* plan = (zl2_frame_plan*)d->h_plan.p;
     const bool has_dict = !d->dict.empty();
-    // ZL_PIPELINE_MAX=<bytes> in the environment lowers the routing limit (experiments: 0 sends everything to the general kernel)
-    static const u64 route_max = getenv("ZL_PIPELINE_MAX") ? std::min<u64>(strtoull(getenv("ZL_PIPELINE_MAX"), nullptr, 10), (u64)ZL2_MAXB * ZL_BLOCK_MAX) : (u64)ZL2_MAXB * ZL_BLOCK_MAX;
+    const u64 route_max = (u64)ZL2_MAXB * ZL_BLOCK_MAX;
     u64 lit_total = 0, seq_total = 0;
     size_t nslow = 0;
     for (size_t i = 0; i < n; i++) {
@@ -415,7 +422,10 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         if (!fast) nslow++;
     }
     const u32 max_slots = (u32)g_num_cu * 4;
-    const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 256), max_slots);  // >= 256 so that skipping routed frames is quick
+    // scratch of the general kernel: one slot per resident workgroup.  Frames routed to it on the host are counted;
+    // the lane pipeline may hand a few more back on the device (12-bit Huffman tables, long table descriptions), so
+    // there are always some slots -- 16, not the 256 of round 1 that cost 168 MB per context and call.
+    const u32 slots = (u32)std::min<size_t>(std::max<size_t>(nslow, 16), max_slots);
     if (!d->d_frames.ensure(n * sizeof(zl_frame_desc)) || !d->d_results.ensure(n * sizeof(u64)) || !d->d_counter.ensure(64) || !d->d_order.ensure(2 * n * sizeof(u32) + 64) ||
         !d->d_lit.ensure((size_t)slots * ZL_LIT_STRIDE) || !d->d_seq.ensure((size_t)slots * 3 * ZL_SEQ_CAP * sizeof(u32)) ||
         !d->d_plan.ensure(n * sizeof(zl2_frame_plan)) || !d->d_frec.ensure(n * sizeof(zl2_frame_rec)) ||
@@ -431,11 +441,22 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // Frames of more blocks than the lane pipeline takes, with a recorded content size and no dictionary
     // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
     // first, one after the other; it leaves each frame's result word on the device.
-    static const bool no_big = getenv("ZL_NO_BIG") != nullptr;  // (experiments: the general kernel takes them instead)
-    for (size_t i = 0; i < n && !no_big; i++) {
+    for (size_t i = 0; i < n; i++) {
         if (has_dict || tbl[i].dst_cap <= route_max || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
-        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side);
+        zl3_hint hint;
+        hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0;
+        if (i < d->host_walk.size() && !d->host_walk[i].blocks.empty()) {
+            hint.host_blocks = d->host_walk[i].blocks.data();
+            hint.nblocks = (u32)d->host_walk[i].blocks.size();
+            hint.end_pos = d->host_walk[i].end_pos;
+        } else if (i == 0 && d->chunk_off.size() > 1 && d->chunk_off.back() <= tbl[i].src_size) {
+            if (!d->d_chunk_off.ensure(d->chunk_off.size() * 8)) return kGpuUnavailable;
+            if (hipMemcpyAsync(d->d_chunk_off.p, d->chunk_off.data(), d->chunk_off.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            hint.d_chunk_off = (const u64*)d->d_chunk_off.p;
+            hint.nchunks = (u32)(d->chunk_off.size() - 1);
+        }
+        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side, &hint);
         if (e3 == 0) { plan[i].route = 3; d->large_frames++; }
         else if (e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
     }
@@ -463,8 +484,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.max_blocks = (u32*)d->d_counter.p + 8;
     f2.order = (u32*)d->d_order.p;  // (the 64-byte counter block is zeroed above; word 0 is the general kernel's queue head)
     f2.ext = nullptr;
-    static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : (getenv("ZL_NO_QUAD") ? 1u : 3u);  // bit 1: the sequence chains of single-block launches on quads of lanes  // (experiments: literal and sequence lanes of single-block launches as two kernels)
-    f2.fuse1 = fuse1;
+    f2.fuse1 = 3u;  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
     f2.big = nullptr;
     if (d->profile >= 2 && d->d_stats.ensure(128)) {
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
@@ -511,12 +531,29 @@ size_t zl_decompress_device_async(zl_dctx* d, void* d_dst, const void* d_src, co
     hipStream_t st = dctx_stream(d, stream);
     if (!d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64))) return kGpuUnavailable;
     memcpy(d->h_frames.p, frames, n * sizeof(zl_frame_desc));
+    d->host_walk.clear();
     size_t e = dctx_enqueue(d, (u8*)d_dst, (const u8*)d_src, n, st);
+    d->chunk_off.clear();  // a hint describes one call
     if (ZL_IS_ERR(e)) return e;
     if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     d->pending = true;
     d->pending_n = n;
     d->pending_stream = st;
+    return 0;
+}
+
+// Tells the next zl_decompress_device_async call that its first frame was written by zl_compress_device_async in the
+// one-frame layout, and where every chunk's run of blocks starts: chunk_sizes as zl_compress_device_finish
+// reported them (the first includes the frame header).  Lets the decoder find the frame's blocks with a lane
+// per chunk instead of one lane for the whole frame; a hint that does not fit the frame is ignored.
+size_t zl_decompress_device_hint(zl_dctx* d, const size_t* chunk_sizes, size_t nchunks) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    d->chunk_off.clear();
+    if (!chunk_sizes || nchunks < 2 || nchunks > 0x7FFFFFFFu) return 0;
+    d->chunk_off.resize(nchunks + 1);
+    u64 run = 0;
+    for (size_t i = 0; i < nchunks; i++) { d->chunk_off[i] = run; run += chunk_sizes[i]; }
+    d->chunk_off[nchunks] = run;
     return 0;
 }
 
@@ -552,11 +589,14 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     // ---- index frames on the host (serial header walk, zstd.c:41335)
     std::vector<zl_frame_desc> table;
     std::vector<u8> known;
+    std::vector<zl_dctx_s::HostWalk> walks;  // per data frame: its blocks when it is large enough for the large-frame pipeline
     size_t pos = 0;
     bool any = false;
+    d->chunk_off.clear();
     while (n - pos >= 5) {
         FrameHeader h;
-        size_t fs = find_frame_size(src + pos, n - pos, &h);
+        zl_dctx_s::HostWalk hw;
+        size_t fs = find_frame_size(src + pos, n - pos, &h, &hw.blocks, &hw.end_pos);
         if (ZL_IS_ERR(fs)) {
             if (any && fs == ZL_ERR(ZL_E_PREFIX_UNKNOWN)) fs = ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:41752
             return fs;
@@ -569,6 +609,8 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             fd.dst_cap = h.content_size;
             table.push_back(fd);
             known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
+            if (hw.blocks.size() <= ZL2_MAXB || hw.blocks.size() != h.nblocks) hw.blocks.clear();  // (small frames take the lane pipeline, which indexes on the device)
+            walks.push_back(std::move(hw));
         }
         any = true;
         pos += fs;
@@ -593,7 +635,9 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         const size_t cnt = j - i;
         if (!d->h_frames.ensure(cnt * sizeof(zl_frame_desc)) || !d->h_results.ensure(cnt * sizeof(u64))) return kGpuUnavailable;
         memcpy(d->h_frames.p, &table[i], cnt * sizeof(zl_frame_desc));
+        d->host_walk.assign(std::make_move_iterator(walks.begin() + i), std::make_move_iterator(walks.begin() + j));
         size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
+        d->host_walk.clear();
         if (ZL_IS_ERR(e)) return e;
         if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);

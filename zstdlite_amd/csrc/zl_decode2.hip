@@ -1285,7 +1285,7 @@ __device__ __forceinline__ void ex_copy(u8* dst, const u8* src, u32 n) {
     if (t < n - body) dst[body + t] = src[body + t];
 }
 
-// Large-frame pipeline (BIG): the workgroup executes one SEGMENT (ZL3_SEG_BLOCKS blocks) of a frame whose
+// Large-frame pipeline (BIG): the workgroup executes one SEGMENT (1 to ZL2_MAXB blocks) of a frame whose
 // other segments run at the same time.  A match that reaches in front of the segment cannot be copied
 // yet: the byte is left "deferred" with the frame position it copies in a.big->link, everything that
 // depends on it inherits that position, and zl3_resolve_kernel fills the bytes in afterwards.
@@ -1320,7 +1320,8 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
     static_assert(sizeof(zl2_blk_rec) == 64, "block records are staged as 16 dwords each");
     if (t < nblocks * 16) S.brec[t] = ((const u32*)br)[t];
     __syncthreads();
-    u64 op = BIG ? (u64)a.big->blk_dst[(size_t)f * ZL3_SEG_BLOCKS] : 0;
+    const u32 seg_blk0 = BIG ? a.big->seg_first[f] : 0u;  // the segment's first block inside the frame
+    u64 op = BIG ? (u64)a.big->blk_dst[seg_blk0] : 0;
     if (first) seg_start = op;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
     const u64 wg_t1 = wg_prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -1332,7 +1333,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         const u8* blk = src + r.src_off;
         u8* bdst = dst + op;
         if (BIG) {  // the history this block starts with was worked out by zl3_offsets_kernel
-            const u32* rs = a.big->rep_start + ((size_t)f * ZL3_SEG_BLOCKS + b) * 3;
+            const u32* rs = a.big->rep_start + ((size_t)seg_blk0 + b) * 3;
             rep0 = rs[0]; rep1 = rs[1]; rep2 = rs[2];
         }
         if (r.type != 2) {
@@ -1345,7 +1346,6 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                 for (u32 i = t * 16; i < body; i += EX_THREADS * 16) __builtin_memcpy(bdst + i, &v, 16);
                 if (t < r.size - body) bdst[body + t] = (u8)v4;
             }
-            if (BIG && r.size <= cap - op) for (u32 i = t; i < r.size; i += EX_THREADS) glink[op + i] = ZL3_ROOT;
             __syncthreads();
             if (S.err) break;
             op += r.size;
@@ -1436,7 +1436,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                             const u32 d = S.b_out[k] + (j - S.b_lit[k]);
                             const u8 v = (u8)(word >> (8 * (j - (u32)jj)));
                             if (linked) { S.img[d + ibase] = v; S.link[d - batch_start] = EX_FINAL; }
-                            else { bdst[d] = v; if (BIG) glink[op + d] = ZL3_ROOT; }
+                            else bdst[d] = v;  // (BIG: the link array starts out all-final, only waiting bytes are written)
                         }
                     }
                 }
@@ -1533,8 +1533,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                         u32* gl = glink + op + batch_start;
                         for (u32 i = t; i < tot_o; i += EX_THREADS) {
                             const bool fin = S.link[i] == EX_FINAL;
-                            gl[i] = fin ? ZL3_ROOT : S.far[i];
-                            if (!fin) a.big->tile_flag[(op + batch_start + i) >> ZL3_TILE_LOG] = 1;
+                            if (!fin) { gl[i] = S.far[i]; a.big->tile_flag[(op + batch_start + i) >> ZL3_TILE_LOG] = 1; }
                         }
                     }
                 }
@@ -1552,8 +1551,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                         const u64 fp = fm - o + (m % o);
                         const u32 defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);
                         if (defer == ZL3_ROOT) to[m] = dst[fp];
-                        else a.big->tile_flag[(fm + m) >> ZL3_TILE_LOG] = 1;
-                        glink[fm + m] = defer;
+                        else { a.big->tile_flag[(fm + m) >> ZL3_TILE_LOG] = 1; glink[fm + m] = defer; }
                     }
                 } else if (o >= 16) {
                     // whole 16-byte pieces while they do not wrap around the period
@@ -1590,7 +1588,6 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         if (S.err) break;
         if (lit_rle) { for (u32 i = t; i < rest; i += EX_THREADS) bdst[out_pos + i] = (u8)rle_byte; }
         else ex_copy(bdst + out_pos, lit + lit_pos, rest);
-        if (BIG) for (u32 i = t; i < rest; i += EX_THREADS) glink[op + out_pos + i] = ZL3_ROOT;
         if (nseq) {  // history after this block (zstd.c:44686)
             const uint4 e = sq[nseq + 1];
             const u32 n0 = ZL2_RESOLVE(e.x), n1 = ZL2_RESOLVE(e.y), n2 = ZL2_RESOLVE(e.z);
@@ -1644,7 +1641,8 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
     } else {
         // a run of consecutive segments per workgroup: matches that stay inside the run are copied here
         // and now, only what reaches in front of it is left to the resolve rounds
-        const u32 f0 = blockIdx.x * ZL3_EXEC_RUN, f1 = f0 + ZL3_EXEC_RUN < a.nframes ? f0 + ZL3_EXEC_RUN : a.nframes;
+        const u32 run = a.big->exec_run;
+        const u32 f0 = blockIdx.x * run, f1 = f0 + run < a.nframes ? f0 + run : a.nframes;
         for (u32 f = f0; f < f1; f++) {
             if (!exec_frame<BIG, PROF>(a, S, f, seg_start, f == f0)) break;
             __syncthreads();
@@ -1687,12 +1685,6 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
     const u32 ngroups = (n + LIT_FRAMES - 1) / LIT_FRAMES;
-    static const bool serial = getenv("ZL_BIG_SERIAL") != nullptr;  // (experiments: the two kernels one after the other)
-    if (serial) {
-        hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, stream, *a);
-        hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
-        return hipGetLastError();
-    }
     if (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(zl2_seq_kernel, dim3(ngroups), dim3(64), 0, side->stream, *a);
     if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
@@ -1702,8 +1694,8 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     return hipGetLastError();
 }
-extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, hipStream_t stream) {
-    hipLaunchKernelGGL((zl2_exec_kernel<true, false>), dim3((a->nframes + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN), dim3(EX_THREADS), 0, stream, *a);
+extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, u32 exec_run, hipStream_t stream) {
+    hipLaunchKernelGGL((zl2_exec_kernel<true, false>), dim3((a->nframes + exec_run - 1) / exec_run), dim3(EX_THREADS), 0, stream, *a);
     return hipGetLastError();
 }
 

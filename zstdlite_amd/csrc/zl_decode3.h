@@ -5,6 +5,13 @@
 #include "zl_format.h"
 #include "zl_kernels.h"
 
+typedef struct { u32 src_off; u32 hdr; } zl3_hblk;  // one block of a frame: where its content starts (behind the 3-byte header, relative to the frame) and the header's 24 bits
+typedef struct {
+    const zl3_hblk* host_blocks;  // the frame's blocks as the host walked them (zl_findFrameCompressedSize does that walk anyway), or null
+    u32 nblocks, end_pos;         // their number; where the last block ends
+    const u64* d_chunk_off;       // device: nchunks + 1 offsets, relative to the frame, of the runs of blocks this library's one-frame layout wrote per chunk, or null
+    u32 nchunks;
+} zl3_hint;
 typedef struct zl3_state_s zl3_state;  // grow-only device buffers, owned by a decompression context
 extern "C" zl3_state* zl3_create(void);
 extern "C" void zl3_free(zl3_state* s);
@@ -12,4 +19,4 @@ extern "C" void zl3_free(zl3_state* s);
 // result word (size or error code) has been written to *d_result on the device, ZL_ERR(ZL_E_FALLBACK)
 // when the general kernel has to take the frame, another error code when the launch itself failed.
 // Synchronises the stream several times.
-extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fd, const u8* d_src, u8* d_dst, u64* d_result, int ignore_checksum, hipStream_t st, const zl2_side* side);
+extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fd, const u8* d_src, u8* d_dst, u64* d_result, int ignore_checksum, hipStream_t st, const zl2_side* side, const zl3_hint* hint);

@@ -8,8 +8,11 @@
 // to the window.  Here each chain is cut where it is cheap to cut:
 //
 //   zl3_walk_kernel     one lane follows the block headers (3 bytes per block)           zstd.c:43075
+//                       -- or the host's own walk is uploaded (host entries), or a lane per chunk walks the chunk's few
+//                       headers (frames of this library's one-frame layout, with the caller's chunk offsets)
 //   zl3_parse_kernel    lane per block: literal / sequence section headers               zstd.c:43146, :43707
-//   zl3_plan_kernel     the frame becomes SEGMENTS of ZL3_SEG_BLOCKS blocks; for each, the earlier blocks whose
+//   zl3_segment_kernel, zl3_plan_kernel   the frame becomes SEGMENTS: a block that describes tables plus the (up to 7) blocks behind it
+//                       that only repeat them; for each segment, the earlier blocks whose
 //                       Huffman tree / FSE tables it inherits are found with a running maximum
 //   zl2_lit_kernel, zl2_seq_kernel (zl_decode2.hip)  the segments go through the lane pipeline's entropy
 //                       kernels as if they were frames; inherited tables are rebuilt in extra rounds;
@@ -17,8 +20,7 @@
 //   zl3_offsets_kernel  one wave: output position and starting repcode history of every block
 //   zl2_exec_kernel<true, false>  workgroup per run of 8 segments, all runs at once: bytes whose source lies in
 //                       another segment are left as links (frame positions)
-//   zl3_copy_kernel     the deferred bytes, in order: one tiny launch per run of segments, so that every
-//                       source is final when it is read (zl3_resolve_kernel: the pointer-jumping variant)
+//   zl3_resolve_kernel  the deferred bytes: rounds in which every waiting byte walks up to 8 links towards the front
 //   zl3_finish_kernel   content size, XXH64 (zstd.c:41646-41660), the frame's result word
 //
 // All integer work; output must be bit-exact with the reference decoder.
@@ -40,7 +42,11 @@ namespace {
 
 struct zl3_dev {  // device pointers of one large-frame decode
     zl3_info* info;
-    zl2_blk_rec* brec;
+    zl3_hblk* hblk;        // per block: where its content starts and its 3-byte header (device walk, chunk-hinted walk, or uploaded from the host's own walk)
+    zl2_blk_rec* braw;     // per block, in frame order: the parsed record
+    u32* seg_first;        // per segment: its first block (nsegs + 1 entries)
+    u32* blk_slot;         // per block: index of its record in brec = segment * ZL2_MAXB + position inside the segment
+    zl2_blk_rec* brec;     // per segment ZL2_MAXB records: what the lane pipeline's kernels read
     zl2_frame_rec* frec;
     zl2_frame_plan* plan;
     zl_frame_desc* frames;
@@ -52,31 +58,24 @@ struct zl3_dev {  // device pointers of one large-frame decode
     u32 cap_blocks;
 };
 
-// record of block b of the frame: segment b / ZL3_SEG_BLOCKS, slot b % ZL3_SEG_BLOCKS of its ZL2_MAXB records
-__device__ __forceinline__ size_t rec_of(u32 b) { return (size_t)(b / ZL3_SEG_BLOCKS) * ZL2_MAXB + b % ZL3_SEG_BLOCKS; }
 __device__ __forceinline__ void info_err(zl3_info* info, u32 code) { atomicCAS(&info->err, 0u, code); }
 
-// ---------------------------------------------------------------------------------------
-// frame header + block walk: one lane (zstd.c:41050-41148, :43075)
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base) {
-    if (threadIdx.x != 0) return;
-    zl3_info* info = d.info;
-    const u8* src = src_base + fd.src_off;
+// frame header (zstd.c:41050-41148) -> info; returns the header size or 0 after recording an error
+__device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_desc& fd, const u8* src) {
     const u64 n = fd.src_size;
-    if (n < 5) { info->err = ZL_E_SRCSIZE_WRONG; return; }
-    if (zl_rd_le(src, 4) != ZL_MAGIC) { info->err = ZL_E_PREFIX_UNKNOWN; return; }
+    if (n < 5) { info->err = ZL_E_SRCSIZE_WRONG; return 0; }
+    if (zl_rd_le(src, 4) != ZL_MAGIC) { info->err = ZL_E_PREFIX_UNKNOWN; return 0; }
     const u32 fhd = src[4];
     const u32 dflag = fhd & 3, single = (fhd >> 5) & 1, fflag = fhd >> 6;
-    if (fhd & 8) { info->err = ZL_E_FRAMEPARAM_UNSUPPORTED; return; }
+    if (fhd & 8) { info->err = ZL_E_FRAMEPARAM_UNSUPPORTED; return 0; }
     const u32 dbytes = dflag == 3 ? 4 : dflag;
     const u32 fbytes = fflag == 0 ? (single ? 1 : 0) : (1u << fflag);
     const u32 hs = 5 + (single ? 0 : 1) + dbytes + fbytes;
-    if (n < hs) { info->err = ZL_E_SRCSIZE_WRONG; return; }
+    if (n < hs) { info->err = ZL_E_SRCSIZE_WRONG; return 0; }
     u32 pos = 5;
     if (!single) {
         const u32 wlog = (src[pos++] >> 3) + 10;
-        if (wlog > 31) { info->err = ZL_E_WINDOW_TOO_LARGE; return; }
+        if (wlog > 31) { info->err = ZL_E_WINDOW_TOO_LARGE; return 0; }
     }
     const u32 did = zl_rd_le(src + pos, dbytes);
     pos += dbytes;
@@ -85,13 +84,26 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
     else if (fflag == 1) fcs = (u64)zl_rd_le(src + pos, 2) + 256;
     else if (fflag == 2) fcs = zl_rd_le(src + pos, 4);
     else fcs = (u64)zl_rd_le(src + pos, 4) | ((u64)zl_rd_le(src + pos + 4, 4) << 32);
-    if (did) { info->err = ZL_E_DICT_WRONG; return; }  // this path never has a dictionary (zstd.c:41318)
+    if (did) { info->err = ZL_E_DICT_WRONG; return 0; }  // this path never has a dictionary (zstd.c:41318)
     // (a frame that does not record its size -- what ZSTD_compressStream2 writes when nothing is pledged -- is
     // bounded by its block count: the host sizes the links from that)
-    if (fcs != ZL_CONTENTSIZE_UNKNOWN && fcs > fd.dst_cap) { info->err = ZL_E_DSTSIZE_TOO_SMALL; return; }
+    if (fcs != ZL_CONTENTSIZE_UNKNOWN && fcs > fd.dst_cap) { info->err = ZL_E_DSTSIZE_TOO_SMALL; return 0; }
     info->fcs = fcs;
     info->has_checksum = (fhd >> 2) & 1;
-    pos = hs;
+    return hs;
+}
+
+// ---------------------------------------------------------------------------------------
+// block walk, three ways.  (1) one lane follows the 3-byte headers (zstd.c:43075): the only way when
+// nothing else is known -- 0.7 us of DRAM latency per block.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base) {
+    if (threadIdx.x != 0) return;
+    zl3_info* info = d.info;
+    const u8* src = src_base + fd.src_off;
+    const u64 n = fd.src_size;
+    u32 pos = zl3_frame_header(info, fd, src);
+    if (!pos) return;
     u32 nb = 0;
     for (;;) {
         if (n - pos < 3) { info->err = ZL_E_SRCSIZE_WRONG; return; }
@@ -103,35 +115,179 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
         if (n - pos < csize) { info->err = ZL_E_SRCSIZE_WRONG; return; }
         if (nb >= d.cap_blocks) { info->err = ZL_E_FALLBACK; return; }  // more, smaller blocks than planned for: the general kernel takes the frame
         if (type != 2 && bsize > ZL_BLOCK_MAX) { info->err = ZL_E_CORRUPTION; return; }  // zstd.c:43085 (block size above the maximum)
-        zl2_blk_rec* r = d.brec + rec_of(nb);
-        r->type = type; r->size = bsize; r->src_off = pos;
+        d.hblk[nb].src_off = pos;
+        d.hblk[nb].hdr = bh;
         nb++;
         pos += csize;
         if (last) break;
     }
     if (info->has_checksum && n - pos < 4) { info->err = ZL_E_CHECKSUM_WRONG; return; }
     info->nblocks = nb;
-    info->nsegs = (nb + ZL3_SEG_BLOCKS - 1) / ZL3_SEG_BLOCKS;
     info->end_pos = pos;
 }
 
+// (2) the frame was written by this library's one-frame layout and the caller knows where every chunk's run of blocks
+// starts (zl_decompress_device_hint): a lane per chunk follows the few headers of its chunk.  Two passes around a scan
+// of the block counts.  The hint is only a hint: every chunk must end exactly where the next one starts, the frame's
+// last block must be the last chunk's last block and no other -- otherwise ZL_E_FALLBACK_WALK sends the frame to (1).
+#define ZL3_CHUNK_BLOCKS_MAX 64u
+__global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, const u64* chunk_off, u32 nchunks, u32* cnt, const u32* first, u32 pass) {
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    zl3_info* info = d.info;
+    if (c >= nchunks) return;
+    const u8* src = src_base + fd.src_off;
+    u64 pos = chunk_off[c];
+    const u64 end = chunk_off[c + 1];
+    if (c == 0) {
+        if (pass == 0) { const u32 hs = zl3_frame_header(info, fd, src); if (!hs) return; info->hdr_size = hs; }
+        pos = info->hdr_size;
+    }
+    u32 nb = 0;
+    bool bad = end > fd.src_size || pos > end;
+    while (!bad && pos < end) {
+        if (end - pos < 3 || nb >= ZL3_CHUNK_BLOCKS_MAX) { bad = true; break; }
+        const u32 bh = zl_rd_le(src + pos, 3);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
+        pos += 3;
+        const u32 csize = (type == 1) ? 1 : bsize;
+        if (type == 3 || end - pos < csize || (type != 2 && bsize > ZL_BLOCK_MAX)) { bad = true; break; }
+        if (pass == 1) { d.hblk[first[c] + nb].src_off = (u32)pos; d.hblk[first[c] + nb].hdr = bh; }
+        nb++;
+        pos += csize;
+        if (last != ((c + 1 == nchunks && pos == end) ? 1u : 0u)) { bad = true; break; }  // Last_Block: the last chunk's last block, and only that one
+    }
+    if (bad || nb == 0) { info_err(info, ZL_E_FALLBACK_WALK); return; }
+    if (pass == 0) cnt[c] = nb;
+}
+__global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_frame_desc fd, const u32* cnt, u32* first, u32 nchunks, const u64* chunk_off) {
+    __shared__ u32 part[1024];
+    zl3_info* info = d.info;
+    if (info->err) return;
+    const u32 t = threadIdx.x, per = (nchunks + 1023) / 1024;
+    const u32 b = t * per, e = b + per < nchunks ? b + per : nchunks;
+    u32 sum = 0;
+    for (u32 i = b; i < e; i++) sum += cnt[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        u32 run = 0;
+        for (u32 i = 0; i < 1024; i++) { const u32 v = part[i]; part[i] = run; run += v; }
+        if (run > d.cap_blocks) info->err = ZL_E_FALLBACK;
+        info->nblocks = run;
+        const u64 end = chunk_off[nchunks];
+        info->end_pos = (u32)end;
+        if (info->has_checksum && fd.src_size - end < 4) info->err = ZL_E_CHECKSUM_WRONG;
+    }
+    __syncthreads();
+    u32 run = part[t];
+    for (u32 i = b; i < e; i++) { first[i] = run; run += cnt[i]; }
+}
+
+// (3) the host has walked the frame already (zl_findFrameCompressedSize does, src/raw-file.c:150) and uploads
+// what it saw: nothing to do on the device but the checks the walk would have made.
+__global__ __launch_bounds__(64) void zl3_host_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nblocks, u32 end_pos) {
+    if (threadIdx.x != 0) return;
+    zl3_info* info = d.info;
+    if (!zl3_frame_header(info, fd, src_base + fd.src_off)) return;
+    if (nblocks > d.cap_blocks) { info->err = ZL_E_FALLBACK; return; }
+    if (info->has_checksum && fd.src_size - end_pos < 4) { info->err = ZL_E_CHECKSUM_WRONG; return; }
+    info->nblocks = nblocks;
+    info->end_pos = end_pos;
+}
+
 // ---------------------------------------------------------------------------------------
-// lane per block: section headers
+// lane per block: section headers; whether the block opens a segment
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void zl3_parse_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base) {
     const u32 b = blockIdx.x * 256 + threadIdx.x;
     zl3_info* info = d.info;
-    if (info->err || b >= info->nblocks) return;
-    zl2_blk_rec r = d.brec[rec_of(b)];
+    if (info->err || (b & ~63u) >= info->nblocks) return;  // (whole waves stay: the count at the end is a ballot)
+    if (b >= info->nblocks) { (void)__ballot(false); return; }
+    const zl3_hblk hb = d.hblk[b];
+    bool dependent = false;
+    zl2_blk_rec r;
+    r.type = (hb.hdr >> 1) & 3; r.size = hb.hdr >> 3; r.src_off = hb.src_off;
     r.lit_mode = 0; r.lit_size = 0; r.lit_a = 0; r.lit_b = 0; r.seq_off = 0; r.seq_len = 0;
     r.lit_dst = 0; r.seq_dst = 0; r.nseq = 0; r.streams = 0; r.seq_modes = 0; r.pad[0] = 0; r.pad[1] = 0;
     if (r.type == 2) {
         u32 lit_bytes = 0;
         const u32 e = parse_block_sections(src_base + fd.src_off + r.src_off, r.size, r, lit_bytes);
-        if (e) { info_err(info, e); return; }
+        if (e) { info_err(info, e); (void)__ballot(false); return; }
         r.pad[0] = lit_bytes;  // (scratch the block's Huffman literals need; consumed by zl3_plan_kernel)
+        // A block that describes a Huffman tree or any sequence table opens a segment: the blocks behind it that only
+        // repeat (treeless literals, Repeat_Mode) ride on its tables in the lane pipeline's kernels, one table build
+        // for up to ZL2_MAXB blocks.  Reference-made blocks describe their own tables: one block per segment.
+        // Reference-made blocks describe their own tables: one block per segment.  A block that needs no table at all
+        // (raw literals, no sequences or predefined tables) rides on nothing: a segment of its own.
+        const u32 m = r.seq_modes;
+        const bool has_modes = r.nseq > 0 && m != 0x100u;
+        const bool seq_repeats = has_modes && ((m >> 6) == 3 || ((m >> 4) & 3) == 3 || ((m >> 2) & 3) == 3);
+        const bool seq_tables = has_modes && ((m >> 6) != 3 || ((m >> 4) & 3) != 3 || ((m >> 2) & 3) != 3);
+        const bool rides = r.lit_mode == 3 || seq_repeats;           // uses tables of an earlier block
+        r.pad[1] = (r.lit_mode == 2 || seq_tables || !rides) ? 1u : 0u;
+        dependent = rides;
+    } else r.pad[1] = 1;  // a raw or RLE block needs no entropy work
+    if (b == 0) r.pad[1] = 1;
+    d.braw[b] = r;
+    // how many blocks ride on earlier tables decides whether segments are formed at all (zl3_segment_kernel)
+    const u64 md = __ballot(dependent && r.pad[1] == 0);  // (blocks that ride and bring nothing of their own: the ones a segment would spare a table rebuild)
+    if ((threadIdx.x & 63) == 0 && md) atomicAdd(&info->ndependent, (u32)__popcll(md));
+}
+
+// ---------------------------------------------------------------------------------------
+// segments: a segment starts at every block that opens one and after every ZL2_MAXB blocks of a run.  One
+// workgroup, two scans over the blocks: the position of the last opener (running maximum), then the segment count.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wg_scan_incl(u32* buf /* 2 x 1024 */, u32 v, bool is_max) {
+    const u32 t = threadIdx.x;
+    u32* cur = buf;
+    u32* nxt = buf + 1024;
+    cur[t] = v;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {
+        u32 x = cur[t];
+        if (t >= d) { const u32 y = cur[t - d]; x = is_max ? (y > x ? y : x) : x + y; }
+        nxt[t] = x;
+        __syncthreads();
+        u32* tmp = cur; cur = nxt; nxt = tmp;
     }
-    d.brec[rec_of(b)] = r;
+    const u32 out = cur[t];
+    __syncthreads();
+    return out;
+}
+__global__ __launch_bounds__(1024) void zl3_segment_kernel(zl3_dev d) {
+    __shared__ u32 buf[2048];
+    __shared__ u32 carry[2];
+    zl3_info* info = d.info;
+    if (info->err) return;
+    const u32 t = threadIdx.x, nb = info->nblocks;
+    // Segments of several blocks take the lane pipeline's multi-block kernels, which a frame of single-table
+    // blocks does not want (its blocks decode fastest on the fused single-block kernel; the few that ride on
+    // earlier tables rebuild them from zl3_plan_kernel's inherited records).  Form segments only where riding
+    // is the rule: this library's own frames (7 of 8 blocks ride), not the reference's (a few per thousand).
+    const bool grouping = info->ndependent * 4u >= nb;
+    if (t == 0) { carry[0] = 0; carry[1] = 0; }  // [0] last opener + 1 so far, [1] segments so far
+    __syncthreads();
+    for (u32 b0 = 0; b0 < nb; b0 += 1024) {
+        const u32 b = b0 + t;
+        const bool on = b < nb;
+        const u32 opener = (on && (!grouping || d.braw[b].pad[1])) ? b + 1 : 0u;
+        u32 last = wg_scan_incl(buf, opener, true);
+        const u32 c0 = carry[0], c1 = carry[1];
+        if (c0 > last) last = c0;  // (block 0 is an opener, so last >= 1 for every block)
+        const u32 idx = on ? b - (last - 1) : 0u;
+        const u32 start = (on && idx % ZL2_MAXB == 0) ? 1u : 0u;
+        const u32 seg_incl = wg_scan_incl(buf, start, false);
+        if (on) {
+            const u32 seg = c1 + seg_incl - 1;
+            d.blk_slot[b] = seg * ZL2_MAXB + idx % ZL2_MAXB;
+            if (start) d.seg_first[seg] = b;
+        }
+        __syncthreads();
+        if (t == 1023) { carry[0] = last; carry[1] = c1 + seg_incl; }
+        __syncthreads();
+    }
+    if (t == 0) { info->nsegs = carry[1]; d.seg_first[carry[1]] = nb; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -144,29 +300,34 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
     __shared__ u32 tile[6][1024];
     __shared__ u64 carry_sum[2];
     __shared__ u32 carry_def[4];
+    __shared__ u32 most_blocks;
     zl3_info* info = d.info;
     if (info->err) return;
-    const u32 t = threadIdx.x, nb = info->nblocks, ns = info->nsegs;
+    const u32 t = threadIdx.x, ns = info->nsegs;
+    if (t == 0) most_blocks = 1;
+    __syncthreads();
     // ---- A: inside each segment: where its blocks' literals and sequences go, totals, last defining blocks
     for (u32 s = t; s < ns; s += 1024) {
         u32 lit = 0, seq = 0, def[4] = {ZL3_NONE, ZL3_NONE, ZL3_NONE, ZL3_NONE};
-        for (u32 k = 0; k < ZL3_SEG_BLOCKS; k++) {
-            const u32 b = s * ZL3_SEG_BLOCKS + k;
-            if (b >= nb) break;
-            zl2_blk_rec* r = d.brec + rec_of(b);
-            if (r->type != 2) continue;
-            r->lit_dst = lit;
-            r->seq_dst = seq;
-            lit += r->pad[0];
-            seq += r->nseq + 2;  // + the totals and final-repcode records the sequence lanes append
-            if (r->lit_mode == 2) def[0] = b;
-            if (r->nseq > 0 && r->seq_modes != 0x100u) {
-                const u32 m = r->seq_modes;
-                if ((m >> 6) != 3) def[1] = b;
-                if (((m >> 4) & 3) != 3) def[2] = b;
-                if (((m >> 2) & 3) != 3) def[3] = b;
+        const u32 b0 = d.seg_first[s], b1 = d.seg_first[s + 1];
+        for (u32 b = b0; b < b1; b++) {
+            zl2_blk_rec r = d.braw[b];
+            if (r.type == 2) {
+                r.lit_dst = lit;
+                r.seq_dst = seq;
+                lit += r.pad[0];
+                seq += r.nseq + 2;  // + the totals and final-repcode records the sequence lanes append
+                if (r.lit_mode == 2) def[0] = b;
+                if (r.nseq > 0 && r.seq_modes != 0x100u) {
+                    const u32 m = r.seq_modes;
+                    if ((m >> 6) != 3) def[1] = b;
+                    if (((m >> 4) & 3) != 3) def[2] = b;
+                    if (((m >> 2) & 3) != 3) def[3] = b;
+                }
             }
+            d.brec[(size_t)s * ZL2_MAXB + (b - b0)] = r;
         }
+        if (b1 - b0 > 1) atomicMax(&most_blocks, b1 - b0);
         u32* o = d.seg_tmp + (size_t)s * 16;
         o[0] = (lit + 15) & ~15u; o[1] = seq; o[2] = def[0]; o[3] = def[1]; o[4] = def[2]; o[5] = def[3];
     }
@@ -203,14 +364,14 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
     // ---- C: segment records
     for (u32 s = t; s < ns; s += 1024) {
         const u32* o = d.seg_tmp + (size_t)s * 16;
+        const u32 b0 = d.seg_first[s], b1 = d.seg_first[s + 1];
         zl2_frame_plan p;
         p.lit_off = (u64)o[6] | ((u64)o[12] << 32);
         p.seq_off = (u64)o[7] | ((u64)o[13] << 32);
         p.lit_cap = o[0]; p.seq_cap = o[1]; p.route = 1; p.pad = 0;
         d.plan[s] = p;
         zl2_frame_rec fr;
-        const u32 left = nb - s * ZL3_SEG_BLOCKS;
-        fr.err = 0; fr.nblocks = left < ZL3_SEG_BLOCKS ? left : ZL3_SEG_BLOCKS; fr.has_checksum = 0; fr.skippable = 0;
+        fr.err = 0; fr.nblocks = b1 - b0; fr.has_checksum = 0; fr.skippable = 0;
         fr.fcs = ZL_CONTENTSIZE_UNKNOWN; fr.end_pos = 0; fr.cost = o[1]; fr.lit_cost = o[0]; fr.pad2 = 0;
         d.frec[s] = fr;
         d.frames[s] = fd;
@@ -220,20 +381,19 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
         none.type = ZL3_NONE;
         zl2_blk_rec* x = d.ext + (size_t)s * 4;
         x[0] = none; x[1] = none; x[2] = none; x[3] = none;
-        if (cur[0] != ZL3_NONE) x[0] = d.brec[rec_of(cur[0])];
+        if (cur[0] != ZL3_NONE) x[0] = d.braw[cur[0]];
         {   // the (up to three) distinct defining blocks of the sequence tables, in block order
             u32 a0 = cur[1], a1 = cur[2], a2 = cur[3];
             if (a0 > a1) { const u32 q = a0; a0 = a1; a1 = q; }   // (ZL3_NONE sorts last)
             if (a1 > a2) { const u32 q = a1; a1 = a2; a2 = q; }
             if (a0 > a1) { const u32 q = a0; a0 = a1; a1 = q; }
             u32 k = 1;
-            if (a0 != ZL3_NONE) x[k++] = d.brec[rec_of(a0)];
-            if (a1 != ZL3_NONE && a1 != a0) x[k++] = d.brec[rec_of(a1)];
-            if (a2 != ZL3_NONE && a2 != a1) x[k++] = d.brec[rec_of(a2)];
+            if (a0 != ZL3_NONE) x[k++] = d.braw[a0];
+            if (a1 != ZL3_NONE && a1 != a0) x[k++] = d.braw[a1];
+            if (a2 != ZL3_NONE && a2 != a1) x[k++] = d.braw[a2];
         }
-        for (u32 k = 0; k < fr.nblocks; k++) {
-            const u32 b = s * ZL3_SEG_BLOCKS + k;
-            const zl2_blk_rec* r = d.brec + rec_of(b);
+        for (u32 b = b0; b < b1; b++) {
+            const zl2_blk_rec* r = d.braw + b;
             if (r->type != 2) continue;
             if (r->lit_mode == 3 && cur[0] == ZL3_NONE) info_err(info, ZL_E_DICT_CORRUPTED);
             if (r->lit_mode == 2) cur[0] = b;
@@ -251,17 +411,48 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
     if (t == 0) {
         info->lit_total = carry_sum[0];
         info->seq_total = carry_sum[1];
-        *d.max_blocks = ZL3_SEG_BLOCKS;  // (which literal-kernel instantiation the segments take)
+        *d.max_blocks = most_blocks;  // (which instantiation of the literal / sequence kernels the segments take: 1 = the single-block ones)
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// after the entropy kernels: output position and starting repcode history of every block.  One wave;
-// the per-block numbers are fetched 64 blocks at a time, the chain itself runs on lane 0 out of LDS.
+// after the entropy kernels: output position and starting repcode history of every block.  One wave, 64
+// blocks at a time, both as prefix scans over the lanes.  The history a block leaves behind is a function of
+// the history it started with: each of the three offsets is a number, or "starting offset j minus k" (the
+// symbols the sequence lanes write, zl_decode2.hip ZL2_REP_SYM).  Such functions compose into functions
+// of the same shape, so the chain through all blocks (zstd.c:44291: every sequence may touch the history)
+// is a scan with that composition, not a walk: round 1 walked it on one lane, 0.2 us per block -- 10 ms
+// for the 51 200 blocks of a 1 GiB frame of this library's own 16 KiB blocks.
 // ---------------------------------------------------------------------------------------
 #define ZL3_RESOLVE(v_, r0_, r1_, r2_) (((v_) >> 31) ? (((v_) & 3u) == 0 ? (r0_) : (((v_) & 3u) == 1 ? (r1_) : (r2_))) - (((v_) & 0x7FFFFFFFu) >> 2) : (v_))
-__global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const u32* seq_scratch) {
-    __shared__ u32 outsz[64], fin[64][3], has[64], o_dst[64], o_rep[64][3];
+// x applied after g = (g0, g1, g2): what x means in terms of the history g started from
+__device__ __forceinline__ u32 rep_compose(u32 x, u32 g0, u32 g1, u32 g2) {
+    if (!(x >> 31)) return x;
+    const u32 j = x & 3u, k = (x & 0x7FFFFFFFu) >> 2;
+    const u32 g = j == 0 ? g0 : (j == 1 ? g1 : g2);
+    if (!(g >> 31)) return g - k;
+    return 0x80000000u | (g & 3u) | ((((g & 0x7FFFFFFFu) >> 2) + k) << 2);
+}
+// lane per block: what the block produces and the history it leaves, gathered from the sequence lanes' records
+// (four dependent loads per block: done by all blocks at once here, not inside the scan)
+__global__ __launch_bounds__(256) void zl3_totals_kernel(zl3_dev d, const u32* seq_scratch, uint4* blk_tot) {
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (d.info->err || b >= d.info->nblocks) return;
+    const u32 slot = d.blk_slot[b];
+    const zl2_blk_rec r = d.brec[slot];
+    uint4 o = make_uint4(0, 0x80000000u, 0x80000001u, 0x80000002u);  // a block without sequences leaves the history as it was
+    if (r.type != 2) o.x = r.size;
+    else if (r.nseq == 0) o.x = r.lit_size;
+    else {
+        const uint4* q = (const uint4*)seq_scratch + d.plan[slot / ZL2_MAXB].seq_off + r.seq_dst;
+        const uint4 tot = q[r.nseq], fh = q[r.nseq + 1];
+        o.x = tot.y + (r.lit_size - tot.x);
+        o.y = fh.x; o.z = fh.y; o.w = fh.z;
+    }
+    blk_tot[b] = o;
+}
+
+__global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const uint4* blk_tot) {
     zl3_info* info = d.info;
     const u32 lane = threadIdx.x, nb = info->nblocks, ns = info->nsegs;
     if (info->err) return;
@@ -273,48 +464,40 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
         for (int k = 32; k >= 1; k >>= 1) { const u32 o = __shfl_xor(first, k, 64); first = o < first ? o : first; }
         if (first != ZL3_NONE) { if (lane == 0) info->err = d.frec[first].err; return; }
     }
-    u64 op = 0;
-    u32 r0 = 1, r1 = 4, r2 = 8;  // zstd.c:41433
+    u64 op = 0;                    // uniform: output bytes in front of this batch
+    u32 r0 = 1, r1 = 4, r2 = 8;    // uniform: history in front of this batch (zstd.c:41433)
     u32 bad = 0;
     for (u32 b0 = 0; b0 < nb; b0 += 64) {
         const u32 b = b0 + lane;
-        u32 sz = 0, h = 0, f0 = 0, f1 = 0, f2 = 0;
-        if (b < nb) {
-            const zl2_blk_rec r = d.brec[rec_of(b)];
-            if (r.type != 2) sz = r.size;
-            else if (r.nseq == 0) sz = r.lit_size;
-            else {
-                const uint4* q = (const uint4*)seq_scratch + d.plan[b / ZL3_SEG_BLOCKS].seq_off + r.seq_dst;
-                const uint4 tot = q[r.nseq], fh = q[r.nseq + 1];
-                sz = tot.y + (r.lit_size - tot.x);
-                h = 1; f0 = fh.x; f1 = fh.y; f2 = fh.z;
+        u32 sz = 0;
+        u32 f0 = 0x80000000u, f1 = 0x80000001u, f2 = 0x80000002u;
+        if (b < nb) { const uint4 o = blk_tot[b]; sz = o.x; f0 = o.y; f1 = o.z; f2 = o.w; }
+        if (__ballot(sz > ZL_BLOCK_MAX)) bad = ZL_E_CORRUPTION;
+        // inclusive scans over the lanes: sizes by addition, histories by composition (the earlier block's function first)
+        u32 acc = sz;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const u32 a = __shfl_up(acc, dd, 64);
+            const u32 g0 = __shfl_up(f0, dd, 64), g1 = __shfl_up(f1, dd, 64), g2 = __shfl_up(f2, dd, 64);
+            if ((int)lane >= dd) {
+                acc += a;
+                const u32 n0 = rep_compose(f0, g0, g1, g2), n1 = rep_compose(f1, g0, g1, g2), n2 = rep_compose(f2, g0, g1, g2);
+                f0 = n0; f1 = n1; f2 = n2;
             }
         }
-        outsz[lane] = sz; has[lane] = h; fin[lane][0] = f0; fin[lane][1] = f1; fin[lane][2] = f2;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (lane == 0) {
-            const u32 cnt = nb - b0 < 64 ? nb - b0 : 64;
-            for (u32 i = 0; i < cnt; i++) {
-                o_dst[i] = (u32)op;
-                o_rep[i][0] = r0; o_rep[i][1] = r1; o_rep[i][2] = r2;
-                if (outsz[i] > ZL_BLOCK_MAX) bad = ZL_E_CORRUPTION;
-                op += outsz[i];
-                if (has[i]) {
-                    const u32 n0 = ZL3_RESOLVE(fin[i][0], r0, r1, r2), n1 = ZL3_RESOLVE(fin[i][1], r0, r1, r2), n2 = ZL3_RESOLVE(fin[i][2], r0, r1, r2);
-                    r0 = n0; r1 = n1; r2 = n2;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        // what the block starts with: the blocks in front of it in this batch, applied to the history in front of the batch
+        u32 e0 = __shfl_up(f0, 1, 64), e1 = __shfl_up(f1, 1, 64), e2 = __shfl_up(f2, 1, 64);
+        if (lane == 0) { e0 = 0x80000000u; e1 = 0x80000001u; e2 = 0x80000002u; }
         if (b < nb) {
-            d.blk_dst[b] = o_dst[lane];
-            d.rep_start[(size_t)b * 3 + 0] = o_rep[lane][0];
-            d.rep_start[(size_t)b * 3 + 1] = o_rep[lane][1];
-            d.rep_start[(size_t)b * 3 + 2] = o_rep[lane][2];
+            d.blk_dst[b] = (u32)(op + acc - sz);
+            d.rep_start[(size_t)b * 3 + 0] = ZL3_RESOLVE(e0, r0, r1, r2);
+            d.rep_start[(size_t)b * 3 + 1] = ZL3_RESOLVE(e1, r0, r1, r2);
+            d.rep_start[(size_t)b * 3 + 2] = ZL3_RESOLVE(e2, r0, r1, r2);
         }
-        __builtin_amdgcn_wave_barrier();
+        const u32 t0 = __shfl(f0, 63, 64), t1 = __shfl(f1, 63, 64), t2 = __shfl(f2, 63, 64);
+        const u32 n0 = ZL3_RESOLVE(t0, r0, r1, r2), n1 = ZL3_RESOLVE(t1, r0, r1, r2), n2 = ZL3_RESOLVE(t2, r0, r1, r2);
+        r0 = n0; r1 = n1; r2 = n2;
+        op += __shfl(acc, 63, 64);
     }
     if (lane == 0) {
         d.blk_dst[nb] = (u32)op;
@@ -326,80 +509,52 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
 }
 
 // ---------------------------------------------------------------------------------------
-// resolve rounds: pointer jumping over the deferred bytes.  A byte whose source became final in an
-// EARLIER launch copies it and becomes final itself (marked with this round's value, so that bytes
-// that became final during this launch are not read before the launch has ended); otherwise it takes
-// over its source's link.  Tiles without pending bytes are skipped.
+// the deferred bytes.  After the exec kernel every output byte is either final (link ZL3_ROOT) or waits
+// for the frame position in its link, which lies in front of its exec workgroup's run and may be waiting
+// itself.  The output is worked through in GROUPS of ZL3_GROUP_BYTES, one launch per group, in order: a
+// waiting byte follows links towards the front until it stands on a byte that is final -- because the
+// exec kernel left it final, or because it lies in front of the group, where every byte has been made
+// final by the launches before this one -- and copies it.  Nothing is written but the output bytes
+// themselves (links stay as they are, so no workgroup depends on what another one of the same launch
+// does), every waiting byte is visited exactly once, and a walk is short: every link leaves its exec
+// run, so it takes at most as many steps as there are runs in a group.  No host round trip between the
+// launches.  (Round 1 made one launch per run: 1023 launches, 8.3 ms for their number alone on the
+// 1 GiB frame; pointer-jumping rounds over the whole frame instead cost more than that in link reads,
+// because text-like frames chain through every run: depth 256 and more.)
 // ---------------------------------------------------------------------------------------
 #define ZL3_MARK_MIN (ZL3_ROOT - 2)
-__global__ __launch_bounds__(256) void zl3_resolve_kernel(u8* dst, u32* link, u32* tile_flag, u64 n, u32 round, zl3_info* info) {
-    __shared__ u32 wg_pending;
-    const u32 tile = blockIdx.x, t = threadIdx.x;
-    if (!tile_flag[tile]) return;
-    if (t == 0) wg_pending = 0;
-    __syncthreads();
-    const u32 cur = (round & 1) ? ZL3_ROOT - 1 : ZL3_ROOT - 2;
-    const u64 base = (u64)tile << ZL3_TILE_LOG;
-    u32 pending = 0;
-    for (u32 i0 = t * 4; i0 < (1u << ZL3_TILE_LOG); i0 += 256 * 4) {
-        const u64 p0 = base + i0;
-        if (p0 >= n) break;
-        u32 lk[4];
-        if (p0 + 4 <= n) { const uint4 v = *(const uint4*)(link + p0); lk[0] = v.x; lk[1] = v.y; lk[2] = v.z; lk[3] = v.w; }
-        else for (int j = 0; j < 4; j++) lk[j] = (p0 + j < n) ? link[p0 + j] : ZL3_ROOT;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 l1 = lk[j];
-            if (l1 >= ZL3_MARK_MIN) continue;
-            if ((u64)l1 >= p0 + j) { info_err(info, ZL_E_CORRUPTION); continue; }  // (links only ever point backwards; a guard against garbage)
-            const u32 l2 = link[l1];
-            if (l2 >= ZL3_MARK_MIN) {
-                if (l2 != cur) { dst[p0 + j] = dst[l1]; link[p0 + j] = cur; }
-                else pending++;
-            } else {
-                link[p0 + j] = l2;
-                pending++;
-            }
-        }
-    }
-    if (pending) atomicAdd(&wg_pending, pending);
-    __syncthreads();
-    if (t == 0) {
-        if (wg_pending) atomicAdd(&info->pending, wg_pending);
-        else tile_flag[tile] = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// resolve, in order: one launch per run of segments (the unit an exec workgroup worked through).  A
-// deferred byte of run R copies a byte of an earlier run, and all of those are final once the
-// launches of the runs in front of R have ended -- so every deferred byte is visited exactly once and
-// no link is ever followed twice.  The launches are tiny (<= 1 MiB of output each); what they cost is
-// their number, not their work.
-// ---------------------------------------------------------------------------------------
+#ifndef ZL3_GROUP_LOG
+#define ZL3_GROUP_LOG 22                       // 4 MiB of output per launch (measured 8 / 4 / 2 / 1 MiB on the 1 GiB reference frame: 7.0 / 5.8 / 6.6 / 8.5 ms)
+#endif
 #define ZL3_COPY_THREADS 256
-#define ZL3_COPY_SLICE 4096u  // output bytes per workgroup
-__global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_copy_kernel(u8* dst, const u32* link, const u32* tile_flag, const u32* blk_dst, u32 run, zl3_info* info) {
-    const u32 nb = info->nblocks;
-    const u32 b0 = run * ZL3_EXEC_RUN * ZL3_SEG_BLOCKS, b1 = b0 + ZL3_EXEC_RUN * ZL3_SEG_BLOCKS < nb ? b0 + ZL3_EXEC_RUN * ZL3_SEG_BLOCKS : nb;
-    const u32 p0 = blk_dst[b0], p1 = blk_dst[b1];
-    const u32 s0 = (p0 & ~3u) + blockIdx.x * ZL3_COPY_SLICE;
-    if (s0 >= p1) return;
-    for (u32 q = s0 + threadIdx.x * 4; q < s0 + ZL3_COPY_SLICE && q < p1; q += ZL3_COPY_THREADS * 4) {
-        if (!tile_flag[q >> ZL3_TILE_LOG]) continue;
+#define ZL3_COPY_SLICE 4096u                   // output bytes per workgroup
+__global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* dst, const u32* link, const u32* tile_flag, u64 gstart, zl3_info* info) {
+    const u64 n = info->produced;
+    const u64 s0 = gstart + (u64)blockIdx.x * ZL3_COPY_SLICE;
+    if (s0 >= n || info->err) return;
+    if (!tile_flag[s0 >> ZL3_TILE_LOG]) return;  // (a slice lies inside one 16 KiB tile)
+    for (u64 q = s0 + threadIdx.x * 4; q < s0 + ZL3_COPY_SLICE && q < n; q += ZL3_COPY_THREADS * 4) {
         const uint4 v = *(const uint4*)(link + q);  // (the link buffer is padded: reading a few entries past the end is fine)
         const u32 lk[4] = {v.x, v.y, v.z, v.w};
+        if (lk[0] >= ZL3_MARK_MIN && lk[1] >= ZL3_MARK_MIN && lk[2] >= ZL3_MARK_MIN && lk[3] >= ZL3_MARK_MIN) continue;
         u32 word = 0;
-        bool any = false;
+        if (q + 4 <= n) __builtin_memcpy(&word, dst + q, 4);  // (the frame may start at any address)
+        else for (int j = 0; j < 4 && q + j < n; j++) word |= (u32)dst[q + j] << (8 * j);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const u32 pos = q + j;
-            if (pos < p0 || pos >= p1 || lk[j] >= ZL3_MARK_MIN) continue;
-            if (!any) { __builtin_memcpy(&word, dst + q, 4); any = true; }  // (the frame may start at any address)
-            if (lk[j] >= pos) { info_err(info, ZL_E_CORRUPTION); continue; }  // (links only ever point backwards; a guard against garbage)
-            word = (word & ~(0xFFu << (8 * j))) | ((u32)dst[lk[j]] << (8 * j));
+            u32 s = lk[j];
+            if (q + j >= n || s >= ZL3_MARK_MIN) continue;
+            if ((u64)s >= q + j) { info_err(info, ZL_E_CORRUPTION); continue; }  // (links only ever point backwards; a guard against garbage)
+            while ((u64)s >= gstart) {
+                const u32 l = link[s];
+                if (l >= ZL3_MARK_MIN) break;                                  // final since the exec kernel
+                if (l >= s) { info_err(info, ZL_E_CORRUPTION); break; }
+                s = l;
+            }
+            word = (word & ~(0xFFu << (8 * j))) | ((u32)dst[s] << (8 * j));
         }
-        if (any) __builtin_memcpy(dst + q, &word, 4);
+        if (q + 4 <= n) __builtin_memcpy(dst + q, &word, 4);
+        else for (int j = 0; j < 4 && q + j < n; j++) dst[q + j] = (u8)(word >> (8 * j));
     }
 }
 
@@ -422,49 +577,83 @@ __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_fram
 }  // namespace
 
 struct zl3_state_s {
-    DevBuf info, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big;
+    DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot;
 };
 
 extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s(); }
 extern "C" void zl3_free(zl3_state* s) {
     if (!s) return;
-    for (DevBuf* b : {&s->info, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word, &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big}) b->release();
+    for (DevBuf* b : {&s->info, &s->hblk, &s->braw, &s->seg_first, &s->blk_slot, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word,
+                      &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot}) b->release();
     delete s;
 }
 
 // Decodes one large frame.  Returns 0 (the result word of the frame has been written on the device),
 // ZL_ERR(ZL_E_FALLBACK) when the frame has to take the general kernel, or another error of the launch itself.
-extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const u8* d_src, u8* d_dst, u64* d_result, int ignore_checksum, hipStream_t st, const zl2_side* side) {
+extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const u8* d_src, u8* d_dst, u64* d_result, int ignore_checksum, hipStream_t st, const zl2_side* side, const zl3_hint* hint) {
     const zl_frame_desc fd = *fdp;
-    // ZL_DEBUG_BIG=1 in the environment prints the time of every stage to stderr (each stamp synchronises the stream)
+#ifdef ZL_DEV_SWITCHES  // development builds: ZL_DEBUG_BIG=1 prints the time of every stage to stderr (each stamp synchronises the stream)
     static const bool dbg = getenv("ZL_DEBUG_BIG") != nullptr;
     auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = dbg ? now() : 0;
     auto stamp = [&](const char* what) { if (dbg) { const double t1 = now(); fprintf(stderr, "[zl3] %-10s %8.3f ms\n", what, t1 - t0); t0 = t1; } };
+#else
+    auto stamp = [](const char*) {};
+#endif
     if (fd.src_size >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // block records are 32-bit
     // (dst_cap may be the room left in the caller's buffer rather than the frame's size: what the frame can produce is bounded by its input too)
     const u64 out_bound = std::min<u64>(fd.dst_cap, fd.src_size * 1024 + ((u64)1 << 20));
-    // blocks planned for: full blocks plus a generous allowance for encoders that split blocks
-    const u32 cap_blocks = (u32)std::min<u64>((out_bound >> 14) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
-    const u32 cap_segs = cap_blocks / ZL3_SEG_BLOCKS;
-    if (!s->info.ensure(sizeof(zl3_info)) || !s->brec.ensure((size_t)cap_segs * ZL2_MAXB * sizeof(zl2_blk_rec)) || !s->frec.ensure((size_t)cap_segs * sizeof(zl2_frame_rec)) ||
-        !s->plan.ensure((size_t)cap_segs * sizeof(zl2_frame_plan)) || !s->frames.ensure((size_t)cap_segs * sizeof(zl_frame_desc)) ||
-        !s->ext.ensure((size_t)cap_segs * 4 * sizeof(zl2_blk_rec)) || !s->blk_dst.ensure(((size_t)cap_blocks + 1) * 4) || !s->rep_start.ensure((size_t)cap_blocks * 12) ||
-        !s->seg_tmp.ensure((size_t)cap_segs * 64) || !s->order.ensure((size_t)cap_segs * 8 + 64) || !s->word.ensure(64) || !s->big.ensure(sizeof(zl3_big)))
+    // blocks planned for: full blocks plus a generous allowance for encoders that split blocks (this library's own cut 16 KiB blocks)
+    u32 cap_blocks = (u32)std::min<u64>((out_bound >> 13) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
+    if (hint && hint->host_blocks && hint->nblocks > cap_blocks) cap_blocks = (hint->nblocks + ZL2_MAXB) & ~(u32)(ZL2_MAXB - 1);
+    const u32 cap_segs = cap_blocks;  // (a segment holds at least one block)
+    if (!s->info.ensure(sizeof(zl3_info)) || !s->hblk.ensure((size_t)cap_blocks * sizeof(zl3_hblk)) || !s->braw.ensure((size_t)cap_blocks * sizeof(zl2_blk_rec)) ||
+        !s->seg_first.ensure(((size_t)cap_segs + 1) * 4) || !s->blk_slot.ensure((size_t)cap_blocks * 4) || !s->blk_dst.ensure(((size_t)cap_blocks + 1) * 4) ||
+        !s->rep_start.ensure((size_t)cap_blocks * 12) || !s->word.ensure(64) || !s->big.ensure(sizeof(zl3_big)))
         return kGpuUnavailable;
     zl3_dev d;
-    d.info = (zl3_info*)s->info.p; d.brec = (zl2_blk_rec*)s->brec.p; d.frec = (zl2_frame_rec*)s->frec.p; d.plan = (zl2_frame_plan*)s->plan.p;
-    d.frames = (zl_frame_desc*)s->frames.p; d.ext = (zl2_blk_rec*)s->ext.p; d.blk_dst = (u32*)s->blk_dst.p; d.rep_start = (u32*)s->rep_start.p;
-    d.seg_tmp = (u32*)s->seg_tmp.p; d.max_blocks = (u32*)s->word.p; d.cap_blocks = cap_blocks;
+    d.info = (zl3_info*)s->info.p; d.hblk = (zl3_hblk*)s->hblk.p; d.braw = (zl2_blk_rec*)s->braw.p; d.seg_first = (u32*)s->seg_first.p; d.blk_slot = (u32*)s->blk_slot.p;
+    d.blk_dst = (u32*)s->blk_dst.p; d.rep_start = (u32*)s->rep_start.p; d.max_blocks = (u32*)s->word.p; d.cap_blocks = cap_blocks;
+    d.brec = nullptr; d.frec = nullptr; d.plan = nullptr; d.frames = nullptr; d.ext = nullptr; d.seg_tmp = nullptr;
     if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    hipLaunchKernelGGL(zl3_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src);
+    // ---- the block table: uploaded from the host's walk, walked per chunk with the caller's chunk offsets, or walked by one lane
+    bool walked = false;
+    if (hint && hint->host_blocks && hint->nblocks) {
+        if (hipMemcpyAsync(d.hblk, hint->host_blocks, (size_t)hint->nblocks * sizeof(zl3_hblk), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        hipLaunchKernelGGL(zl3_host_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src, hint->nblocks, hint->end_pos);
+        walked = true;
+    } else if (hint && hint->d_chunk_off && hint->nchunks) {
+        const u32 nc = hint->nchunks;
+        if (!s->cnt.ensure((size_t)nc * 4) || !s->first.ensure((size_t)nc * 4)) return kGpuUnavailable;
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u);
+        hipLaunchKernelGGL(zl3_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d, fd, (const u32*)s->cnt.p, (u32*)s->first.p, nc, hint->d_chunk_off);
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 1u);
+        zl3_info probe;
+        if (hipMemcpyAsync(&probe, d.info, sizeof(probe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (probe.err == ZL_E_FALLBACK_WALK) { if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC); }  // the hint does not describe this frame: walk it
+        else walked = true;
+    }
+    if (!walked) hipLaunchKernelGGL(zl3_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_parse_kernel, dim3((cap_blocks + 255) / 256), dim3(256), 0, st, d, fd, d_src);
-    hipLaunchKernelGGL(zl3_plan_kernel, dim3(1), dim3(1024), 0, st, d, fd);
+    hipLaunchKernelGGL(zl3_segment_kernel, dim3(1), dim3(1024), 0, st, d);
     zl3_info info;
     if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    stamp("index");
-    if (dbg) fprintf(stderr, "[zl3] blocks %u segments %u literals %llu sequences %llu err %u\n", info.nblocks, info.nsegs, (unsigned long long)info.lit_total, (unsigned long long)info.seq_total, info.err);
+    stamp("walk+parse");
     if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
+    if (!info.err) {
+        const size_t ns = info.nsegs;
+        if (!s->brec.ensure(ns * ZL2_MAXB * sizeof(zl2_blk_rec)) || !s->frec.ensure(ns * sizeof(zl2_frame_rec)) || !s->plan.ensure(ns * sizeof(zl2_frame_plan)) ||
+            !s->frames.ensure(ns * sizeof(zl_frame_desc)) || !s->ext.ensure(ns * 4 * sizeof(zl2_blk_rec)) || !s->seg_tmp.ensure(ns * 64) || !s->order.ensure(ns * 8 + 64))
+            return kGpuUnavailable;
+        d.brec = (zl2_blk_rec*)s->brec.p; d.frec = (zl2_frame_rec*)s->frec.p; d.plan = (zl2_frame_plan*)s->plan.p; d.frames = (zl_frame_desc*)s->frames.p;
+        d.ext = (zl2_blk_rec*)s->ext.p; d.seg_tmp = (u32*)s->seg_tmp.p;
+        hipLaunchKernelGGL(zl3_plan_kernel, dim3(1), dim3(1024), 0, st, d, fd);
+        if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        stamp("plan");
+    }
+#ifdef ZL_DEV_SWITCHES
+    if (dbg) fprintf(stderr, "[zl3] blocks %u segments %u literals %llu sequences %llu err %u\n", info.nblocks, info.nsegs, (unsigned long long)info.lit_total, (unsigned long long)info.seq_total, info.err);
+#endif
     // output positions the links must cover: the recorded size, else what the blocks can produce at most (and the caller has room for)
     const u64 span = info.fcs != ZL_CONTENTSIZE_UNKNOWN ? info.fcs : std::min<u64>(fd.dst_cap, (u64)info.nblocks * ZL_BLOCK_MAX);
     if (span >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // links are 32-bit
@@ -473,37 +662,32 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
             return kGpuUnavailable;
         zl3_big big;
-        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start;
+        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = ZL3_EXEC_RUN; big.pad = 0;
         if (hipMemcpyAsync(s->big.p, &big, sizeof(big), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemsetAsync(s->tile_flag.p, 0, ntiles * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        // every byte starts out final; the exec kernel writes the links of the waiting ones only (a plain fill at memory speed
+        // instead of one more 4-byte store per output byte from the exec kernel's flush loops)
+        if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         zl2_args a;
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
         a.ext = d.ext; a.big = (const zl3_big*)s->big.p;
-        static const u32 fuse1 = getenv("ZL_NO_FUSE1") ? 0u : (getenv("ZL_NO_QUAD") ? 1u : 3u);
-        a.fuse1 = fuse1;
+        a.fuse1 = 3u;
         stamp("alloc");
         if (zl2_launch_segments_entropy(&a, st, side) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("entropy");
-        hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const u32*)s->seq.p);
+        if (!s->tot.ensure((size_t)cap_blocks * 16)) return kGpuUnavailable;
+        hipLaunchKernelGGL(zl3_totals_kernel, dim3((info.nblocks + 255) / 256), dim3(256), 0, st, d, (const u32*)s->seq.p, (uint4*)s->tot.p);
+        hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const uint4*)s->tot.p);
         stamp("offsets");
-        if (zl2_launch_segments_exec(&a, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (zl2_launch_segments_exec(&a, ZL3_EXEC_RUN, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("exec");
+        // the deferred bytes: one launch per group of output, in order (the first group has nothing in front of it to wait for,
+        // but bytes of its later runs may wait for its earlier ones)
+        for (u64 g = 0; g < span; g += (u64)1 << ZL3_GROUP_LOG)
+            hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << ZL3_GROUP_LOG) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
+                               d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, g, d.info);
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        static const bool jumping = getenv("ZL_BIG_JUMPING") != nullptr;  // (experiments: the pointer-jumping rounds instead of the in-order launches)
-        if (!info.err && !jumping) {
-            const u32 nruns = (info.nsegs + ZL3_EXEC_RUN - 1) / ZL3_EXEC_RUN;
-            for (u32 run = 1; run < nruns; run++)
-                hipLaunchKernelGGL(zl3_copy_kernel, dim3((ZL3_EXEC_RUN * ZL3_SEG_BLOCKS * ZL_BLOCK_MAX + 4) / ZL3_COPY_SLICE + 1), dim3(ZL3_COPY_THREADS), 0, st,
-                                   d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, (const u32*)d.blk_dst, run, d.info);
-        }
-        for (u32 round = 0; !info.err && jumping; round++) {
-            if (hipMemsetAsync(&d.info->pending, 0, 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-            hipLaunchKernelGGL(zl3_resolve_kernel, dim3((u32)ntiles), dim3(256), 0, st, d_dst + fd.dst_off, (u32*)s->link.p, (u32*)s->tile_flag.p, span, round, d.info);
-            if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-            if (dbg) fprintf(stderr, "[zl3] round %u pending %u\n", round, info.pending);
-            if (info.err || info.pending == 0 || round >= 80) break;
-        }
         stamp("resolve");
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
     }

@@ -12,6 +12,7 @@
 #define ZL2_MAXB 8          // blocks per frame handled there; more -> general kernel
 #define ZL2_WG_FRAMES (64 / ZL2_MAXB)  // frames per entropy workgroup: one sequence lane per (frame, block) fills a wave
 #define ZL_E_FALLBACK 118   // internal: "route this frame to the general kernel", never returned to callers
+#define ZL_E_FALLBACK_WALK 117  // internal: the caller's chunk offsets do not describe this frame: walk its blocks instead
 #define ZL_E_DONE 119       // internal: the frame was decoded by the large-frame pipeline (zl_decode3.hip) before this launch
 
 struct zl2_frame_plan {     // per frame, computed on the host from the frame table
@@ -89,15 +90,14 @@ struct zl2_args {
     u32* max_blocks;  // device words, zeroed before the launch: [0] the largest block count of a frame on the pipeline (set by zl2_index_kernel), [1] frames left to the general kernel
     u32* order;       // 2 x nframes entries: the frames sorted by decreasing sequence count, then by decreasing literal bytes (zl2_order_kernel)
     u32 fuse1;        // launches whose frames all have one block: literal and sequence lanes in ONE kernel (zl2_entropy1_kernel); 0: two kernels (experiments)
-    // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments of ZL3_SEG_BLOCKS consecutive blocks of ONE frame
+    // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
     const zl2_blk_rec* ext;   // per segment 4 records of earlier blocks whose tables the segment inherits: [0] Huffman tree, [1..3] sequence tables in block order; type 0xFFFFFFFF: none.  Null on the ordinary path
     const struct zl3_big* big;  // execution state shared by the segments.  Null on the ordinary path
 };
 // Large-frame pipeline: what the segment workgroups of zl2_exec_kernel<true> share.
 #define ZL3_ROOT 0xFFFFFFFFu      // link value of a byte that is final in the output (marks of later rounds: ZL3_ROOT - 1, - 2)
-#define ZL3_SEG_BLOCKS 1          // blocks per segment: reference-made blocks bring their own tables, so more blocks per segment would only queue up behind one another in the entropy lanes
 #ifndef ZL3_EXEC_RUN
-#define ZL3_EXEC_RUN 8            // consecutive segments one exec workgroup works through
+#define ZL3_EXEC_RUN 8            // consecutive segments one exec workgroup works through (zl3_big::exec_run)
 #endif
 #define ZL3_TILE_LOG 14           // resolve rounds skip 16 KiB tiles without pending bytes
 struct zl3_info {                 // one per large frame, device memory
@@ -106,11 +106,11 @@ struct zl3_info {                 // one per large frame, device memory
     u32 has_checksum;
     u64 fcs;
     u32 end_pos;                  // where the checksum sits
-    u32 pad;
+    u32 hdr_size;                 // frame header bytes (chunk-hinted walk)
     u64 lit_total, seq_total;     // scratch the segments need: literal bytes, 16-byte sequence records
     u64 produced;                 // regenerated bytes (zl3_offsets_kernel)
-    u32 pending;                  // bytes still waiting for their source after the last resolve round
-    u32 pad2;
+    u32 pending;                  // (unused)
+    u32 ndependent;               // blocks that ride on the tables of an earlier block (treeless literals, Repeat_Mode)
 };
 struct zl3_big {
     zl3_info* info;
@@ -118,6 +118,9 @@ struct zl3_big {
     u32* tile_flag;               // per 16 KiB of output: some byte is pending
     const u32* blk_dst;           // per block: first output position (nblocks + 1 entries)
     const u32* rep_start;         // per block: repcode history it starts with (3 words)
+    const u32* seg_first;         // per segment: its first block
+    u32 exec_run;                 // consecutive segments one exec workgroup works through
+    u32 pad;
 };
 
 struct zl2_side {           // owned by the decompression context: lets the two entropy kernels run side by side
@@ -127,7 +130,7 @@ struct zl2_side {           // owned by the decompression context: lets the two 
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev);
 // large-frame pipeline: the entropy kernels / the exec kernel over the segments of one frame
 extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t stream, const zl2_side* side);
-extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, hipStream_t stream);
+extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, u32 exec_run, hipStream_t stream);
 
 extern "C" hipError_t zl_launch_decode(const zl_decode_args* a, u32 nslots, hipStream_t stream);
 extern "C" hipError_t zl_launch_digest_dict(const u8* d_dict, u32 n, void* d_tables, hipStream_t stream);

@@ -11,12 +11,13 @@ from ._lib import FrameT, ZstdError, is_error
 
 CHUNK = 128 << 10
 ZL_c_compressionLevel, ZL_c_checksumFlag, ZL_c_profile, ZL_d_profile, ZL_d_forceIgnoreChecksum = 100, 201, 9001, 9002, 1002
+ZL_c_frameLayout = 9003
 
 
 class DeviceCodec:
     """One compression + one decompression context bound to the current torch device."""
 
-    def __init__(self, level=3, include_checksum=False, validate_checksum=True, profile=False):
+    def __init__(self, level=3, include_checksum=False, validate_checksum=True, profile=False, frame_layout="auto"):
         if not torch.cuda.is_available():
             raise ZstdError("DeviceCodec needs a HIP device; there is no CPU fallback")
         self.L = _lib.lib()
@@ -25,6 +26,8 @@ class DeviceCodec:
         self.L.zl_CCtx_setParameter(self.cctx, ZL_c_compressionLevel, level)
         if include_checksum:
             self.L.zl_CCtx_setParameter(self.cctx, ZL_c_checksumFlag, 1)
+        # device entries default to independent frames; "one_frame" = the windowed single-frame layout (include/zl_hip.h)
+        self.L.zl_CCtx_setParameter(self.cctx, ZL_c_frameLayout, {"auto": 0, "frames": 1, "one_frame": 2}[frame_layout])
         if not validate_checksum:
             self.L.zl_DCtx_setParameter(self.dctx, ZL_d_forceIgnoreChecksum, 1)
         if profile:  # True / 1: per-kernel HIP events; 2: also in-kernel phase stamps (slows the kernels down)
@@ -88,12 +91,17 @@ class DeviceCodec:
         cs[-1] = n - (k - 1) * CHUNK
         return cs
 
-    def decompress(self, src, table, dst):
+    def decompress(self, src, table, dst, chunk_sizes=None):
         """Decode the frames listed in `table` (n x 4 uint64: src_off, src_size, dst_off, dst_cap)
-        from the uint8 CUDA tensor src into dst.  Returns (total bytes, per-frame results)."""
+        from the uint8 CUDA tensor src into dst.  Returns (total bytes, per-frame results).
+        chunk_sizes: for ONE frame written by compress() in the one-frame layout, the per-chunk sizes it
+        returned (zl_decompress_device_hint: the decoder then walks the frame's blocks a lane per chunk)."""
         assert src.is_cuda and dst.is_cuda
         tbl = np.ascontiguousarray(table, dtype=np.uint64)
         n = tbl.shape[0]
+        if chunk_sizes is not None and n == 1:
+            cs = np.ascontiguousarray(chunk_sizes, dtype=np.uint64)
+            self.L.zl_decompress_device_hint(self.dctx, cs.ctypes.data_as(C.POINTER(C.c_size_t)), len(cs))
         r = self.L.zl_decompress_device_async(self.dctx, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()),
                                               tbl.ctypes.data_as(C.POINTER(FrameT)), n, self._stream())
         if is_error(r):
@@ -111,6 +119,9 @@ class DeviceCodec:
         out = {}
         if not is_error(self.L.zl_cctx_kernel_ms(self.cctx, c)):
             out.update(match=c[0], entropy=c[1], scan=c[2], gather=c[3])
+            f = C.c_double(0)
+            if not is_error(self.L.zl_cctx_far_ms(self.cctx, C.byref(f))) and f.value:
+                out.update(far=f.value)
         if not is_error(self.L.zl_dctx_kernel_ms(self.dctx, d)):
             out.update(decode=d[0], d_index=d[1], d_entropy=d[2], d_exec=d[3], d_general=d[4])
         return out
