@@ -18,11 +18,18 @@
 // ---- far matches (single-frame "windowed" layout): a hash table in HBM over SAMPLED positions of the whole input,
 // built before the match kernel runs, gives every 32-byte neighbourhood at most one offset worth trying
 // that reaches further back than the chunk's own LDS tables (up to ZL_FAR_GROUP - 1 chunks = the frame's window).
-#define ZL_FAR_SAMPLE_LOG 4                      // one position in 16 is inserted / probed (content-defined: top hash bits zero)
-#define ZL_FAR_BUCKET_LOG 13                     // buckets per group of chunks
+#ifndef ZL_FAR_SAMPLE_LOG
+#define ZL_FAR_SAMPLE_LOG 3                      // one position in 8 is inserted / probed (content-defined: top hash bits zero)
+#endif
+#ifndef ZL_FAR_BUCKET_LOG
+#define ZL_FAR_BUCKET_LOG 14
+#endif
+// ZL_FAR_BUCKET_LOG:                     // buckets per group of chunks
 #define ZL_FAR_GROUP 16                          // chunks per table group = slots per bucket: one 64-byte line
 #define ZL_FAR_WLOG 21                           // window the frame header declares: ZL_FAR_GROUP chunks of 128 KiB (the reference's level 3 uses the same, zstd.c:29529)
-#define ZL_FAR_HINT_LOG 5                        // one hint word per 32 input bytes
+#ifndef ZL_FAR_HINT_LOG
+#define ZL_FAR_HINT_LOG 4                        // one hint word per 16 input bytes
+#endif
 #define ZL_FAR_TABLE_BYTES(nchunks) ((((size_t)(nchunks) + ZL_FAR_GROUP - 1) / ZL_FAR_GROUP) * ((size_t)ZL_FAR_GROUP << ZL_FAR_BUCKET_LOG) * 4)
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 

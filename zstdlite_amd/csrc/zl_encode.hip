@@ -40,7 +40,13 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
 #define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
-#define LANE_MATCH_CAP 40  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
+#ifndef LANE_MATCH_CAP
+#define LANE_MATCH_CAP 40
+#endif
+#ifndef LANE_MATCH_CAP_FAR
+#define LANE_MATCH_CAP_FAR 72  // the windowed layout verifies further: python sources +0.9 % ratio for 5 % of match time
+#endif
+// LANE_MATCH_CAP:  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
 #define MIN_MATCH 4
 
 __device__ __forceinline__ u64 ld64(const u8* p) {
@@ -56,6 +62,16 @@ __device__ __forceinline__ u64 ld64(const u8* p) {
 #endif
 __device__ __forceinline__ u32 hash8(u64 v) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
 __device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_SHORT_BYTES)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
+// the windowed layout hashes 5 bytes, the reference's minimum match at level 3 (zstd.c:29529): on real text the
+// 5-byte repeats are worth more than the table pressure they cost (python sources: +2.4 % ratio); the synthetic
+// bench inputs prefer 6 (fewer, longer candidates: faster and no worse)
+#ifndef ZL_SHORT_BYTES_FAR
+#define ZL_SHORT_BYTES_FAR 5
+#endif
+template <bool FAR>
+__device__ __forceinline__ u32 hash_short(u64 v) {
+    return FAR ? (u32)(((v << (64 - 8 * ZL_SHORT_BYTES_FAR)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)) : hash5(v);
+}
 __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
     const u64 x = a ^ b;
     return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
@@ -167,6 +183,9 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #ifndef ZL_DENSE_SEQS
 #define ZL_DENSE_SEQS 24  // sequences per 512 bytes from which on the stride-1 body is used
 #endif
+#ifndef ZL_DENSE_SEQS_FAR
+#define ZL_DENSE_SEQS_FAR 8  // the same for the windowed layout, whose callers sit behind PCIe and asked for the reference's ratio
+#endif
 // DICT: a dictionary's content sits in front of every chunk.  A template parameter: without it the
 // position arithmetic, the pointer selects and the straddle tests of the dictionary fold away (5.93 -> 5.80 ms).
 // PROF: the in-kernel phase stamps of ZL_c_profile = 2 (compiled out otherwise: 0.7 %).
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 q_r[j] = q_l[j] = q_s[j] = V;
                 if (can_match[j]) {
                     hl[j] = hash8(v[j]);
-                    hs[j] = hash5(v[j]);
+                    hs[j] = hash_short<FAR>(v[j]);
                     word_l[j] = S.tbl_long[hl[j] >> 1];
                     word_s[j] = S.tbl_short[hs[j] >> 1];
                     if (search) {
@@ -293,6 +312,29 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     else if (same_sl) w_s[j] = w_l[j];
                 }
             }
+            // FAR: what the window itself holds.  The match tables know positions in front of the window only (the
+            // window's own are inserted at its end), so a repeat at a distance below 256 -- the next line of a
+            // listing, the next record -- would go unseen.  A small third table is filled AS the window is looked
+            // up, wave after wave: wave k sees the positions of waves 0..k-1 (and whatever earlier windows left).
+            // It shares LDS with an array of the stride-2 body; its candidates are verified like all others.
+            u64 w_i = 0;
+            u32 q_i = 0;
+            bool have_i = false;
+            if (FAR) {
+                unsigned short* const intra = (unsigned short*)S.jump[1];
+                const u32 slot = hs[0] & (WIN - 1);
+                const u32 pw = ip + t;
+                u32 e_i = 0;
+                for (u32 ph = 0; ph < 4; ph++) {
+                    if (ph == (t >> 6) && can_match[0]) { e_i = intra[slot]; intra[slot] = (unsigned short)(pw + 1); }
+                    if (ph < 3) lds_barrier();
+                }
+                const u32 d_i = (pw + 1 - e_i) & 0xFFFF;
+                have_i = search && can_match[0] && e_i != 0 && d_i != 0 && d_i <= pw;
+                q_i = pw - d_i;
+                if (have_i && ((have_l[0] && q_i == q_l[0]) || (have_s[0] && q_i == q_s[0]) || (have_r[0] && q_i == q_r[0]))) have_i = false;  // (already among the others)
+                if (have_i) w_i = ld64(src + q_i);
+            }
             {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN + t;
                 pref_ip = ip + WIN;
@@ -309,10 +351,14 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
                     if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
                     if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
+                    if (FAR && have_i) {  // (nearer than anything the tables can name: wins ties)
+                        const u32 l_i = common_bytes(v[j], w_i);
+                        if (l_i >= MIN_MATCH + 1 && l_i >= best_len[j] && !(best_len[j] == l_i && best_off[j] == rep)) { best_len[j] = l_i; best_off[j] = p - q_i; q_best[j] = q_i; }
+                    }
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
-                    while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < LANE_MATCH_CAP && p + best_len[j] + 8 <= n) {
+                    while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < (FAR ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP) && p + best_len[j] + 8 <= n) {
                         const u32 qv = q_best[j] + best_len[j];
                         if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
                         const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(at(qv)));
@@ -485,7 +531,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 far_off2 = 0;
             if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
             if (can0) {
-                hl0 = hash8(v0); hs0 = hash5(v0);
+                hl0 = hash8(v0); hs0 = hash_short<FAR>(v0);
                 wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1];
                 if (search) {
                     const u32 el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF, es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF;
@@ -500,7 +546,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 }
             }
             if (can1) {  // the odd position is only inserted: its table words are read here, next to the others
-                hl1 = hash8(v1); hs1 = hash5(v1);
+                hl1 = hash8(v1); hs1 = hash_short<FAR>(v1);
                 wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
             u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
@@ -529,7 +575,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (have_s && best_len < 8 && l_s >= MIN_MATCH && l_s > best_len) { best_len = l_s; best_off = p - q_s; q_best = q_s; }
                 if (FAR && have_f && best_len < 8 && common_bytes(v0, w_f) == 8) { best_len = 8; best_off = far_off2; q_best = p - far_off2; }
                 // extend while whole 8-byte words keep matching
-                while (best_len >= 8 && (best_len & 7) == 0 && best_len < LANE_MATCH_CAP && p + best_len + 8 <= n) {
+                while (best_len >= 8 && (best_len & 7) == 0 && best_len < (FAR ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP) && p + best_len + 8 <= n) {
                     const u32 l = common_bytes(ld64(src + p + best_len), ld64(at(q_best + best_len)));
                     best_len += l;
                     if (l < 8) break;
@@ -690,7 +736,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nlit += to - ip;
             ip = to;
         }
-        dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= ZL_DENSE_SEQS);
+        dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= (FAR ? ZL_DENSE_SEQS_FAR : ZL_DENSE_SEQS));
     }
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
@@ -869,10 +915,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
                 }
             }
         }
-        // the longest hit of each 32-byte neighbourhood (ties: the larger offset -- any fixed rule will do)
+        // the longest hit of each neighbourhood (ties: the larger offset -- any fixed rule will do)
 #pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
-        if ((t & 31) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best;
+        for (int d = (1 << ZL_FAR_HINT_LOG) / 2; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+        if ((t & ((1u << ZL_FAR_HINT_LOG) - 1)) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best;
     }
 }
 
