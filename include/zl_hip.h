@@ -57,6 +57,11 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 #define ZL_layout_auto 0
 #define ZL_layout_frames 1
 #define ZL_layout_one_frame 2
+/* Host entries (zl_compress2, zl_decompressDCtx) overlap the upload, the kernels and the download of large inputs
+ * (sections of 64 MiB on several streams; the download runs on a second host thread).  1 (default) / 0: one after the
+ * other, as round 1 did -- kept for measurements.  The bytes written are the same either way. */
+#define ZL_c_pipeline 9004
+#define ZL_d_pipeline 9005
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
 #define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
 

@@ -208,3 +208,56 @@ def test_dictionary_compression_of_small_objects(ref, oracle):
     c2 = z.zstd_compress(items[20], cctx=z.zstd_cctx(dict=rawd))
     assert z.zstd_info(c2)["dict_id"] == 0
     assert ref.decompress(c2, len(items[20]), dict=rawd) == items[20]
+
+
+# ---- the one-frame (windowed) layout: zl_compress2's default for inputs above one chunk --------------------------
+@pytest.mark.parametrize("n", [131073, 262144, (2 << 20) - 1, 2 << 20, (2 << 20) + 1, 5000000])
+def test_one_frame_is_one_standard_frame(n, ref):
+    """What zstd_compress() writes is ONE zstd frame, as ZSTD_compress2 does (src/raw-file.c:74): the first-frame
+    helpers of the reference's read side (src/raw-file.c:150-155) see all of it, the reference decoder regenerates
+    it, and so do we.  Sizes around the 2 MiB window: Single_Segment up to it, a Window_Descriptor above."""
+    data = (GENERATORS["text"](n // 2, seed=n) + GENERATORS["iid10"](n - n // 2, seed=n + 1))
+    comp = z.zstd_compress(data)
+    assert ref.L.ZSTD_findFrameCompressedSize(comp, len(comp)) == len(comp)
+    assert ref.L.ZSTD_getFrameContentSize(comp, len(comp)) == n
+    info = z.zstd_info(comp)
+    assert info["compressed_size"] == len(comp) and info["uncompressed_size"] == n
+    assert ref.decompress(comp, n) == data
+    assert z.zstd_decompress(comp) == data
+    assert z.zstd_compress(data) == comp  # deterministic
+
+
+@pytest.mark.parametrize("name,n", [("records", 16 << 20), ("corpus", None)])
+def test_ratio_within_five_percent_on_long_range_inputs(name, n, ref):
+    """north_star's ratio bar on inputs whose redundancy lies further back than one 128 KiB chunk (VERDICT r1:
+    the four SURVEY inputs hold nothing beyond a few hundred bytes): repeats at 1 MiB distance, and real text."""
+    from zl_testlib import LONG_RANGE
+    data = LONG_RANGE[name](n)
+    comp = z.zstd_compress(data)
+    theirs = len(ref.compress(data, level=3))
+    assert ref.decompress(comp, len(data)) == data
+    assert z.zstd_decompress(comp) == data
+    assert len(comp) <= theirs * 1.05, (name, len(data) / len(comp), len(data) / theirs)
+
+
+def test_frame_layout_option_and_device_hint(ref):
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    from zl_testlib import LONG_RANGE
+    data = LONG_RANGE["records"](3 << 20) + GENERATORS["text"](1 << 20)
+    frames = z.zstd_compress(data, frame_layout="frames")
+    one = z.zstd_compress(data, frame_layout="one_frame")
+    assert ref.L.ZSTD_findFrameCompressedSize(frames, len(frames)) < len(frames)  # the first of many
+    assert z.zstd_decompress(frames) == data and z.zstd_decompress(one) == data
+    assert len(one) < len(frames) / 2  # only the one-frame layout sees the 1 MiB repeats
+    # device entries: independent frames by default; one frame on request, decoded with and without the chunk hint
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    codec = DeviceCodec(frame_layout="one_frame")
+    dst, total, sizes = codec.compress(src)
+    assert bytes(dst[:total].cpu().numpy()) == one
+    back = torch.empty_like(src)
+    tbl = codec.frame_table([total], [len(data)])
+    for hint in (sizes, None, sizes[::-1].copy(), sizes[:-1]):  # a hint that does not fit the frame is ignored
+        back.zero_()
+        got, _ = codec.decompress(dst, tbl, back, chunk_sizes=hint)
+        assert got == len(data) and torch.equal(back, src)

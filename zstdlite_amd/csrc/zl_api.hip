@@ -125,6 +125,7 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr, std:
 // =========================================================================================
 struct zl_dctx_s {
     int ignore_checksum = 0;
+    int pipeline = 1;  // ZL_d_pipeline
     std::vector<u8> dict;
     u32 dict_id = 0;
     bool dict_formatted = false;
@@ -314,7 +315,8 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     switch (param) {
     case ZL_d_forceIgnoreChecksum: d->ignore_checksum = value ? 1 : 0; return 0;
     case ZL_d_stableOutBuffer: return 0;
-    case ZL_d_profile: d->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
+    case ZL_d_profile: d->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
+    case ZL_d_pipeline: d->pipeline = value ? 1 : 0; return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }

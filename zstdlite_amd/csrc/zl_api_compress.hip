@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/zl_hip.h"
@@ -21,12 +23,23 @@ struct zl_cctx_s {
     int checksum = 0;
     int nb_workers = 0;
     int layout = 0;  // ZL_c_frameLayout: 0 auto, 1 independent frames, 2 one frame
+    int pipeline = 1;  // ZL_c_pipeline: host entries overlap upload, kernels and download for large inputs
     std::vector<u8> dict;
     bool dict_uploaded = false, dict_formatted = false;
     u32 dict_id = 0, dict_content_off = 0, dict_use = 0;  // dict_use: trailing content bytes the matcher can reach
     DevBuf d_dict, d_dict_tables, d_dict_hash, d_cdict;
     hipStream_t own_stream = nullptr;
-    DevBuf d_src, d_dst, d_chunks, d_lits, d_seqs, d_sst, d_meta, d_staged, d_fsize, d_foff, d_totals, d_far_table, d_far_hints;
+    DevBuf d_src, d_dst, d_chunks, d_fsize, d_foff, d_totals;
+    // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
+    // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
+    struct EncSet {
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints;
+        hipStream_t st = nullptr;
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+    };
+    EncSet sets[3];
+    hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    std::vector<hipEvent_t> pipe_events;  // grow-only pool for the pipeline
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
     // pending device-resident call
     bool pending = false;
@@ -98,23 +111,103 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
     return 0;
 }
 
-// Enqueue the whole encoder over a chunk table already written to c->h_chunks (nchunks entries):
-// E1 -> E2 -> size scan -> gather, in groups that reuse the scratch.  Frames end up back to
-// back in d_dst; per-chunk sizes in d_fsize, per-group running totals in d_totals[g+1].
-// joined_total != 0: the chunks are the consecutive pieces of ONE input of that many bytes and become one frame
-// (windowed layout: far matches, one header, one Last_Block).
+// One launch group: far passes (windowed layout) -> E1 -> E2 -> size scan -> gather for chunks [first, first + cnt) on
+// stream st, with scratch set `es`.  The group's frames land behind those of group g - 1 in d_dst: its size scan starts
+// from d_totals[g] (wait_prev: an event behind which that word is valid, when the groups run on different streams) and
+// leaves d_totals[g + 1]; scanned: recorded behind the scan, if given.
+size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8* d_src, size_t first, u32 cnt, size_t nchunks, size_t g, hipStream_t st,
+                          u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned) {
+    const bool joined = joined_total != 0;
+    if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * ZL_LIT_STRIDE_ENC) || !es.seqs.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(zl_seq)) ||
+        !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(ushort4)) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
+        return kGpuUnavailable;
+    if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4))) return kGpuUnavailable;
+    c->far_valid = false;
+    if (joined) {
+        if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
+        // the far table over this launch group's input, then the hint words the match kernel reads
+        zl_far_args f;
+        f.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
+        f.src = d_src;
+        f.total = joined_total;
+        f.chunk_base = (u32)first;
+        f.pad = 0;
+        f.table = (u32*)es.far_table.p;
+        f.hints = (u32*)es.far_hints.p;
+        if (hipMemsetAsync(f.table, 0, ZL_FAR_TABLE_BYTES(cnt), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (zl_launch_far_build(&f, cnt, st) != hipSuccess || zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    zl_match_args m;
+    m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
+    m.src = d_src;
+    m.lits = (u8*)es.lits.p;
+    m.seqs = (zl_seq*)es.seqs.p;
+    m.meta = (zl_chunk_meta*)es.meta.p;
+    m.lit_stride = ZL_LIT_STRIDE_ENC;
+    m.seq_stride = ZL_SEQ_STRIDE;
+    m.stats = nullptr;
+    m.sparse_only = c->level < 3 ? 1u : 0u;
+    m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
+    m.dict_len = c->dict_use;
+    m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
+    m.far_hints = joined ? (const u32*)es.far_hints.p : nullptr;
+    if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
+        (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
+        m.stats = (u64*)c->d_stats.p;
+    }
+    if (prof) (void)hipEventRecord(c->ev[0], st);
+    if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) (void)hipEventRecord(c->ev[1], st);
+    zl_entropy_args e;
+    e.chunks = m.chunks;
+    e.src = d_src;
+    e.lits = m.lits;
+    e.seqs = m.seqs;
+    e.meta = m.meta;
+    e.seq_states = (ushort4*)es.sst.p;
+    e.out = (u8*)es.staged.p;
+    e.frame_size = (u32*)c->d_fsize.p + first;
+    e.lit_stride = ZL_LIT_STRIDE_ENC;
+    e.seq_stride = ZL_SEQ_STRIDE;
+    e.out_stride = ZL_OUT_STRIDE;
+    e.checksum = (u32)c->checksum;
+    e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
+    e.joined = joined ? 1u : 0u;
+    e.chunk_base = (u32)first;
+    e.total_chunks = (u32)nchunks;
+    e.wlog = ZL_FAR_WLOG;
+    e.total_size = joined_total;
+    e.cdict = (c->dict_use && c->dict_formatted) ? c->d_cdict.p : nullptr;
+    e.stats = m.stats ? m.stats + 8 : nullptr;
+    if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) (void)hipEventRecord(c->ev[2], st);
+    u64* totals = (u64*)c->d_totals.p;
+    if (wait_prev && hipStreamWaitEvent(st, wait_prev, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (zl_launch_scan_sizes(e.frame_size, (u64*)c->d_foff.p + first, totals + g, totals + g + 1, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (scanned && hipEventRecord(scanned, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) (void)hipEventRecord(c->ev[3], st);
+    zl_gather_args ga;
+    ga.staged = e.out;
+    ga.frame_size = e.frame_size;
+    ga.frame_off = (const u64*)c->d_foff.p + first;
+    ga.dst = d_dst;
+    ga.out_stride = ZL_OUT_STRIDE;
+    if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) { (void)hipEventRecord(c->ev[4], st); c->ev_valid = true; }
+    return 0;
+}
+
+// Enqueue the whole encoder over a chunk table already written to c->h_chunks (nchunks entries), one launch group
+// after the other on one stream.  Frames end up back to back in d_dst; per-chunk sizes in d_fsize, per-group running
+// totals in d_totals[g+1].  joined_total != 0: the chunks are the consecutive pieces of ONE input of that many bytes
+// and become one frame (windowed layout: far matches, one header, one Last_Block).
 size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st, u64 joined_total = 0) {
     { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
     const bool joined = joined_total != 0;
-    const size_t group = std::min<size_t>(nchunks, ZL_GROUP_CHUNKS);
     const size_t ngroups = (nchunks + ZL_GROUP_CHUNKS - 1) / ZL_GROUP_CHUNKS;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
-        !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) ||
-        !c->d_meta.ensure(group * sizeof(zl_chunk_meta)) || !c->d_lits.ensure(group * (size_t)ZL_LIT_STRIDE_ENC) ||
-        !c->d_seqs.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(zl_seq)) || !c->d_sst.ensure(group * (size_t)ZL_SEQ_STRIDE * sizeof(ushort4)) ||
-        !c->d_staged.ensure(group * (size_t)ZL_OUT_STRIDE))
+        !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)))
         return kGpuUnavailable;
-    if (joined && (!c->d_far_table.ensure(ZL_FAR_TABLE_BYTES(group)) || !c->d_far_hints.ensure(group * (size_t)ZL_FAR_HINT_WORDS * 4))) return kGpuUnavailable;
     if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const bool prof = c->profile && ngroups == 1;
@@ -124,74 +217,8 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     for (size_t g = 0; g < ngroups; g++) {
         const size_t first = g * ZL_GROUP_CHUNKS;
         const u32 cnt = (u32)std::min<size_t>(ZL_GROUP_CHUNKS, nchunks - first);
-        c->far_valid = false;
-        if (joined) {
-            if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
-            // the far table over this launch group's input, then the hint words the match kernel reads
-            zl_far_args f;
-            f.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
-            f.src = d_src;
-            f.total = joined_total;
-            f.table = (u32*)c->d_far_table.p;
-            f.hints = (u32*)c->d_far_hints.p;
-            if (hipMemsetAsync(f.table, 0, ZL_FAR_TABLE_BYTES(cnt), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-            if (zl_launch_far_build(&f, cnt, st) != hipSuccess || zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        }
-        zl_match_args m;
-        m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
-        m.src = d_src;
-        m.lits = (u8*)c->d_lits.p;
-        m.seqs = (zl_seq*)c->d_seqs.p;
-        m.meta = (zl_chunk_meta*)c->d_meta.p;
-        m.lit_stride = ZL_LIT_STRIDE_ENC;
-        m.seq_stride = ZL_SEQ_STRIDE;
-        m.stats = nullptr;
-        m.sparse_only = c->level < 3 ? 1u : 0u;
-        m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
-        m.dict_len = c->dict_use;
-        m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
-        m.far_hints = joined ? (const u32*)c->d_far_hints.p : nullptr;
-        if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
-            (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
-            m.stats = (u64*)c->d_stats.p;
-        }
-        if (prof) (void)hipEventRecord(c->ev[0], st);
-        if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (prof) (void)hipEventRecord(c->ev[1], st);
-        zl_entropy_args e;
-        e.chunks = m.chunks;
-        e.src = d_src;
-        e.lits = m.lits;
-        e.seqs = m.seqs;
-        e.meta = m.meta;
-        e.seq_states = (ushort4*)c->d_sst.p;
-        e.out = (u8*)c->d_staged.p;
-        e.frame_size = (u32*)c->d_fsize.p + first;
-        e.lit_stride = ZL_LIT_STRIDE_ENC;
-        e.seq_stride = ZL_SEQ_STRIDE;
-        e.out_stride = ZL_OUT_STRIDE;
-        e.checksum = (u32)c->checksum;
-        e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
-        e.joined = joined ? 1u : 0u;
-        e.chunk_base = (u32)first;
-        e.total_chunks = (u32)nchunks;
-        e.wlog = ZL_FAR_WLOG;
-        e.total_size = joined_total;
-        e.cdict = (c->dict_use && c->dict_formatted) ? c->d_cdict.p : nullptr;
-        e.stats = m.stats ? m.stats + 8 : nullptr;
-        if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (prof) (void)hipEventRecord(c->ev[2], st);
-        u64* totals = (u64*)c->d_totals.p;
-        if (zl_launch_scan_sizes(e.frame_size, (u64*)c->d_foff.p + first, totals + g, totals + g + 1, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (prof) (void)hipEventRecord(c->ev[3], st);
-        zl_gather_args ga;
-        ga.staged = e.out;
-        ga.frame_size = e.frame_size;
-        ga.frame_off = (const u64*)c->d_foff.p + first;
-        ga.dst = d_dst;
-        ga.out_stride = ZL_OUT_STRIDE;
-        if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (prof) { (void)hipEventRecord(c->ev[4], st); c->ev_valid = true; }
+        const size_t e = cctx_enqueue_group(c, c->sets[0], d_dst, d_src, first, cnt, nchunks, g, st, joined_total, prof, nullptr, nullptr);
+        if (ZL_IS_ERR(e)) return e;
     }
     if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64))) return kGpuUnavailable;
     if (hipMemcpyAsync(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -245,7 +272,11 @@ size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
     if (c->ev_far) (void)hipEventDestroy(c->ev_far);
-    DevBuf* bufs[] = {&c->d_far_table, &c->d_far_hints, &c->d_src, &c->d_dst, &c->d_chunks, &c->d_lits, &c->d_seqs, &c->d_sst, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_meta, &c->d_staged, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
+    for (auto& es : c->sets) es.release();
+    for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+    DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
     for (PinBuf* b : pins) b->release();
@@ -276,6 +307,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
         if (value < 0 || value > 2) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
         c->layout = value;
         return 0;
+    case ZL_c_pipeline: c->pipeline = value ? 1 : 0; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -368,12 +400,100 @@ size_t zl_cctx_phase_stats(const zl_cctx* c, unsigned long long* out8) {
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+// Host buffers, large input: the three legs of the call -- upload, kernels, download -- overlap.  The input goes up
+// in sections of ZL_PIPE_CHUNKS chunks (64 MiB) on a copy stream; each section's kernels run on one of ZL_PIPE_SETS
+// streams with its own scratch as soon as its bytes have arrived (a section alone fills a third of the device: three in
+// flight keep it busy); a second host thread brings every section's frames down as soon as they are packed, while this
+// thread is still uploading (PCIe carries both directions at once; a pageable hipMemcpy occupies its caller).
+// The bytes written are those of the one-stream path: sections are the unit of far history in both (ZL_FAR_SECTION_LOG).
+#define ZL_PIPE_CHUNKS ((size_t)1 << ZL_FAR_SECTION_LOG)
+#define ZL_PIPE_SETS 3
+#define ZL_PIPE_MIN_BYTES ((size_t)192 << 20)   // below this one launch group over everything is faster than sections
+size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n, bool one_frame) {
+    { const size_t pd = cctx_prepare_dict(c, cctx_stream(c, nullptr)); if (ZL_IS_ERR(pd)) return pd; }
+    const size_t nchunks = fill_chunk_table(c, n);
+    if (ZL_IS_ERR(nchunks)) return nchunks;
+    const size_t ngroups = (nchunks + ZL_PIPE_CHUNKS - 1) / ZL_PIPE_CHUNKS;
+    const size_t bound = zl_compressBound(n);
+    if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16) || !c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
+        !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64)))
+        return kGpuUnavailable;
+    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
+    if (!c->down_stream && hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
+    for (int k = 0; k < ZL_PIPE_SETS; k++)
+        if (!c->sets[k].st && hipStreamCreateWithFlags(&c->sets[k].st, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
+    while (c->pipe_events.size() < 3 * ngroups + 1) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
+        c->pipe_events.push_back(e);
+    }
+    hipEvent_t* ev_up = c->pipe_events.data();             // section g has arrived
+    hipEvent_t* ev_scan = ev_up + ngroups;                 // d_totals[g + 1] is valid
+    hipEvent_t* ev_done = ev_scan + ngroups;               // section g's frames are packed in d_dst
+    hipEvent_t ev_table = c->pipe_events[3 * ngroups];
+    c->ev_valid = false;
+    if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, c->copy_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), c->copy_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipEventRecord(ev_table, c->copy_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    for (int k = 0; k < ZL_PIPE_SETS; k++) if (hipStreamWaitEvent(c->sets[k].st, ev_table, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    // the download thread: section after section, as their frames become ready
+    std::atomic<size_t> enqueued{0};
+    std::atomic<bool> failed{false};
+    size_t down_result = 0, down_total = 0;
+    std::thread down([&]() {
+        (void)hipSetDevice(dev);
+        u64 have = 0;
+        for (size_t g = 0; g < ngroups; g++) {
+            while (enqueued.load(std::memory_order_acquire) <= g) { if (failed.load()) return; std::this_thread::yield(); }
+            if (hipEventSynchronize(ev_done[g]) != hipSuccess) { down_result = ZL_ERR(ZL_E_GENERIC); return; }
+            u64 upto = 0;
+            if (hipMemcpyAsync(&upto, (const u64*)c->d_totals.p + g + 1, 8, hipMemcpyDeviceToHost, c->down_stream) != hipSuccess || hipStreamSynchronize(c->down_stream) != hipSuccess) { down_result = ZL_ERR(ZL_E_GENERIC); return; }
+            if (upto > cap) { down_result = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL); return; }
+            if (upto > have && (hipMemcpyAsync(dst + have, (const u8*)c->d_dst.p + have, upto - have, hipMemcpyDeviceToHost, c->down_stream) != hipSuccess || hipStreamSynchronize(c->down_stream) != hipSuccess)) { down_result = ZL_ERR(ZL_E_GENERIC); return; }
+            have = upto;
+        }
+        down_total = (size_t)have;
+    });
+    size_t err = 0;
+    for (size_t g = 0; g < ngroups && !err; g++) {
+        const size_t first = g * ZL_PIPE_CHUNKS;
+        const u32 cnt = (u32)std::min<size_t>(ZL_PIPE_CHUNKS, nchunks - first);
+        const size_t off = first * (size_t)ZL_CHUNK, len = std::min<size_t>((size_t)cnt * ZL_CHUNK, n - off);
+        if (hipMemcpyAsync((u8*)c->d_src.p + off, src + off, len, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess || hipEventRecord(ev_up[g], c->copy_stream) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
+        zl_cctx_s::EncSet& es = c->sets[g % ZL_PIPE_SETS];
+        if (hipStreamWaitEvent(es.st, ev_up[g], 0) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
+        err = cctx_enqueue_group(c, es, (u8*)c->d_dst.p, (const u8*)c->d_src.p, first, cnt, nchunks, g, es.st, one_frame ? (u64)n : 0, false, g ? ev_scan[g - 1] : nullptr, ev_scan[g]);
+        if (ZL_IS_ERR(err)) break;
+        err = 0;
+        if (hipEventRecord(ev_done[g], es.st) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
+        enqueued.store(g + 1, std::memory_order_release);
+    }
+    if (err) failed.store(true);
+    down.join();
+    for (int k = 0; k < ZL_PIPE_SETS; k++) (void)hipStreamSynchronize(c->sets[k].st);
+    (void)hipStreamSynchronize(c->copy_stream);
+    if (err) return err;
+    if (down_result) return down_result;
+    c->pending_chunks = nchunks;
+    c->pending_groups = ngroups;
+    return down_total;
+}
+}  // namespace
+
+extern "C" {
+
 // replaces ZSTD_compress2 (zstd.h:599): host buffers in and out.
 size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+    if (n >= ZL_PIPE_MIN_BYTES && c->pipeline) return compress2_pipelined(c, (u8*)dst, cap, (const u8*)src, n, use_one_frame(c, n, true));
     hipStream_t st = cctx_stream(c, nullptr);
     const size_t bound = zl_compressBound(n);
     if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16)) return kGpuUnavailable;

@@ -30,6 +30,8 @@
 #ifndef ZL_FAR_HINT_LOG
 #define ZL_FAR_HINT_LOG 4                        // one hint word per 16 input bytes
 #endif
+#define ZL_FAR_SECTION_LOG 9                      // far history does not cross sections of 512 chunks (64 MiB): a section is what the host entries
+                                                 // upload, compress and download as one pipeline stage, and the output must not depend on how a call was staged
 #define ZL_FAR_TABLE_BYTES(nchunks) ((((size_t)(nchunks) + ZL_FAR_GROUP - 1) / ZL_FAR_GROUP) * ((size_t)ZL_FAR_GROUP << ZL_FAR_BUCKET_LOG) * 4)
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 
@@ -70,7 +72,9 @@ struct zl_match_args {
 struct zl_far_args {
     const zl_chunk_desc* chunks;  // the chunks of ONE contiguous input, in order
     const u8* src;
-    u64 total;             // bytes of that input (positions whose 8 bytes would run past it are not hashed)
+    u64 total;             // bytes of that input (positions whose 8 bytes would run past it -- or past their section -- are not hashed)
+    u32 chunk_base;        // index, inside the input, of chunks[0] (a multiple of ZL_FAR_GROUP)
+    u32 pad;
     u32* table;            // ZL_FAR_TABLE_BYTES(nchunks), zeroed before zl_launch_far_build
     u32* hints;            // per chunk ZL_FAR_HINT_WORDS words, written by zl_launch_far_probe
 };

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
+    if (FAR) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
@@ -847,8 +848,9 @@ __device__ __forceinline__ size_t far_slot(u32 chunk, u32 bucket) {
     return ((((size_t)(chunk / ZL_FAR_GROUP)) << ZL_FAR_BUCKET_LOG) + bucket) * ZL_FAR_GROUP + (chunk % ZL_FAR_GROUP);
 }
 // positions p < far_limit have their 8 bytes inside the input
-__device__ __forceinline__ u32 far_limit(const zl_far_args& a, const zl_chunk_desc& cd) {
-    const u64 left = a.total - cd.src_off;
+__device__ __forceinline__ u32 far_limit(const zl_far_args& a, const zl_chunk_desc& cd, u32 cg /* chunk index inside the input */) {
+    const u64 sec_end = ((u64)((cg >> ZL_FAR_SECTION_LOG) + 1) << ZL_FAR_SECTION_LOG) * ZL_CHUNK;  // (the input starts at source offset 0)
+    const u64 left = (a.total < sec_end ? a.total : sec_end) - cd.src_off;
     return left >= (u64)cd.src_size + 8 ? cd.src_size : (left >= 8 ? (u32)(left - 7) : 0u);
 }
 
@@ -856,7 +858,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
-    const u32 lim = far_limit(a, cd);
+    const u32 lim = far_limit(a, cd, a.chunk_base + c);
     for (u32 ip = 0; ip < lim; ip += ENC_THREADS) {
         const u32 p = ip + t;
         bool on = false;
@@ -884,18 +886,19 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
     const u32 c = blockIdx.x, t = threadIdx.x;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
-    const u32 n = cd.src_size, lim = far_limit(a, cd);
+    const u32 n = cd.src_size, lim = far_limit(a, cd, a.chunk_base + c);
+    const u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
     u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
     for (u32 ip = 0; ip < n; ip += ENC_THREADS) {
         const u32 p = ip + t;
         u32 best = 0;
         u64 v = 0, h = 1ull << 63;
         if (p < lim) { v = ld64(src + p); h = far_hash(v); }
-        if (far_sampled(h) && c > 0) {
+        if (far_sampled(h) && back > 0) {
             const u32 bucket = far_bucket(h), tag = far_tag(h);
             u32 e[ZL_FAR_GROUP - 1];  // the 15 slots travel together: one round trip
 #pragma unroll
-            for (u32 k = 1; k < ZL_FAR_GROUP; k++) e[k - 1] = k <= c ? a.table[far_slot(c - k, bucket)] : 0u;
+            for (u32 k = 1; k < ZL_FAR_GROUP; k++) e[k - 1] = k <= back ? a.table[far_slot(c - k, bucket)] : 0u;
             u32 off = 0;  // of the nearest chunk whose slot carries our tag
 #pragma unroll
             for (u32 k = ZL_FAR_GROUP - 1; k >= 1; k--) {
