@@ -33,10 +33,30 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(host_bytes, log):
-    """The reference's CPU path on this box's host cores: ZSTD_compress2(level 3) then
-    ZSTD_decompressDCtx on the same 1 GiB vector, one pass, buffers pre-touched.  TEST/BENCH
-    infrastructure (oracle/_ref), never on the product path."""
+def _cpu_info():
+    model, smt = "unknown", None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        smt = open("/sys/devices/system/cpu/smt/active").read().strip() == "1"
+    except OSError:
+        pass
+    return model, smt
+
+
+def cpu_baseline(host_bytes, log, frames=None, reps=3):
+    """The reference's CPU path on this box's host cores: ZSTD_compress2(level 3) and
+    ZSTD_decompressDCtx on the same 1 GiB vector, buffers pre-touched, best of `reps` passes: (i) one thread,
+    (ii) compression with nbWorkers = host cores, (iii) decode of a set of independent frames (`frames`: the HIP
+    encoder's per-chunk frames of the same vector) with one thread per core, each calling ZSTD_decompressDCtx on
+    its own frames -- libzstd has no multi-threaded decoder.  TEST/BENCH infrastructure (oracle/_ref), never on
+    the product path."""
+    import threading
     from zl_testlib import REF_SO, have_ref
     if not have_ref():
         return None
@@ -53,6 +73,8 @@ def cpu_baseline(host_bytes, log):
     L.ZSTD_decompressDCtx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.ZSTD_freeCCtx.argtypes = [C.c_void_p]
     L.ZSTD_freeDCtx.argtypes = [C.c_void_p]
+    L.ZSTD_getErrorName.restype = C.c_char_p
+    L.ZSTD_getErrorName.argtypes = [C.c_size_t]
     n = host_bytes.size
     cap = L.ZSTD_compressBound(n)
     comp = np.empty(cap, dtype=np.uint8)
@@ -62,33 +84,192 @@ def cpu_baseline(host_bytes, log):
     res = {}
     ncores = os.cpu_count() or 1
     for label, workers in (("mt", ncores), ("1t", 0)):  # 1-thread output stays in the buffer for the decode leg
-        cctx = L.ZSTD_createCCtx()
-        L.ZSTD_CCtx_setParameter(cctx, 100, 3)
-        if workers:
-            L.ZSTD_CCtx_setParameter(cctx, 400, workers)
-        t0 = time.perf_counter()
-        csize = L.ZSTD_compress2(cctx, comp.ctypes.data, cap, host_bytes.ctypes.data, n)
-        tc = time.perf_counter() - t0
-        L.ZSTD_freeCCtx(cctx)
-        res[label] = (tc, csize)
-        log(f"cpu libzstd compress {label}: {n / tc / 1e9:.3f} GB/s, {csize} bytes")
+        best = 1e9
+        for _ in range(reps if label == "mt" else max(1, reps - 1)):
+            cctx = L.ZSTD_createCCtx()
+            L.ZSTD_CCtx_setParameter(cctx, 100, 3)
+            if workers:
+                L.ZSTD_CCtx_setParameter(cctx, 400, workers)
+            t0 = time.perf_counter()
+            csize = L.ZSTD_compress2(cctx, comp.ctypes.data, cap, host_bytes.ctypes.data, n)
+            best = min(best, time.perf_counter() - t0)
+            L.ZSTD_freeCCtx(cctx)
+        res[label] = (best, csize)
+        log(f"cpu libzstd compress {label}: {n / best / 1e9:.3f} GB/s, {csize} bytes")
     tc, csize = res["1t"]
-    dctx = L.ZSTD_createDCtx()
-    t0 = time.perf_counter()
-    r = L.ZSTD_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, csize)
-    td = time.perf_counter() - t0
-    L.ZSTD_freeDCtx(dctx)
-    L.ZSTD_getErrorName.restype = C.c_char_p
-    L.ZSTD_getErrorName.argtypes = [C.c_size_t]
+    td = 1e9
+    for _ in range(reps):
+        dctx = L.ZSTD_createDCtx()
+        t0 = time.perf_counter()
+        r = L.ZSTD_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, csize)
+        td = min(td, time.perf_counter() - t0)
+        L.ZSTD_freeDCtx(dctx)
     assert r == n, (r, L.ZSTD_getErrorName(r))
     assert np.array_equal(back, host_bytes)
+    ref_frame = comp[:csize].copy()
+    mt_decode = None
+    if frames is not None:  # (iii): frames = (blob, sizes, content sizes); thread k takes every ncores-th run of frames
+        blob, fs, cs = frames
+        src_off = np.concatenate([[0], np.cumsum(fs)[:-1]]).astype(np.int64)
+        dst_off = np.concatenate([[0], np.cumsum(cs)[:-1]]).astype(np.int64)
+        nthreads = min(ncores, len(fs))
+        back.fill(0)
+
+        def work(k):
+            dctx = L.ZSTD_createDCtx()
+            per = -(-len(fs) // nthreads)
+            for i in range(k * per, min(len(fs), (k + 1) * per)):
+                L.ZSTD_decompressDCtx(dctx, back.ctypes.data + int(dst_off[i]), int(cs[i]), blob.ctypes.data + int(src_off[i]), int(fs[i]))
+            L.ZSTD_freeDCtx(dctx)
+        best = 1e9
+        for _ in range(reps):
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            best = min(best, time.perf_counter() - t0)
+        assert np.array_equal(back, host_bytes)
+        mt_decode = {"GBps": n / best / 1e9, "threads": nthreads, "frames": int(len(fs))}
+        log(f"cpu libzstd decode of {len(fs)} frames on {nthreads} threads: {n / best / 1e9:.2f} GB/s")
+    model, smt = _cpu_info()
     return {
         "value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
-        "sample": f"the full {n >> 20} MiB bench vector, one pass: ZSTD_compress2(level 3) + ZSTD_decompressDCtx, bundled libzstd 1.5.6 built -O2 from the reference source (oracle/_ref), 1 thread",
+        "sample": f"the full {n >> 20} MiB bench vector, best of {reps}: ZSTD_compress2(level 3) + ZSTD_decompressDCtx, bundled libzstd 1.5.6 built -O2 from the reference source (oracle/_ref), 1 thread",
         "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / csize, "compressed_bytes": int(csize),
         "compress_GBps_nbWorkers": n / res["mt"][0] / 1e9, "nbWorkers": ncores, "host_cores": ncores,
-        "_frame": comp[:csize],  # (the reference's single frame of the whole vector: input of the N1 leg, removed before printing)
+        "decompress_frames_threads": mt_decode, "cpu_model": model, "smt_active": smt, "best_of": reps,
+        "_frame": ref_frame,  # (the reference's single frame of the whole vector: input of the N1 leg, removed before printing)
     }
+
+
+def one_frame_leg(device, src, log):
+    """The windowed layout (include/zl_hip.h ZL_c_frameLayout: ONE frame, matches up to 2 MiB back across chunks: what
+    zl_compress2 writes by default), device-resident: compress, then decode with the chunk hint."""
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    n = int(src.numel())
+    codec = DeviceCodec(level=3, profile=True, frame_layout="one_frame")
+    comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
+    back = torch.empty(n, dtype=torch.uint8, device=device)
+    tc = td = 1e9
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, total, fs = codec.compress(src, comp)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        back.zero_()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        got, _ = codec.decompress(comp, codec.frame_table([total], [n]), back, chunk_sizes=fs)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        if it:
+            tc, td = min(tc, t1 - t0), min(td, t3 - t2)
+    assert got == n and torch.equal(back, src), "one-frame round trip is not bit-exact"
+    km = codec.kernel_ms()
+    codec.close()
+    return {"ratio": n / total, "compressed_bytes": int(total), "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9,
+            "compress_kernel_ms": {k: km[k] for k in ("far", "match", "entropy", "scan", "gather") if k in km}, "bit_exact": True}
+
+
+def long_range_leg(device, log):
+    """Ratio on inputs whose redundancy lies further back than one 128 KiB chunk (tests/zl_testlib.LONG_RANGE), through the
+    host entry as the reference's glue calls it, next to the reference's level 3; both decoders check the bytes."""
+    import zstdlite_amd as z
+    from zl_testlib import LONG_RANGE, Ref, have_ref
+    ref = Ref() if have_ref() else None
+    out = {}
+    for name, nbytes in (("records", 64 << 20), ("corpus", None)):
+        data = LONG_RANGE[name](nbytes)
+        comp = z.zstd_compress(data)
+        frames = z.zstd_compress(data, frame_layout="frames")
+        assert z.zstd_decompress(comp) == data
+        row = {"bytes": len(data), "ratio_one_frame": len(data) / len(comp), "ratio_independent_frames": len(data) / len(frames)}
+        if ref is not None:
+            theirs = ref.compress(data, level=3)
+            assert ref.decompress(comp, len(data)) == data
+            row["ratio_reference_level3"] = len(data) / len(theirs)
+            row["compressed_size_ours_over_cpu"] = len(comp) / len(theirs)
+        out[name] = row
+        log(f"long range {name}: {row}")
+    return out
+
+
+def c4_leg(log, nitems=100000):
+    """BASELINE config C4: zstd_serialize() of 100k small list elements with a trained dictionary.  Objects: pickled dicts of
+    10-39 of 50 names -> small ints (the README / vignette dictionary example's shape, README.md:283-293), about 430
+    bytes each; dictionary: ZDICT_trainFromBuffer (size 5000) over the first 2000, by the reference library."""
+    import pickle
+    import zstdlite_amd as z
+    from zl_testlib import Ref, have_ref
+    if not have_ref():
+        return None
+    ref = Ref()
+    rng = np.random.default_rng(3)
+    names = [f"name_{i:02d}_{'x' * (i % 7)}" for i in range(50)]
+    t0 = time.perf_counter()
+    items = []
+    for _ in range(nitems):
+        perm = rng.permutation(50)[: int(rng.integers(10, 40))]
+        items.append(pickle.dumps({names[j]: int(rng.integers(0, 1000)) for j in perm}, protocol=4))
+    d = ref.train_dict(items[:2000], 5000)
+    raw = sum(map(len, items))
+    cctx = z.zstd_cctx(dict=d)
+    z.zstd_compress_batch(items[:1000], cctx=cctx)  # warm up: dictionary digest, scratch
+    t1 = time.perf_counter()
+    ours = z.zstd_compress_batch(items, cctx=cctx)
+    t_ours = time.perf_counter() - t1
+    sample = items[::50]
+    t1 = time.perf_counter()
+    cpu = [ref.compress(x, level=3, dict=d) for x in sample]
+    t_cpu = time.perf_counter() - t1
+    for i in range(0, nitems, 997):
+        assert ref.decompress(ours[i], len(items[i]), dict=d) == items[i]
+    t1 = time.perf_counter()
+    back = z.zstd_decompress_batch(ours, dict=d)
+    t_dec = time.perf_counter() - t1
+    assert back == items
+    log(f"C4: {nitems} objects prepared in {t1 - t0:.1f}s")
+    return {"objects": nitems, "mean_bytes": raw / nitems, "dict_bytes": len(d), "ratio": raw / sum(map(len, ours)),
+            "ratio_reference_same_dict": sum(map(len, sample)) / sum(map(len, cpu)), "compress_objects_per_s": nitems / t_ours,
+            "decompress_objects_per_s": nitems / t_dec, "reference_compress_objects_per_s_1_thread": len(sample) / t_cpu,
+            "checked": "every 997th frame through the reference decoder with the dictionary; all through ours"}
+
+
+def end_to_end_leg(host, device, log):
+    """What the R glue's call costs: zl_compress2 / zl_decompressDCtx with HOST buffers (src/raw-file.c:74,189), PCIe both
+    ways included, next to the PCIe rate of this box measured the same way (pageable host memory)."""
+    import torch
+    from zstdlite_amd import _lib
+    L = _lib.lib()
+    n = host.size
+    cap = L.zl_compressBound(n)
+    comp = np.empty(cap, dtype=np.uint8); comp.fill(1)
+    back = np.empty(n, dtype=np.uint8); back.fill(1)
+    out = {}
+    for layout, code in (("one_frame", 0), ("independent_frames", 1)):
+        cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+        L.zl_CCtx_setParameter(cctx, 9003, code)
+        tc = td = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter(); r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n); t1 = time.perf_counter()
+            assert not _lib.is_error(r), _lib.error_name(r)
+            r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r); t2 = time.perf_counter()
+            assert r2 == n, _lib.error_name(r2)
+            tc, td = min(tc, t1 - t0), min(td, t2 - t1)
+        assert np.array_equal(back, host)
+        L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+        out[layout] = {"compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "compressed_bytes": int(r)}
+    d = torch.empty(n, dtype=torch.uint8, device=device)
+    hb = torch.from_numpy(back)
+    th = tdn = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); d.copy_(torch.from_numpy(host)); torch.cuda.synchronize(); th = min(th, time.perf_counter() - t0)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); hb.copy_(d); torch.cuda.synchronize(); tdn = min(tdn, time.perf_counter() - t0)
+    out["pcie_GBps_measured"] = {"h2d": n / th / 1e9, "d2h": n / tdn / 1e9, "how": "torch copy of the same 1 GiB between pageable host memory and HBM, best of 3"}
+    out["compress_GBps"] = out["one_frame"]["compress_GBps"]   # the default layout of the host entries
+    out["decompress_GBps"] = out["one_frame"]["decompress_GBps"]
+    log(f"end to end: {out}")
+    return out
 
 
 def n1_decode(codec, device, frame, src, log):
@@ -201,6 +382,16 @@ class _DryCodec:
         return {}
 
 
+def _kernel_sources_hash():
+    """Identity of the kernels a PMC summary was taken at (scripts/summarize_profiles.py stamps the same)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "zstdlite_amd", "csrc", "*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -218,6 +409,7 @@ def main():
     ap.add_argument("--size", type=int, default=1 << 30, help="raw bytes per GPU (default 1 GiB)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-c2", action="store_true", help="skip the 10k x 64 KiB frame decode leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the one-frame, long-range, C4 and end-to-end legs")
     ap.add_argument("--dry", action="store_true", help="control flow only, CPU ranks over gloo (tests); prints no measurement")
     args = ap.parse_args()
 
@@ -380,19 +572,32 @@ def main():
             dom = max(single, key=single.get)
             alg = n + csize  # N_in + N_comp (compress) == N_out + N_comp (decompress)
             ach = alg / (kms[dom] / 1e3) / 1e9
-            traffic = None
+            # HBM bytes per launch of that kernel from the PMC passes kept under profiles/ (separate rocprofv3 --pmc runs of
+            # this same command, scripts/profile_round.sh).  The summary names the kernel sources it was taken at: when
+            # they have changed since, the number describes another kernel and is not reported.
+            traffic, traffic_from = None, None
             pmc = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1:] or [""]
             pmc = pmc[0]
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    if pj.get("_kernel_sources_sha256") == _kernel_sources_hash():
+                        traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                        traffic_from = os.path.basename(pmc)
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false>", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
+            # the practical ceiling next to the 8 TB/s specification: a device-to-device copy of the same vector
+            cp = torch.empty_like(src)
+            tcp = 1e9
+            for _ in range(5):
+                torch.cuda.synchronize(); t0c = time.perf_counter(); cp.copy_(src); torch.cuda.synchronize(); tcp = min(tcp, time.perf_counter() - t0c)
+            del cp
+            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false, false>", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
                                                            "gather": "zl_gather_kernel", "d_index": "zl2_index_kernel", "d_entropy": "zl2_seq_kernel",
                                                            "d_exec": "zl2_exec_kernel<false, false>", "d_general": "zl_decode_kernel"}[dom],
                                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": kms[dom]}
+                               "traffic_source": traffic_from, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": kms[dom],
+                               "device_copy_ceiling_GBps": 2 * n / tcp / 1e9, "frac_of_copy_ceiling": ach / (2 * n / tcp / 1e9)}
         # ---- per-input ratios next to BASELINE.md section 2
         per = {}
         for i, k in enumerate(kinds):
@@ -400,12 +605,25 @@ def main():
             _, tot, _ = codec.compress(part.contiguous(), comp)
             per[k] = {"bytes": int(part.numel()), "compressed": int(tot), "ratio": part.numel() / tot}
         out["per_input"] = per
+        if world == 1 and not args.no_extra:
+            for name, leg in (("one_frame_layout", lambda: one_frame_leg(device, src, log)), ("long_range", lambda: long_range_leg(device, log)),
+                              ("c4_small_objects_dict", lambda: c4_leg(log))):
+                try:
+                    out[name] = leg()
+                except Exception as e:  # informative legs; never lose the headline line to them
+                    out[name] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             # ---- cpu_baseline leg: the only place bench.py touches oracle/ (the reference libzstd
             # built into oracle/_ref): timed on the host cores, and -- for BASELINE config C2 -- used
             # to produce the 10k x 64 KiB level-3 frames whose GPU decode is checked against plaintext
             host = src.cpu().numpy()
-            cb = cpu_baseline(host, log)
+            if not args.no_extra:
+                try:
+                    out["end_to_end"] = end_to_end_leg(host, device, log)
+                except Exception as e:
+                    out["end_to_end"] = {"error": repr(e)}
+            _, tot_f, fs_f = codec.compress(src, comp)  # the per-chunk frames of the vector: input of the threaded CPU decode
+            cb = cpu_baseline(host, log, frames=(comp[:tot_f].cpu().numpy(), np.asarray(fs_f, dtype=np.int64), np.asarray(content, dtype=np.int64)))
             if cb is not None:
                 ref_frame = cb.pop("_frame")
                 out["cpu_baseline"] = cb

@@ -60,6 +60,12 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 /* Host entries (zl_compress2, zl_decompressDCtx) overlap the upload, the kernels and the download of large inputs
  * (sections of 64 MiB on several streams; the download runs on a second host thread).  1 (default) / 0: one after the
  * other, as round 1 did -- kept for measurements.  The bytes written are the same either way. */
+/* zl_compress2 appends a seek table: a skippable frame (zstd.h:138; ignored by every standard decoder,
+ * zstd.c:41722-41733, and by a reader that takes the first frame only) listing the compressed size of every 128 KiB
+ * chunk.  zl_decompressDCtx and zl_index_frames find it from the end of the buffer and skip the serial walk over
+ * every block header of the data in front of it; the table is checked against the data, never trusted.  Off by default:
+ * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written. */
+#define ZL_c_seekTable 9006
 #define ZL_c_pipeline 9004
 #define ZL_d_pipeline 9005
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */

@@ -110,7 +110,7 @@ def test_serialize_roundtrip():
     """tests/testthat/test-round-trip.R:3-44 (pickle stands in for R's serialize)."""
     obj = {"mtcars": [[21.0, 6, 160.0], [22.8, 4, 108.0]], "s": "x" * 1000, "v": np.arange(100000).tolist()}
     assert z.zstd_unserialize(z.zstd_serialize(obj)) == obj
-    assert z.zstd_unserialize(z.zstd_serialize(obj, level=7, num_threads=2)) == obj
+    assert z.zstd_unserialize(z.zstd_serialize(obj, level=5, num_threads=2)) == obj
 
 
 def test_batch_compress(oracle):
@@ -261,3 +261,47 @@ def test_frame_layout_option_and_device_hint(ref):
         back.zero_()
         got, _ = codec.decompress(dst, tbl, back, chunk_sizes=hint)
         assert got == len(data) and torch.equal(back, src)
+
+
+def test_c1_mtcars_head_shape_on_the_gpu(ref, oracle):
+    """Config C1's input (tests/golden/make_c1.py) through the HIP path: the same frame header as the README shows for
+    the reference (README.md:102: 28 b5 2f fd 60 e8 02) and both CPU decoders regenerate the 1000 bytes.  Size: 531 bytes
+    against the reference's 471 on the same bytes -- an input of four match windows, where the reference's per-position
+    table updates and its second and third repeat offsets (zstd.c:29909-30116) count most; the 5 % bar of north_star
+    is met from a few KiB up (tests above), not here, and the bound below keeps the gap from growing unnoticed."""
+    import os
+    from zl_testlib import GOLDEN
+    buf = open(os.path.join(GOLDEN, "c1_mtcars_head.bin"), "rb").read()
+    comp = z.zstd_compress(buf)
+    assert comp[:7] == bytes.fromhex("28b52ffd60e802")
+    assert len(comp) <= len(ref.compress(buf, level=3)) * 1.15
+    assert ref.decompress(comp, 1000) == buf and oracle.decompress(comp) == buf and z.zstd_decompress(comp) == buf
+
+
+@pytest.mark.parametrize("layout", ["auto", "frames"])
+def test_seek_table_is_skippable_and_spares_the_walk(layout, ref):
+    """the optional seek table is a skippable frame (zstd.h:138) behind the data.  The reference decoder
+    skips it (zstd.c:41722-41733), a first-frame reader never sees it, our decoder reads the chunk sizes from it -- and
+    falls back to the walk when the table does not describe the data."""
+    import ctypes as C
+    from zstdlite_amd import _lib
+    data = GENERATORS["text"](700000, seed=5) + GENERATORS["iid10"](500000, seed=6) + GENERATORS["rand"](200000, seed=7)
+    plain = z.zstd_compress(data, frame_layout=layout)
+    comp = z.zstd_compress(data, frame_layout=layout, seek_table=True)
+    nchunks = -(-len(data) // 131072)
+    assert comp[:len(plain)] == plain and len(comp) == len(plain) + 8 + 4 * nchunks + 20
+    assert int.from_bytes(comp[len(plain):len(plain) + 4], "little") == 0x184D2A5E
+    assert ref.decompress(comp, len(data)) == data           # the whole buffer: the table is skipped
+    assert z.zstd_decompress(comp) == data                   # through the table
+    L = _lib.lib()
+    frames = (_lib.FrameT * (nchunks + 1))()
+    cnt = L.zl_index_frames(comp, len(comp), frames, nchunks + 1)
+    assert cnt == (1 if layout == "auto" else nchunks)
+    assert sum(frames[i].dst_cap for i in range(cnt)) == len(data)
+    # a table that lies about one size still sums up only if another lies too: both chunks then fail to decode from where
+    # the table says they start, and the decoder goes back to walking the data
+    bad = bytearray(comp)
+    t0 = len(plain) + 8
+    a = int.from_bytes(bad[t0:t0 + 4], "little"); b = int.from_bytes(bad[t0 + 4:t0 + 8], "little")
+    bad[t0:t0 + 4] = (a + 1).to_bytes(4, "little"); bad[t0 + 4:t0 + 8] = (b - 1).to_bytes(4, "little")
+    assert z.zstd_decompress(bytes(bad)) == data

@@ -112,3 +112,21 @@ def test_live_reference_differential(oracle, ref, gen):
             assert not ref.L.ZSTD_isError(rc) and rout == oout, (gen, k, pos)
         if ref.L.ZSTD_isError(rc):
             assert is_error(oc), (gen, k, pos, ref.error_name(rc))
+
+
+def test_c1_shape_mtcars_head_serialization(oracle, ref):
+    """BASELINE config C1 (zstd_serialize(head(mtcars)) round trip via the bundled CPU libzstd) without R: the 1000-byte
+    native-binary serialization built by hand (tests/golden/make_c1.py) goes through the reference's call sequence
+    (src/serialize.c:73-91,171-197).  README.md:96-105 pins the shape: frame header 28 b5 2f fd 60 e8 02 -- content size
+    1000 in a single-segment frame -- and 482 bytes in all (our buffer differs from R's own in a few bytes the README
+    does not show, so the size is checked to a few per cent, the header exactly)."""
+    import sys
+    sys.path.insert(0, os.path.join(GOLDEN))
+    import make_c1
+    buf = open(os.path.join(GOLDEN, "c1_mtcars_head.bin"), "rb").read()
+    assert len(buf) == 1000 and buf == make_c1.build()
+    comp = ref.compress(buf, level=3)
+    assert comp[:7] == make_c1.README_FIRST_100[:7]
+    assert abs(len(comp) - 482) <= 24
+    assert ref.L.ZSTD_getFrameContentSize(comp, len(comp)) == 1000 and ref.L.ZSTD_findFrameCompressedSize(comp, len(comp)) == len(comp)
+    assert oracle.decompress(comp) == buf and ref.decompress(comp, 1000) == buf

@@ -33,6 +33,7 @@ ZL_c_compressionLevel = 100
 ZL_c_checksumFlag = 201
 ZL_c_nbWorkers = 400
 ZL_c_frameLayout = 9003  # include/zl_hip.h: 0 auto, 1 independent frames, 2 one frame
+ZL_c_seekTable = 9006
 ZL_d_forceIgnoreChecksum = 1002
 _UNKNOWN = (1 << 64) - 1
 _ERROR = (1 << 64) - 2
@@ -92,6 +93,13 @@ def _init_cctx_with_opts(opts, quiet=False):
             level = max(-5, min(22, int(val)))  # src/cctx.c:261-263
             if is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_compressionLevel, level)):
                 raise ZstdError("init_cctx(): Bad compression level")
+            got = C.c_int(0)
+            L.zl_CCtx_getParameter(cctx._ptr, ZL_c_compressionLevel, C.byref(got))
+            if got.value != level and level > 3 and not quiet:
+                # the HIP encoder has no lazy / optimal parser (the reference's levels >= 5): say so instead of
+                # silently writing something else than was asked for
+                warnings.warn(f"init_cctx(): level {level} runs at this encoder's operating point {got.value} "
+                              "(levels above 3 only deepen the far-match search; see include/zl_hip.h)")
         elif name == "num_threads":
             if int(val) > 1:
                 L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))
@@ -101,6 +109,9 @@ def _init_cctx_with_opts(opts, quiet=False):
                     raise ZstdError("init_cctx(): Couldn't set checksum flag")
         elif name == "dict":
             dict_ = val
+        elif name == "seek_table":  # (not in the reference: include/zl_hip.h ZL_c_seekTable)
+            if val and is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_seekTable, 1)):
+                raise ZstdError("init_cctx(): Couldn't set the seek-table flag")
         elif name == "frame_layout":  # (not in the reference: include/zl_hip.h ZL_c_frameLayout)
             code = {"auto": 0, "frames": 1, "one_frame": 2}.get(val)
             if code is None or is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_frameLayout, code)):
@@ -137,13 +148,16 @@ def _init_dctx_with_opts(opts, quiet=False):
     return dctx
 
 
-def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None, frame_layout="auto"):
+def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None, frame_layout="auto", seek_table=False):
     """R/cctx.R:38-48 -> init_cctx_ (src/cctx.c:323).  frame_layout is this library's own knob (the reference
     always writes one frame): "auto" = one frame from zstd_compress / zstd_serialize, "frames" = one
-    independent frame per 128 KiB (fastest to decode; first-frame readers see the first chunk only)."""
+    independent frame per 128 KiB (fastest to decode; first-frame readers see the first chunk only).  seek_table appends
+    a skippable frame listing every chunk's compressed size: standard decoders ignore it, this library's
+    decoder uses it instead of walking every block header."""
     return _init_cctx_with_opts({"level": level, "num_threads": num_threads, "include_checksum": include_checksum,
                                  **({"dict": dict} if dict is not None else {}),
-                                 **({"frame_layout": frame_layout} if frame_layout != "auto" else {})})
+                                 **({"frame_layout": frame_layout} if frame_layout != "auto" else {}),
+                                 **({"seek_table": True} if seek_table else {})})
 
 
 def zstd_dctx(validate_checksum=True, dict=None):

@@ -118,6 +118,35 @@ size_t find_frame_size(const u8* src, size_t n, FrameHeader* out = nullptr, std:
     return pos;
 }
 
+// the seek table zl_compress2 may append (zl_format.h, ZL_c_seekTable), found from the end of the buffer.  Accepted only
+// when it describes the bytes in front of it exactly; what it says about them is still checked by whoever decodes them.
+struct SeekTable {
+    u64 content = 0;
+    u32 nchunks = 0;
+    bool one_frame = false;
+    const u8* sizes = nullptr;  // nchunks little-endian u32
+    size_t data_bytes = 0;      // bytes in front of the table
+};
+bool read_seek_table(const u8* src, size_t n, SeekTable& t) {
+    if (n < ZL_INDEX_BYTES(2)) return false;
+    const u8* f = src + n - ZL_INDEX_FOOTER;
+    if (rd_le(f + 16, 4) != ZL_INDEX_TAG) return false;
+    t.content = rd_le64(f);
+    t.nchunks = rd_le(f + 8, 4);
+    t.one_frame = (rd_le(f + 12, 4) & 1) != 0;
+    if (t.nchunks < 2 || t.nchunks > 0x3FFFFFFFu) return false;
+    const size_t need = ZL_INDEX_BYTES(t.nchunks);
+    if (need > n) return false;
+    const u8* idx = src + n - need;
+    if (rd_le(idx, 4) != ZL_MAGIC_INDEX || rd_le(idx + 4, 4) != need - 8) return false;
+    if (t.content == 0 || (t.content + ZL_BLOCK_MAX - 1) / ZL_BLOCK_MAX != t.nchunks) return false;
+    t.sizes = idx + 8;
+    t.data_bytes = n - need;
+    u64 sum = 0;
+    for (u32 i = 0; i < t.nchunks; i++) sum += rd_le(t.sizes + 4 * (size_t)i, 4);
+    return sum == t.data_bytes;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -266,6 +295,17 @@ size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t ca
     const u8* src = (const u8*)src_;
     size_t pos = 0, count = 0;
     u64 dst_off = 0;
+    SeekTable st;
+    if (read_seek_table(src, n, st) && !st.one_frame) {  // one frame per chunk, sizes listed: no walk (the frames are checked when they are decoded)
+        for (u32 i = 0; i < st.nchunks; i++) {
+            const u32 fs = rd_le(st.sizes + 4 * (size_t)i, 4);
+            const u64 cs = i + 1 < st.nchunks ? ZL_BLOCK_MAX : st.content - (u64)i * ZL_BLOCK_MAX;
+            if (i < cap) { frames[i].src_off = pos; frames[i].src_size = fs; frames[i].dst_off = dst_off; frames[i].dst_cap = cs; }
+            pos += fs;
+            dst_off += cs;
+        }
+        return st.nchunks;
+    }
     while (n - pos >= 5) {
         FrameHeader h;
         size_t fs = find_frame_size(src + pos, n - pos, &h);
@@ -583,11 +623,67 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
 // zstd.c:41798 ZSTD_decompressDCtx -> :41671 ZSTD_decompressMultiFrame, frames decoded in
 // parallel.  A frame without a recorded content size ends a launch group: its size is only
 // known once decoded, so later frames are placed after reading it back.
+namespace {
+// zl_decompressDCtx of a buffer that ends in a seek table: the frame table comes from the table, not from a walk over
+// every block header.  Returns ZL_ERR(ZL_E_FALLBACK) when the table and the data disagree anywhere: the caller then walks.
+size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t) {
+    if (t.content > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    hipStream_t st = dctx_stream(d, nullptr);
+    if (!d->d_src.ensure(t.data_bytes + 16) || !d->d_dst.ensure(t.content + 16)) return kGpuUnavailable;
+    if (hipMemcpyAsync(d->d_src.p, src, t.data_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t cnt = t.one_frame ? 1 : t.nchunks;
+    if (!d->h_frames.ensure(cnt * sizeof(zl_frame_desc)) || !d->h_results.ensure(cnt * sizeof(u64))) return kGpuUnavailable;
+    zl_frame_desc* tbl = (zl_frame_desc*)d->h_frames.p;
+    d->host_walk.clear();
+    d->chunk_off.clear();
+    if (t.one_frame) {
+        FrameHeader h;
+        if (ZL_IS_ERR(parse_frame_header(h, src, t.data_bytes)) || h.skippable || h.content_size != t.content || h.dict_id) return ZL_ERR(ZL_E_FALLBACK);
+        tbl[0].src_off = 0; tbl[0].src_size = t.data_bytes; tbl[0].dst_off = 0; tbl[0].dst_cap = t.content;
+        d->chunk_off.resize((size_t)t.nchunks + 1);
+        u64 run = 0;
+        for (u32 i = 0; i < t.nchunks; i++) { d->chunk_off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
+        d->chunk_off[t.nchunks] = run;
+    } else {
+        u64 pos = 0, out = 0;
+        for (u32 i = 0; i < t.nchunks; i++) {
+            const u32 fs = rd_le(t.sizes + 4 * (size_t)i, 4);
+            const u64 cs = i + 1 < t.nchunks ? ZL_BLOCK_MAX : t.content - (u64)i * ZL_BLOCK_MAX;
+            tbl[i].src_off = pos; tbl[i].src_size = fs; tbl[i].dst_off = out; tbl[i].dst_cap = cs;
+            pos += fs;
+            out += cs;
+        }
+    }
+    size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
+    d->chunk_off.clear();
+    if (ZL_IS_ERR(e)) return e;
+    if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const u64* r = (const u64*)d->h_results.p;
+    u64 total = 0;
+    for (size_t k = 0; k < cnt; k++) {
+        if (ZL_IS_ERR(r[k])) return ZL_ERR(ZL_E_FALLBACK);  // table or data: let the walk decide which, and name the error
+        total += r[k];
+    }
+    if (total != t.content) return ZL_ERR(ZL_E_FALLBACK);
+    if (hipMemcpyAsync(dst, d->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    return (size_t)total;
+}
+}  // namespace
+
 size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n) {
     if (!d) return ZL_ERR(ZL_E_GENERIC);
     if (!device_ok()) return kGpuUnavailable;
     if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     const u8* src = (const u8*)src_;
+    {   // a buffer that ends in this library's seek table needs no walk
+        SeekTable t;
+        if (d->dict.empty() && read_seek_table(src, n, t)) {
+            if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+            const size_t r = decompress_with_seek_table(d, (u8*)dst, cap, src, t);
+            if (r != ZL_ERR(ZL_E_FALLBACK)) return r;
+        }
+    }
     // ---- index frames on the host (serial header walk, zstd.c:41335)
     std::vector<zl_frame_desc> table;
     std::vector<u8> known;

@@ -24,6 +24,8 @@ struct zl_cctx_s {
     int nb_workers = 0;
     int layout = 0;  // ZL_c_frameLayout: 0 auto, 1 independent frames, 2 one frame
     int pipeline = 1;  // ZL_c_pipeline: host entries overlap upload, kernels and download for large inputs
+    bool any_small = false;  // the chunk table being enqueued holds inputs of at most one chunk (zl_chunk_desc::flags bit 0)
+    int seek_table = 0;  // ZL_c_seekTable: zl_compress2 appends the skippable seek-table frame (zl_format.h)
     std::vector<u8> dict;
     bool dict_uploaded = false, dict_formatted = false;
     u32 dict_id = 0, dict_content_off = 0, dict_use = 0;  // dict_use: trailing content bytes the matcher can reach
@@ -131,7 +133,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         f.src = d_src;
         f.total = joined_total;
         f.chunk_base = (u32)first;
-        f.pad = 0;
+        f.sample_log = c->level >= 9 ? 1u : (c->level >= 5 ? 2u : (u32)ZL_FAR_SAMPLE_LOG);  // the operating points above level 3: denser far sampling
         f.table = (u32*)es.far_table.p;
         f.hints = (u32*)es.far_hints.p;
         if (hipMemsetAsync(f.table, 0, ZL_FAR_TABLE_BYTES(cnt), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -151,6 +153,8 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.dict_len = c->dict_use;
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
     m.far_hints = joined ? (const u32*)es.far_hints.p : nullptr;
+    m.intra = c->any_small ? 1u : 0u;
+    m.pad0 = 0;
     if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
         (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
         m.stats = (u64*)c->d_stats.p;
@@ -240,6 +244,24 @@ bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
     return host_entry;
 }
 
+// the seek table behind `total` bytes of output (zl_format.h), from the per-chunk sizes in c->h_fsize
+size_t append_seek_table(const zl_cctx* c, u8* dst, size_t cap, size_t total, size_t nchunks, u64 content, bool one_frame) {
+    const size_t need = ZL_INDEX_BYTES(nchunks);
+    if (nchunks > 0x3FFFFFFFu) return total;
+    if (total + need > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    u8* p = dst + total;
+    auto w32 = [&](u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); p += 4; };
+    w32(ZL_MAGIC_INDEX);
+    w32((u32)(need - 8));
+    const u32* fs = (const u32*)c->h_fsize.p;
+    for (size_t i = 0; i < nchunks; i++) w32(fs[i]);
+    w32((u32)content); w32((u32)(content >> 32));
+    w32((u32)nchunks);
+    w32(one_frame ? 1u : 0u);
+    w32(ZL_INDEX_TAG);
+    return total + need;
+}
+
 size_t fill_chunk_table(zl_cctx* c, size_t n) {
     const size_t nchunks = chunks_of(n);
     if (!c->h_chunks.ensure(nchunks * sizeof(zl_chunk_desc))) return kGpuUnavailable;
@@ -247,8 +269,9 @@ size_t fill_chunk_table(zl_cctx* c, size_t n) {
     for (size_t i = 0; i < nchunks; i++) {
         t[i].src_off = (u64)i * ZL_CHUNK;
         t[i].src_size = (u32)std::min<size_t>(ZL_CHUNK, n - i * (size_t)ZL_CHUNK);
-        t[i].flags = 0;
+        t[i].flags = nchunks == 1 ? 1u : 0u;
     }
+    c->any_small = nchunks == 1;
     return nchunks;
 }
 
@@ -261,7 +284,7 @@ extern "C" {
 // this bound is also large enough for what the reference would have produced.
 size_t zl_compressBound(size_t n) {
     const size_t zb = n + (n >> 8) + (n < ZL_BLOCK_MAX ? ((ZL_BLOCK_MAX - n) >> 11) : 0);
-    return zb + chunks_of(n) * ZL_FRAME_OVERHEAD;
+    return zb + chunks_of(n) * ZL_FRAME_OVERHEAD + ZL_INDEX_BYTES(chunks_of(n));  // (room for the optional seek table, ZL_c_seekTable)
 }
 
 size_t zl_compress_device_nframes(size_t n) { return chunks_of(n); }
@@ -287,16 +310,22 @@ size_t zl_freeCCtx(zl_cctx* c) {
 }
 
 // zstd.c:23223 ZSTD_CCtx_setParameter for the parameters the glue uses (src/cctx.c:72-95,265-284).
-// The encoder has two operating points: levels >= 3 run the double-hash parse with the dense (stride-1)
-// body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529), levels < 3 probe every other
-// position throughout (cf. the step of ZSTD_fast, zstd.c:29340).  Measured against the reference at
-// the same level: within 5 % of its ratio at levels 1, 2 and 3 (tests/test_compress_gpu.py).
+// The encoder has these operating points, and a context remembers the one it runs at, not the number it was asked for
+// (zl_CCtx_getParameter and the host mirror's zstd_cctx_settings report that):
+//   levels < 3   every other position probed throughout (cf. the step of ZSTD_fast, zstd.c:29340); reported as given
+//   level 3, 4   the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
+//                in the one-frame layout one position in 8 takes part in the far search.  Reported as 3.
+//   levels 5..8  the same parse, one position in 4 in the far search.  Reported as 5.
+//   levels >= 9  one position in 2.  Reported as 9.
+// Measured against the reference at the same level: within 5 % of its ratio at levels 1, 2 and 3
+// (tests/test_compress_gpu.py).  The lazy and optimal parsers behind the reference's levels >= 5 (zstd.c:31546-33746) are
+// not built: above 3 only the far search deepens, and the ratio falls behind the reference's at those levels.
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value;
+        c->level = value >= 9 ? 9 : (value >= 5 ? 5 : (value >= 3 ? 3 : value));
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
@@ -308,6 +337,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
         c->layout = value;
         return 0;
     case ZL_c_pipeline: c->pipeline = value ? 1 : 0; return 0;
+    case ZL_c_seekTable: c->seek_table = value ? 1 : 0; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -319,6 +349,7 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     case ZL_c_checksumFlag: *value = c->checksum; return 0;
     case ZL_c_nbWorkers: *value = c->nb_workers; return 0;
     case ZL_c_frameLayout: *value = c->layout; return 0;
+    case ZL_c_seekTable: *value = c->seek_table; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -481,6 +512,10 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     if (down_result) return down_result;
     c->pending_chunks = nchunks;
     c->pending_groups = ngroups;
+    if (c->seek_table && nchunks > 1) {
+        if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || hipMemcpy(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        return append_seek_table(c, dst, cap, down_total, nchunks, n, one_frame);
+    }
     return down_total;
 }
 }  // namespace
@@ -507,6 +542,7 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
     if (total > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
     if (hipMemcpyAsync(dst, c->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (c->seek_table && nchunks > 1) return append_seek_table(c, (u8*)dst, cap, total, nchunks, n, use_one_frame(c, n, true));
     return total;
 }
 
@@ -533,6 +569,7 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         !c->d_src.ensure(in_total + 16) || !c->d_dst.ensure(bound_total + 16))
         return kGpuUnavailable;
     zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
+    c->any_small = false;
     for (size_t i = 0; i < n; i++) {
         if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
         const size_t k = chunks_of(sizes[i]);
@@ -540,7 +577,8 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
             zl_chunk_desc& d = t[first_chunk[i] + j];
             d.src_off = in_off[i] + j * (size_t)ZL_CHUNK;
             d.src_size = (u32)std::min<size_t>(ZL_CHUNK, sizes[i] - j * (size_t)ZL_CHUNK);
-            d.flags = 0;
+            d.flags = k == 1 ? 1u : 0u;
+            if (k == 1) c->any_small = true;
         }
     }
     if (in_total && hipMemcpyAsync(c->d_src.p, c->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);

@@ -38,7 +38,7 @@
 struct zl_chunk_desc {
     u64 src_off;   // first byte of the chunk inside the source buffer
     u32 src_size;  // <= ZL_CHUNK
-    u32 flags;     // reserved
+    u32 flags;     // bit 0: the chunk is a whole input of its own (at most one chunk): look for repeats inside the match window too
 };
 
 struct zl_seq {
@@ -66,6 +66,8 @@ struct zl_match_args {
     u32 dict_len;     // dictionary content bytes that sit, as history, in front of every chunk (0: none)
     const u8* dict;   // those bytes
     const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)
+    u32 intra;             // some chunk of the launch has flags bit 0 set (selects the kernel instantiation that can honour it)
+    u32 pad0;
     const u32* far_hints;  // windowed layout only: per chunk ZL_FAR_HINT_WORDS words, [25:0] an offset worth trying around these 32 bytes (0: none)
 };
 
@@ -74,7 +76,7 @@ struct zl_far_args {
     const u8* src;
     u64 total;             // bytes of that input (positions whose 8 bytes would run past it -- or past their section -- are not hashed)
     u32 chunk_base;        // index, inside the input, of chunks[0] (a multiple of ZL_FAR_GROUP)
-    u32 pad;
+    u32 sample_log;        // one position in 2^sample_log takes part (ZL_FAR_SAMPLE_LOG at level 3; higher levels sample more densely)
     u32* table;            // ZL_FAR_TABLE_BYTES(nchunks), zeroed before zl_launch_far_build
     u32* hints;            // per chunk ZL_FAR_HINT_WORDS words, written by zl_launch_far_probe
 };

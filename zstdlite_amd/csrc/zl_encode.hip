@@ -193,7 +193,11 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 // front of it: every 32-byte neighbourhood brings at most one offset found by the far table (zl_far_*_kernel below),
 // tried as a fourth candidate by every lane of the neighbourhood -- the lane the table hit extends it forwards, the
 // lanes in front of it backwards -- and a repeat offset may point in front of the chunk as well.
-template <bool DICT, bool PROF, bool FAR>
+// INTRA: the intra-window table (see the dense body) is compiled in; it is used by every chunk of the windowed layout and,
+// elsewhere, by the chunks whose descriptor asks for it: inputs of at most one chunk, where most of what repeats does so
+// within a few hundred bytes (a 1000-byte serialized data frame: 585 -> about 470 bytes).  The bulk path of large inputs
+// in the independent-frames layout runs without it (three more barriers per window).
+template <bool DICT, bool PROF, bool FAR, bool INTRA>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     __shared__ MatchShared S;
     ZL_POISON(S, 4);
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
-    if (FAR) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
+    const bool intra_on = INTRA && (FAR || (cd.flags & 1u));  // uniform
+    if (INTRA) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u64 w_i = 0;
             u32 q_i = 0;
             bool have_i = false;
-            if (FAR) {
+            if (INTRA && intra_on) {
                 unsigned short* const intra = (unsigned short*)S.jump[1];
                 const u32 slot = hs[0] & (WIN - 1);
                 const u32 pw = ip + t;
@@ -352,9 +357,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
                     if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
                     if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
-                    if (FAR && have_i) {  // (nearer than anything the tables can name: wins ties)
+                    if (INTRA && have_i) {  // (nearer than anything the tables can name: wins ties)
                         const u32 l_i = common_bytes(v[j], w_i);
-                        if (l_i >= MIN_MATCH + 1 && l_i >= best_len[j] && !(best_len[j] == l_i && best_off[j] == rep)) { best_len[j] = l_i; best_off[j] = p - q_i; q_best[j] = q_i; }
+                        if (l_i >= MIN_MATCH + 1 && l_i >= best_len[j] && !(best_len[j] == l_i && best_off[j] == rep)) { best_len[j] = l_i; best_off[j] = p - q_i; q_best[j] = D + q_i; }  // (q_best is a virtual position; q_i a chunk position)
                     }
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
@@ -841,9 +846,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* con
 // All chunks but the last are ZL_CHUNK bytes and contiguous, so chunk k steps back are k * ZL_CHUNK bytes.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 far_hash(u64 v) { return v * 0x9E3779B185EBCA87ULL; }
-__device__ __forceinline__ bool far_sampled(u64 h) { return (h >> (64 - ZL_FAR_SAMPLE_LOG)) == 0; }
-__device__ __forceinline__ u32 far_bucket(u64 h) { return (u32)(h >> (64 - ZL_FAR_SAMPLE_LOG - ZL_FAR_BUCKET_LOG)) & ((1u << ZL_FAR_BUCKET_LOG) - 1); }
-__device__ __forceinline__ u32 far_tag(u64 h) { return (u32)(h >> (64 - ZL_FAR_SAMPLE_LOG - ZL_FAR_BUCKET_LOG - 15)) & 0x7FFFu; }
+// (sl: how many top bits of the hash must be zero for a position to take part: one in 2^sl does -- the level's knob)
+__device__ __forceinline__ bool far_sampled(u64 h, u32 sl) { return (h >> (64 - sl)) == 0; }
+__device__ __forceinline__ u32 far_bucket(u64 h, u32 sl) { return (u32)(h >> (64 - sl - ZL_FAR_BUCKET_LOG)) & ((1u << ZL_FAR_BUCKET_LOG) - 1); }
+__device__ __forceinline__ u32 far_tag(u64 h, u32 sl) { return (u32)(h >> (64 - sl - ZL_FAR_BUCKET_LOG - 15)) & 0x7FFFu; }
 __device__ __forceinline__ size_t far_slot(u32 chunk, u32 bucket) {
     return ((((size_t)(chunk / ZL_FAR_GROUP)) << ZL_FAR_BUCKET_LOG) + bucket) * ZL_FAR_GROUP + (chunk % ZL_FAR_GROUP);
 }
@@ -865,9 +871,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a
         u32 bucket = 0, val = 0;
         if (p < lim) {
             const u64 h = far_hash(ld64(src + p));
-            on = far_sampled(h);
-            bucket = far_bucket(h);
-            val = (p << 15) | far_tag(h);
+            on = far_sampled(h, a.sample_log);
+            bucket = far_bucket(h, a.sample_log);
+            val = (p << 15) | far_tag(h, a.sample_log);
         }
         // one insert per bucket and wave -- the wave's highest position wins anyway, and a run of equal
         // bytes would otherwise send 64 atomics to one word
@@ -894,8 +900,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
         u32 best = 0;
         u64 v = 0, h = 1ull << 63;
         if (p < lim) { v = ld64(src + p); h = far_hash(v); }
-        if (far_sampled(h) && back > 0) {
-            const u32 bucket = far_bucket(h), tag = far_tag(h);
+        if (far_sampled(h, a.sample_log) && back > 0) {
+            const u32 bucket = far_bucket(h, a.sample_log), tag = far_tag(h, a.sample_log);
             u32 e[ZL_FAR_GROUP - 1];  // the 15 slots travel together: one round trip
 #pragma unroll
             for (u32 k = 1; k < ZL_FAR_GROUP; k++) e[k - 1] = k <= back ? a.table[far_slot(c - k, bucket)] : 0u;
@@ -938,10 +944,12 @@ extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hip
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -2122,7 +2130,7 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false>, ENC_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false, false>, ENC_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
     return n;
 }
