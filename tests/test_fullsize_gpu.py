@@ -107,3 +107,61 @@ def test_c2_ten_thousand_64k_reference_frames(codec):
     total, res = codec.decompress(blob, tbl, out)
     assert total == nframes * fsz and (res == fsz).all()
     assert torch.equal(out, want)
+
+
+def test_one_gib_ten_times_on_fresh_contexts():
+    """Stress (a 1-in-15 wrong byte was found by hand in round 1): the 1 GiB round trip ten times over, a
+    fresh pair of contexts each time, both layouts alternating -- same compressed bytes every time, bit-exact output."""
+    dev = torch.device("cuda", 0)
+    n = 1 << 30
+    src, _, _ = gen_mixed(n, dev)
+    back = torch.empty_like(src)
+    digests = {}
+    for it in range(10):
+        layout = ("frames", "one_frame")[it & 1]
+        c = DeviceCodec(frame_layout=layout)
+        comp, total, fs = c.compress(src)
+        dig = (total, int(comp[: total // 8 * 8].view(torch.int64).sum().item()), int(comp[total // 8 * 8: total].to(torch.int64).sum().item()))
+        assert digests.setdefault(layout, dig) == dig, (it, layout)
+        back.zero_()
+        if layout == "frames":
+            got, _ = c.decompress(comp, c.frame_table(fs, c.chunk_content_sizes(n)), back)
+        else:
+            got, _ = c.decompress(comp, c.frame_table([total], [n]), back, chunk_sizes=fs)
+        assert got == n and torch.equal(back, src), (it, layout)
+        c.close()
+        del comp
+
+
+def test_host_entry_sections_write_the_same_bytes_as_one_launch():
+    """zl_compress2 of a large input uploads, compresses and downloads in sections on several streams (ZL_c_pipeline);
+    what it writes must not depend on that: same bytes as the one-stream path and as the device entry, both layouts."""
+    from zstdlite_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = 320 << 20
+    src, _, _ = gen_mixed(n, dev)
+    host = src.cpu().numpy()
+    cap = L.zl_compressBound(n)
+    outs = {}
+    for layout, code in (("one_frame", 2), ("frames", 1)):
+        for pipe in (1, 0):
+            cctx = L.zl_createCCtx()
+            L.zl_CCtx_setParameter(cctx, 9003, code)
+            L.zl_CCtx_setParameter(cctx, 9004, pipe)
+            buf = np.empty(cap, dtype=np.uint8)
+            r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+            assert not _lib.is_error(r), _lib.error_name(r)
+            outs[(layout, pipe)] = buf[:r].copy()
+            L.zl_freeCCtx(cctx)
+        assert np.array_equal(outs[(layout, 1)], outs[(layout, 0)]), layout
+        c = DeviceCodec(frame_layout=layout)
+        comp, total, _ = c.compress(src)
+        assert total == len(outs[(layout, 1)]) and np.array_equal(comp[:total].cpu().numpy(), outs[(layout, 1)]), layout
+        c.close()
+    dctx = L.zl_createDCtx()
+    back = np.empty(n, dtype=np.uint8)
+    for key, blob in outs.items():
+        back.fill(0)
+        assert L.zl_decompressDCtx(dctx, back.ctypes.data, n, blob.ctypes.data, len(blob)) == n and np.array_equal(back, host), key
+    L.zl_freeDCtx(dctx)

@@ -16,6 +16,7 @@ buffers.  `zstd_serialize` uses pickle where the reference uses R's native seria
 """
 import ctypes as C
 import pickle
+import threading
 import warnings
 
 import numpy as np
@@ -148,6 +149,31 @@ def _init_dctx_with_opts(opts, quiet=False):
     return dctx
 
 
+# Calls without an explicit context (the reference builds -- and leaks -- a fresh one per call, src/raw-file.c:60-75,170-176)
+# reuse one context per thread and option set: a HIP context owns streams and grow-only device buffers, and building
+# them anew for every small object cost more than the compression.  Contexts are single-caller objects
+# (include/zl_hip.h), hence one cache per thread.
+_tls = threading.local()
+
+
+def _cached_ctx(kind, opts):
+    try:
+        key = (kind, tuple(sorted((k, v if not isinstance(v, (bytearray, memoryview, np.ndarray)) else bytes(v)) for k, v in opts.items())))
+        hash(key)
+    except TypeError:
+        key = None
+    make = _init_cctx_with_opts if kind == "c" else _init_dctx_with_opts
+    if key is None:
+        return make(opts)
+    cache = _tls.__dict__.setdefault("ctx", {})
+    ctx = cache.get(key)
+    if ctx is None:
+        if len(cache) >= 8:  # a handful of option sets at most; drop the oldest
+            cache.pop(next(iter(cache)))
+        ctx = cache[key] = make(opts)
+    return ctx
+
+
 def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None, frame_layout="auto", seek_table=False):
     """R/cctx.R:38-48 -> init_cctx_ (src/cctx.c:323).  frame_layout is this library's own knob (the reference
     always writes one frame): "auto" = one frame from zstd_compress / zstd_serialize, "frames" = one
@@ -197,7 +223,7 @@ def _compress_bytes(src_ptr, src_size, cctx, opts, who):
     L = _lib.lib()
     cap = L.zl_compressBound(src_size)
     dst = np.empty(cap, dtype=np.uint8)
-    ctx = _init_cctx_with_opts(opts) if cctx is None else cctx  # opts only honoured without a cctx
+    ctx = _cached_ctx("c", opts) if cctx is None else cctx  # opts only honoured without a cctx
     r = L.zl_compress2(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, src_ptr, src_size)
     if is_error(r):
         raise ZstdError(f"{who}(): Compression error. {_lib.error_name(r)}")
@@ -238,7 +264,7 @@ def _decompress_bytes(src, dctx, opts, who):
     if cap == _UNKNOWN:
         raise ZstdError(f"{who}(): frame does not record its content size")
     dst = np.empty(max(cap, 1), dtype=np.uint8)
-    ctx = _init_dctx_with_opts(opts) if dctx is None else dctx
+    ctx = _cached_ctx("d", opts) if dctx is None else dctx
     r = L.zl_decompressDCtx(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, ptr, csize)
     if is_error(r):
         raise ZstdError(f"{who}(): De-compression error. {_lib.error_name(r)}")
@@ -275,7 +301,11 @@ def zstd_serialize(robj, *, dst=None, cctx=None, use_file_streaming=False, **opt
 
 
 def zstd_unserialize(src, *, dctx=None, use_file_streaming=False, **opts):
-    """R/serialize.R:74-84 -> zstd_unserialize_ (src/serialize.c:149-240)."""
+    """R/serialize.R:74-84 -> zstd_unserialize_ (src/serialize.c:149-240).
+
+    TRUST: this mirror serializes with pickle where the reference uses R's native serialization, and unpickling
+    runs code the bytes name.  R's unserialize() has no such property: only unserialize what you (or someone you
+    trust) serialized; for anything else use zstd_decompress() and parse the bytes yourself."""
     if isinstance(src, str) and use_file_streaming:  # src/serialize.c:158-160 -> zstd_unserialize_stream_file (src/serialize-file-in.c:104)
         return pickle.loads(_stream_read(src, dctx, opts, "zstd_unserialize_stream_file_"))
     if isinstance(src, str):
@@ -343,7 +373,7 @@ def zstd_compress_batch(xs, *, cctx=None, **opts):
     n = len(xs)
     if n == 0:
         return []
-    ctx = _init_cctx_with_opts(opts) if cctx is None else cctx
+    ctx = _cached_ctx("c", opts) if cctx is None else cctx
     srcs = [_as_buffer(x, "zstd_compress_batch()") for x in xs]
     sizes = (C.c_size_t * n)(*[s[1] for s in srcs])
     caps = [L.zl_compressBound(s[1]) for s in srcs]
@@ -367,7 +397,7 @@ def zstd_decompress_batch(srcs, *, dctx=None, **opts):
     n = len(srcs)
     if n == 0:
         return []
-    ctx = _init_dctx_with_opts(opts) if dctx is None else dctx
+    ctx = _cached_ctx("d", opts) if dctx is None else dctx
     bufs = [_as_buffer(s, "zstd_decompress_batch()") for s in srcs]
     sizes = (C.c_size_t * n)(*[b[1] for b in bufs])
     caps = []
