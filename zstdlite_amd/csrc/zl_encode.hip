@@ -599,104 +599,127 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
 #endif
         if (has_match && best_off != rep && best_len + (back_ok ? 1u : 0u) < ZL_SPARSE_MIN) has_match = false;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
-            const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            lds_barrier();
-            // ---- lazy evaluation against the next probed position (two bytes on): giving up this match costs two literals
-            if (has_match && t + 1 < ENC_THREADS) {
-                const u32 nxc = S.cand[t + 1];
-                if (nxc) {
-    #ifndef ZL_LAZY_BIAS
-    #define ZL_LAZY_BIAS 8
-    #endif
-                    const int g1 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1)) + ZL_LAZY_BIAS;
-                    const int g2 = 4 * (int)(nxc & 0xFF) - (int)(31 - __clz((nxc >> 8) + 1));
-                    if (g2 > g1) has_match = false;
-                }
-            }
-            // the byte behind a match that ends on an odd position is a literal of this lane
-            const u32 mend = 2 * t + best_len;  // window-relative end of the match
-            const bool odd_end = has_match && (mend & 1) && p + best_len < n;
-            u32 tail_byte = 0;
-            if (odd_end) tail_byte = src[p + best_len];
-            // ---- greedy parse over the 256 nodes (even positions): wave-local closure, chain, marks
-            const u32 nxt = has_match ? ((mend + 1) >> 1) : t + 1u;  // next node on the path
-            u32 jr[6];
-            u32 jp = nxt;
-    #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                jr[r] = jp;
-                const u32 far = __shfl(jp, (int)((jp - wbase) & 63), 64);
-                jp = (jp < wbase + 64) ? far : jp;
-            }
-            S.jump[0][t] = (u16)jp;  // where a path entering at node t leaves this wave's segment
-            lds_barrier();
-            u32 enter = carry_n, my_entry = 0xFFFFFFFFu;
-    #pragma unroll
-            for (u32 k = 0; k < 4; k++) {
-                if (enter < 64 * (k + 1)) {
-                    if (k == wave) my_entry = enter;
-                    enter = S.jump[0][enter];
-                }
-            }
-            const u32 next_carry = enter - ENC_THREADS;
-            S.mark[t] = (t == my_entry) ? 1 : 0;
-    #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                asm volatile("" ::: "memory");
-                if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
-            }
-            asm volatile("" ::: "memory");
-            const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            const bool on_path = S.mark[t] != 0;
-            const bool is_seq = on_path && has_match;
-            // backward extension by one byte.  The byte in front of an on-path node is a literal owned by the
-            // node before it on the path: the odd byte of a lane without a match, or the byte behind a match
-            // that ends on an odd position.  The wanting lane raises a flag in its slot, the owner answers
-            // in the second array; both then count one literal less / one match byte more.
-            const bool givable = on_path && nxt < ENC_THREADS && (has_match ? odd_end : in1);
-            S.cand[t] = (is_seq && back_ok) ? 1u : 0u;
-            S.jump[1][t] = 0;
-            lds_barrier();
-            const bool give = givable && S.cand[nxt] != 0;
-            if (give) S.jump[1][nxt] = 1;
-            lds_barrier();
-            const bool ext = S.jump[1][t] != 0;
-            const u32 nl_base = !on_path ? 0u : (has_match ? (odd_end ? 1u : 0u) : (in1 ? 2u : (in0 ? 1u : 0u)));
-            const u32 nl_mine = nl_base - (give ? 1u : 0u);
-            // compaction ranks from ballots (literal counts are 0..2: two bit planes)
-            u32 ex_s, ex_l, tot_s, tot_l;
+            // does any lane of the workgroup hold a match?  (one word per wave next to the candidates, read behind the same barrier)
             {
-                const u64 ms = __ballot(is_seq), m1 = __ballot((nl_mine & 1) != 0), m2 = __ballot((nl_mine & 2) != 0);
-                const u64 below = (1ull << (t & 63)) - 1;
-                const u32 ws = (u32)__popcll(ms), wl = (u32)__popcll(m1) + 2 * (u32)__popcll(m2);
-                if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16);
-                lds_barrier();
-                u32 pre = 0, tot = 0;
-    #pragma unroll
-                for (u32 w = 0; w < 4; w++) {
-                    const u32 x = S.scan_a[w];
-                    if (w < wave) pre += x;
-                    tot += x;
+                const u64 many = __ballot(has_match);
+                if ((t & 63) == 0) S.scan_b[t >> 6] = many ? 1u : 0u;
+            }
+            const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+            u64 s2 = s1;
+            lds_barrier();
+            const bool any_match = (S.scan_b[0] | S.scan_b[1] | S.scan_b[2] | S.scan_b[3]) != 0;  // uniform
+            u32 tot_s = 0, tot_l = 0;
+            if (!any_match) {
+                // ---- a window without a single match -- the rule on data that does not repeat -- needs no parse: every node from
+                // the entry point on is on the path and gives its two bytes (what is left of them at the end of the chunk)
+                if (!covered && t >= carry_n) {
+                    const u32 ex = 2 * (t - carry_n);
+                    if (in0) lits[nlit + ex] = (u8)v0;
+                    if (in1) lits[nlit + ex + 1] = (u8)(v0 >> 8);
                 }
-                ex_s = (pre & 0xFFFF) + (u32)__popcll(ms & below);
-                ex_l = (pre >> 16) + (u32)__popcll(m1 & below) + 2 * (u32)__popcll(m2 & below);
-                tot_s = tot & 0xFFFF;
-                tot_l = tot >> 16;
+                if (!covered && ip + 2 * carry_n < n) {
+                    const u32 left = n - (ip + 2 * carry_n), span = 2 * (ENC_THREADS - carry_n);
+                    tot_l = left < span ? left : span;
+                }
+                carry = covered ? carry - WIN2 : 0u;
+            } else {
+                // ---- lazy evaluation against the next probed position (two bytes on): giving up this match costs two literals
+                if (has_match && t + 1 < ENC_THREADS) {
+                    const u32 nxc = S.cand[t + 1];
+                    if (nxc) {
+        #ifndef ZL_LAZY_BIAS
+        #define ZL_LAZY_BIAS 8
+        #endif
+                        const int g1 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1)) + ZL_LAZY_BIAS;
+                        const int g2 = 4 * (int)(nxc & 0xFF) - (int)(31 - __clz((nxc >> 8) + 1));
+                        if (g2 > g1) has_match = false;
+                    }
+                }
+                // the byte behind a match that ends on an odd position is a literal of this lane
+                const u32 mend = 2 * t + best_len;  // window-relative end of the match
+                const bool odd_end = has_match && (mend & 1) && p + best_len < n;
+                u32 tail_byte = 0;
+                if (odd_end) tail_byte = src[p + best_len];
+                // ---- greedy parse over the 256 nodes (even positions): wave-local closure, chain, marks
+                const u32 nxt = has_match ? ((mend + 1) >> 1) : t + 1u;  // next node on the path
+                u32 jr[6];
+                u32 jp = nxt;
+        #pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    jr[r] = jp;
+                    const u32 far = __shfl(jp, (int)((jp - wbase) & 63), 64);
+                    jp = (jp < wbase + 64) ? far : jp;
+                }
+                S.jump[0][t] = (u16)jp;  // where a path entering at node t leaves this wave's segment
+                lds_barrier();
+                u32 enter = carry_n, my_entry = 0xFFFFFFFFu;
+        #pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    if (enter < 64 * (k + 1)) {
+                        if (k == wave) my_entry = enter;
+                        enter = S.jump[0][enter];
+                    }
+                }
+                const u32 next_carry = enter - ENC_THREADS;
+                S.mark[t] = (t == my_entry) ? 1 : 0;
+        #pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    asm volatile("" ::: "memory");
+                    if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
+                }
+                asm volatile("" ::: "memory");
+                s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
+                const bool on_path = S.mark[t] != 0;
+                const bool is_seq = on_path && has_match;
+                // backward extension by one byte.  The byte in front of an on-path node is a literal owned by the
+                // node before it on the path: the odd byte of a lane without a match, or the byte behind a match
+                // that ends on an odd position.  The wanting lane raises a flag in its slot, the owner answers
+                // in the second array; both then count one literal less / one match byte more.
+                const bool givable = on_path && nxt < ENC_THREADS && (has_match ? odd_end : in1);
+                S.cand[t] = (is_seq && back_ok) ? 1u : 0u;
+                S.jump[1][t] = 0;
+                lds_barrier();
+                const bool give = givable && S.cand[nxt] != 0;
+                if (give) S.jump[1][nxt] = 1;
+                lds_barrier();
+                const bool ext = S.jump[1][t] != 0;
+                const u32 nl_base = !on_path ? 0u : (has_match ? (odd_end ? 1u : 0u) : (in1 ? 2u : (in0 ? 1u : 0u)));
+                const u32 nl_mine = nl_base - (give ? 1u : 0u);
+                // compaction ranks from ballots (literal counts are 0..2: two bit planes)
+                u32 ex_s, ex_l;
+                {
+                    const u64 ms = __ballot(is_seq), m1 = __ballot((nl_mine & 1) != 0), m2 = __ballot((nl_mine & 2) != 0);
+                    const u64 below = (1ull << (t & 63)) - 1;
+                    const u32 ws = (u32)__popcll(ms), wl = (u32)__popcll(m1) + 2 * (u32)__popcll(m2);
+                    if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16);
+                    lds_barrier();
+                    u32 pre = 0, tot = 0;
+        #pragma unroll
+                    for (u32 w = 0; w < 4; w++) {
+                        const u32 x = S.scan_a[w];
+                        if (w < wave) pre += x;
+                        tot += x;
+                    }
+                    ex_s = (pre & 0xFFFF) + (u32)__popcll(ms & below);
+                    ex_l = (pre >> 16) + (u32)__popcll(m1 & below) + 2 * (u32)__popcll(m2 & below);
+                    tot_s = tot & 0xFFFF;
+                    tot_l = tot >> 16;
+                }
+                if (is_seq) {
+                    zl_seq sq;
+                    sq.lit_cum = nlit + ex_l;
+                    sq.match_len = best_len + (ext ? 1u : 0u);
+                    sq.offset = best_off;
+                    sq.pos = p - (ext ? 1u : 0u);
+                    seqs[nseq + ex_s] = sq;
+                    if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
+                    if (odd_end && !give) lits[nlit + ex_l] = (u8)tail_byte;
+                } else if (nl_mine) {
+                    lits[nlit + ex_l] = (u8)v0;
+                    if (nl_mine == 2) lits[nlit + ex_l + 1] = (u8)(v0 >> 8);
+                }
+                carry = covered ? carry - WIN2 : 2 * next_carry;
             }
-            if (is_seq) {
-                zl_seq sq;
-                sq.lit_cum = nlit + ex_l;
-                sq.match_len = best_len + (ext ? 1u : 0u);
-                sq.offset = best_off;
-                sq.pos = p - (ext ? 1u : 0u);
-                seqs[nseq + ex_s] = sq;
-                if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
-                if (odd_end && !give) lits[nlit + ex_l] = (u8)tail_byte;
-            } else if (nl_mine) {
-                lits[nlit + ex_l] = (u8)v0;
-                if (nl_mine == 2) lits[nlit + ex_l + 1] = (u8)(v0 >> 8);
-            }
-            carry = covered ? carry - WIN2 : 2 * next_carry;
             const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- insert both positions of every lane (most recent position wins)
             if (ZL_INSERT_CAS) {
