@@ -883,30 +883,42 @@ __device__ __forceinline__ u32 far_limit(const zl_far_args& a, const zl_chunk_de
     return left >= (u64)cd.src_size + 8 ? cd.src_size : (left >= 8 ? (u32)(left - 7) : 0u);
 }
 
+// (both kernels work through FAR_UNROLL windows of 256 positions per trip, phase by phase, so that the loads of all of
+// them are in flight together: one window per trip left a single 8-byte load per lane between two dependent waits --
+// 5.5 + 6.9 ms for 1 GiB at one position in eight)
+#define FAR_UNROLL 4
 __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
-    for (u32 ip = 0; ip < lim; ip += ENC_THREADS) {
-        const u32 p = ip + t;
-        bool on = false;
-        u32 bucket = 0, val = 0;
-        if (p < lim) {
-            const u64 h = far_hash(ld64(src + p));
-            on = far_sampled(h, a.sample_log);
-            bucket = far_bucket(h, a.sample_log);
-            val = (p << 15) | far_tag(h, a.sample_log);
-        }
-        // one insert per bucket and wave -- the wave's highest position wins anyway, and a run of equal
-        // bytes would otherwise send 64 atomics to one word
-        u64 m = __ballot(on);
-        while (m) {
-            const int first = __ffsll((unsigned long long)m) - 1;
-            const u32 b = __shfl(bucket, first, 64);
-            const u64 same = __ballot(on && bucket == b);
-            if (lane == 63u - (u32)__clzll((long long)same)) atomicMax(a.table + far_slot(c, b), val);
-            m &= ~same;
+    const u32 sl = a.sample_log;
+    for (u32 ip = 0; ip < lim; ip += ENC_THREADS * FAR_UNROLL) {
+        u64 v[FAR_UNROLL];
+#pragma unroll
+        for (int k = 0; k < FAR_UNROLL; k++) { const u32 p = ip + k * ENC_THREADS + t; v[k] = p < lim ? ld64(src + p) : 0; }
+#pragma unroll
+        for (int k = 0; k < FAR_UNROLL; k++) {
+            const u32 p = ip + k * ENC_THREADS + t;
+            const u64 h = far_hash(v[k]);
+            const bool on = p < lim && far_sampled(h, sl);
+            const u32 bucket = far_bucket(h, sl), val = (p << 15) | far_tag(h, sl);
+            // One insert per bucket and wave is enough -- the wave's highest position wins anyway -- and a run of equal bytes
+            // (or a short period) would otherwise send up to 64 atomics to one word.  Sampled lanes are few and their buckets
+            // differ on ordinary data: the duplicates are only looked for when a wave has suspiciously many of them.
+            const u64 m = __ballot(on);
+            if ((u32)__popcll(m) <= (64u >> sl) * 3u + 4u) {
+                if (on) atomicMax(a.table + far_slot(c, bucket), val);
+            } else {
+                u64 rest = m;
+                while (rest) {
+                    const int first = __ffsll((unsigned long long)rest) - 1;
+                    const u32 b = __shfl(bucket, first, 64);
+                    const u64 same = __ballot(on && bucket == b);
+                    if (lane == 63u - (u32)__clzll((long long)same)) atomicMax(a.table + far_slot(c, b), val);
+                    rest &= ~same;
+                }
+            }
         }
     }
 }
@@ -917,40 +929,61 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size, lim = far_limit(a, cd, a.chunk_base + c);
     const u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
+    const u32 sl = a.sample_log;
     u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
-    for (u32 ip = 0; ip < n; ip += ENC_THREADS) {
-        const u32 p = ip + t;
-        u32 best = 0;
-        u64 v = 0, h = 1ull << 63;
-        if (p < lim) { v = ld64(src + p); h = far_hash(v); }
-        if (far_sampled(h, a.sample_log) && back > 0) {
-            const u32 bucket = far_bucket(h, a.sample_log), tag = far_tag(h, a.sample_log);
-            u32 e[ZL_FAR_GROUP - 1];  // the 15 slots travel together: one round trip
+    for (u32 ip = 0; ip < n; ip += ENC_THREADS * FAR_UNROLL) {
+        u64 v[FAR_UNROLL];
+        u32 off[FAR_UNROLL], best[FAR_UNROLL];
+        // ---- the positions' bytes
 #pragma unroll
-            for (u32 k = 1; k < ZL_FAR_GROUP; k++) e[k - 1] = k <= back ? a.table[far_slot(c - k, bucket)] : 0u;
-            u32 off = 0;  // of the nearest chunk whose slot carries our tag
+        for (int k = 0; k < FAR_UNROLL; k++) { const u32 p = ip + k * ENC_THREADS + t; v[k] = p < lim ? ld64(src + p) : 0; }
+        // ---- the slots of the 15 chunks in front (two 64-byte lines per sampled position): all windows' loads travel together
+        u32 e[FAR_UNROLL][ZL_FAR_GROUP - 1];
+        u32 tag[FAR_UNROLL];
+        bool on[FAR_UNROLL];
 #pragma unroll
-            for (u32 k = ZL_FAR_GROUP - 1; k >= 1; k--) {
-                const u32 x = e[k - 1];
-                if (x != 0 && (x & 0x7FFFu) == tag) off = k * ZL_CHUNK + p - (x >> 15);
-            }
-            if (off) {
-                const u8* q = src + p - off;
-                if (ld64(q) == v) {
-                    u32 len = 8;
-                    while (len < 32 && p + len < lim) {
-                        const u32 l = common_bytes(ld64(src + p + len), ld64(q + len));
-                        len += l;
-                        if (l < 8) break;
-                    }
-                    best = (len << 26) | off;
-                }
-            }
+        for (int k = 0; k < FAR_UNROLL; k++) {
+            const u32 p = ip + k * ENC_THREADS + t;
+            const u64 h = far_hash(v[k]);
+            on[k] = p < lim && back > 0 && far_sampled(h, sl);
+            tag[k] = far_tag(h, sl);
+            const u32 bucket = far_bucket(h, sl);
+#pragma unroll
+            for (u32 q = 1; q < ZL_FAR_GROUP; q++) e[k][q - 1] = (on[k] && q <= back) ? a.table[far_slot(c - q, bucket)] : 0u;
         }
-        // the longest hit of each neighbourhood (ties: the larger offset -- any fixed rule will do)
+        // ---- the nearest chunk whose slot carries our tag; its bytes
+        u64 w[FAR_UNROLL];
 #pragma unroll
-        for (int d = (1 << ZL_FAR_HINT_LOG) / 2; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
-        if ((t & ((1u << ZL_FAR_HINT_LOG) - 1)) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best;
+        for (int k = 0; k < FAR_UNROLL; k++) {
+            const u32 p = ip + k * ENC_THREADS + t;
+            off[k] = 0;
+#pragma unroll
+            for (u32 q = ZL_FAR_GROUP - 1; q >= 1; q--) {
+                const u32 x = e[k][q - 1];
+                if (x != 0 && (x & 0x7FFFu) == tag[k]) off[k] = q * ZL_CHUNK + p - (x >> 15);
+            }
+            w[k] = off[k] ? ld64(src + p - off[k]) : ~v[k];
+        }
+        // ---- verify, measure (up to 32 bytes), and keep the longest hit of every neighbourhood (ties: the larger offset -- any
+        // fixed rule will do)
+#pragma unroll
+        for (int k = 0; k < FAR_UNROLL; k++) {
+            const u32 p = ip + k * ENC_THREADS + t;
+            best[k] = 0;
+            if (off[k] && w[k] == v[k]) {
+                const u8* q = src + p - off[k];
+                u32 len = 8;
+                while (len < 32 && p + len < lim) {
+                    const u32 l = common_bytes(ld64(src + p + len), ld64(q + len));
+                    len += l;
+                    if (l < 8) break;
+                }
+                best[k] = (len << 26) | off[k];
+            }
+#pragma unroll
+            for (int d = (1 << ZL_FAR_HINT_LOG) / 2; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best[k], d, 64); best[k] = o > best[k] ? o : best[k]; }
+            if ((t & ((1u << ZL_FAR_HINT_LOG) - 1)) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best[k];
+        }
     }
 }
 
