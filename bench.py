@@ -401,6 +401,65 @@ def _free_port():
     return p
 
 
+def inproc_main(args):
+    """--inproc: the multi-GPU path as the reference package could call it -- R is one process (src/init.c:90-99), so the
+    sharding sits behind zl_compress2 / zl_decompressDCtx: N device slots, each uploading, coding and downloading its own
+    contiguous run of 64 MiB sections from its own host thread.  One step = zstd_compress + zstd_decompress of N x --size
+    bytes of HOST memory (weak scaling), PCIe both ways inside the timed region: an end-to-end number, not the
+    device-resident headline.  Slot s runs on device s mod the number of visible devices."""
+    import torch
+    from zstdlite_amd import _lib
+    from zstdlite_amd.device import gen_mixed
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    L = _lib.lib()
+    ndev = torch.cuda.device_count()
+    slots = args.gpus
+    n = args.size * slots
+    dev = torch.device("cuda", 0)
+    host = np.concatenate([gen_mixed(args.size, dev)[0].cpu().numpy() for _ in range(slots)]) if slots > 1 else gen_mixed(args.size, dev)[0].cpu().numpy()
+    cap = L.zl_compressBound(n)
+    comp = np.empty(cap, dtype=np.uint8); comp.fill(1)
+    back = np.empty(n, dtype=np.uint8); back.fill(1)
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    L.zl_CCtx_setParameter(cctx, 9007, slots)
+    L.zl_DCtx_setParameter(dctx, 9008, slots)
+    L.zl_CCtx_setParameter(cctx, 9006, 1)  # the seek table lets the decoder deal ONE frame out over the slots
+    tc = td = 0.0
+
+    def step():
+        nonlocal tc, td
+        t0 = time.perf_counter()
+        r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
+        t1 = time.perf_counter()
+        assert not _lib.is_error(r), _lib.error_name(r)
+        r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+        t2 = time.perf_counter()
+        assert r2 == n, _lib.error_name(r2)
+        tc += t1 - t0
+        td += t2 - t1
+        return r
+    for _ in range(args.warmup):
+        step()
+    tc = td = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        csize = step()
+    elapsed = time.perf_counter() - t0
+    assert np.array_equal(back, host), "round trip is not bit-exact"
+    print(json.dumps({
+        "metric": "GB/s zstd_compress+zstd_decompress on 1 GiB raw, level 3; ratio vs CPU", "mode": "inproc (host buffers, PCIe inside the timed region)",
+        "value": n * args.steps / elapsed / 1e9, "unit": "GB/s", "n_gpus": slots, "devices_visible": ndev, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"zl_compress2 then zl_decompressDCtx of {n >> 20} MiB of host memory ({args.size >> 20} MiB per device slot), level 3, one-frame layout with seek table",
+                   "parallelism": f"{slots} device slot(s) on {ndev} visible device(s) behind one call, contiguous runs of 64 MiB sections, no collective"},
+        "ratio": n / csize, "compressed_bytes": int(csize), "bit_exact_roundtrip": True,
+        "compress_GBps": n * args.steps / tc / 1e9, "decompress_GBps": n * args.steps / td / 1e9,
+        "slots_used": {"compress": int(L.zl_cctx_last_slots(cctx)), "decompress": int(L.zl_dctx_last_slots(dctx))}}), flush=True)
+    L.zl_freeCCtx(cctx)
+    L.zl_freeDCtx(dctx)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -411,7 +470,10 @@ def main():
     ap.add_argument("--no-c2", action="store_true", help="skip the 10k x 64 KiB frame decode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the one-frame, long-range, C4 and end-to-end legs")
     ap.add_argument("--dry", action="store_true", help="control flow only, CPU ranks over gloo (tests); prints no measurement")
+    ap.add_argument("--inproc", action="store_true", help="ONE process: the host entries of the C-ABI spread every call over --gpus device slots (ZL_c_devices / ZL_d_devices): what an R caller gets")
     args = ap.parse_args()
+    if args.inproc:
+        return inproc_main(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Launched without torchrun: start the N ranks ourselves.  This parent has not touched the GPU

@@ -66,6 +66,13 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * every block header of the data in front of it; the table is checked against the data, never trusted.  Off by default:
  * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written. */
 #define ZL_c_seekTable 9006
+/* Devices behind one call: zl_compress2 / zl_decompressDCtx of a large host buffer deal its 64 MiB sections out
+ * over this many device slots -- slot s on device s mod hipGetDeviceCount() --, each with its own host thread, upload and
+ * download (its own PCIe link; nothing is funnelled through one device).  1 (default): the current device only.  0: every
+ * visible device, one per 512 MiB of input at least.  The bytes written do not depend on the number of devices.
+ * Decompression spreads independent frames, and one frame of this library when a seek table says where its chunks are. */
+#define ZL_c_devices 9007
+#define ZL_d_devices 9008
 #define ZL_c_pipeline 9004
 #define ZL_d_pipeline 9005
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
@@ -224,6 +231,10 @@ size_t zl_dctx_kernel_ms(const zl_dctx *dctx, double *ms);
  * the whole device: what ZSTD_compress2 writes for inputs above 128 KiB, src/raw-file.c:74) rather
  * than with one workgroup.  Lets tests and benchmarks assert which path ran. */
 size_t zl_dctx_large_frames(const zl_dctx *dctx);
+/* Device slots the last zl_compress2 / zl_decompressDCtx call spread its work over (ZL_c_devices / ZL_d_devices): 1 when it ran on
+ * the current device alone.  Lets tests assert that the sharded path ran. */
+size_t zl_cctx_last_slots(const zl_cctx *cctx);
+size_t zl_dctx_last_slots(const zl_dctx *dctx);
 
 /* library / device info */
 const char *zl_versionString(void); /* ZSTD_versionString twin for src/serialize.c:26 */

@@ -165,3 +165,47 @@ def test_host_entry_sections_write_the_same_bytes_as_one_launch():
         back.fill(0)
         assert L.zl_decompressDCtx(dctx, back.ctypes.data, n, blob.ctypes.data, len(blob)) == n and np.array_equal(back, host), key
     L.zl_freeDCtx(dctx)
+
+
+def _host_roundtrip(L, host, layout, devices, seek):
+    from zstdlite_amd import _lib
+    n = host.size
+    cap = L.zl_compressBound(n)
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    L.zl_CCtx_setParameter(cctx, 9003, layout)
+    L.zl_CCtx_setParameter(cctx, 9006, seek)
+    assert L.zl_CCtx_setParameter(cctx, 9007, devices) == 0 and L.zl_DCtx_setParameter(dctx, 9008, devices) == 0
+    buf = np.empty(cap, dtype=np.uint8)
+    r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+    assert not _lib.is_error(r), _lib.error_name(r)
+    back = np.zeros(n, dtype=np.uint8)
+    r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, buf.ctypes.data, r)
+    assert r2 == n, _lib.error_name(r2)
+    assert np.array_equal(back, host)
+    used = (int(L.zl_cctx_last_slots(cctx)), int(L.zl_dctx_last_slots(dctx)))
+    L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+    return buf[:r].copy(), used
+
+
+def test_device_slots_behind_the_host_entries():
+    """SURVEY 8e inside one process (the reference is one process: src/init.c:90-99): ZL_c_devices / ZL_d_devices deal the
+    sections of a large host buffer out over device slots.  The bytes written must not depend on the number of slots; a
+    slot count above the number of devices puts several slots on one device, which is how one GPU tests the path (with
+    more than one device the same test spreads over them)."""
+    from zstdlite_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = (640 << 20) + 12345
+    host = gen_mixed(n, dev)[0].cpu().numpy()
+    for layout in (2, 1):           # one frame, independent frames
+        for seek in (1, 0):         # (without a seek table one frame is decoded by one device)
+            one, used = _host_roundtrip(L, host, layout, 1, seek)
+            assert used == (1, 1)
+            for slots in (2, 3):
+                got, used = _host_roundtrip(L, host, layout, slots, seek)
+                assert np.array_equal(got, one), (layout, seek, slots)
+                # compression always shards; decompression does unless it is ONE frame without a seek table
+                assert used == (slots, 1 if (layout == 2 and not seek) else slots), (layout, seek, slots, used)
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device: the slots shared it; the multi-device leg needs more")
+    assert np.array_equal(_host_roundtrip(L, host, 2, 0, 1)[0], one)  # 0: every visible device

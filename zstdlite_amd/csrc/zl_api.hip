@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/zl_hip.h"
@@ -185,6 +186,10 @@ struct zl_dctx_s {
     struct HostWalk { std::vector<zl3_hblk> blocks; u32 end_pos = 0; };
     std::vector<HostWalk> host_walk;   // host entries: per frame of the current launch group, the blocks the host walked (empty: none)
     std::vector<u64> chunk_off;        // device entries: zl_decompress_device_hint, consumed by the next call
+    bool run_headerless = false, run_not_last = false;  // the "frame" of the call is one device's run of a frame's chunks (decompress sharding)
+    int devices = 1;                   // ZL_d_devices
+    int last_slots = 1;                // device slots the last zl_decompressDCtx call used
+    std::vector<zl_dctx_s*> peers;
     DevBuf d_chunk_off;
     size_t large_frames = 0;
     bool ev_valid = false;
@@ -338,6 +343,8 @@ size_t zl_freeDCtx(zl_dctx* d) {
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
                       &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off};
     for (DevBuf* b : bufs) b->release();
+    for (zl_dctx* p : d->peers) (void)zl_freeDCtx(p);
+    d->peers.clear();
     zl3_free(d->big);
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
@@ -356,7 +363,11 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     case ZL_d_forceIgnoreChecksum: d->ignore_checksum = value ? 1 : 0; return 0;
     case ZL_d_stableOutBuffer: return 0;
     case ZL_d_profile: d->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
-    case ZL_d_pipeline: d->pipeline = value ? 1 : 0; return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
+    case ZL_d_pipeline: d->pipeline = value ? 1 : 0; return 0;
+    case ZL_d_devices:
+        if (value < 0 || value > 64) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        d->devices = value;
+        return 0;  // 1: per-kernel events; 2: also in-kernel phase stamps
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -369,6 +380,7 @@ size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
 }
 
 size_t zl_dctx_large_frames(const zl_dctx* d) { return d ? d->large_frames : 0; }
+size_t zl_dctx_last_slots(const zl_dctx* d) { return d ? (size_t)d->last_slots : 0; }
 
 // not part of the public header: phase cycle sums.  [0..7] general kernel {H, B, A, A||B wall, C, blocks,
 // sequences, huffman literals}; [8..13] lane-parallel exec kernel {scan, literals, matches, flush, batches, blocks}
@@ -484,10 +496,10 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
     // first, one after the other; it leaves each frame's result word on the device.
     for (size_t i = 0; i < n; i++) {
-        if (has_dict || tbl[i].dst_cap <= route_max || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
+        if (has_dict || (tbl[i].dst_cap <= route_max && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
-        hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0;
+        hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
         if (i < d->host_walk.size() && !d->host_walk[i].blocks.empty()) {
             hint.host_blocks = d->host_walk[i].blocks.data();
             hint.nblocks = (u32)d->host_walk[i].blocks.size();
@@ -497,6 +509,8 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             if (hipMemcpyAsync(d->d_chunk_off.p, d->chunk_off.data(), d->chunk_off.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             hint.d_chunk_off = (const u64*)d->d_chunk_off.p;
             hint.nchunks = (u32)(d->chunk_off.size() - 1);
+            hint.headerless = d->run_headerless ? 1u : 0u;
+            hint.not_last = d->run_not_last ? 1u : 0u;
         }
         const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side, &hint);
         if (e3 == 0) { plan[i].route = 3; d->large_frames++; }
@@ -623,11 +637,83 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
 // zstd.c:41798 ZSTD_decompressDCtx -> :41671 ZSTD_decompressMultiFrame, frames decoded in
 // parallel.  A frame without a recorded content size ends a launch group: its size is only
 // known once decoded, so later frames are placed after reading it back.
+}  // extern "C"
+
 namespace {
 // zl_decompressDCtx of a buffer that ends in a seek table: the frame table comes from the table, not from a walk over
 // every block header.  Returns ZL_ERR(ZL_E_FALLBACK) when the table and the data disagree anywhere: the caller then walks.
+size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t);
+
+// how many device slots a call over `bytes` of output uses (ZL_d_devices; 0: every device, one per 512 MiB at least)
+int dctx_slots(const zl_dctx* d, size_t bytes, size_t units) {
+    int slots = d->devices;
+    if (slots == 0) { int nd = 1; (void)hipGetDeviceCount(&nd); slots = (int)std::min<size_t>((size_t)nd, bytes / ((size_t)512 << 20)); }
+    if ((size_t)slots > units) slots = (int)units;
+    return slots < 1 ? 1 : slots;
+}
+template <class Fn>
+void run_on_slots(int slots, Fn&& fn) {
+    int ndev = 1, home = 0;
+    (void)hipGetDeviceCount(&ndev);
+    (void)hipGetDevice(&home);
+    std::vector<std::thread> th;
+    for (int s = 0; s < slots; s++) th.emplace_back([&, s]() { (void)hipSetDevice(s % (ndev < 1 ? 1 : ndev)); fn(s); });
+    for (auto& x : th) x.join();
+    (void)hipSetDevice(home);
+}
+bool ensure_peers(zl_dctx* d, int slots) {
+    while (d->peers.size() < (size_t)slots) {
+        zl_dctx* p = zl_createDCtx();
+        if (!p) return false;
+        d->peers.push_back(p);
+    }
+    for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; }
+    return true;
+}
+
+// Several devices behind zl_decompressDCtx with a seek table: the chunks are dealt out in contiguous, section-aligned runs
+// (no match of this library's frames crosses a section, include/zl_hip.h), every slot uploads, decodes and downloads its
+// run on its own device.  Frames layout: a run is a buffer of whole frames.  One frame: a run is a piece of the frame --
+// only the first has the header, only the last the Last_Block -- which the large-frame pipeline takes with the chunk walk.
+size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, const SeekTable& t, int slots) {
+    const size_t sec = (size_t)1 << 9, nsec = (t.nchunks + sec - 1) / sec;  // ZL_FAR_SECTION_LOG (zl_encode.h): 512 chunks
+    if ((size_t)slots > nsec) slots = (int)nsec;
+    if (slots < 2 || !ensure_peers(d, slots)) return ZL_ERR(ZL_E_FALLBACK);
+    std::vector<u64> off((size_t)t.nchunks + 1);
+    u64 run = 0;
+    for (u32 i = 0; i < t.nchunks; i++) { off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
+    off[t.nchunks] = run;
+    std::vector<size_t> res(slots, 0);
+    run_on_slots(slots, [&](int s) {
+        const size_t c0 = std::min<size_t>(t.nchunks, (nsec * (size_t)s / (size_t)slots) * sec), c1 = std::min<size_t>(t.nchunks, (nsec * (size_t)(s + 1) / (size_t)slots) * sec);
+        if (c0 == c1) return;
+        const u64 out0 = (u64)c0 * ZL_BLOCK_MAX, out1 = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, t.content);
+        zl_dctx* p = d->peers[s];
+        SeekTable sub = t;
+        sub.nchunks = (u32)(c1 - c0);
+        sub.sizes = t.sizes + 4 * c0;
+        sub.data_bytes = (size_t)(off[c1] - off[c0]);
+        sub.content = out1 - out0;
+        p->run_headerless = t.one_frame && c0 != 0;
+        p->run_not_last = t.one_frame && c1 != t.nchunks;
+        res[s] = decompress_with_seek_table(p, dst + out0, (size_t)(out1 - out0), src + off[c0], sub);
+        p->run_headerless = p->run_not_last = false;
+        if (!ZL_IS_ERR(res[s]) && res[s] != out1 - out0) res[s] = ZL_ERR(ZL_E_FALLBACK);
+    });
+    for (int s = 0; s < slots; s++) if (ZL_IS_ERR(res[s])) return res[s];
+    d->last_slots = slots;
+    return (size_t)t.content;
+}
+
 size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t) {
     if (t.content > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    if (!d->run_headerless && !d->run_not_last && d->dict.empty()) {
+        const int slots = dctx_slots(d, (size_t)t.content, ((size_t)t.nchunks + 511) / 512);
+        if (slots > 1) {
+            const size_t r = decompress_sharded_with_seek_table(d, dst, src, t, slots);
+            if (r != ZL_ERR(ZL_E_FALLBACK)) return r;
+        }
+    }
     hipStream_t st = dctx_stream(d, nullptr);
     if (!d->d_src.ensure(t.data_bytes + 16) || !d->d_dst.ensure(t.content + 16)) return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_src.p, src, t.data_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -638,7 +724,8 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
     d->chunk_off.clear();
     if (t.one_frame) {
         FrameHeader h;
-        if (ZL_IS_ERR(parse_frame_header(h, src, t.data_bytes)) || h.skippable || h.content_size != t.content || h.dict_id) return ZL_ERR(ZL_E_FALLBACK);
+        if (!d->run_headerless && (ZL_IS_ERR(parse_frame_header(h, src, t.data_bytes)) || h.skippable || h.dict_id)) return ZL_ERR(ZL_E_FALLBACK);
+        if (!d->run_headerless && !d->run_not_last && h.content_size != t.content) return ZL_ERR(ZL_E_FALLBACK);
         tbl[0].src_off = 0; tbl[0].src_size = t.data_bytes; tbl[0].dst_off = 0; tbl[0].dst_cap = t.content;
         d->chunk_off.resize((size_t)t.nchunks + 1);
         u64 run = 0;
@@ -671,11 +758,14 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
 }
 }  // namespace
 
+extern "C" {
+
 size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n) {
     if (!d) return ZL_ERR(ZL_E_GENERIC);
     if (!device_ok()) return kGpuUnavailable;
     if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     const u8* src = (const u8*)src_;
+    d->last_slots = 1;
     {   // a buffer that ends in this library's seek table needs no walk
         SeekTable t;
         if (d->dict.empty() && read_seek_table(src, n, t)) {
@@ -716,6 +806,35 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     if (pos != n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
     if (table.empty()) return 0;
     if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+    {   // several devices: independent frames with recorded sizes are dealt out in contiguous runs, a buffer of whole frames each
+        u64 content = 0;
+        bool all_known = true;
+        for (size_t k = 0; k < table.size(); k++) { all_known = all_known && known[k]; content += known[k] ? table[k].dst_cap : 0; }
+        const int slots = (all_known && d->dict.empty() && table.size() >= 2) ? dctx_slots(d, (size_t)content, table.size() / 2) : 1;
+        if (slots > 1 && content <= cap && ensure_peers(d, slots)) {
+            std::vector<size_t> cut(slots + 1, 0), res(slots, 0);
+            std::vector<u64> out_at(slots + 1, 0);
+            {   // cut where the running content passes s / slots of the total
+                u64 run = 0;
+                size_t k = 0;
+                for (int s = 1; s < slots; s++) {
+                    while (k < table.size() && run < content * (u64)s / (u64)slots) run += table[k++].dst_cap;
+                    cut[s] = k;
+                    out_at[s] = run;
+                }
+                cut[slots] = table.size();
+                out_at[slots] = content;
+            }
+            run_on_slots(slots, [&](int s) {
+                if (cut[s] == cut[s + 1]) return;
+                const u64 in0 = table[cut[s]].src_off, in1 = cut[s + 1] < table.size() ? table[cut[s + 1]].src_off : (u64)n;
+                res[s] = zl_decompressDCtx(d->peers[s], (u8*)dst + out_at[s], (size_t)(out_at[s + 1] - out_at[s]), src + in0, (size_t)(in1 - in0));
+            });
+            for (int s = 0; s < slots; s++) if (ZL_IS_ERR(res[s])) return res[s];
+            d->last_slots = slots;
+            return (size_t)content;
+        }
+    }
     hipStream_t st = dctx_stream(d, nullptr);
     if (!d->d_src.ensure(n + 16) || !d->d_dst.ensure(cap + 16)) return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);

@@ -25,6 +25,9 @@ struct zl_cctx_s {
     int layout = 0;  // ZL_c_frameLayout: 0 auto, 1 independent frames, 2 one frame
     int pipeline = 1;  // ZL_c_pipeline: host entries overlap upload, kernels and download for large inputs
     bool any_small = false;  // the chunk table being enqueued holds inputs of at most one chunk (zl_chunk_desc::flags bit 0)
+    int last_slots = 1;  // device slots the last zl_compress2 call used
+    int devices = 1;     // ZL_c_devices: device slots zl_compress2 spreads a large input over (0: every visible device)
+    std::vector<zl_cctx_s*> peers;  // one context per slot, created on first use
     int seek_table = 0;  // ZL_c_seekTable: zl_compress2 appends the skippable seek-table frame (zl_format.h)
     std::vector<u8> dict;
     bool dict_uploaded = false, dict_formatted = false;
@@ -117,8 +120,9 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
 // stream st, with scratch set `es`.  The group's frames land behind those of group g - 1 in d_dst: its size scan starts
 // from d_totals[g] (wait_prev: an event behind which that word is valid, when the groups run on different streams) and
 // leaves d_totals[g + 1]; scanned: recorded behind the scan, if given.
+// frame_chunk0: where the chunk table's entry 0 sits inside the frame (non-zero for a device's shard of an input).
 size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8* d_src, size_t first, u32 cnt, size_t nchunks, size_t g, hipStream_t st,
-                          u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned) {
+                          u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned, size_t frame_chunk0 = 0) {
     const bool joined = joined_total != 0;
     if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * ZL_LIT_STRIDE_ENC) || !es.seqs.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(zl_seq)) ||
         !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(ushort4)) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
@@ -132,7 +136,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         f.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
         f.src = d_src;
         f.total = joined_total;
-        f.chunk_base = (u32)first;
+        f.chunk_base = (u32)(frame_chunk0 + first);
         f.sample_log = c->level >= 9 ? 1u : (c->level >= 5 ? 2u : (u32)ZL_FAR_SAMPLE_LOG);  // the operating points above level 3: denser far sampling
         f.table = (u32*)es.far_table.p;
         f.hints = (u32*)es.far_hints.p;
@@ -177,7 +181,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
     e.joined = joined ? 1u : 0u;
-    e.chunk_base = (u32)first;
+    e.chunk_base = (u32)(frame_chunk0 + first);
     e.total_chunks = (u32)nchunks;
     e.wlog = ZL_FAR_WLOG;
     e.total_size = joined_total;
@@ -295,6 +299,8 @@ size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
     if (c->ev_far) (void)hipEventDestroy(c->ev_far);
+    for (zl_cctx* p : c->peers) (void)zl_freeCCtx(p);
+    c->peers.clear();
     for (auto& es : c->sets) es.release();
     for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -338,6 +344,10 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
         return 0;
     case ZL_c_pipeline: c->pipeline = value ? 1 : 0; return 0;
     case ZL_c_seekTable: c->seek_table = value ? 1 : 0; return 0;
+    case ZL_c_devices:
+        if (value < 0 || value > 64) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        c->devices = value;
+        return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -350,6 +360,7 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
     case ZL_c_nbWorkers: *value = c->nb_workers; return 0;
     case ZL_c_frameLayout: *value = c->layout; return 0;
     case ZL_c_seekTable: *value = c->seek_table; return 0;
+    case ZL_c_devices: *value = c->devices; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -418,6 +429,7 @@ size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
     for (int k = 0; k < 4; k++) ms[k] = c->kernel_ms[k];
     return 0;
 }
+size_t zl_cctx_last_slots(const zl_cctx* c) { return c ? (size_t)c->last_slots : 0; }
 size_t zl_cctx_far_ms(const zl_cctx* c, double* ms) {
     if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     *ms = c->far_ms;
@@ -443,12 +455,31 @@ namespace {
 #define ZL_PIPE_CHUNKS ((size_t)1 << ZL_FAR_SECTION_LOG)
 #define ZL_PIPE_SETS 3
 #define ZL_PIPE_MIN_BYTES ((size_t)192 << 20)   // below this one launch group over everything is faster than sections
-size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n, bool one_frame) {
+// A RANGE of an input: chunks [chunk0, chunk0 + nchunks) of an input of n_total bytes in total_chunks chunks (chunk0 a
+// multiple of the section size) -- the whole input, or one device's shard of it (compress2_sharded).  src points at the
+// range's first byte.  With dst: the range's frames are brought down there as they are packed (cap bytes) and the byte
+// count is returned; without: they are left packed in c->d_dst and the count is returned.
+size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n_total, bool one_frame, size_t chunk0 = 0, size_t nchunks_range = 0, size_t total_chunks = 0) {
     { const size_t pd = cctx_prepare_dict(c, cctx_stream(c, nullptr)); if (ZL_IS_ERR(pd)) return pd; }
-    const size_t nchunks = fill_chunk_table(c, n);
-    if (ZL_IS_ERR(nchunks)) return nchunks;
+    const bool whole = nchunks_range == 0;
+    const size_t all_chunks = whole ? chunks_of(n_total) : total_chunks;
+    const size_t nchunks = whole ? all_chunks : nchunks_range;
+    const size_t range_off = chunk0 * (size_t)ZL_CHUNK;
+    const size_t n = std::min<size_t>(nchunks * (size_t)ZL_CHUNK, n_total - range_off);  // bytes of the range
+    {   // the range's chunk table: source offsets are positions in the INPUT (the far search and the frame header reason in those)
+        if (!c->h_chunks.ensure(nchunks * sizeof(zl_chunk_desc))) return kGpuUnavailable;
+        zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
+        for (size_t i = 0; i < nchunks; i++) {
+            t[i].src_off = range_off + (u64)i * ZL_CHUNK;
+            t[i].src_size = (u32)std::min<size_t>(ZL_CHUNK, n - i * (size_t)ZL_CHUNK);
+            t[i].flags = 0;
+        }
+        c->any_small = false;
+    }
     const size_t ngroups = (nchunks + ZL_PIPE_CHUNKS - 1) / ZL_PIPE_CHUNKS;
     const size_t bound = zl_compressBound(n);
+    const u8* const d_src_base = nullptr;  // (set below: the device buffer holds the range only; kernels index it by input position)
+    (void)d_src_base;
     if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16) || !c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64)))
         return kGpuUnavailable;
@@ -479,7 +510,7 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     std::thread down([&]() {
         (void)hipSetDevice(dev);
         u64 have = 0;
-        for (size_t g = 0; g < ngroups; g++) {
+        for (size_t g = 0; g < ngroups && dst; g++) {
             while (enqueued.load(std::memory_order_acquire) <= g) { if (failed.load()) return; std::this_thread::yield(); }
             if (hipEventSynchronize(ev_done[g]) != hipSuccess) { down_result = ZL_ERR(ZL_E_GENERIC); return; }
             u64 upto = 0;
@@ -498,7 +529,7 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         if (hipMemcpyAsync((u8*)c->d_src.p + off, src + off, len, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess || hipEventRecord(ev_up[g], c->copy_stream) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
         zl_cctx_s::EncSet& es = c->sets[g % ZL_PIPE_SETS];
         if (hipStreamWaitEvent(es.st, ev_up[g], 0) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
-        err = cctx_enqueue_group(c, es, (u8*)c->d_dst.p, (const u8*)c->d_src.p, first, cnt, nchunks, g, es.st, one_frame ? (u64)n : 0, false, g ? ev_scan[g - 1] : nullptr, ev_scan[g]);
+        err = cctx_enqueue_group(c, es, (u8*)c->d_dst.p, (const u8*)c->d_src.p - range_off, first, cnt, all_chunks, g, es.st, one_frame ? (u64)n_total : 0, false, g ? ev_scan[g - 1] : nullptr, ev_scan[g], chunk0);
         if (ZL_IS_ERR(err)) break;
         err = 0;
         if (hipEventRecord(ev_done[g], es.st) != hipSuccess) { err = ZL_ERR(ZL_E_GENERIC); break; }
@@ -512,11 +543,72 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     if (down_result) return down_result;
     c->pending_chunks = nchunks;
     c->pending_groups = ngroups;
-    if (c->seek_table && nchunks > 1) {
+    if (!dst) {  // a shard: its frames stay on its device until every shard's size is known
+        u64 upto = 0;
+        if (hipMemcpy(&upto, (const u64*)c->d_totals.p + ngroups, 8, hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        return (size_t)upto;
+    }
+    if (c->seek_table && nchunks > 1 && whole) {
         if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || hipMemcpy(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         return append_seek_table(c, dst, cap, down_total, nchunks, n, one_frame);
     }
     return down_total;
+}
+
+// Several devices behind one call (the reference is one process, src/init.c:90-99, so the sharding has to sit
+// behind the ABI): the input's sections are dealt out in contiguous runs, one per device slot -- frames and sections are
+// self-contained, so no device needs another's bytes --, every slot uploads and compresses its run on its own device
+// from its own host thread (its own PCIe link: no root funnel), and once all sizes are known every slot downloads its
+// frames to their final place.  The bytes written are those one device writes.  Slot s runs on device s mod the number
+// of devices: ZL_c_devices above that number puts several slots on one device (which is how the path is tested on one).
+size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n, bool one_frame, int slots) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return kGpuUnavailable;
+    const size_t nchunks = chunks_of(n), nsec = (nchunks + ZL_PIPE_CHUNKS - 1) / ZL_PIPE_CHUNKS;
+    if ((size_t)slots > nsec) slots = (int)nsec;
+    while (c->peers.size() < (size_t)slots) {
+        zl_cctx* p = zl_createCCtx();
+        if (!p) return ZL_ERR(ZL_E_MEMORY);
+        c->peers.push_back(p);
+    }
+    std::vector<size_t> first(slots + 1), bytes(slots, 0);
+    for (int s = 0; s <= slots; s++) first[s] = std::min(nchunks, (nsec * (size_t)s / (size_t)slots) * ZL_PIPE_CHUNKS);
+    int home = 0;
+    (void)hipGetDevice(&home);
+    auto run = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (int s = 0; s < slots; s++) th.emplace_back([&, s]() { (void)hipSetDevice(s % ndev); fn(s); });
+        for (auto& t : th) t.join();
+    };
+    run([&](int s) {
+        zl_cctx* p = c->peers[s];
+        p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict;
+        if (p->dict != c->dict || p->dict_id != c->dict_id) { p->dict_uploaded = false; p->dict_formatted = c->dict_formatted; p->dict_id = c->dict_id; }
+        const size_t cnt = first[s + 1] - first[s];
+        bytes[s] = cnt ? compress2_pipelined(p, nullptr, 0, src + first[s] * (size_t)ZL_CHUNK, n, one_frame, first[s], cnt, nchunks) : 0;
+    });
+    size_t total = 0;
+    std::vector<size_t> at(slots);
+    for (int s = 0; s < slots; s++) { if (ZL_IS_ERR(bytes[s])) return bytes[s]; at[s] = total; total += bytes[s]; }
+    if (total > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    std::vector<size_t> res(slots, 0);
+    run([&](int s) {
+        if (bytes[s] && hipMemcpy(dst + at[s], c->peers[s]->d_dst.p, bytes[s], hipMemcpyDeviceToHost) != hipSuccess) res[s] = ZL_ERR(ZL_E_GENERIC);
+    });
+    (void)hipSetDevice(home);
+    for (int s = 0; s < slots; s++) if (res[s]) return res[s];
+    if (c->seek_table && nchunks > 1) {  // every slot's per-chunk sizes, in order
+        if (!c->h_fsize.ensure(nchunks * sizeof(u32))) return kGpuUnavailable;
+        size_t err = 0;
+        run([&](int s) {
+            const size_t cnt = first[s + 1] - first[s];
+            if (cnt && hipMemcpy((u32*)c->h_fsize.p + first[s], c->peers[s]->d_fsize.p, cnt * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) err = ZL_ERR(ZL_E_GENERIC);
+        });
+        (void)hipSetDevice(home);
+        if (err) return err;
+        return append_seek_table(c, dst, cap, total, nchunks, n, one_frame);
+    }
+    return total;
 }
 }  // namespace
 
@@ -528,7 +620,13 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
-    if (n >= ZL_PIPE_MIN_BYTES && c->pipeline) return compress2_pipelined(c, (u8*)dst, cap, (const u8*)src, n, use_one_frame(c, n, true));
+    if (n >= ZL_PIPE_MIN_BYTES && c->pipeline) {
+        int slots = c->devices;
+        if (slots == 0) { int nd = 1; (void)hipGetDeviceCount(&nd); slots = (int)std::min<size_t>((size_t)nd, n / ((size_t)512 << 20)); }  // auto: a device per 512 MiB at least
+        c->last_slots = 1;
+        if (slots > 1 && c->dict.empty()) { c->last_slots = (int)std::min<size_t>((size_t)slots, (chunks_of(n) + ZL_PIPE_CHUNKS - 1) / ZL_PIPE_CHUNKS); return compress2_sharded(c, (u8*)dst, cap, (const u8*)src, n, use_one_frame(c, n, true), slots); }
+        return compress2_pipelined(c, (u8*)dst, cap, (const u8*)src, n, use_one_frame(c, n, true));
+    }
     hipStream_t st = cctx_stream(c, nullptr);
     const size_t bound = zl_compressBound(n);
     if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16)) return kGpuUnavailable;

@@ -11,6 +11,8 @@ typedef struct {
     u32 nblocks, end_pos;         // their number; where the last block ends
     const u64* d_chunk_off;       // device: nchunks + 1 offsets, relative to the frame, of the runs of blocks this library's one-frame layout wrote per chunk, or null
     u32 nchunks;
+    u32 headerless;               // the bytes are a run of a frame's blocks without its header (one device's shard of a frame of this library, section-aligned): the content size is fd->dst_cap, no checksum
+    u32 not_last;                 // ... and the run does not hold the frame's last block
 } zl3_hint;
 typedef struct zl3_state_s zl3_state;  // grow-only device buffers, owned by a decompression context
 extern "C" zl3_state* zl3_create(void);

@@ -61,7 +61,7 @@ struct zl3_dev {  // device pointers of one large-frame decode
 __device__ __forceinline__ void info_err(zl3_info* info, u32 code) { atomicCAS(&info->err, 0u, code); }
 
 // frame header (zstd.c:41050-41148) -> info; returns the header size or 0 after recording an error
-__device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_desc& fd, const u8* src) {
+__device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_desc& fd, const u8* src, bool whole = true) {
     const u64 n = fd.src_size;
     if (n < 5) { info->err = ZL_E_SRCSIZE_WRONG; return 0; }
     if (zl_rd_le(src, 4) != ZL_MAGIC) { info->err = ZL_E_PREFIX_UNKNOWN; return 0; }
@@ -87,6 +87,7 @@ __device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_d
     if (did) { info->err = ZL_E_DICT_WRONG; return 0; }  // this path never has a dictionary (zstd.c:41318)
     // (a frame that does not record its size -- what ZSTD_compressStream2 writes when nothing is pledged -- is
     // bounded by its block count: the host sizes the links from that)
+    if (!whole) { info->fcs = fd.dst_cap; info->has_checksum = 0; return hs; }  // the first run of a frame dealt out over several devices: it regenerates what its share of the output holds
     if (fcs != ZL_CONTENTSIZE_UNKNOWN && fcs > fd.dst_cap) { info->err = ZL_E_DSTSIZE_TOO_SMALL; return 0; }
     info->fcs = fcs;
     info->has_checksum = (fhd >> 2) & 1;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
 // of the block counts.  The hint is only a hint: every chunk must end exactly where the next one starts, the frame's
 // last block must be the last chunk's last block and no other -- otherwise ZL_E_FALLBACK_WALK sends the frame to (1).
 #define ZL3_CHUNK_BLOCKS_MAX 64u
-__global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, const u64* chunk_off, u32 nchunks, u32* cnt, const u32* first, u32 pass) {
+__global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, const u64* chunk_off, u32 nchunks, u32* cnt, const u32* first, u32 pass, u32 headerless, u32 not_last) {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     zl3_info* info = d.info;
     if (c >= nchunks) return;
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame
     u64 pos = chunk_off[c];
     const u64 end = chunk_off[c + 1];
     if (c == 0) {
-        if (pass == 0) { const u32 hs = zl3_frame_header(info, fd, src); if (!hs) return; info->hdr_size = hs; }
+        if (pass == 0) {
+            if (headerless) { info->fcs = fd.dst_cap; info->has_checksum = 0; info->hdr_size = 0; }
+            else { const u32 hs = zl3_frame_header(info, fd, src, !not_last); if (!hs) return; info->hdr_size = hs; }
+        }
         pos = info->hdr_size;
     }
     u32 nb = 0;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame
         if (pass == 1) { d.hblk[first[c] + nb].src_off = (u32)pos; d.hblk[first[c] + nb].hdr = bh; }
         nb++;
         pos += csize;
-        if (last != ((c + 1 == nchunks && pos == end) ? 1u : 0u)) { bad = true; break; }  // Last_Block: the last chunk's last block, and only that one
+        if (last != ((!not_last && c + 1 == nchunks && pos == end) ? 1u : 0u)) { bad = true; break; }  // Last_Block: the last chunk's last block, and only that one
     }
     if (bad || nb == 0) { info_err(info, ZL_E_FALLBACK_WALK); return; }
     if (pass == 0) cnt[c] = nb;
@@ -625,14 +629,15 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     } else if (hint && hint->d_chunk_off && hint->nchunks) {
         const u32 nc = hint->nchunks;
         if (!s->cnt.ensure((size_t)nc * 4) || !s->first.ensure((size_t)nc * 4)) return kGpuUnavailable;
-        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u);
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u, hint->headerless, hint->not_last);
         hipLaunchKernelGGL(zl3_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d, fd, (const u32*)s->cnt.p, (u32*)s->first.p, nc, hint->d_chunk_off);
-        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 1u);
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 1u, hint->headerless, hint->not_last);
         zl3_info probe;
         if (hipMemcpyAsync(&probe, d.info, sizeof(probe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (probe.err == ZL_E_FALLBACK_WALK) { if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC); }  // the hint does not describe this frame: walk it
         else walked = true;
     }
+    if (!walked && hint && hint->headerless) return ZL_ERR(ZL_E_FALLBACK);  // (a run of blocks without a header has no other way in)
     if (!walked) hipLaunchKernelGGL(zl3_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_parse_kernel, dim3((cap_blocks + 255) / 256), dim3(256), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_segment_kernel, dim3(1), dim3(1024), 0, st, d);
