@@ -200,12 +200,13 @@ def test_device_slots_behind_the_host_entries():
     for layout in (2, 1):           # one frame, independent frames
         for seek in (1, 0):         # (without a seek table one frame is decoded by one device)
             one, used = _host_roundtrip(L, host, layout, 1, seek)
-            assert used == (1, 1)
+            # one device: compression pipelines inside its one slot; decompression overlaps upload, decode and download by
+            # running three slots on the device (ZL_d_pipeline) -- unless it is ONE frame without a seek table
+            assert used == (1, 1 if (layout == 2 and not seek) else 3), (layout, seek, used)
             for slots in (2, 3):
                 got, used = _host_roundtrip(L, host, layout, slots, seek)
                 assert np.array_equal(got, one), (layout, seek, slots)
-                # compression always shards; decompression does unless it is ONE frame without a seek table
-                assert used == (slots, 1 if (layout == 2 and not seek) else slots), (layout, seek, slots, used)
+                assert used[0] == slots and (used[1] == 1 if (layout == 2 and not seek) else used[1] >= slots), (layout, seek, slots, used)
     if torch.cuda.device_count() < 2:
         pytest.skip("one device: the slots shared it; the multi-device leg needs more")
     assert np.array_equal(_host_roundtrip(L, host, 2, 0, 1)[0], one)  # 0: every visible device

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -644,23 +645,44 @@ namespace {
 // every block header.  Returns ZL_ERR(ZL_E_FALLBACK) when the table and the data disagree anywhere: the caller then walks.
 size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t);
 
-// how many device slots a call over `bytes` of output uses (ZL_d_devices; 0: every device, one per 512 MiB at least)
-int dctx_slots(const zl_dctx* d, size_t bytes, size_t units) {
-    int slots = d->devices;
-    if (slots == 0) { int nd = 1; (void)hipGetDeviceCount(&nd); slots = (int)std::min<size_t>((size_t)nd, bytes / ((size_t)512 << 20)); }
-    if ((size_t)slots > units) slots = (int)units;
-    return slots < 1 ? 1 : slots;
+// How many slots a call over `bytes` of output is dealt out over, and how deep each device's pipeline is.  Devices:
+// ZL_d_devices (0: every visible one, one per 512 MiB at least).  Depth: a slot uploads, decodes and downloads its run
+// one after the other from its own host thread, so three slots on ONE device overlap the three legs (ZL_d_pipeline;
+// only worth it from 128 MiB per slot up).  Slot s runs on device (s / depth) mod the number of devices -- with
+// ZL_d_devices = 1 that is the caller's current device.
+struct SlotPlan { int slots, depth; };
+SlotPlan dctx_slots(const zl_dctx* d, size_t bytes, size_t units) {
+    int devs = d->devices;
+    if (devs == 0) { int nd = 1; (void)hipGetDeviceCount(&nd); devs = (int)std::min<size_t>((size_t)nd, bytes / ((size_t)512 << 20)); }
+    if (devs < 1) devs = 1;
+    int depth = (d->pipeline && bytes / (size_t)devs >= ((size_t)384 << 20)) ? 3 : 1;
+    size_t slots = (size_t)devs * (size_t)depth;
+    if (slots > units) { slots = units; depth = 1; }
+    SlotPlan p;
+    p.slots = slots < 1 ? 1 : (int)slots;
+    p.depth = depth;
+    return p;
 }
+// plan.slots worker threads take `nruns` runs in order, fn(worker, run).  More runs than workers: the workers drift apart,
+// so one is uploading while another downloads (all starting their uploads together, as equal shares would, leaves the
+// two directions of the link to take turns).
 template <class Fn>
-void run_on_slots(int slots, Fn&& fn) {
+void run_on_slots(const zl_dctx* d, SlotPlan plan, size_t nruns, Fn&& fn) {
     int ndev = 1, home = 0;
     (void)hipGetDeviceCount(&ndev);
     (void)hipGetDevice(&home);
+    std::atomic<size_t> next{0};
     std::vector<std::thread> th;
-    for (int s = 0; s < slots; s++) th.emplace_back([&, s]() { (void)hipSetDevice(s % (ndev < 1 ? 1 : ndev)); fn(s); });
+    for (int w = 0; w < plan.slots; w++)
+        th.emplace_back([&, w]() {
+            (void)hipSetDevice(d->devices == 1 ? home : (w / plan.depth) % (ndev < 1 ? 1 : ndev));
+            for (size_t r = next.fetch_add(1); r < nruns; r = next.fetch_add(1)) fn(w, r);
+        });
     for (auto& x : th) x.join();
     (void)hipSetDevice(home);
 }
+// runs a call is cut into: three per worker when workers share a device (depth > 1), one each otherwise; at most `units`
+inline size_t runs_for(SlotPlan plan, size_t units) { return std::min<size_t>(units, (size_t)plan.slots * (plan.depth > 1 ? 3 : 1)); }
 bool ensure_peers(zl_dctx* d, int slots) {
     while (d->peers.size() < (size_t)slots) {
         zl_dctx* p = zl_createDCtx();
@@ -675,20 +697,21 @@ bool ensure_peers(zl_dctx* d, int slots) {
 // (no match of this library's frames crosses a section, include/zl_hip.h), every slot uploads, decodes and downloads its
 // run on its own device.  Frames layout: a run is a buffer of whole frames.  One frame: a run is a piece of the frame --
 // only the first has the header, only the last the Last_Block -- which the large-frame pipeline takes with the chunk walk.
-size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, const SeekTable& t, int slots) {
+size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, const SeekTable& t, SlotPlan plan) {
     const size_t sec = (size_t)1 << 9, nsec = (t.nchunks + sec - 1) / sec;  // ZL_FAR_SECTION_LOG (zl_encode.h): 512 chunks
-    if ((size_t)slots > nsec) slots = (int)nsec;
+    const int slots = plan.slots;
     if (slots < 2 || !ensure_peers(d, slots)) return ZL_ERR(ZL_E_FALLBACK);
+    const size_t nruns = runs_for(plan, nsec);
     std::vector<u64> off((size_t)t.nchunks + 1);
     u64 run = 0;
     for (u32 i = 0; i < t.nchunks; i++) { off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
     off[t.nchunks] = run;
-    std::vector<size_t> res(slots, 0);
-    run_on_slots(slots, [&](int s) {
-        const size_t c0 = std::min<size_t>(t.nchunks, (nsec * (size_t)s / (size_t)slots) * sec), c1 = std::min<size_t>(t.nchunks, (nsec * (size_t)(s + 1) / (size_t)slots) * sec);
+    std::vector<size_t> res(nruns, 0);
+    run_on_slots(d, plan, nruns, [&](int w, size_t s) {
+        const size_t c0 = std::min<size_t>(t.nchunks, (nsec * s / nruns) * sec), c1 = std::min<size_t>(t.nchunks, (nsec * (s + 1) / nruns) * sec);
         if (c0 == c1) return;
         const u64 out0 = (u64)c0 * ZL_BLOCK_MAX, out1 = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, t.content);
-        zl_dctx* p = d->peers[s];
+        zl_dctx* p = d->peers[w];
         SeekTable sub = t;
         sub.nchunks = (u32)(c1 - c0);
         sub.sizes = t.sizes + 4 * c0;
@@ -700,7 +723,7 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
         p->run_headerless = p->run_not_last = false;
         if (!ZL_IS_ERR(res[s]) && res[s] != out1 - out0) res[s] = ZL_ERR(ZL_E_FALLBACK);
     });
-    for (int s = 0; s < slots; s++) if (ZL_IS_ERR(res[s])) return res[s];
+    for (size_t s = 0; s < nruns; s++) if (ZL_IS_ERR(res[s])) return res[s];
     d->last_slots = slots;
     return (size_t)t.content;
 }
@@ -708,9 +731,9 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
 size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t) {
     if (t.content > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
     if (!d->run_headerless && !d->run_not_last && d->dict.empty()) {
-        const int slots = dctx_slots(d, (size_t)t.content, ((size_t)t.nchunks + 511) / 512);
-        if (slots > 1) {
-            const size_t r = decompress_sharded_with_seek_table(d, dst, src, t, slots);
+        const SlotPlan plan = dctx_slots(d, (size_t)t.content, ((size_t)t.nchunks + 511) / 512);
+        if (plan.slots > 1) {
+            const size_t r = decompress_sharded_with_seek_table(d, dst, src, t, plan);
             if (r != ZL_ERR(ZL_E_FALLBACK)) return r;
         }
     }
@@ -810,27 +833,31 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         u64 content = 0;
         bool all_known = true;
         for (size_t k = 0; k < table.size(); k++) { all_known = all_known && known[k]; content += known[k] ? table[k].dst_cap : 0; }
-        const int slots = (all_known && d->dict.empty() && table.size() >= 2) ? dctx_slots(d, (size_t)content, table.size() / 2) : 1;
+        SlotPlan plan;
+        plan.slots = 1; plan.depth = 1;
+        if (all_known && d->dict.empty() && table.size() >= 2) plan = dctx_slots(d, (size_t)content, table.size() / 512);
+        const int slots = plan.slots;
         if (slots > 1 && content <= cap && ensure_peers(d, slots)) {
-            std::vector<size_t> cut(slots + 1, 0), res(slots, 0);
-            std::vector<u64> out_at(slots + 1, 0);
-            {   // cut where the running content passes s / slots of the total
+            const size_t nruns = runs_for(plan, table.size() / 512);
+            std::vector<size_t> cut(nruns + 1, 0), res(nruns, 0);
+            std::vector<u64> out_at(nruns + 1, 0);
+            {   // cut where the running content passes s / nruns of the total
                 u64 run = 0;
                 size_t k = 0;
-                for (int s = 1; s < slots; s++) {
-                    while (k < table.size() && run < content * (u64)s / (u64)slots) run += table[k++].dst_cap;
+                for (size_t s = 1; s < nruns; s++) {
+                    while (k < table.size() && run < content * (u64)s / (u64)nruns) run += table[k++].dst_cap;
                     cut[s] = k;
                     out_at[s] = run;
                 }
-                cut[slots] = table.size();
-                out_at[slots] = content;
+                cut[nruns] = table.size();
+                out_at[nruns] = content;
             }
-            run_on_slots(slots, [&](int s) {
+            run_on_slots(d, plan, nruns, [&](int w, size_t s) {
                 if (cut[s] == cut[s + 1]) return;
                 const u64 in0 = table[cut[s]].src_off, in1 = cut[s + 1] < table.size() ? table[cut[s + 1]].src_off : (u64)n;
-                res[s] = zl_decompressDCtx(d->peers[s], (u8*)dst + out_at[s], (size_t)(out_at[s + 1] - out_at[s]), src + in0, (size_t)(in1 - in0));
+                res[s] = zl_decompressDCtx(d->peers[w], (u8*)dst + out_at[s], (size_t)(out_at[s + 1] - out_at[s]), src + in0, (size_t)(in1 - in0));
             });
-            for (int s = 0; s < slots; s++) if (ZL_IS_ERR(res[s])) return res[s];
+            for (size_t s = 0; s < nruns; s++) if (ZL_IS_ERR(res[s])) return res[s];
             d->last_slots = slots;
             return (size_t)content;
         }
