@@ -38,9 +38,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
@@ -127,7 +127,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * ZL_LIT_STRIDE_ENC) || !es.seqs.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(zl_seq)) ||
         !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(ushort4)) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
         return kGpuUnavailable;
-    if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4))) return kGpuUnavailable;
+    if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
     c->far_valid = false;
     if (joined) {
         if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
@@ -140,7 +140,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         f.sample_log = c->level >= 9 ? 1u : (c->level >= 5 ? 2u : (u32)ZL_FAR_SAMPLE_LOG);  // the operating points above level 3: denser far sampling
         f.table = (u32*)es.far_table.p;
         f.hints = (u32*)es.far_hints.p;
-        if (hipMemsetAsync(f.table, 0, ZL_FAR_TABLE_BYTES(cnt), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        f.lists = (u32*)es.far_lists.p;
         if (zl_launch_far_build(&f, cnt, st) != hipSuccess || zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     zl_match_args m;

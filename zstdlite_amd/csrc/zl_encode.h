@@ -25,14 +25,16 @@
 #define ZL_FAR_BUCKET_LOG 14
 #endif
 // ZL_FAR_BUCKET_LOG:                     // buckets per group of chunks
-#define ZL_FAR_GROUP 16                          // chunks per table group = slots per bucket: one 64-byte line
+#define ZL_FAR_GROUP 16                          // a chunk looks into the ZL_FAR_GROUP - 1 chunks in front of it
 #define ZL_FAR_WLOG 21                           // window the frame header declares: ZL_FAR_GROUP chunks of 128 KiB (the reference's level 3 uses the same, zstd.c:29529)
 #ifndef ZL_FAR_HINT_LOG
 #define ZL_FAR_HINT_LOG 4                        // one hint word per 16 input bytes
 #endif
 #define ZL_FAR_SECTION_LOG 9                      // far history does not cross sections of 512 chunks (64 MiB): a section is what the host entries
                                                  // upload, compress and download as one pipeline stage, and the output must not depend on how a call was staged
-#define ZL_FAR_TABLE_BYTES(nchunks) ((((size_t)(nchunks) + ZL_FAR_GROUP - 1) / ZL_FAR_GROUP) * ((size_t)ZL_FAR_GROUP << ZL_FAR_BUCKET_LOG) * 4)
+#define ZL_FAR_TABLE_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)4 << ZL_FAR_BUCKET_LOG))   // one column of 2^ZL_FAR_BUCKET_LOG words per chunk
+#define ZL_FAR_LIST_CAP 20480u                    // sampled positions a chunk may list (expected at one in eight: 16384); what exceeds it is not probed
+#define ZL_FAR_LIST_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)ZL_FAR_LIST_CAP * 8 + 64))
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 
 struct zl_chunk_desc {
@@ -77,7 +79,8 @@ struct zl_far_args {
     u64 total;             // bytes of that input (positions whose 8 bytes would run past it -- or past their section -- are not hashed)
     u32 chunk_base;        // index, inside the input, of chunks[0] (a multiple of ZL_FAR_GROUP)
     u32 sample_log;        // one position in 2^sample_log takes part (ZL_FAR_SAMPLE_LOG at level 3; higher levels sample more densely)
-    u32* table;            // ZL_FAR_TABLE_BYTES(nchunks), zeroed before zl_launch_far_build
+    u32* table;            // ZL_FAR_TABLE_BYTES(nchunks): per chunk a column of 2^ZL_FAR_BUCKET_LOG words, written whole by zl_launch_far_build
+    u32* lists;            // ZL_FAR_LIST_BYTES(nchunks): per chunk a count (16 words) and up to ZL_FAR_LIST_CAP pairs {bucket | tag << 14, position}
     u32* hints;            // per chunk ZL_FAR_HINT_WORDS words, written by zl_launch_far_probe
 };
 

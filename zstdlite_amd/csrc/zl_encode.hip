@@ -54,6 +54,11 @@ __device__ __forceinline__ u64 ld64(const u8* p) {
     __builtin_memcpy(&v, p, 8);
     return v;
 }
+__device__ __forceinline__ uint4 ld128(const u8* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
 #ifndef ZL_LONG_BYTES
 #define ZL_LONG_BYTES 8
 #endif
@@ -859,13 +864,17 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* con
 // 8 bytes are zero -- a property of the content, so the two occurrences of a repeat are sampled alike
 // (the idea of the reference's long-distance matcher, zstd.c:33790 ZSTD_ldm_*, restated for a machine
 // that cannot walk the input in order).  Two passes over the input, both one workgroup per chunk:
-//   zl_far_build_kernel  table[group of 16 chunks][bucket][chunk mod 16] = max (position in chunk << 15 | tag);
-//                        "max" makes the content independent of scheduling (determinism), one slot per
-//                        chunk keeps a later chunk from hiding an earlier one from the chunks in between
-//   zl_far_probe_kernel  every sampled position reads the slots of the 15 chunks in front of its own
-//                        (the two 64-byte lines of its bucket), checks the nearest one whose tag agrees
-//                        against the bytes, and the longest hit of every 32-byte neighbourhood becomes
-//                        that neighbourhood's hint word: the offset the match kernel tries there.
+//   zl_far_build_kernel  the chunk's COLUMN of the table -- column[bucket] = max (position in chunk << 15 | tag) --
+//                        is built in LDS (plain LDS atomics) and written out whole, coalesced: no cell of the table
+//                        belongs to two chunks, so nothing needs a device-wide atomic; "max" makes the content
+//                        independent of scheduling (determinism).  The sampled positions are also LISTED.
+//   zl_far_probe_kernel  streams the columns of the 15 chunks in front through LDS, nearest first; every listed
+//                        position (held in registers) looks its bucket up in each, checks a tag hit against the
+//                        bytes, and the longest hit of every 16-byte neighbourhood becomes that neighbourhood's
+//                        hint word: the offset the match kernel tries there.
+// (The first version kept one 64-byte line of 16 chunk slots per bucket, filled with device atomics and read with
+// two random line fetches per sampled position: bound by random transactions -- 384 M of them per GiB, 12 ms.
+// Columns make every table access but the verification a coalesced stream: 8 GiB of reads per GiB of input.)
 // All chunks but the last are ZL_CHUNK bytes and contiguous, so chunk k steps back are k * ZL_CHUNK bytes.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 far_hash(u64 v) { return v * 0x9E3779B185EBCA87ULL; }
@@ -873,116 +882,152 @@ __device__ __forceinline__ u64 far_hash(u64 v) { return v * 0x9E3779B185EBCA87UL
 __device__ __forceinline__ bool far_sampled(u64 h, u32 sl) { return (h >> (64 - sl)) == 0; }
 __device__ __forceinline__ u32 far_bucket(u64 h, u32 sl) { return (u32)(h >> (64 - sl - ZL_FAR_BUCKET_LOG)) & ((1u << ZL_FAR_BUCKET_LOG) - 1); }
 __device__ __forceinline__ u32 far_tag(u64 h, u32 sl) { return (u32)(h >> (64 - sl - ZL_FAR_BUCKET_LOG - 15)) & 0x7FFFu; }
-__device__ __forceinline__ size_t far_slot(u32 chunk, u32 bucket) {
-    return ((((size_t)(chunk / ZL_FAR_GROUP)) << ZL_FAR_BUCKET_LOG) + bucket) * ZL_FAR_GROUP + (chunk % ZL_FAR_GROUP);
-}
-// positions p < far_limit have their 8 bytes inside the input
+// positions p < far_limit have their 8 bytes inside the input and inside the chunk's section
 __device__ __forceinline__ u32 far_limit(const zl_far_args& a, const zl_chunk_desc& cd, u32 cg /* chunk index inside the input */) {
     const u64 sec_end = ((u64)((cg >> ZL_FAR_SECTION_LOG) + 1) << ZL_FAR_SECTION_LOG) * ZL_CHUNK;  // (the input starts at source offset 0)
     const u64 left = (a.total < sec_end ? a.total : sec_end) - cd.src_off;
     return left >= (u64)cd.src_size + 8 ? cd.src_size : (left >= 8 ? (u32)(left - 7) : 0u);
 }
-
-// (both kernels work through FAR_UNROLL windows of 256 positions per trip, phase by phase, so that the loads of all of
-// them are in flight together: one window per trip left a single 8-byte load per lane between two dependent waits --
-// 5.5 + 6.9 ms for 1 GiB at one position in eight)
+#define FAR_COL (1u << ZL_FAR_BUCKET_LOG)
 #define FAR_UNROLL 4
+static_assert(ZL_FAR_BUCKET_LOG + 15 <= 32 - 3, "a list key holds bucket and tag");
+
+// (A workgroup holds a 64 KiB column in LDS, so only two fit a CU: what hides the memory latency is the number of loads
+// each thread keeps in flight, not the number of waves.  Every thread takes 8 consecutive positions from ONE 16-byte
+// load, four such loads per trip.)
+#define FAR_SPAN 8u                     // positions per thread and load
 __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
+    __shared__ u32 col[FAR_COL];
+    __shared__ u32 count;
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
     const u32 sl = a.sample_log;
-    for (u32 ip = 0; ip < lim; ip += ENC_THREADS * FAR_UNROLL) {
-        u64 v[FAR_UNROLL];
-#pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) { const u32 p = ip + k * ENC_THREADS + t; v[k] = p < lim ? ld64(src + p) : 0; }
+    u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
+    for (u32 i = t; i < FAR_COL; i += ENC_THREADS) col[i] = 0;
+    if (t == 0) count = 0;
+    {   // the chunk's hint words start out empty (the probe kernel raises them with atomicMax)
+        uint4* h4 = (uint4*)(a.hints + (size_t)c * ZL_FAR_HINT_WORDS);
+        for (u32 i = t; i < ZL_FAR_HINT_WORDS / 4; i += ENC_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (u32 ip = 0; ip < lim; ip += ENC_THREADS * FAR_SPAN * FAR_UNROLL) {
+        uint4 w[FAR_UNROLL];
 #pragma unroll
         for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p = ip + k * ENC_THREADS + t;
-            const u64 h = far_hash(v[k]);
-            const bool on = p < lim && far_sampled(h, sl);
-            const u32 bucket = far_bucket(h, sl), val = (p << 15) | far_tag(h, sl);
-            // One insert per bucket and wave is enough -- the wave's highest position wins anyway -- and a run of equal bytes
-            // (or a short period) would otherwise send up to 64 atomics to one word.  Sampled lanes are few and their buckets
-            // differ on ordinary data: the duplicates are only looked for when a wave has suspiciously many of them.
-            const u64 m = __ballot(on);
-            if ((u32)__popcll(m) <= (64u >> sl) * 3u + 4u) {
-                if (on) atomicMax(a.table + far_slot(c, bucket), val);
-            } else {
-                u64 rest = m;
-                while (rest) {
-                    const int first = __ffsll((unsigned long long)rest) - 1;
-                    const u32 b = __shfl(bucket, first, 64);
-                    const u64 same = __ballot(on && bucket == b);
-                    if (lane == 63u - (u32)__clzll((long long)same)) atomicMax(a.table + far_slot(c, b), val);
-                    rest &= ~same;
+            const u32 p0 = ip + (k * ENC_THREADS + t) * FAR_SPAN;
+            w[k] = make_uint4(0, 0, 0, 0);
+            if (p0 + 16 <= lim + 7) w[k] = ld128(src + p0);               // 16 bytes from p0 lie inside what far_limit guards (lim + 7 bytes are readable)
+            else for (u32 i = 0; i < 16 && p0 + i < lim + 7; i++) ((u32*)&w[k])[i >> 2] |= (u32)src[p0 + i] << (8 * (i & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < FAR_UNROLL; k++) {
+            const u32 p0 = ip + (k * ENC_THREADS + t) * FAR_SPAN;
+            const u64 lo = (u64)w[k].x | ((u64)w[k].y << 32), hi = (u64)w[k].z | ((u64)w[k].w << 32);
+            u32 mine = 0, keys[FAR_SPAN];
+#pragma unroll
+            for (u32 j = 0; j < FAR_SPAN; j++) {
+                const u64 v = j == 0 ? lo : ((lo >> (8 * j)) | (hi << (64 - 8 * j)));
+                const u64 h = far_hash(v);
+                const bool on = p0 + j < lim && far_sampled(h, sl);
+                const u32 bucket = far_bucket(h, sl), tag = far_tag(h, sl);
+                keys[j] = bucket | (tag << ZL_FAR_BUCKET_LOG);
+                if (on) { atomicMax(&col[bucket], ((p0 + j) << 15) | tag); mine |= 1u << j; }
+            }
+            // the list: one slot per sampled position, handed out per wave
+            u32 cnt = (u32)__popc(mine), inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            const u32 wave_total = __shfl(inc, 63, 64);
+            if (wave_total) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&count, wave_total);
+                base = __shfl(base, 0, 64);
+                u32 idx = base + inc - cnt;
+#pragma unroll
+                for (u32 j = 0; j < FAR_SPAN; j++) {
+                    if ((mine >> j) & 1) {
+                        if (idx < ZL_FAR_LIST_CAP) *(uint2*)(list + 16 + 2 * (size_t)idx) = make_uint2(keys[j], p0 + j);
+                        idx++;
+                    }
                 }
             }
         }
     }
+    __syncthreads();
+    if (t == 0) list[0] = count < ZL_FAR_LIST_CAP ? count : ZL_FAR_LIST_CAP;
+    uint4* out = (uint4*)(a.table + (size_t)c * FAR_COL);
+    const uint4* in = (const uint4*)col;
+    for (u32 i = t; i < FAR_COL / 4; i += ENC_THREADS) out[i] = in[i];
 }
 
+#define FAR_PER_THREAD 64u   // listed positions a thread holds in registers at a time
 __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
+    __shared__ u32 col[FAR_COL];
     const u32 c = blockIdx.x, t = threadIdx.x;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
-    const u32 n = cd.src_size, lim = far_limit(a, cd, a.chunk_base + c);
-    const u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
-    const u32 sl = a.sample_log;
+    const u32 lim = far_limit(a, cd, a.chunk_base + c);
+    u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
+    if (back > ZL_FAR_GROUP - 1) back = ZL_FAR_GROUP - 1;
+    if (back == 0) return;
+    const u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
+    const u32 count = list[0];
     u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
-    for (u32 ip = 0; ip < n; ip += ENC_THREADS * FAR_UNROLL) {
-        u64 v[FAR_UNROLL];
-        u32 off[FAR_UNROLL], best[FAR_UNROLL];
-        // ---- the positions' bytes
+    for (u32 seg = 0; seg < count; seg += ENC_THREADS * FAR_PER_THREAD) {
+        // key[e]: bucket | tag << 14 while the entry is looking; the offset it found once it has (bit e of `found`)
+        u32 key[FAR_PER_THREAD], pos[FAR_PER_THREAD];
+        u64 open = 0, found = 0;
 #pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) { const u32 p = ip + k * ENC_THREADS + t; v[k] = p < lim ? ld64(src + p) : 0; }
-        // ---- the slots of the 15 chunks in front (two 64-byte lines per sampled position): all windows' loads travel together
-        u32 e[FAR_UNROLL][ZL_FAR_GROUP - 1];
-        u32 tag[FAR_UNROLL];
-        bool on[FAR_UNROLL];
-#pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p = ip + k * ENC_THREADS + t;
-            const u64 h = far_hash(v[k]);
-            on[k] = p < lim && back > 0 && far_sampled(h, sl);
-            tag[k] = far_tag(h, sl);
-            const u32 bucket = far_bucket(h, sl);
-#pragma unroll
-            for (u32 q = 1; q < ZL_FAR_GROUP; q++) e[k][q - 1] = (on[k] && q <= back) ? a.table[far_slot(c - q, bucket)] : 0u;
+        for (u32 e = 0; e < FAR_PER_THREAD; e++) {
+            const u32 i = seg + e * ENC_THREADS + t;  // (consecutive threads read consecutive pairs)
+            key[e] = 0; pos[e] = 0;
+            if (i < count) { const uint2 kp = *(const uint2*)(list + 16 + 2 * (size_t)i); key[e] = kp.x; pos[e] = kp.y; open |= 1ull << e; }
         }
-        // ---- the nearest chunk whose slot carries our tag; its bytes
-        u64 w[FAR_UNROLL];
-#pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p = ip + k * ENC_THREADS + t;
-            off[k] = 0;
-#pragma unroll
-            for (u32 q = ZL_FAR_GROUP - 1; q >= 1; q--) {
-                const u32 x = e[k][q - 1];
-                if (x != 0 && (x & 0x7FFFu) == tag[k]) off[k] = q * ZL_CHUNK + p - (x >> 15);
+        // ---- the columns of the chunks in front, nearest first: an entry stops at the first one that carries its tag
+        for (u32 k = 1; k <= back; k++) {
+            {
+                const uint4* in = (const uint4*)(a.table + (size_t)(c - k) * FAR_COL);
+                uint4* out = (uint4*)col;
+                for (u32 i = t; i < FAR_COL / 4; i += ENC_THREADS) out[i] = in[i];
             }
-            w[k] = off[k] ? ld64(src + p - off[k]) : ~v[k];
-        }
-        // ---- verify, measure (up to 32 bytes), and keep the longest hit of every neighbourhood (ties: the larger offset -- any
-        // fixed rule will do)
+            __syncthreads();
+            u32 x[FAR_PER_THREAD];
 #pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p = ip + k * ENC_THREADS + t;
-            best[k] = 0;
-            if (off[k] && w[k] == v[k]) {
-                const u8* q = src + p - off[k];
+            for (u32 e = 0; e < FAR_PER_THREAD; e++) x[e] = col[key[e] & (FAR_COL - 1)];  // (found entries read a harmless word)
+#pragma unroll
+            for (u32 e = 0; e < FAR_PER_THREAD; e++) {
+                const bool hit = ((open >> e) & 1) && x[e] != 0 && (x[e] & 0x7FFFu) == (key[e] >> ZL_FAR_BUCKET_LOG);
+                if (hit) { key[e] = k * ZL_CHUNK + pos[e] - (x[e] >> 15); open &= ~(1ull << e); found |= 1ull << e; }
+            }
+            __syncthreads();
+        }
+        // ---- check the hits against the bytes (eight at a time, so that their loads travel together), measure them (up to
+        // 32 bytes) and raise the hint word of their neighbourhood: the longest hit wins (ties: the larger offset)
+#pragma unroll
+        for (u32 e0 = 0; e0 < FAR_PER_THREAD; e0 += 8) {
+            if (!((found >> e0) & 0xFF)) continue;
+            u64 va[8], vb[8];
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                const bool on = (found >> (e0 + j)) & 1;
+                va[j] = on ? ld64(src + pos[e0 + j]) : 0;
+                vb[j] = on ? ld64(src + pos[e0 + j] - key[e0 + j]) : 1;
+            }
+#pragma unroll
+            for (u32 j = 0; j < 8; j++) {
+                if (va[j] != vb[j]) continue;
+                const u32 p = pos[e0 + j], off = key[e0 + j];
+                const u8* q = src + p - off;
                 u32 len = 8;
                 while (len < 32 && p + len < lim) {
                     const u32 l = common_bytes(ld64(src + p + len), ld64(q + len));
                     len += l;
                     if (l < 8) break;
                 }
-                best[k] = (len << 26) | off[k];
+                atomicMax(hints + (p >> ZL_FAR_HINT_LOG), (len << 26) | off);
             }
-#pragma unroll
-            for (int d = (1 << ZL_FAR_HINT_LOG) / 2; d >= 1; d >>= 1) { const u32 o = __shfl_xor(best[k], d, 64); best[k] = o > best[k] ? o : best[k]; }
-            if ((t & ((1u << ZL_FAR_HINT_LOG) - 1)) == 0 && p < n) hints[p >> ZL_FAR_HINT_LOG] = best[k];
         }
     }
 }
@@ -1446,11 +1491,6 @@ __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed *
     return written + 1;
 }
 
-__device__ __forceinline__ uint4 ld128(const u8* p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
 // workgroup-wide byte copy, 16 bytes per thread and trip (global memory takes unaligned vectors)
 __device__ __forceinline__ void copy_wg(u8* dst, const u8* src, u32 n) {
     const u32 t = threadIdx.x, body = n & ~15u;
