@@ -229,3 +229,24 @@ def test_c_consumer_round_trips(tmp_path):
     out = subprocess.run([_build_c_consumer(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "round trips ok" in out.stdout and out.stdout.strip().endswith("ok")
+
+
+@needs_ref
+def test_pledged_stream_above_one_job_is_one_frame(ref):
+    """A stream whose size is pledged (what the reference's file writer does, src/raw-file-out.c:62) is ONE frame however
+    many 64 MiB jobs it takes: the same bytes zl_compress2 writes for the whole input, so the reference's one-shot reader
+    (first frame only, src/raw-file.c:150-155) gets all of it.  Without a pledge every job is a frame of its own."""
+    import torch
+    from zstdlite_amd.device import gen_mixed
+    n = (150 << 20) + 4321
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    cctx = z.zstd_cctx()
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    blob = b"".join([comp.feed(data[off:off + 7000001]) for off in range(0, n, 7000001)] + [comp.finish()])
+    assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob) and ref.L.ZSTD_getFrameContentSize(blob, len(blob)) == n
+    assert blob == z.zstd_compress(data)
+    assert ref.decompress(blob, n) == data and z.zstd_decompress(blob) == data
+    loose = stream.Compressor(cctx._ptr)
+    blob2 = b"".join([loose.feed(data[off:off + 7000001]) for off in range(0, n, 7000001)] + [loose.finish()])
+    assert ref.L.ZSTD_findFrameCompressedSize(blob2, len(blob2)) < len(blob2)  # three frames
+    assert z.zstd_decompress(blob2) == data and ref_stream_decompress(ref, blob2) == data

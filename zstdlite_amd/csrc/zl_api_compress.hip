@@ -753,7 +753,17 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         const size_t n = S.stage.size(), bound = zl_compressBound(n), old = S.out.size();
         u8* at = S.out.grow(bound);
         if (!at) return ZL_ERR(ZL_E_MEMORY);
-        const size_t r = zl_compress2(c, at, bound, S.stage.p, n);
+        // With the size pledged (what the reference's file writer does, src/raw-file-out.c:62) and the one-frame layout the
+        // jobs are consecutive runs of ONE frame -- the bytes zl_compress2 writes for the whole input, so that a reader that
+        // takes the first frame gets all of it.  Jobs are whole sections (64 MiB), the unit the far search never crosses.
+        // Without a pledge every job is a frame of its own (the total is not known when the first header is written).
+        const u64 pledged = S.pledged;
+        size_t r;
+        if (pledged != ZL_CONTENTSIZE_UNKNOWN && pledged > ZL_STREAM_JOB && use_one_frame(c, (size_t)pledged, true) && S.consumed <= pledged &&
+            (S.consumed - n) % ZL_STREAM_JOB == 0 && (n == ZL_STREAM_JOB || S.consumed == pledged))
+            r = compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged));
+        else
+            r = zl_compress2(c, at, bound, S.stage.p, n);
         S.out.n = old + (ZL_IS_ERR(r) ? 0 : r);
         if (ZL_IS_ERR(r)) return r;
         S.stage.clear();
