@@ -87,8 +87,8 @@ const char *zl_getErrorName(size_t code);
 
 /* ---- sizes ------------------------------------------------------------------------------
  * zl_compressBound replaces ZSTD_compressBound (zstd.h:232; call sites src/raw-file.c:52,
- * src/serialize.c:73).  The GPU encoder emits one independent frame per 128 KiB chunk, so
- * its bound is the sum of per-frame bounds; it is always >= ZSTD_compressBound(srcSize). */
+ * src/serialize.c:73).  Covers every layout the encoder can write (one frame per 128 KiB chunk is the
+ * largest: the sum of per-frame bounds) plus the optional seek table; always >= ZSTD_compressBound(srcSize). */
 size_t zl_compressBound(size_t srcSize);
 
 /* First-frame helpers, exact twins of ZSTD_findFrameCompressedSize (zstd.h:210) and
@@ -97,8 +97,9 @@ size_t zl_compressBound(size_t srcSize);
 size_t zl_findFrameCompressedSize(const void *src, size_t srcSize);
 unsigned long long zl_getFrameContentSize(const void *src, size_t srcSize);
 
-/* Whole-buffer helpers for concatenated frames (what zl_compress2 produces for inputs
- * larger than one chunk).  zl_findDecompressedSize is the twin of
+/* Whole-buffer helpers for concatenated frames (what the independent-frames layout produces for inputs
+ * larger than one chunk: device-resident and batch entries, checksum and dictionary contexts).
+ * zl_findDecompressedSize is the twin of
  * ZSTD_findDecompressedSize (zstd.h:1484): sum of the content sizes of all frames.
  * zl_findAllFramesCompressedSize: total bytes covered by complete frames from src[0]. */
 unsigned long long zl_findDecompressedSize(const void *src, size_t srcSize);
@@ -114,7 +115,10 @@ size_t zl_CCtx_getParameter(const zl_cctx *cctx, int param, int *value);
 size_t zl_CCtx_loadDictionary(zl_cctx *cctx, const void *dict, size_t dictSize); /* copied, as zstd.c:23826-23830 */
 
 /* replaces ZSTD_compress2 (zstd.h:599; call sites src/raw-file.c:74, src/serialize.c:91):
- * host src -> host dst, complete zstd frame(s) with content size recorded. */
+ * host src -> host dst.  ONE complete zstd frame with the content size recorded, as the reference writes
+ * (ZL_c_frameLayout; a checksum or dictionary context writes one frame per 128 KiB chunk instead).  Large
+ * inputs are uploaded, compressed and downloaded in overlapping 64 MiB sections (ZL_c_pipeline), optionally
+ * on several devices (ZL_c_devices); the bytes written depend on neither. */
 size_t zl_compress2(zl_cctx *cctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize);
 
 /* ---- decompression context: ZSTD_createDCtx / ZSTD_freeDCtx / ZSTD_DCtx_setParameter /
@@ -127,9 +131,10 @@ size_t zl_DCtx_getParameter(const zl_dctx *dctx, int param, int *value);
 size_t zl_DCtx_loadDictionary(zl_dctx *dctx, const void *dict, size_t dictSize);
 
 /* replaces ZSTD_decompressDCtx (zstd.h:290; call sites src/raw-file.c:189,
- * src/serialize.c:197): decodes every frame in [src, src+srcSize) (concatenated frames
- * are decoded in parallel, one workgroup per frame; skippable frames skipped), verifies
- * content size and checksum, returns bytes regenerated. */
+ * src/serialize.c:197): decodes every frame in [src, src+srcSize) -- concatenated small frames in
+ * parallel on the lane pipeline, a frame of many blocks (what ZSTD_compress2 and zl_compress2 write for
+ * large inputs) spread over the whole device by the large-frame pipeline, skippable frames skipped --
+ * verifies content size and checksum, returns bytes regenerated. */
 size_t zl_decompressDCtx(zl_dctx *dctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize);
 
 /* dictionary id helpers: ZSTD_getDictID_fromDict / ZSTD_getDictID_fromFrame
@@ -169,10 +174,11 @@ size_t zl_decompress_device_finish(zl_dctx *dctx, size_t *results);
  * it is checked against the frame and ignored when it does not fit; it is forgotten after one call. */
 size_t zl_decompress_device_hint(zl_dctx *dctx, const size_t *chunkSizes, size_t nchunks);
 
-/* Compress d_src[0..srcSize) into d_dst as concatenated frames (one per 128 KiB chunk).
- * d_dst must hold zl_compressBound(srcSize) bytes.  After _finish, frameSizes (host, may
- * be NULL, capacity zl_compress_device_nframes(srcSize)) holds each frame's compressed
- * size; the frames are contiguous in d_dst.  Returns total compressed bytes. */
+/* Compress d_src[0..srcSize) into d_dst: concatenated frames, one per 128 KiB chunk (the default of this
+ * entry), or ONE frame (ZL_c_frameLayout = ZL_layout_one_frame).  d_dst must hold zl_compressBound(srcSize)
+ * bytes.  After _finish, frameSizes (host, may be NULL, capacity zl_compress_device_nframes(srcSize)) holds
+ * the compressed size of every chunk -- its frame, or its run of blocks inside the one frame (the first
+ * includes the frame header): what zl_decompress_device_hint takes.  Returns total compressed bytes. */
 size_t zl_compress_device_nframes(size_t srcSize);
 size_t zl_compress_device_async(zl_cctx *cctx, void *d_dst, size_t dstCapacity, const void *d_src, size_t srcSize,
                                 void *stream);
@@ -191,10 +197,12 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  *
  * Compression: input is collected on the host into jobs of 64 MiB (libzstd's own multi-threaded
  * streaming cuts jobs the same way, zstd.c:36848); every full job -- and the rest at ZL_e_flush /
- * ZL_e_end -- goes through the same kernels as zl_compress2, so the stream is a concatenation of
- * frames of at most 128 KiB of content each: valid zstd that ZSTD_decompressStream / ZSTD_decompress
- * read (and whose first frame records only its own content size: deviation H1 of INTEGRATION.md
- * applies to a reader that sizes its buffer from the first 18 bytes, src/raw-file-in.c:66).
+ * ZL_e_end -- goes through the same kernels as zl_compress2.  With the size pledged
+ * (zl_CCtx_setPledgedSrcSize, what src/raw-file-out.c:74 does) the jobs are consecutive runs of blocks of
+ * ONE frame: byte for byte what zl_compress2 writes for the whole input, so a reader that sizes its
+ * buffer from the frame header (src/raw-file-in.c:66) or takes the first frame gets everything.
+ * Without a pledge every job is a frame of its own with its own recorded size: valid zstd that
+ * ZSTD_decompressStream / ZSTD_decompress read frame after frame.
  * Returns the bytes still waiting to be handed out (0 at ZL_e_end: the session is complete), or an
  * error code.  Decompression: input is collected until it holds complete frames; those are decoded
  * at once (all routes of zl_decompressDCtx, frames without a recorded size included) and handed out

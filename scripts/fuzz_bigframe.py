@@ -16,6 +16,10 @@ for gen, n, kw in (("text", 1200000, {"level": 3}), ("iid10", 1300000, {"level":
                    ("text", 2500000, {"level": 9}), ("iid10", 1100000, {"level": 19})):
     d = GENERATORS[gen](n, seed=n) + (bytes(200000) if gen == "int20" else b"")
     base.append((ref.compress(d, **kw), len(d)))
+# frames of this library's own one-frame layout: segments of several blocks that share tables, far matches across chunks
+from zl_testlib import LONG_RANGE
+for d in (GENERATORS["text"](900000, seed=5) + GENERATORS["iid10"](500000, seed=6), LONG_RANGE["records"](3 << 20)[: (2 << 20) + 300000], LONG_RANGE["corpus"](1500000)):
+    base.append((z.zstd_compress(d), len(d)))
 print(len(base), "base frames;", sum(len(f) for f, _ in base), "compressed bytes")
 dctx = z.zstd_dctx()
 bad_accept = bad_reject = accepted = rejected = 0
@@ -55,6 +59,21 @@ for rd in range(rounds):
             if not is_error(code):
                 bad_reject += 1
                 print("GPU rejected a frame the oracle accepts: frame", i, _lib.error_name(res[i]), "oracle size", code)
+    # the same damaged frames through the host entry, one by one: the host walks the blocks and uploads what it saw
+    for i, (f, n) in enumerate(frames[:: 3]):
+        code, out = o.decompress_code(f, n)
+        buf = np.zeros(max(n, 1), dtype=np.uint8)
+        r1 = L.zl_decompressDCtx(dctx._ptr, buf.ctypes.data, n, f, len(f))
+        if not is_error(r1):
+            accepted += 1
+            if is_error(code) or r1 != code or buf[:r1].tobytes() != out:
+                bad_accept += 1
+                print("host entry accepted, oracle disagrees: frame", 3 * i, "gpu", r1, "oracle", code if not is_error(code) else o.error_name(code))
+        else:
+            rejected += 1
+            if not is_error(code):
+                bad_reject += 1
+                print("host entry rejected a frame the oracle accepts: frame", 3 * i, _lib.error_name(r1), "oracle size", code)
     print(f"round {rd}: {accepted} accepted, {rejected} rejected, {bad_accept} wrong accepts, {bad_reject} wrong rejects, large frames so far {L.zl_dctx_large_frames(dctx._ptr)}, {time.time() - t0:.0f}s", flush=True)
 assert bad_accept == 0 and bad_reject == 0
 print("ok")
