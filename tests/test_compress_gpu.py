@@ -305,3 +305,18 @@ def test_seek_table_is_skippable_and_spares_the_walk(layout, ref):
     a = int.from_bytes(bad[t0:t0 + 4], "little"); b = int.from_bytes(bad[t0 + 4:t0 + 8], "little")
     bad[t0:t0 + 4] = (a + 1).to_bytes(4, "little"); bad[t0 + 4:t0 + 8] = (b - 1).to_bytes(4, "little")
     assert z.zstd_decompress(bytes(bad)) == data
+
+
+def test_level_five_deepens_the_far_search(ref):
+    """Levels >= 5 run the encoder's second operating point above level 2 (include/zl_hip.h): one position in four takes
+    part in the far search instead of one in eight.  The lazy / optimal parsers behind the reference's levels >= 5 are not
+    built, so the bar is what the knob does: clearly smaller output than level 3, valid for both decoders."""
+    import warnings
+    from zl_testlib import LONG_RANGE
+    data = LONG_RANGE["corpus"](None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l3, l5 = z.zstd_compress(data, level=3), z.zstd_compress(data, level=5)
+    assert len(l5) < len(l3) * 0.985, (len(l3), len(l5))
+    assert len(l5) <= len(ref.compress(data, level=3)) * 1.03
+    assert ref.decompress(l5, len(data)) == data and z.zstd_decompress(l5) == data

@@ -137,7 +137,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         f.src = d_src;
         f.total = joined_total;
         f.chunk_base = (u32)(frame_chunk0 + first);
-        f.sample_log = c->level >= 9 ? 1u : (c->level >= 5 ? 2u : (u32)ZL_FAR_SAMPLE_LOG);  // the operating points above level 3: denser far sampling
+        f.sample_log = c->level >= 5 ? 2u : (u32)ZL_FAR_SAMPLE_LOG;  // the operating points above level 3: denser far sampling
         f.table = (u32*)es.far_table.p;
         f.hints = (u32*)es.far_hints.p;
         f.lists = (u32*)es.far_lists.p;
@@ -321,8 +321,8 @@ size_t zl_freeCCtx(zl_cctx* c) {
 //   levels < 3   every other position probed throughout (cf. the step of ZSTD_fast, zstd.c:29340); reported as given
 //   level 3, 4   the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
 //                in the one-frame layout one position in 8 takes part in the far search.  Reported as 3.
-//   levels 5..8  the same parse, one position in 4 in the far search.  Reported as 5.
-//   levels >= 9  one position in 2.  Reported as 9.
+//   levels >= 5  the same parse, one position in 4 in the far search (python sources: 4.24 -> 4.34 against the reference's
+//                level-3 4.43, for twice the far-search time).  Reported as 5.
 // Measured against the reference at the same level: within 5 % of its ratio at levels 1, 2 and 3
 // (tests/test_compress_gpu.py).  The lazy and optimal parsers behind the reference's levels >= 5 (zstd.c:31546-33746) are
 // not built: above 3 only the far search deepens, and the ratio falls behind the reference's at those levels.
@@ -331,7 +331,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value >= 9 ? 9 : (value >= 5 ? 5 : (value >= 3 ? 3 : value));
+        c->level = value >= 5 ? 5 : (value >= 3 ? 3 : value);
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;

@@ -33,7 +33,7 @@
 #define ZL_FAR_SECTION_LOG 9                      // far history does not cross sections of 512 chunks (64 MiB): a section is what the host entries
                                                  // upload, compress and download as one pipeline stage, and the output must not depend on how a call was staged
 #define ZL_FAR_TABLE_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)4 << ZL_FAR_BUCKET_LOG))   // one column of 2^ZL_FAR_BUCKET_LOG words per chunk
-#define ZL_FAR_LIST_CAP 20480u                    // sampled positions a chunk may list (expected at one in eight: 16384); what exceeds it is not probed
+#define ZL_FAR_LIST_CAP 40960u                    // sampled positions a chunk may list (expected: 16384 at one in eight, 32768 at one in four); what exceeds it is not probed
 #define ZL_FAR_LIST_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)ZL_FAR_LIST_CAP * 8 + 64))
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 
