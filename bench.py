@@ -284,19 +284,26 @@ def n1_decode(codec, device, frame, src, log):
     tbl = codec.frame_table([int(frame.size)], [n])
     before = int(_lib.lib().zl_dctx_large_frames(codec.dctx))
     best = 1e9
-    for it in range(3):
+    host = np.ascontiguousarray(frame)
+    best_h = 1e9
+    for it in range(6):
+        with_host = it >= 3  # the second three: the caller still holds the bytes in host memory, the block walk happens there
         d_dst.zero_()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        total, _ = codec.decompress(d_src, tbl, d_dst)
+        total, _ = codec.decompress(d_src, tbl, d_dst, host_copy=host if with_host else None)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if it:
-            best = min(best, dt)
-    took = int(_lib.lib().zl_dctx_large_frames(codec.dctx)) - before
+        if it % 3:
+            if with_host:
+                best_h = min(best_h, dt)
+            else:
+                best = min(best, dt)
+    took = (int(_lib.lib().zl_dctx_large_frames(codec.dctx)) - before) // 2
     assert total == n and torch.equal(d_dst, src), "N1 decode mismatch"
     log(f"N1: one reference frame of {n >> 20} MiB decoded at {n / best / 1e9:.2f} GB/s (large-frame pipeline: {took == 3})")
     return {"frame_content_bytes": n, "compressed_bytes": int(frame.size), "decompress_GBps": n / best / 1e9, "ms": best * 1e3,
+            "decompress_GBps_blocks_walked_on_host": n / best_h / 1e9, "ms_blocks_walked_on_host": best_h * 1e3,
             "large_frame_pipeline": took == 3, "bit_exact": True}
 
 

@@ -173,6 +173,10 @@ size_t zl_decompress_device_finish(zl_dctx *dctx, size_t *results);
  * lane per chunk instead of following 3-byte headers through the whole frame on one lane (zstd.c:43075).  Only a hint:
  * it is checked against the frame and ignored when it does not fit; it is forgotten after one call. */
 size_t zl_decompress_device_hint(zl_dctx *dctx, const size_t *chunkSizes, size_t nchunks);
+/* Optional, before zl_decompress_device_async: the caller still holds the compressed bytes in host memory (hostSrc[0..n)
+ * equals d_src[0..n); typically it read a file and uploaded it).  The block headers of large frames are then walked on
+ * the host, as zl_findFrameCompressedSize does (zstd.c:41335), instead of by one GPU lane.  Forgotten after one call. */
+size_t zl_decompress_device_hint_host_copy(zl_dctx *dctx, const void *hostSrc, size_t n);
 
 /* Compress d_src[0..srcSize) into d_dst: concatenated frames, one per 128 KiB chunk (the default of this
  * entry), or ONE frame (ZL_c_frameLayout = ZL_layout_one_frame).  d_dst must hold zl_compressBound(srcSize)

@@ -107,3 +107,34 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("ok")
+
+
+def test_seek_table_is_read_from_the_end_of_the_buffer(golden):
+    """SURVEY 8f N4, host side only (no GPU): zl_index_frames takes the frame table from the seek table this library may
+    append (include/zl_hip.h ZL_c_seekTable; layout in csrc/zl_format.h) instead of walking block headers -- shown with two
+    reference-made frames whose first block header is damaged: the walk fails, the table still answers.  A table whose
+    sizes do not add up is ignored."""
+    import struct
+    cases, _ = golden
+    a = next(c for c in cases if c["gen"] == "text" and c["n"] == 131072 and c["level"] == 3 and not c.get("checksum"))
+    b = next(c for c in cases if c["gen"] == "iid10" and c["n"] == 65536 and c["level"] == 3 and not c.get("checksum"))
+    data = a["comp"] + b["comp"]
+    content = a["n"] + b["n"]
+
+    def table(sizes, content_bytes, flags=0):
+        payload = b"".join(struct.pack("<I", x) for x in sizes) + struct.pack("<QIII", content_bytes, len(sizes), flags, 0x58494C5A)
+        return struct.pack("<II", 0x184D2A5E, len(payload)) + payload
+    L = _lib.lib()
+    frames = (_lib.FrameT * 4)()
+    good = data + table([len(a["comp"]), len(b["comp"])], content)
+    assert L.zl_index_frames(good, len(good), frames, 4) == 2
+    assert [(f.src_off, f.src_size, f.dst_off, f.dst_cap) for f in frames[:2]] == [(0, len(a["comp"]), 0, 131072), (len(a["comp"]), len(b["comp"]), 131072, 65536)]
+    assert L.zl_findFrameCompressedSize(good, len(good)) == len(a["comp"])  # a first-frame reader is not affected
+    assert L.zl_findDecompressedSize(good, len(good)) == content            # ... nor one that takes every frame: the table is skippable
+    broken = bytearray(good)
+    broken[9] |= 0x06  # first block header of frame a: reserved block type -> the header walk fails
+    assert _lib.is_error(L.zl_index_frames(bytes(broken[: len(data)]), len(data), frames, 4))
+    assert L.zl_index_frames(bytes(broken), len(broken), frames, 4) == 2      # ... the table does not walk
+    lying = data + table([len(a["comp"]) + 1, len(b["comp"])], content)
+    assert L.zl_index_frames(lying, len(lying), frames, 4) == 2               # sizes do not add up: ignored, walked instead
+    assert frames[0].src_size == len(a["comp"])

@@ -167,3 +167,29 @@ def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
     r = _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data), new, len(new))
     assert r == len(data) and bytes(out) == data
     assert large_frames(dctx) == 0
+
+
+def test_host_copy_hint_walks_the_blocks_on_the_host(ref):
+    """zl_decompress_device_hint_host_copy: a device-resident caller that still holds the compressed bytes in host memory
+    lets the block headers of a large frame be walked there.  Same output; a host copy that does not match the device
+    bytes must not be trusted beyond the block table (here: a damaged copy -> the device still decodes what IT holds, or
+    reports an error -- never silently wrong bytes)."""
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    data = GENERATORS["text"](3000000, seed=3) + GENERATORS["iid10"](2000000, seed=4)
+    comp = np.frombuffer(ref.compress(data, level=3), dtype=np.uint8).copy()
+    codec = DeviceCodec()
+    d_src = torch.from_numpy(comp).cuda()
+    want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros(len(data), dtype=torch.uint8, device="cuda")
+    tbl = codec.frame_table([comp.size], [len(data)])
+    for host in (None, comp):
+        out.zero_()
+        got, _ = codec.decompress(d_src, tbl, out, host_copy=host)
+        assert got == len(data) and torch.equal(out, want)
+    bad = comp.copy()
+    bad[len(bad) // 2] ^= 0x55  # some block's payload differs on the host: the block table is still right, the device bytes decide
+    out.zero_()
+    got, _ = codec.decompress(d_src, tbl, out, host_copy=bad)
+    assert got == len(data) and torch.equal(out, want)
+    codec.close()

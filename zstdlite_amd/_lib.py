@@ -51,6 +51,7 @@ SYMBOLS = [
     ("zl_decompress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameT), C.c_size_t, C.c_void_p]),
     ("zl_decompress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),
     ("zl_decompress_device_hint", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t), C.c_size_t]),
+    ("zl_decompress_device_hint_host_copy", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("zl_compress_device_nframes", C.c_size_t, [C.c_size_t]),
     ("zl_compress_device_async", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("zl_compress_device_finish", C.c_size_t, [C.c_void_p, C.POINTER(C.c_size_t)]),

@@ -91,7 +91,7 @@ class DeviceCodec:
         cs[-1] = n - (k - 1) * CHUNK
         return cs
 
-    def decompress(self, src, table, dst, chunk_sizes=None):
+    def decompress(self, src, table, dst, chunk_sizes=None, host_copy=None):
         """Decode the frames listed in `table` (n x 4 uint64: src_off, src_size, dst_off, dst_cap)
         from the uint8 CUDA tensor src into dst.  Returns (total bytes, per-frame results).
         chunk_sizes: for ONE frame written by compress() in the one-frame layout, the per-chunk sizes it
@@ -99,6 +99,8 @@ class DeviceCodec:
         assert src.is_cuda and dst.is_cuda
         tbl = np.ascontiguousarray(table, dtype=np.uint64)
         n = tbl.shape[0]
+        if host_copy is not None:  # numpy uint8 array with the same bytes as src (zl_decompress_device_hint_host_copy)
+            self.L.zl_decompress_device_hint_host_copy(self.dctx, C.c_void_p(host_copy.ctypes.data), host_copy.size)
         if chunk_sizes is not None and n == 1:
             cs = np.ascontiguousarray(chunk_sizes, dtype=np.uint64)
             self.L.zl_decompress_device_hint(self.dctx, cs.ctypes.data_as(C.POINTER(C.c_size_t)), len(cs))
