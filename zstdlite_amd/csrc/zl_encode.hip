@@ -84,7 +84,10 @@ __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
 // wait for every literal / sequence store of the emit phase at each of the ~14 barriers of an
-// iteration; nothing in this kernel hands global data from one thread to another.
+// iteration; nothing in the window loop hands global data from one thread to another.  RULE: any code of
+// this kernel that reads global memory another thread of the workgroup wrote (today: only the merge pass
+// behind the loop, which re-reads the sequences) must use zl_sync_global() -- vmcnt(0) + barrier -- not
+// this; tests/test_fullsize_gpu.py::test_one_gib_ten_times_on_fresh_contexts is the net under it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct MatchShared {

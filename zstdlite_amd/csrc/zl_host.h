@@ -11,11 +11,16 @@
 
 namespace {
 
-// ZL_DEBUG=1 in the environment prints every failing HIP call to stderr
+// Development builds (-DZL_DEV_SWITCHES: `python -m zstdlite_amd.build --variant dev -DZL_DEV_SWITCHES`) read a few
+// environment switches; the product build reads none.  ZL_DEBUG=1 prints every failing HIP call to stderr.
 static inline bool zl_hip_ok(hipError_t e, const char* what) {
     if (e == hipSuccess) return true;
+#ifdef ZL_DEV_SWITCHES
     static const bool dbg = getenv("ZL_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "[zl_hip] %s failed: %s\n", what, hipGetErrorString(e));
+#else
+    (void)what;
+#endif
     return false;
 }
 
@@ -33,8 +38,10 @@ struct DevBuf {
         // ZL_POISON_MEM=1 in the environment fills every new device buffer with a pattern: a kernel that
         // reads scratch it has not written then fails reproducibly instead of depending on what the
         // allocation held before (debug aid)
+#ifdef ZL_DEV_SWITCHES
         static const bool poison = getenv("ZL_POISON_MEM") != nullptr;
         if (poison) { (void)hipMemset(p, 0xEE, want); (void)hipDeviceSynchronize(); }  // (the contexts' streams do not wait for the null stream)
+#endif
         return true;
     }
     void release() {
