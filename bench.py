@@ -394,7 +394,7 @@ def _kernel_sources_hash():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "zstdlite_amd", "csrc", "*"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "zstdlite_amd", "csrc", "*.h*"))):  # the product kernels (csrc/experiments/ is not part of the library)
         h.update(open(f, "rb").read())
     return h.hexdigest()
 

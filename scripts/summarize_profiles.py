@@ -92,7 +92,7 @@ for k in sorted(set(dur) | set(fetch) | set(write)):
 # which kernels these numbers describe: bench.py reports roofline.traffic only while the sources are the same
 import hashlib
 h = hashlib.sha256()
-for f in sorted(glob.glob(os.path.join(ROOT, "zstdlite_amd", "csrc", "*"))):
+for f in sorted(glob.glob(os.path.join(ROOT, "zstdlite_amd", "csrc", "*.h*"))):  # the product kernels (csrc/experiments/ is not part of the library)
     h.update(open(f, "rb").read())
 short["_kernel_sources_sha256"] = h.hexdigest()
 json.dump(summary, open(os.path.join(P, f"{rnd}_kernel_summary.json"), "w"), indent=1)

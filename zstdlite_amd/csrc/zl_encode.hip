@@ -38,57 +38,7 @@
 #define PPT 1              // positions per thread and iteration (2 was measured: same speed, 0.8 % worse ratio)
 #define WIN (ENC_THREADS * PPT)  // positions examined per iteration
 #define WIN_LOG (PPT == 1 ? 8 : 9)
-#define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
-#define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
-#ifndef LANE_MATCH_CAP
-#define LANE_MATCH_CAP 40
-#endif
-#ifndef LANE_MATCH_CAP_FAR
-#define LANE_MATCH_CAP_FAR 72  // the windowed layout verifies further: python sources +0.9 % ratio for 5 % of match time
-#endif
-// LANE_MATCH_CAP:  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
-#define MIN_MATCH 4
-
-__device__ __forceinline__ u64 ld64(const u8* p) {
-    u64 v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-__device__ __forceinline__ uint4 ld128(const u8* p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
-}
-#ifndef ZL_LONG_BYTES
-#define ZL_LONG_BYTES 8
-#endif
-#ifndef ZL_SHORT_BYTES
-#define ZL_SHORT_BYTES 6
-#endif
-__device__ __forceinline__ u32 hash8(u64 v) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
-__device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_SHORT_BYTES)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
-// the windowed layout hashes 5 bytes, the reference's minimum match at level 3 (zstd.c:29529): on real text the
-// 5-byte repeats are worth more than the table pressure they cost (python sources: +2.4 % ratio); the synthetic
-// bench inputs prefer 6 (fewer, longer candidates: faster and no worse)
-#ifndef ZL_SHORT_BYTES_FAR
-#define ZL_SHORT_BYTES_FAR 5
-#endif
-template <bool FAR>
-__device__ __forceinline__ u32 hash_short(u64 v) {
-    return FAR ? (u32)(((v << (64 - 8 * ZL_SHORT_BYTES_FAR)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)) : hash5(v);
-}
-__device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
-    const u64 x = a ^ b;
-    return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
-// wait for every literal / sequence store of the emit phase at each of the ~14 barriers of an
-// iteration; nothing in the window loop hands global data from one thread to another.  RULE: any code of
-// this kernel that reads global memory another thread of the workgroup wrote (today: only the merge pass
-// behind the loop, which re-reads the sequences) must use zl_sync_global() -- vmcnt(0) + barrier -- not
-// this; tests/test_fullsize_gpu.py::test_one_gib_ten_times_on_fresh_contexts is the net under it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#include "zl_match_common.h"
 
 struct MatchShared {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
@@ -1046,12 +996,24 @@ extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hip
     return hipGetLastError();
 }
 
+// -DZL_MATCH_WIDE=1 (variant builds only, `python -m zstdlite_amd.build --variant wide -DZL_MATCH_WIDE=1`) sends the bulk path to
+// csrc/experiments/zl_match_wide.hip: one 1024-thread workgroup per CU with the search window in LDS.  Measured slower
+// (DESIGN.md 3.3), kept as the record of the experiment.
+#ifndef ZL_MATCH_WIDE
+#define ZL_MATCH_WIDE 0
+#endif
+#if ZL_MATCH_WIDE
+extern "C" hipError_t zl_launch_match_wide(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+#endif
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
     if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+#if ZL_MATCH_WIDE
+    else return zl_launch_match_wide(a, nchunks, stream);
+#endif
     else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();

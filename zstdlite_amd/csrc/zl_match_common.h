@@ -1,0 +1,57 @@
+// zl_match_common.h -- what the two match kernels (zl_encode.hip: 256 threads per chunk, global candidate gathers;
+// zl_match_wide.hip: 1024 threads per chunk, the search window resident in LDS) share: hashes, byte compares, the
+// LDS-only barrier.
+#pragma once
+#include "zl_device.h"
+
+#define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
+#define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
+#ifndef LANE_MATCH_CAP
+#define LANE_MATCH_CAP 40
+#endif
+#ifndef LANE_MATCH_CAP_FAR
+#define LANE_MATCH_CAP_FAR 72  // the windowed layout verifies further: python sources +0.9 % ratio for 5 % of match time
+#endif
+// LANE_MATCH_CAP:  // per-lane verification stops here; longer matches continue as repeat-offset pieces and are merged in E2
+#define MIN_MATCH 4
+
+__device__ __forceinline__ u64 ld64(const u8* p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint4 ld128(const u8* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+#ifndef ZL_LONG_BYTES
+#define ZL_LONG_BYTES 8
+#endif
+#ifndef ZL_SHORT_BYTES
+#define ZL_SHORT_BYTES 6
+#endif
+__device__ __forceinline__ u32 hash8(u64 v) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> (64 - LONG_LOG)); }
+__device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_SHORT_BYTES)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)); }
+// the windowed layout hashes 5 bytes, the reference's minimum match at level 3 (zstd.c:29529): on real text the
+// 5-byte repeats are worth more than the table pressure they cost (python sources: +2.4 % ratio); the synthetic
+// bench inputs prefer 6 (fewer, longer candidates: faster and no worse)
+#ifndef ZL_SHORT_BYTES_FAR
+#define ZL_SHORT_BYTES_FAR 5
+#endif
+template <bool FAR>
+__device__ __forceinline__ u32 hash_short(u64 v) {
+    return FAR ? (u32)(((v << (64 - 8 * ZL_SHORT_BYTES_FAR)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)) : hash5(v);
+}
+__device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
+    const u64 x = a ^ b;
+    return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// wait for every literal / sequence store of the emit phase at each of the ~14 barriers of an
+// iteration; nothing in the window loop hands global data from one thread to another.  RULE: any code of
+// this kernel that reads global memory another thread of the workgroup wrote (today: only the merge pass
+// behind the loop, which re-reads the sequences) must use zl_sync_global() -- vmcnt(0) + barrier -- not
+// this; tests/test_fullsize_gpu.py::test_one_gib_ten_times_on_fresh_contexts is the net under it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
