@@ -40,13 +40,14 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #include "zl_match_common.h"
 
-struct MatchShared {
+template <int SLOG>
+struct MatchSharedT {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
     // mean the nearest such position in front of it, so candidates reach 64 KiB back (an older entry
     // aliases to a wrong position and fails verification).  Half the LDS of 32-bit entries: six
     // workgroups per CU instead of three, and this kernel is latency-bound.
     u32 tbl_long[(1 << LONG_LOG) / 2];
-    u32 tbl_short[(1 << SHORT_LOG) / 2];
+    u32 tbl_short[(1 << SLOG) / 2];
     u16 jump[2][WIN];
     u8 mark[WIN];
     u32 cand[WIN];  // [7:0] match length, [31:8] offset of each lane's best match
@@ -155,9 +156,37 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 // elsewhere, by the chunks whose descriptor asks for it: inputs of at most one chunk, where most of what repeats does so
 // within a few hundred bytes (a 1000-byte serialized data frame: 585 -> about 470 bytes).  The bulk path of large inputs
 // in the independent-frames layout runs without it (three more barriers per window).
+// A short match at a long distance costs more than the literals it replaces (an offset of 2^k takes k extra bits on top
+// of the three codes; a literal of compressible data 3-5 bits): matches below ZL_SHORT_LEN bytes are kept only with a
+// repeat offset or an offset below 2^ZL_SHORT_OFFLOG.
+#ifndef ZL_SHORT_LEN
+#define ZL_SHORT_LEN 0
+#endif
+#ifndef ZL_SHORT_OFFLOG
+#define ZL_SHORT_OFFLOG 12
+#endif
+#ifndef ZL_SHORT_LEN_FAR
+#define ZL_SHORT_LEN_FAR 0
+#endif
+// The short table's candidates are fetched only from this far back (0 = as far as the table knows).
+#ifndef ZL_SHORT_REACH
+#define ZL_SHORT_REACH 0
+#endif
+template <bool FAR>
+__device__ __forceinline__ bool short_in_reach(u32 dist) { return FAR || ZL_SHORT_REACH == 0 || dist <= ZL_SHORT_REACH; }
+template <bool FAR>
+__device__ __forceinline__ bool worth_it(u32 len, u32 off, u32 rep) {
+    const u32 need = FAR ? ZL_SHORT_LEN_FAR : ZL_SHORT_LEN;
+    return need == 0 || len >= need || off == rep || off < (1u << ZL_SHORT_OFFLOG);
+}
 template <bool DICT, bool PROF, bool FAR, bool INTRA>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
-    __shared__ MatchShared S;
+    // The bulk path (no dictionary, independent frames, inputs larger than a chunk) runs with half the short table: its
+    // candidates are nearer (mean age = table size), so their gathers hit closer caches -- 1 GiB mix: match 5.74 -> 4.98 ms
+    // for 0.1 % of ratio (text -1.2 %, python sources -2.4 %; a distance cap on the short candidates bought the same time
+    // for twice the ratio: DESIGN.md 3.3).  The other instantiations keep 2^12 entries.
+    constexpr int SLOG = (DICT || FAR || INTRA) ? SHORT_LOG : SHORT_LOG_BULK;
+    __shared__ MatchSharedT<SLOG> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = zl_spread(blockIdx.x, nchunks);
@@ -182,9 +211,12 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
         return q >= D ? src + (q - D) : dict + q;
     };
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
-    for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
+    for (u32 i = t; i < (1u << SLOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
     const bool intra_on = INTRA && (FAR || (cd.flags & 1u));  // uniform
+    // (a launch that mixes small inputs with chunks of large ones -- a batch -- must write for every chunk what a launch of
+    // its own would: the chunks of large inputs hash as the bulk instantiation does)
+    const u32 sshift = (INTRA && !DICT && !FAR && !intra_on) ? 64u - SHORT_LOG_BULK : 64u - (u32)SLOG;
     if (INTRA) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
@@ -238,7 +270,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 q_r[j] = q_l[j] = q_s[j] = V;
                 if (can_match[j]) {
                     hl[j] = hash8(v[j]);
-                    hs[j] = hash_short<FAR>(v[j]);
+                    hs[j] = hash_short<FAR>(v[j], sshift);
                     word_l[j] = S.tbl_long[hl[j] >> 1];
                     word_s[j] = S.tbl_short[hs[j] >> 1];
                     if (search) {
@@ -247,7 +279,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                         have_r[j] = rep && V + reach >= rep;
                         have_f[j] = FAR && far_off[j] != 0 && far_off[j] != rep && p + reach >= far_off[j];
                         have_l[j] = el != 0 && dl != 0 && dl <= V;
-                        have_s[j] = es != 0 && ds != 0 && ds <= V;
+                        have_s[j] = es != 0 && ds != 0 && ds <= V && short_in_reach<FAR>(ds);
                         if (have_r[j]) q_r[j] = V - rep;
                         if (have_l[j]) q_l[j] = V - dl;
                         if (have_s[j]) q_s[j] = V - ds;
@@ -334,7 +366,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             bool has_match[PPT];
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
-                has_match[j] = best_len[j] >= MIN_MATCH;
+                has_match[j] = best_len[j] >= MIN_MATCH && worth_it<FAR>(best_len[j], best_off[j], rep);
                 S.cand[t + ENC_THREADS * j] = has_match[j] ? (best_len[j] | (best_off[j] << 8)) : 0u;
             }
             const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -495,7 +527,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 far_off2 = 0;
             if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
             if (can0) {
-                hl0 = hash8(v0); hs0 = hash_short<FAR>(v0);
+                hl0 = hash8(v0); hs0 = hash_short<FAR>(v0, sshift);
                 wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1];
                 if (search) {
                     const u32 el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF, es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF;
@@ -503,14 +535,14 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     have_r = rep && p + reach >= rep;
                     have_f = FAR && far_off2 != 0 && far_off2 != rep && p + reach >= far_off2;
                     have_l = el != 0 && dl != 0 && dl <= p;
-                    have_s = es != 0 && ds != 0 && ds <= p;
+                    have_s = es != 0 && ds != 0 && ds <= p && short_in_reach<FAR>(ds);
                     if (have_r) q_r = p - rep;
                     if (have_l) q_l = p - dl;
                     if (have_s) q_s = p - ds;
                 }
             }
             if (can1) {  // the odd position is only inserted: its table words are read here, next to the others
-                hl1 = hash8(v1); hs1 = hash_short<FAR>(v1);
+                hl1 = hash8(v1); hs1 = hash_short<FAR>(v1, sshift);
                 wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
             u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
@@ -545,7 +577,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (l < 8) break;
                 }
             }
-            bool has_match = best_len >= MIN_MATCH;
+            bool has_match = best_len >= MIN_MATCH && worth_it<FAR>(best_len, best_off, rep);
             // A repeat that began on the odd position in front of p is found here one byte late.  The byte in
             // front of the candidate is fetched now (it is needed when the sequence is written): if it
             // equals the byte in front of p and that byte is still a free literal, the match starts there.
@@ -787,7 +819,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
 // The match tables as they look after the last byte of a dictionary's content: one workgroup walks the
 // content window by window with the same ordered insert as the encoder (run once per loaded dictionary).
 __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* content, u32 n, u32* out) {
-    __shared__ MatchShared S;
+    __shared__ MatchSharedT<SHORT_LOG> S;
     const u32 t = threadIdx.x;
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = 0;
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = 0;

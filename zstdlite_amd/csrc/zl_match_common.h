@@ -4,8 +4,12 @@
 #pragma once
 #include "zl_device.h"
 
-#define LONG_LOG 13        // 8-byte-hash table: 2^13 u32 entries (32 KiB LDS)
-#define SHORT_LOG 12       // 5-byte-hash table: 2^12 u32 entries (16 KiB LDS)
+#ifndef LONG_LOG
+#define LONG_LOG 13        // 8-byte-hash table: 2^13 16-bit entries (16 KiB LDS)
+#endif
+#ifndef SHORT_LOG
+#define SHORT_LOG 12       // 6-byte-hash table: 2^12 16-bit entries (8 KiB LDS)
+#endif
 #ifndef LANE_MATCH_CAP
 #define LANE_MATCH_CAP 40
 #endif
@@ -39,9 +43,12 @@ __device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_S
 #ifndef ZL_SHORT_BYTES_FAR
 #define ZL_SHORT_BYTES_FAR 5
 #endif
+#ifndef SHORT_LOG_BULK
+#define SHORT_LOG_BULK 11  // the bulk instantiation of the match kernel (zl_encode.hip says why)
+#endif
 template <bool FAR>
-__device__ __forceinline__ u32 hash_short(u64 v) {
-    return FAR ? (u32)(((v << (64 - 8 * ZL_SHORT_BYTES_FAR)) * 0xC2B2AE3D27D4EB4FULL) >> (64 - SHORT_LOG)) : hash5(v);
+__device__ __forceinline__ u32 hash_short(u64 v, u32 shift /* 64 - log2 of the table's entries */) {
+    return (u32)(((v << (64 - 8 * (FAR ? ZL_SHORT_BYTES_FAR : ZL_SHORT_BYTES))) * 0xC2B2AE3D27D4EB4FULL) >> shift);
 }
 __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
     const u64 x = a ^ b;
