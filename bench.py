@@ -266,6 +266,37 @@ def end_to_end_leg(host, device, log):
         torch.cuda.synchronize(); t0 = time.perf_counter(); d.copy_(torch.from_numpy(host)); torch.cuda.synchronize(); th = min(th, time.perf_counter() - t0)
         torch.cuda.synchronize(); t0 = time.perf_counter(); hb.copy_(d); torch.cuda.synchronize(); tdn = min(tdn, time.perf_counter() - t0)
     out["pcie_GBps_measured"] = {"h2d": n / th / 1e9, "d2h": n / tdn / 1e9, "how": "torch copy of the same 1 GiB between pageable host memory and HBM, best of 3"}
+    # is the link full duplex for this process?  the upload of the compressed bytes and the download of the output, each on its
+    # own stream from its own host thread, alone and at the same time (scripts/dev/exp_duplex.py measures more variants)
+    try:
+        import threading
+        nc = int(out["independent_frames"]["compressed_bytes"])
+        up_src = torch.from_numpy(comp[:nc]); up_dst = torch.empty(nc, dtype=torch.uint8, device=device)
+        s_up, s_dn = torch.cuda.Stream(device), torch.cuda.Stream(device)
+
+        def up():
+            with torch.cuda.stream(s_up):
+                up_dst.copy_(up_src); s_up.synchronize()
+
+        def down():
+            with torch.cuda.stream(s_dn):
+                hb.copy_(d); s_dn.synchronize()
+
+        def timed(fns):
+            best = 1e9
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                ths = [threading.Thread(target=f) for f in fns]
+                [x.start() for x in ths]; [x.join() for x in ths]
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            return best
+        t_up, t_dn, t_both = timed([up]), timed([down]), timed([up, down])
+        out["pcie_GBps_measured"].update({"upload_compressed_ms": t_up * 1e3, "download_output_ms": t_dn * 1e3, "both_at_once_ms": t_both * 1e3,
+                                          "full_duplex": bool(t_both < 0.8 * (t_up + t_dn))})
+        # what a decompress (compress) call from host memory cannot beat on this box: its bytes over the link
+        out["transfer_floor_GBps"] = n / t_both / 1e9
+    except Exception as e:  # the measurement is a note next to the numbers, never a reason to lose them
+        out["pcie_GBps_measured"]["duplex_error"] = repr(e)
     out["compress_GBps"] = out["one_frame"]["compress_GBps"]   # the default layout of the host entries
     out["decompress_GBps"] = out["one_frame"]["decompress_GBps"]
     log(f"end to end: {out}")

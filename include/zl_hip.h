@@ -38,7 +38,10 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 
 /* parameter ids: numerically identical to ZSTD_cParameter / ZSTD_dParameter so that
  * src/cctx.c:265-284 and src/dctx.c:99,163 compile unchanged against the twins */
-#define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel */
+#define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel.  Three operating points: < 3 (every other position
+                                   * probed), 3-4 (the double-hash parse), >= 5 (match tables four times the size, longer
+                                   * verification, denser far search: slower, smaller output).  zl_CCtx_getParameter reports
+                                   * the point a context runs at (as given below 3; 3 or 5 above). */
 #define ZL_c_checksumFlag 201     /* zstd.h:440  ZSTD_c_checksumFlag     */
 #define ZL_c_nbWorkers 400        /* zstd.h:449  ZSTD_c_nbWorkers (accepted, ignored: the GPU path is always parallel) */
 #define ZL_c_stableInBuffer 1006  /* zstd.h:2083 ZSTD_c_stableInBuffer  (accepted, no-op) */

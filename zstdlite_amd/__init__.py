@@ -100,7 +100,7 @@ def _init_cctx_with_opts(opts, quiet=False):
                 # the HIP encoder has no lazy / optimal parser (the reference's levels >= 5): say so instead of
                 # silently writing something else than was asked for
                 warnings.warn(f"init_cctx(): level {level} runs at this encoder's operating point {got.value} "
-                              "(levels above 3 only deepen the far-match search; see include/zl_hip.h)")
+                              "(operating points: < 3, 3 and 5 -- larger match tables and a deeper far search; see include/zl_hip.h)")
         elif name == "num_threads":
             if int(val) > 1:
                 L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))

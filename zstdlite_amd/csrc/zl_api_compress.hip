@@ -153,6 +153,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.seq_stride = ZL_SEQ_STRIDE;
     m.stats = nullptr;
     m.sparse_only = c->level < 3 ? 1u : 0u;
+    m.hi = c->level >= 5 ? 1u : 0u;
     m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
     m.dict_len = c->dict_use;
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
@@ -321,11 +322,14 @@ size_t zl_freeCCtx(zl_cctx* c) {
 //   levels < 3   every other position probed throughout (cf. the step of ZSTD_fast, zstd.c:29340); reported as given
 //   level 3, 4   the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
 //                in the one-frame layout one position in 8 takes part in the far search.  Reported as 3.
-//   levels >= 5  the same parse, one position in 4 in the far search (python sources: 4.24 -> 4.34 against the reference's
-//                level-3 4.43, for twice the far-search time).  Reported as 5.
+//   levels >= 5  the same parse with match tables four times the size (2^14 + 2^13 entries, three workgroups per CU instead
+//                of seven), verification up to 72 bytes per lane and one position in 4 in the far search.  64 MiB of text:
+//                4.36 -> 4.46 (the reference's level 5: 4.46); python sources, one frame: 4.24 -> 4.41 (reference level 3
+//                4.43, level 5 4.77); independent frames 3.48 -> 3.68.  1 GiB mix: match 5.0 -> 8.1 ms.  Reported as 5.
+//                Contexts with a dictionary keep the level-3 tables (the dictionary's table image has their size).
 // Measured against the reference at the same level: within 5 % of its ratio at levels 1, 2 and 3
 // (tests/test_compress_gpu.py).  The lazy and optimal parsers behind the reference's levels >= 5 (zstd.c:31546-33746) are
-// not built: above 3 only the far search deepens, and the ratio falls behind the reference's at those levels.
+// not built: above 5 nothing deepens further, and the ratio falls behind the reference's at those levels.
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     switch (param) {

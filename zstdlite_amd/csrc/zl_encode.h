@@ -65,6 +65,7 @@ struct zl_match_args {
     u32 seq_stride;
     u64* stats;  // optional (profiling): cycles {find, parse, emit, insert, iterations}
     u32 sparse_only;  // levels below 3: the stride-2 body throughout (faster, lower ratio on match-dense data)
+    u32 hi;           // levels >= 5: larger match tables, longer per-lane verification (slower, higher ratio)
     u32 dict_len;     // dictionary content bytes that sit, as history, in front of every chunk (0: none)
     const u8* dict;   // those bytes
     const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)

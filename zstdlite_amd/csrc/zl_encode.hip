@@ -40,13 +40,13 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #include "zl_match_common.h"
 
-template <int SLOG>
+template <int LLOG, int SLOG>
 struct MatchSharedT {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
     // mean the nearest such position in front of it, so candidates reach 64 KiB back (an older entry
     // aliases to a wrong position and fails verification).  Half the LDS of 32-bit entries: six
     // workgroups per CU instead of three, and this kernel is latency-bound.
-    u32 tbl_long[(1 << LONG_LOG) / 2];
+    u32 tbl_long[(1 << LLOG) / 2];
     u32 tbl_short[(1 << SLOG) / 2];
     u16 jump[2][WIN];
     u8 mark[WIN];
@@ -179,14 +179,21 @@ __device__ __forceinline__ bool worth_it(u32 len, u32 off, u32 rep) {
     const u32 need = FAR ? ZL_SHORT_LEN_FAR : ZL_SHORT_LEN;
     return need == 0 || len >= need || off == rep || off < (1u << ZL_SHORT_OFFLOG);
 }
-template <bool DICT, bool PROF, bool FAR, bool INTRA>
+// HI: the operating point of levels >= 5 (no dictionary): tables of 2^14 + 2^13 entries (48 KiB of LDS: three workgroups per
+// CU instead of seven) and verification up to 72 bytes per lane.  The CPU model of the parse (scripts/dev/sim/sim.c) gives
+// text +3.2 %, python sources +5.3 % of ratio for it; what the device gives and costs is in DESIGN.md 3.4.
+template <bool DICT, bool PROF, bool FAR, bool INTRA, bool HI = false>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
+    static_assert(!(DICT && HI), "the dictionary's table image has the base sizes");
+    constexpr int LLOG = HI ? LONG_LOG_HI : LONG_LOG;
+    constexpr u32 lshift = 64u - (u32)LLOG;
+    constexpr u32 lane_cap = (FAR || HI) ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP;
     // The bulk path (no dictionary, independent frames, inputs larger than a chunk) runs with half the short table: its
     // candidates are nearer (mean age = table size), so their gathers hit closer caches -- 1 GiB mix: match 5.74 -> 4.98 ms
     // for 0.1 % of ratio (text -1.2 %, python sources -2.4 %; a distance cap on the short candidates bought the same time
     // for twice the ratio: DESIGN.md 3.3).  The other instantiations keep 2^12 entries.
-    constexpr int SLOG = (DICT || FAR || INTRA) ? SHORT_LOG : SHORT_LOG_BULK;
-    __shared__ MatchSharedT<SLOG> S;
+    constexpr int SLOG = HI ? SHORT_LOG_HI : ((DICT || FAR || INTRA) ? SHORT_LOG : SHORT_LOG_BULK);
+    __shared__ MatchSharedT<LLOG, SLOG> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = zl_spread(blockIdx.x, nchunks);
@@ -210,13 +217,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
         if (FAR) return src + (ptrdiff_t)(i32)q;
         return q >= D ? src + (q - D) : dict + q;
     };
-    for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
+    for (u32 i = t; i < (1u << LLOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
     for (u32 i = t; i < (1u << SLOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
     if (t == 0) S.rep = 0;
     const bool intra_on = INTRA && (FAR || (cd.flags & 1u));  // uniform
     // (a launch that mixes small inputs with chunks of large ones -- a batch -- must write for every chunk what a launch of
     // its own would: the chunks of large inputs hash as the bulk instantiation does)
-    const u32 sshift = (INTRA && !DICT && !FAR && !intra_on) ? 64u - SHORT_LOG_BULK : 64u - (u32)SLOG;
+    const u32 sshift = (INTRA && !DICT && !FAR && !HI && !intra_on) ? 64u - SHORT_LOG_BULK : 64u - (u32)SLOG;
     if (INTRA) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 const u32 V = D + p;  // virtual position
                 q_r[j] = q_l[j] = q_s[j] = V;
                 if (can_match[j]) {
-                    hl[j] = hash8(v[j]);
+                    hl[j] = hash_long(v[j], lshift);
                     hs[j] = hash_short<FAR>(v[j], sshift);
                     word_l[j] = S.tbl_long[hl[j] >> 1];
                     word_s[j] = S.tbl_short[hs[j] >> 1];
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
-                    while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < (FAR ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP) && p + best_len[j] + 8 <= n) {
+                    while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < lane_cap && p + best_len[j] + 8 <= n) {
                         const u32 qv = q_best[j] + best_len[j];
                         if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
                         const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(at(qv)));
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 far_off2 = 0;
             if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
             if (can0) {
-                hl0 = hash8(v0); hs0 = hash_short<FAR>(v0, sshift);
+                hl0 = hash_long(v0, lshift); hs0 = hash_short<FAR>(v0, sshift);
                 wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1];
                 if (search) {
                     const u32 el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF, es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 }
             }
             if (can1) {  // the odd position is only inserted: its table words are read here, next to the others
-                hl1 = hash8(v1); hs1 = hash_short<FAR>(v1, sshift);
+                hl1 = hash_long(v1, lshift); hs1 = hash_short<FAR>(v1, sshift);
                 wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
             u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (have_s && best_len < 8 && l_s >= MIN_MATCH && l_s > best_len) { best_len = l_s; best_off = p - q_s; q_best = q_s; }
                 if (FAR && have_f && best_len < 8 && common_bytes(v0, w_f) == 8) { best_len = 8; best_off = far_off2; q_best = p - far_off2; }
                 // extend while whole 8-byte words keep matching
-                while (best_len >= 8 && (best_len & 7) == 0 && best_len < (FAR ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP) && p + best_len + 8 <= n) {
+                while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap && p + best_len + 8 <= n) {
                     const u32 l = common_bytes(ld64(src + p + best_len), ld64(at(q_best + best_len)));
                     best_len += l;
                     if (l < 8) break;
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
 // The match tables as they look after the last byte of a dictionary's content: one workgroup walks the
 // content window by window with the same ordered insert as the encoder (run once per loaded dictionary).
 __global__ __launch_bounds__(ENC_THREADS) void zl_dict_hash_kernel(const u8* content, u32 n, u32* out) {
-    __shared__ MatchSharedT<SHORT_LOG> S;
+    __shared__ MatchSharedT<LONG_LOG, SHORT_LOG> S;
     const u32 t = threadIdx.x;
     for (u32 i = t; i < (1u << LONG_LOG) / 2; i += ENC_THREADS) S.tbl_long[i] = 0;
     for (u32 i = t; i < (1u << SHORT_LOG) / 2; i += ENC_THREADS) S.tbl_short[i] = 0;
@@ -1039,6 +1046,12 @@ extern "C" hipError_t zl_launch_match_wide(const zl_match_args* a, u32 nchunks, 
 #endif
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
+    if (a->hi && !a->dict_len) {  // levels >= 5
+        if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+        else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+        else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+        return hipGetLastError();
+    }
     if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);

@@ -43,6 +43,13 @@ __device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_S
 #ifndef ZL_SHORT_BYTES_FAR
 #define ZL_SHORT_BYTES_FAR 5
 #endif
+#ifndef LONG_LOG_HI
+#define LONG_LOG_HI 14     // levels >= 5
+#endif
+#ifndef SHORT_LOG_HI
+#define SHORT_LOG_HI 13
+#endif
+__device__ __forceinline__ u32 hash_long(u64 v, u32 shift /* 64 - log2 of the table's entries */) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> shift); }
 #ifndef SHORT_LOG_BULK
 #define SHORT_LOG_BULK 11  // the bulk instantiation of the match kernel (zl_encode.hip says why)
 #endif
