@@ -163,10 +163,14 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #define ZL_SHORT_LEN 0
 #endif
 #ifndef ZL_SHORT_OFFLOG
-#define ZL_SHORT_OFFLOG 12
+#define ZL_SHORT_OFFLOG 13
 #endif
+// (one-frame layout, whose short hash covers 5 bytes: a 5-byte match needs an offset below 8 KiB.  64 MiB of iid10
+// 2.236 -> 2.276, python sources 4.321 -> 4.316, text unchanged; 7 bytes / 4 KiB: iid10 2.305 but the sources 4.293.
+// The independent-frames layout runs without the rule: its 6-byte hash finds few such matches, and there the rule cost
+// the sources 0.8 % for nothing.)
 #ifndef ZL_SHORT_LEN_FAR
-#define ZL_SHORT_LEN_FAR 0
+#define ZL_SHORT_LEN_FAR 6
 #endif
 // The short table's candidates are fetched only from this far back (0 = as far as the table knows).
 #ifndef ZL_SHORT_REACH
@@ -1046,7 +1050,9 @@ extern "C" hipError_t zl_launch_match_wide(const zl_match_args* a, u32 nchunks, 
 #endif
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    if (a->hi && !a->dict_len) {  // levels >= 5
+    // levels >= 5, and the one-frame layout at every level: its callers sit behind PCIe (host entries: 34 GB/s of link against
+    // 50-60 GB/s of kernels) and asked for the reference's ratio, so it always takes the larger tables
+    if ((a->hi || a->far_hints) && !a->dict_len) {
         if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
