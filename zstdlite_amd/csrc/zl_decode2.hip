@@ -949,8 +949,16 @@ __device__ __forceinline__ u32 seq_chain_quad(SeqShared& S, const SeqLane& L, u3
         u32 Dw = (c - 1) >> 5;                      // dword that holds the top unread bit; the window is w[Dw - 3 .. Dw]
         zl_v4u32 x = *(const zl_v4u32*)(w + Dw - 3);
         zl_v4u32* ring = (zl_v4u32*)&S.ring[0][lane];
+        // The table entry of the NEXT sequence is asked for as soon as its state is known -- in front of the values, the
+        // repcode rules and the record of this one -- and carried round the loop: the look-up is the loop's dependent
+        // chain.  (volatile: left to itself the compiler sinks the whole state computation behind the record store,
+        // because nothing in this iteration uses it, and the chain then runs end to end.)
+        u32 m_a = role != 1 ? ~0u : 0u, m_b = (role == 0 || role == 3) ? ~0u : 0u, m_c = role != 0 ? ~0u : 0u, m_d = (role == 1 || role == 3) ? ~0u : 0u;
+        asm volatile("" : "+v"(m_a), "+v"(m_b), "+v"(m_c), "+v"(m_d));  // (kept in vector registers: told what they hold, the compiler turns the ANDs back into selects)
+        typedef __attribute__((address_space(3))) const volatile u32 lds_cvu32;  // (through a generic pointer a volatile load is a flat load with a wait behind it)
+        const u32 ent_at = (u32)(uintptr_t)&L.ent[ebase];  // LDS byte offset of this lane's table
+        u32 ce = *(lds_cvu32*)(uintptr_t)(ent_at + 4 * s);
         while (i < nseq && Dw >= 4) {
-            const u32 ce = L.ent[ebase + s];
             const u32 sym = (ce >> 16) & 0xFF, e = ce >> 24, b = (ce >> 10) & 0xF;
             const u32 pk = e | (b << 8);
             const u32 p0 = quad_get<0>(pk), p1 = quad_get<1>(pk), p2 = quad_get<2>(pk);
@@ -959,12 +967,15 @@ __device__ __forceinline__ u32 seq_chain_quad(SeqShared& S, const SeqLane& L, u3
             // stream order below the cursor: offset bits, match-length bits, literal-length bits, then the state bits LL, ML, OF
             const u32 e_all = e_of + e_ml + e_ll;
             const u32 T = e_all + ((b_ll + b_ml + b_of) & keep);
-            const u32 above_e = role == 1 ? 0u : (role == 2 ? e_of : e_of + e_ml);
-            const u32 above_s = e_all + (role == 0 ? 0u : (role == 2 ? b_ll : b_ll + b_ml));
+            // (per-lane masks instead of selects on the role: the selects' lane masks live in scalar registers, of
+            // which this kernel has none to spare -- each cost a v_readlane per sequence)
+            const u32 above_e = (m_a & e_of) + (m_b & e_ml);            // role 1: 0; role 2: e_of; roles 0, 3: e_of + e_ml
+            const u32 above_s = e_all + (m_c & b_ll) + (m_d & b_ml);    // role 0: 0; role 2: b_ll; roles 1, 3: b_ll + b_ml
             const u32 top = c - ((Dw - 3) << 5);  // the cursor inside the window: 97..128
             const u32 extra = window_bits(x, top - above_e - e, e);
             const u32 u = window_bits(x, top - above_s - (b & keep), b & keep);
             s = (ce & 0x3FF) + u;
+            ce = *(lds_cvu32*)(uintptr_t)(ent_at + 4 * s);
             c -= T;
             const u32 Dn = (c - 1) >> 5;
             // (the same address in all four lanes, asked for before the values are needed.  Dn >= 1 here, so the load may
