@@ -825,9 +825,17 @@ __device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lan
             nav += f__ ? 32 : 0;                                     \
             used += f__ ? 1 : 0;                                     \
         }
+        // The three table entries of the NEXT sequence are asked for as soon as its states are known -- in front of the
+        // values, the repcode rules and the record of this one -- and carried round the loop, and the stream's next dwords
+        // right behind them.  (volatile, through LDS pointers: left to itself the compiler sinks the whole state
+        // computation behind the record store, because nothing in this iteration uses it, and the loop's dependent chain
+        // -- look-up, field cuts, states, look-up -- then runs end to end through everything else.)
+        typedef __attribute__((address_space(3))) const volatile u32 lds_cvu32;
+        const u32 ent_at = (u32)(uintptr_t)&L.ent[0];
+        u32 cl = 0, cm = 0, co = 0;
+        if (go) { cl = *(lds_cvu32*)(uintptr_t)(ent_at + 4 * sl); cm = *(lds_cvu32*)(uintptr_t)(ent_at + 2048 + 4 * sm); co = *(lds_cvu32*)(uintptr_t)(ent_at + 4096 + 4 * so); }
         for (; go && i < nseq && idx >= 5; i++) {
             u32 used = 0;
-            const u32 cl = L.ent[sl], cm = L.ent[512 + sm], co = L.ent[1024 + so];
             const u32 yl = (cl >> 16) & 0xFF, ym = (cm >> 16) & 0xFF, yo = co >> 24;
             const u32 nl = cl >> 24, nm = cm >> 24;
             const u32 bl = (cl >> 10) & 0xF, bm = (cm >> 10) & 0xF, bo = (co >> 10) & 0xF;
@@ -843,6 +851,13 @@ __device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lan
             so = (co & 0x3FF) + (u & ((1u << bo) - 1));
             sm = (cm & 0x3FF) + ((u >> bo) & ((1u << bm) - 1));
             sl = (cl & 0x3FF) + (u >> (bo + bm));
+            cl = *(lds_cvu32*)(uintptr_t)(ent_at + 4 * sl);
+            cm = *(lds_cvu32*)(uintptr_t)(ent_at + 2048 + 4 * sm);
+            co = *(lds_cvu32*)(uintptr_t)(ent_at + 4096 + 4 * so);
+            idx -= (i32)used;
+#ifndef ZL_EXP_NOLOAD
+            t4 = *(const zl_v4u*)(w + idx - 3);
+#endif
             const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];  // baselines: off the critical chain
             const u32 ofv = (1u << yo) + ofx;
             const u32 ml = (tm & 0xFFFFFF) + (x >> nl);  // match-length bits above literal-length bits
@@ -863,11 +878,7 @@ __device__ __forceinline__ u32 seq_chain(SeqShared& S, const SeqLane& L, u32 lan
             lit_used += ll;
             out_used += ll + ml;
             bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
-            idx -= (i32)used;
             ring[(i & 7) * 64] = rec;
-#ifndef ZL_EXP_NOLOAD
-            t4 = *(const zl_v4u*)(w + idx - 3);
-#endif
             if ((i & 7) == 7) {
                 zl_v4u* o = (zl_v4u*)(oseq + (i - 7));
 #pragma unroll
