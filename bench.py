@@ -692,7 +692,7 @@ def main():
             for _ in range(5):
                 torch.cuda.synchronize(); t0c = time.perf_counter(); cp.copy_(src); torch.cuda.synchronize(); tcp = min(tcp, time.perf_counter() - t0c)
             del cp
-            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false, false, false>", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
+            out["roofline"] = {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false, false, false, false>", "entropy": "zl_entropy_kernel", "scan": "zl_scan_sizes_kernel",
                                                            "gather": "zl_gather_kernel", "d_index": "zl2_index_kernel", "d_entropy": "zl2_seq_kernel",
                                                            "d_exec": "zl2_exec_kernel<false, false>", "d_general": "zl_decode_kernel"}[dom],
                                "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,

@@ -74,7 +74,7 @@ def pmc(path):
 fetch = pmc(one("pmc_fetch/*/*counter_collection.csv"))
 write = pmc(one("pmc_write/*/*counter_collection.csv"))
 summary, short = {}, {}
-names = {"zl_match_auto_kernel": "match", "zl_match_auto_kernel<false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true>": "match_small", "zl_far_build_kernel": "far_build", "zl_far_probe_kernel": "far_probe", "zl_match_auto_kernel<false, false>": "match", "zl_match_auto_kernel<false, true>": "match", "zl_match_auto_kernel<true, false>": "match_dict", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
+names = {"zl_match_auto_kernel": "match", "zl_match_auto_kernel<false, false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true, false>": "match_small", "zl_match_auto_kernel<false, false, false, false, true>": "match_level5", "zl_match_auto_kernel<false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true>": "match_small", "zl_far_build_kernel": "far_build", "zl_far_probe_kernel": "far_probe", "zl_match_auto_kernel<false, false>": "match", "zl_match_auto_kernel<false, true>": "match", "zl_match_auto_kernel<true, false>": "match_dict", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
          "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_entropy1_kernel": "d_entropy1", "zl2_lit_kernel": "d_entropy_lit", "zl2_lit_kernel<8>": "d_entropy_lit", "zl2_lit_kernel<1>": "d_entropy_lit1", "zl2_order_kernel": "d_order", "zl2_exec_kernel": "d_exec", "zl2_exec_kernel<false>": "d_exec", "zl2_exec_kernel<true>": "d_exec_large", "zl2_exec_kernel<false, false>": "d_exec", "zl2_exec_kernel<false, true>": "d_exec", "zl2_exec_kernel<true, false>": "d_exec_large"}
 for k in sorted(set(dur) | set(fetch) | set(write)):
     base = k.split("(")[0].replace("void ", "")
