@@ -232,3 +232,45 @@ def test_damaged_frames_agree_with_the_oracle(oracle):
             accepted += 1
             assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
     assert 0 < accepted < m
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (reference libzstd) to make the frames")
+def test_damaged_single_block_frames_in_a_batch_that_is_cut_in_two(oracle):
+    """A batch of 1024+ single-block frames is dealt out in two parts that run side by side (zl2_launch: the cheap half's
+    entropy and exec kernels next to the expensive half's chains).  Reference-made frames of one block each, most of them
+    damaged by 1-3 flipped bits: the GPU must accept exactly the frames the oracle accepts, with the same bytes."""
+    import ctypes as C
+    from zstdlite_amd import _lib
+    from zl_testlib import GENERATORS, Ref, is_error
+    ref = Ref()
+    rng = np.random.default_rng(23)
+    base = []
+    for gen in ("text", "iid10", "rand"):
+        for n in (3000, 30000, 65536):
+            base.append((ref.compress(GENERATORS[gen](n, seed=n + 3), level=3), n))
+    frames = []
+    for f, n in base:
+        for k in range(130):
+            b = bytearray(f)
+            if k % 5:  # every fifth frame stays whole
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(4, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append((bytes(b), n))
+    m = len(frames)
+    assert m >= 1024
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _, n in frames]
+    srcs = [np.frombuffer(f, dtype=np.uint8) for f, _ in frames]
+    res = (C.c_size_t * m)()
+    dctx = z.zstd_dctx()
+    r = _lib.lib().zl_decompress_batch(dctx._ptr, m, (C.c_void_p * m)(*[x.ctypes.data for x in outs]), (C.c_size_t * m)(*[n for _, n in frames]),
+                                       (C.c_void_p * m)(*[x.ctypes.data for x in srcs]), (C.c_size_t * m)(*[len(f) for f, _ in frames]), res)
+    assert not is_error(r)
+    accepted = 0
+    for i, (f, n) in enumerate(frames):
+        code, out = oracle.decompress_code(f, n)
+        if is_error(res[i]):
+            assert is_error(code), (i, _lib.error_name(res[i]), code)
+        else:
+            accepted += 1
+            assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
+    assert accepted >= m // 5

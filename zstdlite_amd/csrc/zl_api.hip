@@ -174,7 +174,7 @@ struct zl_dctx_s {
     // diagnostics
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // start, after index, after entropy lanes, after exec, end
-    zl2_side side = {nullptr, nullptr, nullptr};
+    zl2_side side = {};
     // streaming session (zl_decompressStream)
     struct {
         ByteBuf acc;  // compressed input not decoded yet (at most one incomplete frame once a call returns)
@@ -356,6 +356,10 @@ size_t zl_freeDCtx(zl_dctx* d) {
     if (d->side.fork) (void)hipEventDestroy(d->side.fork);
     if (d->side.join) (void)hipEventDestroy(d->side.join);
     if (d->side.stream) (void)hipStreamDestroy(d->side.stream);
+    for (int k = 0; k < 3; k++) {
+        if (d->side.part_join[k]) (void)hipEventDestroy(d->side.part_join[k]);
+        if (d->side.part_stream[k]) (void)hipStreamDestroy(d->side.part_stream[k]);
+    }
     delete d;
     return 0;
 }
@@ -494,6 +498,10 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             hipEventCreateWithFlags(&d->side.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->side.join, hipEventDisableTiming) != hipSuccess)
             return kGpuUnavailable;
+        for (int k = 0; k < 3; k++)
+            if (hipStreamCreateWithFlags(&d->side.part_stream[k], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&d->side.part_join[k], hipEventDisableTiming) != hipSuccess)
+                return kGpuUnavailable;
     }
     // Frames of more blocks than the lane pipeline takes, with a recorded content size and no dictionary
     // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
@@ -545,6 +553,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.ext = nullptr;
     f2.fuse1 = 3u;  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
     f2.big = nullptr;
+    f2.part = 0;
     if (d->profile >= 2 && d->d_stats.ensure(128)) {
         (void)hipMemsetAsync(d->d_stats.p, 0, 128, st);
         f2.stats = (u64*)d->d_stats.p + 8;

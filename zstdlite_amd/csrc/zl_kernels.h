@@ -93,7 +93,27 @@ struct zl2_args {
     // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
     const zl2_blk_rec* ext;   // per segment 4 records of earlier blocks whose tables the segment inherits: [0] Huffman tree, [1..3] sequence tables in block order; type 0xFFFFFFFF: none.  Null on the ordinary path
     const struct zl3_big* big;  // execution state shared by the segments.  Null on the ordinary path
+    // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there):
+    // 0 all of it; 1 + k: part k of max_blocks[2] equal parts, most expensive first.  Whether and how often the batch is
+    // cut is decided on the device (zl2_order_kernel writes max_blocks[2]; 1 = not cut).
+    u32 part;
 };
+#define ZL2_MAX_PARTS 4
+// the groups (of ZL2_WG_FRAMES frames of the sequence order) a launch covers
+__device__ __forceinline__ void zl2_part_range(const zl2_args& a, u32& g_lo, u32& g_hi, bool& split) {
+    const u32 all = (a.nframes + 7) / 8;
+    g_lo = 0; g_hi = all; split = false;
+    if (a.part) {
+        u32 np = a.max_blocks[2];
+        if (np < 1) np = 1;
+        if (np > ZL2_MAX_PARTS) np = ZL2_MAX_PARTS;
+        const u32 k = a.part - 1;
+        split = np > 1;
+        if (k >= np) { g_lo = g_hi = 0; return; }  // (a launch for a part the batch does not have)
+        g_lo = (u32)((u64)all * k / np);
+        g_hi = (u32)((u64)all * (k + 1) / np);
+    }
+}
 // Large-frame pipeline: what the segment workgroups of zl2_exec_kernel<true> share.
 #define ZL3_ROOT 0xFFFFFFFFu      // link value of a byte that is final in the output (marks of later rounds: ZL3_ROOT - 1, - 2)
 #ifndef ZL3_EXEC_RUN
@@ -126,6 +146,8 @@ struct zl3_big {
 struct zl2_side {           // owned by the decompression context: lets the two entropy kernels run side by side
     hipStream_t stream;
     hipEvent_t fork, join;
+    hipStream_t part_stream[3];  // the cheaper parts of a large batch run here, entropy and exec, next to the expensive part's chains
+    hipEvent_t part_join[3];
 };
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev);
 // large-frame pipeline: the entropy kernels / the exec kernel over the segments of one frame
