@@ -178,6 +178,9 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #endif
 template <bool FAR>
 __device__ __forceinline__ bool short_in_reach(u32 dist) { return FAR || ZL_SHORT_REACH == 0 || dist <= ZL_SHORT_REACH; }
+#ifndef ZL_BACK_BULK
+#define ZL_BACK_BULK 0
+#endif
 #ifndef ZL_BACK_MAX
 #define ZL_BACK_MAX 8   // bytes a sequence of the stride-1 body may reach back into the literals in front of it (0: off)
 #endif
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // backward extension of matches (stride-1 body): everywhere but on the bulk path -- the chunks of large inputs at level 3
     // in the independent-frames layout, whose measure is GB/s: there it cost 6.7 % of match time (5.09 -> 5.43 ms) for 0.4 %
     // of the mix's ratio (text +4.0 %, python sources +1.2 %).  Uniform.
-    const bool back_on = ZL_BACK_MAX != 0 && (FAR || HI || DICT || intra_on);
+    const bool back_on = ZL_BACK_MAX != 0 && (ZL_BACK_BULK || FAR || HI || DICT || intra_on);
     if (INTRA) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
@@ -397,6 +400,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 const u32 p = ip + t, q = q_best[0];
                 // (one frame: the source must stay inside the chunk's section -- sections are self-contained, zl_encode.h)
                 const bool src_ok = FAR ? ((i32)q + (i32)reach_sec >= 8) : (DICT ? (q >= D + 8 || (q <= D && q >= 8)) : q >= 8);
+                // (every lane that holds a match: whether the byte in front of it is a free literal is known only behind the
+                // lazy rule and the parse; asking only lanes whose lower neighbour holds no match lost most of the gain --
+                // a neighbour's shorter match that the lazy rule drops is exactly the case in which the extension pays)
                 back_ok = has_match[0] && (t & 63) >= 8 && p >= 8 && src_ok;
                 if (back_ok) back_theirs = ld64(at(q - 8));
                 const u32 lo = __shfl_up((u32)v[0], 8, 64), hi = __shfl_up((u32)(v[0] >> 32), 8, 64);
