@@ -163,9 +163,6 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
 // (measured on 10 000 reference-made 64 KiB frames of three kinds in turn: 12.9 -> ms below for the
 // literal + sequence lanes).  Only the schedule depends on it: any permutation is correct.
 // ---------------------------------------------------------------------------------------
-#ifndef ZL2_PARTS
-#define ZL2_PARTS 2          // equal parts a batch of single-block frames is cut into (at most ZL2_MAX_PARTS)
-#endif
 #ifndef ZL2_SPLIT_MIN
 #define ZL2_SPLIT_MIN 1024   // frames from which on a batch may be cut in two (zl2_launch)
 #endif
@@ -198,14 +195,12 @@ __global__ __launch_bounds__(1024) void zl2_order_kernel(zl2_args a) {
         cnt[t] = pre + inc - mine;
         __syncthreads();
         if (pass == 0 && t == 0) {
-            // Where the batch is cut in two (zl2_launch): launches of single-block frames only, ZL2_SPLIT_PCT per cent of the
-            // groups from the cheap end.  (A cut by cost -- frames below a half, a third, a quarter of the longest chain --
-            // was measured on 10 000 reference-made 64 KiB frames: the iid10 third has nearly as many sequences as the text
-            // third, the cut put both on the expensive side and nothing moved; the even cut: 7.0 -> 6.4 ms.)
-            const u32 all = (n + 7) / 8;
-            u32 gs = all;
-            (void)all;
-            gs = (*a.max_blocks <= 1 && n >= ZL2_SPLIT_MIN) ? ZL2_PARTS : 1u;  // (the number of parts)
+            // How a large batch is scheduled (zl2_launch).  Single-block frames: in two halves side by side.  (A cut by cost --
+            // frames below a half, a third, a quarter of the longest chain -- was measured on 10 000 reference-made 64 KiB
+            // frames: the iid10 third has nearly as many sequences as the text third, the cut put both on the expensive side
+            // and nothing moved; the even cut: 7.0 -> 6.3 ms.)  Multi-block frames: not cut (zl2_launch says what was tried).
+            u32 gs = ZL2_MODE_WHOLE;
+            if (n >= ZL2_SPLIT_MIN && *a.max_blocks <= 1) gs = ZL2_MODE_HALVES;
             a.max_blocks[2] = gs;
         }
         __syncthreads();
@@ -527,8 +522,8 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
     const u32 sub = t & 3, grp = (t >> 2) % LIT_FRAMES, b = t / (4 * LIT_FRAMES);
     const u32 slot = wg * LIT_FRAMES + grp;
     // longest literal streams first -- unless the batch is cut in two: both roles must then agree on which frames a part holds
-    u32 pg_lo, pg_hi; bool psplit;
-    zl2_part_range(a, pg_lo, pg_hi, psplit);
+    u32 pg0, pg1; bool psplit;
+    zl2_part_range(a, pg0, pg1, psplit);
     const u32 f = slot < a.nframes ? a.order[(psplit ? 0u : a.nframes) + slot] : 0xFFFFFFFFu;
     LitGroupT<MB>& g = G[grp];
     if (t < LIT_FRAMES) G[t].ok = 0;
@@ -1228,10 +1223,10 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, 1) void zl2_lit_kernel(zl2_arg
     ZL_POISON(G, 1);
     const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
-    u32 g_lo, g_hi; bool split;
-    zl2_part_range(a, g_lo, g_hi, split);
-    if (g_lo + blockIdx.x >= g_hi) return;
-    lit_role<MB>(a, G, &rounds, g_lo + blockIdx.x);
+    u32 g0, g1; bool split;
+    zl2_part_range(a, g0, g1, split);
+    if (g0 + blockIdx.x >= g1) return;
+    lit_role<MB>(a, G, &rounds, g0 + blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(clock64() - t0));  // profile: cycles per literal workgroup
 }
 __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
@@ -1241,10 +1236,10 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
     ZL_POISON(S, 1);
     const bool prof = ZL_ROLE_STAMPS && a.stats != nullptr && threadIdx.x == 0;
     const long long t0 = prof ? clock64() : 0;
-    u32 g_lo, g_hi; bool split;
-    zl2_part_range(a, g_lo, g_hi, split);
-    if (g_lo + blockIdx.x >= g_hi) return;
-    seq_role<false>(a, S, &rounds, g_lo + blockIdx.x);
+    u32 g0, g1; bool split;
+    zl2_part_range(a, g0, g1, split);
+    if (g0 + blockIdx.x >= g1) return;
+    seq_role<false>(a, S, &rounds, g0 + blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[7], (unsigned long long)(clock64() - t0));  // profile: cycles per sequence workgroup
 }
 
@@ -1688,10 +1683,10 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
     ZL_POISON(S, 2);
     u64 seg_start = 0;
     if (!BIG) {
-        u32 g_lo, g_hi; bool split;
-        zl2_part_range(a, g_lo, g_hi, split);
-        const u32 slot = g_lo * LIT_FRAMES + blockIdx.x;
-        if (slot >= g_hi * LIT_FRAMES || slot >= a.nframes) return;
+        u32 g0, g1; bool split;
+        zl2_part_range(a, g0, g1, split);
+        const u32 slot = g0 * LIT_FRAMES + blockIdx.x;
+        if (slot >= g1 * LIT_FRAMES || slot >= a.nframes) return;
         (void)exec_frame<BIG, PROF>(a, S, a.order[slot], seg_start, true);  // long frames first
     } else {
         // a run of consecutive segments per workgroup: matches that stay inside the run are copied here
@@ -1708,30 +1703,39 @@ __global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_a
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-// The entropy kernels of one part of the cost-sorted order on `stream` (sequence lanes of multi-block launches on
-// `seq_stream`, joined back before the exec kernel when it is another stream), then the exec kernel of the same frames.
-// Grids are sized for the whole batch: where the part ends is known on the device only; workgroups beyond it return at once.
-static hipError_t zl2_launch_part(zl2_args a, u32 part, hipStream_t stream, hipStream_t seq_stream, hipEvent_t fork, hipEvent_t join, hipEvent_t* ev) {
+// The entropy kernels in one role of the schedule.  Grids are sized for the whole batch: which groups a role covers is known on
+// the device only; workgroups beyond them return at once.  (The sequence lanes of multi-block launches run on `seq_stream`
+// next to the literal lanes and are joined back before this returns.)
+static hipError_t zl2_launch_entropy(zl2_args a, u32 role, hipStream_t stream, hipStream_t seq_stream, hipEvent_t fork, hipEvent_t join) {
     const u32 n = a.nframes, ng = (n + LIT_FRAMES - 1) / LIT_FRAMES;
-    a.part = part;
+    a.part = role;
     if (seq_stream != stream && (hipEventRecord(fork, stream) != hipSuccess || hipStreamWaitEvent(seq_stream, fork, 0) != hipSuccess)) return hipErrorUnknown;
     hipLaunchKernelGGL(zl2_seq_kernel, dim3(ng), dim3(64), 0, seq_stream, a);
     hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ng), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, a);
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ng), dim3(LIT_FRAMES * 4), 0, stream, a);
     hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ng), dim3(64), 0, stream, a);
     if (seq_stream != stream && (hipEventRecord(join, seq_stream) != hipSuccess || hipStreamWaitEvent(stream, join, 0) != hipSuccess)) return hipErrorUnknown;
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    if (a.stats) hipLaunchKernelGGL((zl2_exec_kernel<false, true>), dim3(n), dim3(EX_THREADS), 0, stream, a);
-    else hipLaunchKernelGGL((zl2_exec_kernel<false, false>), dim3(n), dim3(EX_THREADS), 0, stream, a);
     return hipGetLastError();
 }
-// A large batch of single-block frames is dealt out in two parts of the cost-sorted order (zl2_order_kernel: most
-// sequences first; it also decides, on the device, whether the batch is cut).  The entropy stage of a frame is one serial
-// chain per block, a CU holds three entropy workgroups, and the exec kernel used to wait for the last of them.  The cheap
-// half now runs entropy AND exec on a stream of its own next to the expensive half's chains, which leaves only the
-// expensive half's exec behind them (10 000 reference-made 64 KiB frames: 7.0 -> 6.4 ms).
-// Batches of multi-block frames (this encoder's own: literal and sequence lanes about level, every kind of input as long
-// as the next) are not cut: measured, the two parts only got in each other's way (decode 3.76 -> 4.06 ms).
+static hipError_t zl2_launch_exec(zl2_args a, u32 role, hipStream_t stream) {
+    a.part = role;
+    if (a.stats) hipLaunchKernelGGL((zl2_exec_kernel<false, true>), dim3(a.nframes), dim3(EX_THREADS), 0, stream, a);
+    else hipLaunchKernelGGL((zl2_exec_kernel<false, false>), dim3(a.nframes), dim3(EX_THREADS), 0, stream, a);
+    return hipGetLastError();
+}
+// A large batch (ZL2_SPLIT_MIN frames or more) may be scheduled in two parts; zl2_order_kernel picks the mode on the device,
+// the host always issues the same launches and those that have nothing to do in the chosen mode return at once.
+//   Single-block frames (ZL2_MODE_HALVES).  The entropy stage of a frame is one serial chain per block, a CU holds three
+//   entropy workgroups, and the exec kernel used to wait for the last of them.  The cheap half of the cost-sorted order now
+//   runs entropy AND exec on a second stream next to the expensive half's chains, which leaves only the expensive half's
+//   exec behind them (10 000 reference-made 64 KiB frames: 7.0 -> 6.3 ms; three or four parts: much slower, the later ones
+//   starve).
+//   Multi-block frames (this encoder's own) are not cut.  Measured: halves side by side only get in each other's way --
+//   literal and sequence lanes are about level there and every kind of input is as long as the next (decode 3.76 ->
+//   4.06 ms); a pipeline over alternate groups (entropy of the odd groups while the exec kernel of the even ones runs)
+//   starves the literal workgroups, which need 113 KiB of a CU's LDS to themselves and find exec workgroups sitting there
+//   (entropy 1.96 -> 3.80 ms, decode 3.84 -> 4.80 ms).  Even an EMPTY launch of that kernel on the critical path costs: it
+//   is not dispatched before a CU has the LDS free (seen as 5.7 instead of 2.6 ms in front of the exec kernel).
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
     if (a->nframes == 0) return hipSuccess;
     const u32 n = a->nframes;
@@ -1743,17 +1747,18 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
         if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
         shaped = true;
     }
-    const u32 parts = (side->part_stream[0] != nullptr && n >= ZL2_SPLIT_MIN) ? (u32)ZL2_PARTS : 1u;
     hipError_t e;
-    // fork: the cheaper parts wait for the order; the expensive part is launched first (its workgroups take their CUs first)
-    if (parts > 1 && hipEventRecord(side->fork, stream) != hipSuccess) return hipErrorUnknown;
-    for (u32 k = 1; k < parts; k++) if (hipStreamWaitEvent(side->part_stream[k - 1], side->fork, 0) != hipSuccess) return hipErrorUnknown;
-    // (the sequence lanes of multi-block launches run on the side stream next to the literal lanes, joined before the exec kernel)
-    if ((e = zl2_launch_part(*a, parts > 1 ? 1u : 0u, stream, side->stream, side->fork, side->join, ev)) != hipSuccess) return e;
-    for (u32 k = 1; k < parts; k++) {
-        hipStream_t ps = side->part_stream[k - 1];
-        if ((e = zl2_launch_part(*a, 1u + k, ps, ps, nullptr, nullptr, nullptr)) != hipSuccess) return e;
-        if (hipEventRecord(side->part_join[k - 1], ps) != hipSuccess || hipStreamWaitEvent(stream, side->part_join[k - 1], 0) != hipSuccess) return hipErrorUnknown;
+    const bool two = side->part_stream[0] != nullptr && n >= ZL2_SPLIT_MIN;
+    hipStream_t s2 = side->part_stream[0];
+    // the second stream waits for the order; the main stream's part is launched first (its workgroups take their CUs first)
+    if (two && (hipEventRecord(side->fork, stream) != hipSuccess || hipStreamWaitEvent(s2, side->fork, 0) != hipSuccess)) return hipErrorUnknown;
+    if ((e = zl2_launch_entropy(*a, two ? ZL2_ROLE_E1 : 0u, stream, side->stream, side->fork, side->join)) != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[1], stream);
+    if ((e = zl2_launch_exec(*a, two ? ZL2_ROLE_X1 : 0u, stream)) != hipSuccess) return e;
+    if (two) {
+        if ((e = zl2_launch_entropy(*a, ZL2_ROLE_ES, s2, s2, nullptr, nullptr)) != hipSuccess) return e;
+        if ((e = zl2_launch_exec(*a, ZL2_ROLE_XS, s2)) != hipSuccess) return e;
+        if (hipEventRecord(side->part_join[0], s2) != hipSuccess || hipStreamWaitEvent(stream, side->part_join[0], 0) != hipSuccess) return hipErrorUnknown;
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();

@@ -93,26 +93,27 @@ struct zl2_args {
     // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
     const zl2_blk_rec* ext;   // per segment 4 records of earlier blocks whose tables the segment inherits: [0] Huffman tree, [1..3] sequence tables in block order; type 0xFFFFFFFF: none.  Null on the ordinary path
     const struct zl3_big* big;  // execution state shared by the segments.  Null on the ordinary path
-    // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there):
-    // 0 all of it; 1 + k: part k of max_blocks[2] equal parts, most expensive first.  Whether and how often the batch is
-    // cut is decided on the device (zl2_order_kernel writes max_blocks[2]; 1 = not cut).
+    // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there).
+    // 0: all of it.  Otherwise the launch's ROLE in the two-part schedule; which groups a role covers depends on the mode
+    // the order kernel chose on the device (max_blocks[2]: ZL2_MODE_*).
     u32 part;
 };
-#define ZL2_MAX_PARTS 4
-// the groups (of ZL2_WG_FRAMES frames of the sequence order) a launch covers
-__device__ __forceinline__ void zl2_part_range(const zl2_args& a, u32& g_lo, u32& g_hi, bool& split) {
+#define ZL2_ROLE_E1 1u   // entropy kernels, main stream
+#define ZL2_ROLE_ES 3u   // entropy kernels, second stream
+#define ZL2_ROLE_X1 4u   // exec kernel, main stream (behind E1)
+#define ZL2_ROLE_XS 5u   // exec kernel, second stream (behind ES)
+#define ZL2_MODE_WHOLE 0u   // the batch is not cut: E1 and X1 cover everything, the other launches return at once
+#define ZL2_MODE_HALVES 1u  // single-block frames: the expensive half of the order on the main stream (E1, X1), the cheap half -- entropy and exec -- beside it (ES, XS)
+// the groups (of ZL2_WG_FRAMES frames of the sequence order) a launch covers: [g0, g1)
+__device__ __forceinline__ void zl2_part_range(const zl2_args& a, u32& g0, u32& g1, bool& split) {
     const u32 all = (a.nframes + 7) / 8;
-    g_lo = 0; g_hi = all; split = false;
-    if (a.part) {
-        u32 np = a.max_blocks[2];
-        if (np < 1) np = 1;
-        if (np > ZL2_MAX_PARTS) np = ZL2_MAX_PARTS;
-        const u32 k = a.part - 1;
-        split = np > 1;
-        if (k >= np) { g_lo = g_hi = 0; return; }  // (a launch for a part the batch does not have)
-        g_lo = (u32)((u64)all * k / np);
-        g_hi = (u32)((u64)all * (k + 1) / np);
-    }
+    g0 = 0; g1 = all; split = false;
+    if (!a.part) return;
+    const u32 mode = a.max_blocks[2];
+    split = mode != ZL2_MODE_WHOLE;
+    const bool main_role = a.part == ZL2_ROLE_E1 || a.part == ZL2_ROLE_X1;
+    if (mode == ZL2_MODE_HALVES) { if (main_role) g1 = all / 2; else g0 = all / 2; }
+    else if (!main_role) g1 = 0;
 }
 // Large-frame pipeline: what the segment workgroups of zl2_exec_kernel<true> share.
 #define ZL3_ROOT 0xFFFFFFFFu      // link value of a byte that is final in the output (marks of later rounds: ZL3_ROOT - 1, - 2)
