@@ -195,6 +195,8 @@ struct zl_dctx_s {
     std::vector<zl_dctx_s*> peers;
     DevBuf d_chunk_off;
     size_t large_frames = 0;
+    u8* sink_host = nullptr;   // host entries decoding one large frame: where its bytes go (zl3_hint::sink_host)
+    u64 sunk = 0;              // ... and how many of them are there already
     bool ev_valid = false;
     double kernel_ms = 0;
     double stage_ms[4] = {0, 0, 0, 0};
@@ -511,6 +513,8 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
         hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
+        hint.sink_host = (n == 1 && d->sink_host) ? d->sink_host : nullptr;  // (a host entry decoding ONE frame: the output is downloaded as it is finished)
+        hint.sunk = &d->sunk;
         if (i < d->host_walk.size() && !d->host_walk[i].blocks.empty()) {
             hint.host_blocks = d->host_walk[i].blocks.data();
             hint.nblocks = (u32)d->host_walk[i].blocks.size();
@@ -915,8 +919,11 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         if (!d->h_frames.ensure(cnt * sizeof(zl_frame_desc)) || !d->h_results.ensure(cnt * sizeof(u64))) return kGpuUnavailable;
         memcpy(d->h_frames.p, &table[i], cnt * sizeof(zl_frame_desc));
         d->host_walk.assign(std::make_move_iterator(walks.begin() + i), std::make_move_iterator(walks.begin() + j));
+        d->sink_host = (table.size() == 1 && known[0] && d->pipeline) ? (u8*)dst : nullptr;
+        d->sunk = 0;
         size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
         d->host_walk.clear();
+        d->sink_host = nullptr;
         if (ZL_IS_ERR(e)) return e;
         if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -927,8 +934,10 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         }
         i = j;
     }
-    if (total) {
-        if (hipMemcpyAsync(dst, d->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    const size_t have = (size_t)std::min<u64>(d->sunk, total);  // what the large-frame pipeline has downloaded beside its last stage
+    d->sunk = 0;
+    if (total > have) {
+        if (hipMemcpyAsync((u8*)dst + have, (const u8*)d->d_dst.p + have, total - have, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     return total;

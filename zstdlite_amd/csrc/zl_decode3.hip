@@ -580,8 +580,11 @@ __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_fram
 
 }  // namespace
 
+#define ZL3_SINK_LOG 26      // host entries: the output is downloaded in pieces of 64 MiB behind the copy stage (zl3_hint::sink_host)
+#define ZL3_SINK_EVENTS 64
 struct zl3_state_s {
     DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot;
+    hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
 };
 
 extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s(); }
@@ -589,6 +592,7 @@ extern "C" void zl3_free(zl3_state* s) {
     if (!s) return;
     for (DevBuf* b : {&s->info, &s->hblk, &s->braw, &s->seg_first, &s->blk_slot, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word,
                       &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot}) b->release();
+    for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -690,12 +694,31 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         stamp("exec");
         // the deferred bytes: one launch per group of output, in order (the first group has nothing in front of it to wait for,
         // but bytes of its later runs may wait for its earlier ones)
-        for (u64 g = 0; g < span; g += (u64)1 << ZL3_GROUP_LOG)
+        const bool sink = hint && hint->sink_host && hint->sunk && info.fcs != ZL_CONTENTSIZE_UNKNOWN && span >= ((u64)2 << ZL3_SINK_LOG) && side && side->part_stream[1];
+        u32 nsink = 0;
+        for (u64 g = 0; g < span; g += (u64)1 << ZL3_GROUP_LOG) {
             hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << ZL3_GROUP_LOG) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
                                d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, g, d.info);
+            const u64 done = g + ((u64)1 << ZL3_GROUP_LOG);
+            if (sink && (done & (((u64)1 << ZL3_SINK_LOG) - 1)) == 0 && done < span && nsink < ZL3_SINK_EVENTS) {
+                if (!s->sink_ev[nsink] && hipEventCreateWithFlags(&s->sink_ev[nsink], hipEventDisableTiming) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+                if (hipEventRecord(s->sink_ev[nsink], st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+                nsink++;
+            }
+        }
+        // the download of what is finished, piece by piece behind the events, on a stream of its own (the host thread waits in
+        // these calls when the memory is pageable; the copy kernels are all queued by now)
+        for (u32 k = 0; k < nsink; k++) {
+            const u64 off = (u64)k << ZL3_SINK_LOG;
+            if (hipStreamWaitEvent(side->part_stream[1], s->sink_ev[k], 0) != hipSuccess ||
+                hipMemcpyAsync(hint->sink_host + fd.dst_off + off, d_dst + fd.dst_off + off, (size_t)1 << ZL3_SINK_LOG, hipMemcpyDeviceToHost, side->part_stream[1]) != hipSuccess)
+                return ZL_ERR(ZL_E_GENERIC);
+        }
+        if (nsink && hipStreamSynchronize(side->part_stream[1]) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("resolve");
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
+        if (nsink && !info.err) *hint->sunk = (u64)nsink << ZL3_SINK_LOG;  // (a frame that failed or goes to the general kernel is downloaded as a whole, whatever was copied)
     }
     hipLaunchKernelGGL(zl3_finish_kernel, dim3(1), dim3(512), 0, st, d.info, fd, d_src, (const u8*)d_dst, d_result, (u32)ignore_checksum);
     stamp("finish");
