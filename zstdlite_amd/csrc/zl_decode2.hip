@@ -30,6 +30,8 @@
 // All integer work; output must be bit-exact with the reference decoder.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdlib>
 
 #include "zl_device.h"
@@ -1742,10 +1744,15 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
     hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    static bool shaped = false;
-    if (!shaped) {
-        if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
-        shaped = true;
+    {   // the literal kernel's dynamic LDS has to be allowed once per DEVICE (one process may drive several: ZL_d_devices)
+        static std::atomic<unsigned long long> shaped{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(shaped.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
+            shaped.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipError_t e;
     const bool two = side->part_stream[0] != nullptr && n >= ZL2_SPLIT_MIN;
