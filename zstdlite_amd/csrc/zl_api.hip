@@ -705,8 +705,24 @@ SlotPlan dctx_slots(const zl_dctx* d, size_t bytes, size_t units) {
 // plan.slots worker threads take `nruns` runs in order, fn(worker, run).  More runs than workers: the workers drift apart,
 // so one is uploading while another downloads (all starting their uploads together, as equal shares would, leaves the
 // two directions of the link to take turns).
+// Worker w's device, and which of the context's peers it uses: a peer's buffers and streams live on ONE device, so the peer
+// is chosen by device first -- peer id mod the number of devices is its device whatever the depth of this call's plan
+// (a call with depth 3 puts workers 0..2 on device 0, a call with depth 1 worker 1 on device 1).
+struct SlotPlace { int device, peer; };
+inline SlotPlace slot_place(const zl_dctx* d, SlotPlan plan, int w, int ndev, int home) {
+    if (d->devices == 1 || ndev < 2) return {home, w};
+    const int group = w / plan.depth, dev = group % ndev, lane = (w % plan.depth) + plan.depth * (group / ndev);
+    return {dev, dev + ndev * lane};
+}
+inline int peers_needed(const zl_dctx* d, SlotPlan plan) {
+    int ndev = 1, home = 0, most = 0;
+    (void)hipGetDeviceCount(&ndev);
+    (void)hipGetDevice(&home);
+    for (int w = 0; w < plan.slots; w++) most = std::max(most, slot_place(d, plan, w, ndev, home).peer);
+    return most + 1;
+}
 template <class Fn>
-void run_on_slots(const zl_dctx* d, SlotPlan plan, size_t nruns, Fn&& fn) {
+void run_on_slots(const zl_dctx* d, SlotPlan plan, size_t nruns, Fn&& fn) {  // fn(peer id, run)
     int ndev = 1, home = 0;
     (void)hipGetDeviceCount(&ndev);
     (void)hipGetDevice(&home);
@@ -714,8 +730,9 @@ void run_on_slots(const zl_dctx* d, SlotPlan plan, size_t nruns, Fn&& fn) {
     std::vector<std::thread> th;
     for (int w = 0; w < plan.slots; w++)
         th.emplace_back([&, w]() {
-            (void)hipSetDevice(d->devices == 1 ? home : (w / plan.depth) % (ndev < 1 ? 1 : ndev));
-            for (size_t r = next.fetch_add(1); r < nruns; r = next.fetch_add(1)) fn(w, r);
+            const SlotPlace at = slot_place(d, plan, w, ndev, home);
+            (void)hipSetDevice(at.device);
+            for (size_t r = next.fetch_add(1); r < nruns; r = next.fetch_add(1)) fn(at.peer, r);
         });
     for (auto& x : th) x.join();
     (void)hipSetDevice(home);
@@ -739,7 +756,7 @@ bool ensure_peers(zl_dctx* d, int slots) {
 size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, const SeekTable& t, SlotPlan plan) {
     const size_t sec = (size_t)1 << 9, nsec = (t.nchunks + sec - 1) / sec;  // ZL_FAR_SECTION_LOG (zl_encode.h): 512 chunks
     const int slots = plan.slots;
-    if (slots < 2 || !ensure_peers(d, slots)) return ZL_ERR(ZL_E_FALLBACK);
+    if (slots < 2 || !ensure_peers(d, peers_needed(d, plan))) return ZL_ERR(ZL_E_FALLBACK);
     const size_t nruns = runs_for(plan, nsec);
     std::vector<u64> off((size_t)t.nchunks + 1);
     u64 run = 0;
@@ -876,7 +893,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         plan.slots = 1; plan.depth = 1;
         if (all_known && d->dict.empty() && table.size() >= 2) plan = dctx_slots(d, (size_t)content, table.size() / 512);
         const int slots = plan.slots;
-        if (slots > 1 && content <= cap && ensure_peers(d, slots)) {
+        if (slots > 1 && content <= cap && ensure_peers(d, peers_needed(d, plan))) {
             const size_t nruns = runs_for(plan, table.size() / 512);
             std::vector<size_t> cut(nruns + 1, 0), res(nruns, 0);
             std::vector<u64> out_at(nruns + 1, 0);
