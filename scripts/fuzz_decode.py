@@ -10,7 +10,8 @@ from zstdlite_amd import _lib
 from zl_testlib import GENERATORS, Oracle, Ref, have_ref, is_error
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-single = len(sys.argv) > 3 and sys.argv[3] == "single"  # only single-block reference frames: the fused entropy kernel with its quad chains
+single = len(sys.argv) > 3 and sys.argv[3] in ("single", "wide")  # only single-block reference frames: the fused entropy kernel with its quad chains
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"  # ... in batches of more than 1024 frames: the two-part schedule of zl2_launch
 o = Oracle(); L = _lib.lib()
 base = []
 for gen in ("text", "iid10", "int20"):
@@ -30,7 +31,7 @@ t0 = time.time()
 for rd in range(rounds):
     frames = []
     for f, n in base:
-        for _ in range(6):
+        for _ in range(110 if wide else 6):
             b = bytearray(f)
             for _ in range(int(rng.integers(1, 4))):
                 pos = int(rng.integers(4, len(b)))  # keep the magic number
