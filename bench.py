@@ -266,21 +266,33 @@ def end_to_end_leg(host, device, log):
         torch.cuda.synchronize(); t0 = time.perf_counter(); d.copy_(torch.from_numpy(host)); torch.cuda.synchronize(); th = min(th, time.perf_counter() - t0)
         torch.cuda.synchronize(); t0 = time.perf_counter(); hb.copy_(d); torch.cuda.synchronize(); tdn = min(tdn, time.perf_counter() - t0)
     out["pcie_GBps_measured"] = {"h2d": n / th / 1e9, "d2h": n / tdn / 1e9, "how": "torch copy of the same 1 GiB between pageable host memory and HBM, best of 3"}
-    # is the link full duplex for this process?  the upload of the compressed bytes and the download of the output, each on its
-    # own stream from its own host thread, alone and at the same time (scripts/dev/exp_duplex.py measures more variants)
+    # Both directions of the link at once: the upload of the compressed bytes and the download of the output, each on its
+    # own stream from its own host thread, alone and at the same time.  Measured (scripts/dev/exp_duplex*.py): a stream is
+    # tied to a copy engine by its first large copy -- the engine that is idle at that moment, for good -- so two streams
+    # overlap only if their first copies did.  Both cases are reported: a pair bound one after the other (what a program
+    # gets that never thought about it) and a pair bound together (pinned scratch: a pageable copy would not return before it
+    # is done).  The calls go through ctypes: torch's copies hold Python's lock.
     try:
+        import ctypes as C
         import threading
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipStreamDestroy.argtypes = [C.c_void_p]
         nc = int(out["independent_frames"]["compressed_bytes"])
-        up_src = torch.from_numpy(comp[:nc]); up_dst = torch.empty(nc, dtype=torch.uint8, device=device)
-        s_up, s_dn = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        up_dst = torch.empty(nc, dtype=torch.uint8, device=device)
+        bind = 16 << 20
+        p_up = torch.zeros(bind, dtype=torch.uint8).pin_memory(); p_dn = torch.zeros(bind, dtype=torch.uint8).pin_memory()
 
-        def up():
-            with torch.cuda.stream(s_up):
-                up_dst.copy_(up_src); s_up.synchronize()
-
-        def down():
-            with torch.cuda.stream(s_dn):
-                hb.copy_(d); s_dn.synchronize()
+        def pair(together):
+            su, sd = C.c_void_p(), C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(su), 1) == 0 and hip.hipStreamCreateWithFlags(C.byref(sd), 1) == 0
+            hip.hipMemcpyAsync(up_dst.data_ptr(), p_up.data_ptr(), bind, 1, su)
+            if not together:
+                hip.hipStreamSynchronize(su)
+            hip.hipMemcpyAsync(p_dn.data_ptr(), d.data_ptr(), bind, 2, sd)
+            hip.hipStreamSynchronize(su); hip.hipStreamSynchronize(sd)
+            return su, sd
 
         def timed(fns):
             best = 1e9
@@ -290,11 +302,26 @@ def end_to_end_leg(host, device, log):
                 [x.start() for x in ths]; [x.join() for x in ths]
                 torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
             return best
-        t_up, t_dn, t_both = timed([up]), timed([down]), timed([up, down])
-        out["pcie_GBps_measured"].update({"upload_compressed_ms": t_up * 1e3, "download_output_ms": t_dn * 1e3, "both_at_once_ms": t_both * 1e3,
+        res = {}
+        for name, together in (("bound_one_after_the_other", False), ("bound_together", True)):
+            su, sd = pair(together)
+
+            def up():
+                hip.hipMemcpyAsync(up_dst.data_ptr(), comp.ctypes.data, nc, 1, su); hip.hipStreamSynchronize(su)
+
+            def down():
+                hip.hipMemcpyAsync(back.ctypes.data, d.data_ptr(), n, 2, sd); hip.hipStreamSynchronize(sd)
+            res[name] = (timed([up]), timed([down]), timed([up, down]))
+            hip.hipStreamDestroy(su); hip.hipStreamDestroy(sd)
+        t_up, t_dn, t_seq = res["bound_one_after_the_other"]
+        t_both = res["bound_together"][2]
+        out["pcie_GBps_measured"].update({"upload_compressed_ms": t_up * 1e3, "download_output_ms": t_dn * 1e3,
+                                          "both_at_once_ms_streams_bound_one_after_the_other": t_seq * 1e3,
+                                          "both_at_once_ms_streams_bound_together": t_both * 1e3,
                                           "full_duplex": bool(t_both < 0.8 * (t_up + t_dn))})
-        # what a decompress (compress) call from host memory cannot beat on this box: its bytes over the link
-        out["transfer_floor_GBps"] = n / t_both / 1e9
+        # what a decompress (compress) call from host memory cannot beat on this box: its bytes over the link, both directions
+        # at once when the copy engines allow it
+        out["transfer_floor_GBps"] = n / min(t_both, t_seq) / 1e9
     except Exception as e:  # the measurement is a note next to the numbers, never a reason to lose them
         out["pcie_GBps_measured"]["duplex_error"] = repr(e)
     out["compress_GBps"] = out["one_frame"]["compress_GBps"]   # the default layout of the host entries
