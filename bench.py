@@ -49,7 +49,7 @@ def _cpu_info():
     return model, smt
 
 
-def cpu_baseline(host_bytes, log, frames=None, reps=3):
+def cpu_baseline(host_bytes, log, frames=None, reps=5):
     """The reference's CPU path on this box's host cores: ZSTD_compress2(level 3) and
     ZSTD_decompressDCtx on the same 1 GiB vector, buffers pre-touched, best of `reps` passes: (i) one thread,
     (ii) compression with nbWorkers = host cores, (iii) decode of a set of independent frames (`frames`: the HIP
