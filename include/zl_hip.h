@@ -208,6 +208,9 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  * (zl_CCtx_setPledgedSrcSize, what src/raw-file-out.c:74 does) the jobs are consecutive runs of blocks of
  * ONE frame: byte for byte what zl_compress2 writes for the whole input, so a reader that sizes its
  * buffer from the frame header (src/raw-file-in.c:66) or takes the first frame gets everything.
+ * Inside such a session ZL_e_flush cuts no run: the frame's runs end at 64 MiB boundaries and at the
+ * pledged end only, so a flush hands out the jobs that are complete and keeps collecting the rest
+ * (the reference's glue never flushes; a frame of its own in mid-frame would be an invalid stream).
  * Without a pledge every job is a frame of its own with its own recorded size: valid zstd that
  * ZSTD_decompressStream / ZSTD_decompress read frame after frame.
  * Returns the bytes still waiting to be handed out (0 at ZL_e_end: the session is complete), or an

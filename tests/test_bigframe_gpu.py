@@ -193,3 +193,46 @@ def test_host_copy_hint_walks_the_blocks_on_the_host(ref):
     got, _ = codec.decompress(d_src, tbl, out, host_copy=bad)
     assert got == len(data) and torch.equal(out, want)
     codec.close()
+
+
+def test_chunk_hints_that_do_not_fit_on_a_fresh_context(ref):
+    """the chunk-hinted block walk stores through a table of first-block indices that exists only when the hint
+    fits; a hint that does not -- as the FIRST call on a context, so that nothing valid is left over from an earlier one --
+    must be ignored without a store going anywhere.  Likewise a crafted seek table whose chunks hold far more blocks than
+    the frame's size allows (64 empty raw blocks per 'chunk')."""
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    from zl_testlib import LONG_RANGE
+    data = LONG_RANGE["records"](3 << 20) + GENERATORS["text"](1 << 20)
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    enc = DeviceCodec(frame_layout="one_frame")
+    dst, total, sizes = enc.compress(src)
+    tbl = enc.frame_table([total], [len(data)])
+    for hint in (sizes[::-1].copy(), sizes[:-1], np.concatenate([sizes[:3], sizes[2:]]), sizes):
+        codec = DeviceCodec()  # fresh: no earlier call has left a valid table behind
+        back = torch.zeros_like(src)
+        got, _ = codec.decompress(dst, tbl, back, chunk_sizes=hint)
+        assert got == len(data) and torch.equal(back, src)
+        codec.close()
+    enc.close()
+    # a buffer that ends in a seek table (one-frame flag) whose 128 'chunks' are 64 empty raw blocks each: 8192 blocks where
+    # the frame's 16 MiB of claimed content plan for about 2100.  Must come back as an error, from a fresh context.
+    nchunks, content = 128, 128 * 131072
+    hdr = bytes.fromhex("28b52ffd") + bytes([0x80 | 0x20]) + content.to_bytes(4, "little")  # Single_Segment, 4-byte content size
+    empty_raw = (0).to_bytes(3, "little")
+    chunks = [empty_raw * 64 for _ in range(nchunks)]
+    chunks[0] = hdr + chunks[0]
+    chunks[-1] = chunks[-1][:-3] + (1).to_bytes(3, "little")  # Last_Block on the very last
+    body = b"".join(chunks)
+    table = b"".join(len(c).to_bytes(4, "little") for c in chunks)
+    footer = content.to_bytes(8, "little") + nchunks.to_bytes(4, "little") + (1).to_bytes(4, "little") + (0x58494C5A).to_bytes(4, "little")
+    payload = table + footer
+    crafted = body + (0x184D2A5E).to_bytes(4, "little") + len(payload).to_bytes(4, "little") + payload
+    L = _lib.lib()
+    dctx = z.zstd_dctx()
+    out = np.zeros(content, dtype=np.uint8)
+    r = L.zl_decompressDCtx(dctx._ptr, out.ctypes.data_as(C.c_void_p), content, crafted, len(crafted))
+    assert _lib.is_error(r)
+    want_r, _ = ref.decompress_code(crafted, content)
+    assert ref.L.ZSTD_isError(want_r)  # the reference rejects it too (content size mismatch)
+    assert z.zstd_decompress(z.zstd_compress(data), dctx=dctx) == data  # the context survives

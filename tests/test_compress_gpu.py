@@ -100,10 +100,15 @@ def test_checksum_adds_four_bytes_per_frame():
     with pytest.raises(z.ZstdError, match="doesn't match checksum"):
         z.zstd_unserialize(bytes(bad))
     assert z.zstd_unserialize(bytes(bad), dctx=z.zstd_dctx(validate_checksum=False)) == dat
-    # a checksum context writes one independent frame per 128 KiB chunk (XXH64 over one huge frame would be one
-    # serial chain): four frames here, each four bytes longer than without
+    # a checksum context writes ONE frame like every other host call (zstd.c:27733: one XXH64 over the whole content): four
+    # bytes longer than without, and the flag in the frame header is the only other difference.  The independent-frames layout
+    # (on request) checks each 128 KiB frame by itself.
     big = GENERATORS["text"](400000)
-    assert len(z.zstd_compress(big, include_checksum=True)) == len(z.zstd_compress(big, frame_layout="frames")) + 4 * 4
+    one, onec = z.zstd_compress(big), z.zstd_compress(big, include_checksum=True)
+    assert len(onec) == len(one) + 4 and onec[:4] == one[:4] and onec[4] == one[4] | 4 and onec[5:-4] == one[5:]
+    assert z.zstd_info(onec)["compressed_size"] == len(onec) and z.zstd_info(onec)["has_checksum"]
+    assert z.zstd_decompress(onec) == big
+    assert len(z.zstd_compress(big, include_checksum=True, frame_layout="frames")) == len(z.zstd_compress(big, frame_layout="frames")) + 4 * 4
 
 
 def test_serialize_roundtrip():
@@ -198,9 +203,10 @@ def test_dictionary_compression_of_small_objects(ref, oracle):
     assert z.zstd_decompress_batch(withd, dict=d) == items
     with pytest.raises(z.ZstdError):
         z.zstd_decompress(withd[0])
-    # a large input with a dictionary: every 128 KiB frame sees the dictionary
+    # a large input with a dictionary: ONE frame whose first chunk sees the dictionary (test_checksum_and_dictionary_contexts_write_one_frame);
+    # in the independent-frames layout, on request, every 128 KiB frame sees it
     big = b"".join(items)
-    comp = z.zstd_compress(big, cctx=cctx)
+    comp = z.zstd_compress(big, cctx=z.zstd_cctx(dict=d, frame_layout="frames"))
     assert z.zstd_decompress(comp, dctx=z.zstd_dctx(dict=d)) == big
     assert ref.decompress(comp[: z.zstd_info(comp)["compressed_size"]], 131072, dict=d) == big[:131072]
     # a raw-content dictionary (no magic): no id in the frame, still history
@@ -225,6 +231,58 @@ def test_one_frame_is_one_standard_frame(n, ref):
     assert ref.decompress(comp, n) == data
     assert z.zstd_decompress(comp) == data
     assert z.zstd_compress(data) == comp  # deterministic
+
+
+@pytest.mark.parametrize("n", [131073, 5000000])
+def test_checksum_and_dictionary_contexts_write_one_frame(n, ref, oracle):
+    """zstd_compress(x, include_checksum=TRUE) and zstd_compress(x, dict=) of an input above 128 KiB used to
+    return one frame per chunk, of which the reference's reader (first frame only, src/raw-file.c:150-155) silently took the
+    first.  They write ONE frame now: the reference's first-frame helper covers all of it, the reference decoder verifies the
+    checksum (zstd.c:27733: XXH64 over the whole content) and finds the dictionary's content in front of the frame
+    (zstd.c:27550).  (320 MiB: tests/test_fullsize_gpu.py.)"""
+    import pickle
+    rng = np.random.default_rng(n)
+    data = GENERATORS["text"](n // 2, seed=n) + GENERATORS["iid10"](n - n // 2, seed=n + 1)
+    # ---- checksum
+    comp = z.zstd_compress(data, include_checksum=True)
+    assert ref.L.ZSTD_findFrameCompressedSize(comp, len(comp)) == len(comp) and ref.L.ZSTD_getFrameContentSize(comp, len(comp)) == n
+    assert z.zstd_info(comp)["has_checksum"]
+    assert ref.decompress(comp, n) == data and oracle.decompress(comp, cap=n) == data and z.zstd_decompress(comp) == data
+    for at in (len(comp) - 1, len(comp) - 4):  # the stored checksum: both decoders must notice
+        bad = bytearray(comp)
+        bad[at] ^= 0x10
+        r, _ = ref.decompress_code(bytes(bad), n)
+        assert ref.error_name(r) == "Restored data doesn't match checksum"
+        with pytest.raises(z.ZstdError, match="doesn't match checksum"):
+            z.zstd_decompress(bytes(bad))
+        assert z.zstd_decompress(bytes(bad), validate_checksum=False) == data
+    assert z.zstd_compress(data, include_checksum=True, seek_table=True)[:len(comp)] == comp
+    assert z.zstd_decompress(z.zstd_compress(data, include_checksum=True, seek_table=True)) == data
+    # ---- dictionary: objects like the dictionary's samples, many of them in one buffer
+    names = [f"name_{i:02d}_{'x' * (i % 7)}" for i in range(50)]
+
+    def obj():
+        perm = rng.permutation(50)[: int(rng.integers(10, 40))]
+        return pickle.dumps({names[j]: int(rng.integers(0, 1000)) for j in perm}, protocol=4)
+    items = [obj() for _ in range(1500)]
+    d = ref.train_dict(items, 5000)
+    body = b""
+    while len(body) < n:
+        body += obj()
+    body = body[:n]
+    for dic, did in ((d, z.zstd_dict_id(d)), (b"".join(items[:10]), 0)):  # a trained dictionary; raw content (no id in the frame)
+        cd = z.zstd_compress(body, dict=dic, include_checksum=True)
+        assert ref.L.ZSTD_findFrameCompressedSize(cd, len(cd)) == len(cd) and ref.L.ZSTD_getFrameContentSize(cd, len(cd)) == n
+        assert z.zstd_info(cd)["dict_id"] == did
+        assert ref.decompress(cd, n, dict=dic) == body and oracle.decompress(cd, cap=n, dict=dic) == body
+        assert z.zstd_decompress(cd, dict=dic) == body
+        assert len(cd) < len(z.zstd_compress(body, include_checksum=True)) * 1.05  # (the first chunk is searched with the dictionary's smaller tables)
+        if did:
+            with pytest.raises(z.ZstdError):
+                z.zstd_decompress(cd)
+    # a reference-made large frame with the dictionary (its first block may ride on the dictionary's tables): bit-exact too
+    rc = ref.compress(body, level=3, dict=d, checksum=True)
+    assert z.zstd_decompress(rc, dict=d) == body
 
 
 @pytest.mark.parametrize("name,n", [("records", 16 << 20), ("corpus", None)])

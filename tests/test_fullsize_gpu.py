@@ -210,3 +210,31 @@ def test_device_slots_behind_the_host_entries():
     if torch.cuda.device_count() < 2:
         pytest.skip("one device: the slots shared it; the multi-device leg needs more")
     assert np.array_equal(_host_roundtrip(L, host, 2, 0, 1)[0], one)  # 0: every visible device
+
+
+def test_checksum_and_dictionary_contexts_write_one_frame_at_320_mib():
+    """The host entry's pipelined path (inputs above 192 MiB go up, through the kernels and down in overlapping 64 MiB
+    sections): with a checksum or a dictionary it writes ONE frame as well -- the XXH64 of the whole content is computed on a
+    host thread beside the upload (zstd.c:27733), the dictionary is history in front of the first chunk (zstd.c:27550).
+    Checked with the reference's own first-frame helper and decoder."""
+    import zstdlite_amd as z
+    from zl_testlib import Ref
+    if not have_ref():
+        pytest.skip("needs the reference build (oracle/_ref)")
+    ref = Ref()
+    n = 320 << 20
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    comp = z.zstd_compress(data, include_checksum=True)
+    assert ref.L.ZSTD_findFrameCompressedSize(comp, len(comp)) == len(comp) and ref.L.ZSTD_getFrameContentSize(comp, len(comp)) == n
+    assert comp[:-4] == z.zstd_compress(data)[:4] + bytes([z.zstd_compress(data)[4] | 4]) + z.zstd_compress(data)[5:]
+    assert ref.decompress(comp, n) == data
+    assert z.zstd_decompress(comp) == data
+    bad = bytearray(comp)
+    bad[-3] ^= 1
+    with pytest.raises(z.ZstdError, match="doesn't match checksum"):
+        z.zstd_decompress(bytes(bad))
+    dic = data[(64 << 20) + 1000:(64 << 20) + 60000]  # raw content that the first chunk does not hold by itself
+    cd = z.zstd_compress(data, dict=dic)
+    assert ref.L.ZSTD_findFrameCompressedSize(cd, len(cd)) == len(cd)
+    assert ref.decompress(cd, n, dict=dic) == data
+    assert z.zstd_decompress(cd, dict=dic) == data

@@ -250,3 +250,27 @@ def test_pledged_stream_above_one_job_is_one_frame(ref):
     blob2 = b"".join([loose.feed(data[off:off + 7000001]) for off in range(0, n, 7000001)] + [loose.finish()])
     assert ref.L.ZSTD_findFrameCompressedSize(blob2, len(blob2)) < len(blob2)  # three frames
     assert z.zstd_decompress(blob2) == data and ref_stream_decompress(ref, blob2) == data
+
+
+@needs_ref
+def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
+    """a pledged stream of more than one 64 MiB job is ONE frame whose runs end at job boundaries; a flush
+    somewhere else must not put a frame of its own into the unterminated one.  It hands out the complete jobs and keeps
+    collecting; the stream stays byte-identical to zl_compress2's and the reference reads it."""
+    import torch
+    from zstdlite_amd.device import gen_mixed
+    n = (200 << 20) + 99
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    cctx = z.zstd_cctx()
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    cut = 74 << 20
+    parts = [comp.feed(data[:cut]), comp.flush(), comp.feed(data[cut:cut + 1000]), comp.flush(), comp.flush(), comp.finish(data[cut + 1000:])]
+    blob = b"".join(parts)
+    assert len(parts[0]) > 0 and parts[1] == b""  # the first job came out with the feed; the flush cut nothing
+    assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob) and ref.L.ZSTD_getFrameContentSize(blob, len(blob)) == n
+    assert blob == z.zstd_compress(data)
+    assert ref.decompress(blob, n) == data
+    # more input than was pledged is an error, not a second frame (zstd.c:24140)
+    over = stream.Compressor(cctx._ptr, pledged=1000)
+    with pytest.raises(stream.ZstdStreamError, match="Src size is incorrect"):
+        over.feed(data[:2000])

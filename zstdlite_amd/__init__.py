@@ -15,6 +15,7 @@ buffers.  `zstd_serialize` uses pickle where the reference uses R's native seria
 (that step sits above the hot path and stays on the CPU in both).
 """
 import ctypes as C
+import hashlib
 import pickle
 import threading
 import warnings
@@ -27,7 +28,7 @@ from ._lib import FrameT, ZstdError, is_error
 __all__ = [
     "zstd_compress", "zstd_decompress", "zstd_serialize", "zstd_unserialize", "zstd_cctx", "zstd_dctx",
     "zstd_cctx_settings", "zstd_dctx_settings", "zstd_info", "zstd_dict_id", "zstd_version",
-    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "zstdfile", "ZstdError",
+    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "zstdfile", "zstd_clear_cache", "ZstdError",
 ]
 
 ZL_c_compressionLevel = 100
@@ -156,9 +157,20 @@ def _init_dctx_with_opts(opts, quiet=False):
 _tls = threading.local()
 
 
+_CACHE_MAX_BYTES = 256 << 20  # a cached context that has served a call larger than this is dropped: its device and pinned buffers only grow
+
+
+def _opt_key(v):
+    """Option value -> hashable cache key; a dictionary is named by length and digest, not by a copy of its bytes."""
+    if isinstance(v, (bytes, bytearray, memoryview, np.ndarray)):
+        b = bytes(v)
+        return ("bytes", len(b), hashlib.blake2b(b, digest_size=16).digest())
+    return v
+
+
 def _cached_ctx(kind, opts):
     try:
-        key = (kind, tuple(sorted((k, v if not isinstance(v, (bytearray, memoryview, np.ndarray)) else bytes(v)) for k, v in opts.items())))
+        key = (kind, tuple(sorted((k, _opt_key(v)) for k, v in opts.items())))
         hash(key)
     except TypeError:
         key = None
@@ -170,8 +182,24 @@ def _cached_ctx(kind, opts):
     if ctx is None:
         if len(cache) >= 8:  # a handful of option sets at most; drop the oldest
             cache.pop(next(iter(cache)))
-        ctx = cache[key] = make(opts)
+        ctx = cache[key] = make(opts)  # (unknown-option warnings come once per option set and thread)
     return ctx
+
+
+def _uncache_if_large(ctx, nbytes):
+    """A context's device and pinned-host buffers are grow-only: one 1 GiB call would leave several GiB held by this
+    thread's cache for good.  Contexts from the cache that served a large call are let go."""
+    if nbytes <= _CACHE_MAX_BYTES:
+        return
+    cache = _tls.__dict__.get("ctx", {})
+    for k, v in list(cache.items()):
+        if v is ctx:
+            del cache[k]
+
+
+def zstd_clear_cache():
+    """Frees the per-thread default contexts (and the device memory they hold) of the calling thread."""
+    _tls.__dict__.pop("ctx", None)
 
 
 def zstd_cctx(level=3, num_threads=1, include_checksum=False, dict=None, frame_layout="auto", seek_table=False):
@@ -225,6 +253,8 @@ def _compress_bytes(src_ptr, src_size, cctx, opts, who):
     dst = np.empty(cap, dtype=np.uint8)
     ctx = _cached_ctx("c", opts) if cctx is None else cctx  # opts only honoured without a cctx
     r = L.zl_compress2(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, src_ptr, src_size)
+    if cctx is None:
+        _uncache_if_large(ctx, src_size)
     if is_error(r):
         raise ZstdError(f"{who}(): Compression error. {_lib.error_name(r)}")
     return dst[:r].tobytes()
@@ -266,6 +296,8 @@ def _decompress_bytes(src, dctx, opts, who):
     dst = np.empty(max(cap, 1), dtype=np.uint8)
     ctx = _cached_ctx("d", opts) if dctx is None else dctx
     r = L.zl_decompressDCtx(ctx._ptr, dst.ctypes.data_as(C.c_void_p), cap, ptr, csize)
+    if dctx is None:
+        _uncache_if_large(ctx, cap)
     if is_error(r):
         raise ZstdError(f"{who}(): De-compression error. {_lib.error_name(r)}")
     return dst[:r].tobytes()

@@ -18,6 +18,7 @@
 #include "zl_host.h"
 #include "zl_kernels.h"
 #include "zl_decode3.h"
+#include "zl_xxh64.h"
 
 static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
 
@@ -190,7 +191,12 @@ struct zl_dctx_s {
     const u8* host_copy = nullptr;     // device entries: zl_decompress_device_hint_host_copy, consumed by the next call
     size_t host_copy_size = 0;
     bool run_headerless = false, run_not_last = false;  // the "frame" of the call is one device's run of a frame's chunks (decompress sharding)
+    u32 run_tail = 0;                  // ... and its last chunk's listed size covers this many footer bytes (the frame's content checksum)
+    u32 dict_rep[3] = {1, 4, 8};       // a formatted dictionary's repeat offsets (zstd.c:42053)
+    bool host_verify = false;          // host entries: the content checksum of frames that take the large-frame pipeline is checked on the host, over the downloaded bytes (zl_xxh64.h)
+    std::vector<u8> took_big;          // per frame of the last dctx_enqueue: 1 when the large-frame pipeline decoded it
     int devices = 1;                   // ZL_d_devices
+    bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
     std::vector<zl_dctx_s*> peers;
     DevBuf d_chunk_off;
@@ -306,7 +312,18 @@ size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t ca
     size_t pos = 0, count = 0;
     u64 dst_off = 0;
     SeekTable st;
-    if (read_seek_table(src, n, st) && !st.one_frame) {  // one frame per chunk, sizes listed: no walk (the frames are checked when they are decoded)
+    bool listed = read_seek_table(src, n, st) && !st.one_frame;
+    if (listed) {  // what the table says is untrusted input: every listed frame must at least start like one and record the size its chunk has
+        u64 at = 0;
+        for (u32 i = 0; i < st.nchunks && listed; i++) {
+            const u32 fs = rd_le(st.sizes + 4 * (size_t)i, 4);
+            const u64 cs = i + 1 < st.nchunks ? ZL_BLOCK_MAX : st.content - (u64)i * ZL_BLOCK_MAX;
+            FrameHeader h;
+            if (fs < 6 || at + fs > st.data_bytes || ZL_IS_ERR(parse_frame_header(h, src + at, fs)) || h.skippable || h.content_size != cs) listed = false;
+            at += fs;
+        }
+    }
+    if (listed) {  // one frame per chunk, sizes listed: no walk over block headers (the frames' contents are checked when they are decoded)
         for (u32 i = 0; i < st.nchunks; i++) {
             const u32 fs = rd_le(st.sizes + 4 * (size_t)i, 4);
             const u64 cs = i + 1 < st.nchunks ? ZL_BLOCK_MAX : st.content - (u64)i * ZL_BLOCK_MAX;
@@ -450,6 +467,7 @@ size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hdr.status) return ZL_ERR(hdr.status);
         d->dict_content_off = hdr.content_off;
+        for (int k = 0; k < 3; k++) d->dict_rep[k] = hdr.rep[k];
     } else {
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
@@ -508,11 +526,22 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // Frames of more blocks than the lane pipeline takes, with a recorded content size and no dictionary
     // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
     // first, one after the other; it leaves each frame's result word on the device.
+    d->took_big.assign(n, 0);
     for (size_t i = 0; i < n; i++) {
-        if (has_dict || (tbl[i].dst_cap <= route_max && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
+        if ((tbl[i].dst_cap <= route_max && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
         hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
+        hint.tail = d->run_headerless ? d->run_tail : ZL3_TAIL_FROM_HEADER;
+        hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0;
+        hint.dict_rep[0] = 1; hint.dict_rep[1] = 4; hint.dict_rep[2] = 8;
+        if (has_dict) {  // the dictionary's content is history in front of the frame; its tables stay with the general kernel (zl_decode3.h)
+            hint.dict_len = (u32)(d->dict.size() - d->dict_content_off);
+            hint.dict_end = (const u8*)d->d_dict.p + d->dict.size();
+            hint.dict_id = d->dict_id;
+            hint.dict_formatted = d->dict_formatted ? 1u : 0u;
+            for (int k = 0; k < 3; k++) hint.dict_rep[k] = d->dict_rep[k];
+        }
         hint.sink_host = (n == 1 && d->sink_host) ? d->sink_host : nullptr;  // (a host entry decoding ONE frame: the output is downloaded as it is finished)
         hint.sunk = &d->sunk;
         if (i < d->host_walk.size() && !d->host_walk[i].blocks.empty()) {
@@ -527,8 +556,8 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             hint.headerless = d->run_headerless ? 1u : 0u;
             hint.not_last = d->run_not_last ? 1u : 0u;
         }
-        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, d->ignore_checksum, st, &d->side, &hint);
-        if (e3 == 0) { plan[i].route = 3; d->large_frames++; }
+        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
+        if (e3 == 0) { plan[i].route = 3; d->large_frames++; d->took_big[i] = 1; }
         else if (e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
     }
     if (hipMemcpyAsync(d->d_frames.p, d->h_frames.p, n * sizeof(zl_frame_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -680,6 +709,18 @@ size_t zl_decompress_device_finish(zl_dctx* d, size_t* results) {
 }  // extern "C"
 
 namespace {
+// Host entries: the content checksum (zstd.c:41646-41660) of a frame that took the large-frame pipeline, checked over the
+// regenerated bytes where they lie in the caller's buffer.  One XXH64 chain through the whole content: a CPU core's work
+// (zl_xxh64.h); frames of at most eight blocks are checked on the device, side by side.
+size_t verify_frame_checksum_on_host(const u8* frame, size_t frame_size, const u8* content, size_t n) {
+    FrameHeader h;
+    if (ZL_IS_ERR(parse_frame_header(h, frame, frame_size)) || h.skippable || !h.has_checksum) return 0;
+    if (frame_size < h.header_size + 3 + 4) return ZL_ERR(ZL_E_CHECKSUM_WRONG);
+    zlx::Xxh64 x;
+    x.update(content, n);
+    return x.low32() == rd_le(frame + frame_size - 4, 4) ? 0 : ZL_ERR(ZL_E_CHECKSUM_WRONG);
+}
+
 // zl_decompressDCtx of a buffer that ends in a seek table: the frame table comes from the table, not from a walk over
 // every block header.  Returns ZL_ERR(ZL_E_FALLBACK) when the table and the data disagree anywhere: the caller then walks.
 size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src, const SeekTable& t);
@@ -691,6 +732,7 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
 // ZL_d_devices = 1 that is the caller's current device.
 struct SlotPlan { int slots, depth; };
 SlotPlan dctx_slots(const zl_dctx* d, size_t bytes, size_t units) {
+    if (d->is_peer) return {1, 1};  // (a peer that re-sharded would spawn threads and peers of its own: up to 9 contexts per device)
     int devs = d->devices;
     if (devs == 0) { int nd = 1; (void)hipGetDeviceCount(&nd); devs = (int)std::min<size_t>((size_t)nd, bytes / ((size_t)512 << 20)); }
     if (devs < 1) devs = 1;
@@ -743,6 +785,7 @@ bool ensure_peers(zl_dctx* d, int slots) {
     while (d->peers.size() < (size_t)slots) {
         zl_dctx* p = zl_createDCtx();
         if (!p) return false;
+        p->is_peer = true;
         d->peers.push_back(p);
     }
     for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; }
@@ -763,6 +806,8 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
     for (u32 i = 0; i < t.nchunks; i++) { off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
     off[t.nchunks] = run;
     std::vector<size_t> res(nruns, 0);
+    u32 tail = 0;  // ONE frame with a content checksum: its 4 bytes are covered by the last chunk's listed size
+    if (t.one_frame) { FrameHeader h; if (!ZL_IS_ERR(parse_frame_header(h, src, t.data_bytes)) && !h.skippable && h.has_checksum) tail = 4; }
     run_on_slots(d, plan, nruns, [&](int w, size_t s) {
         const size_t c0 = std::min<size_t>(t.nchunks, (nsec * s / nruns) * sec), c1 = std::min<size_t>(t.nchunks, (nsec * (s + 1) / nruns) * sec);
         if (c0 == c1) return;
@@ -775,12 +820,18 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
         sub.content = out1 - out0;
         p->run_headerless = t.one_frame && c0 != 0;
         p->run_not_last = t.one_frame && c1 != t.nchunks;
+        p->run_tail = (t.one_frame && c1 == t.nchunks) ? tail : 0u;
         res[s] = decompress_with_seek_table(p, dst + out0, (size_t)(out1 - out0), src + off[c0], sub);
         p->run_headerless = p->run_not_last = false;
+        p->run_tail = 0;
         if (!ZL_IS_ERR(res[s]) && res[s] != out1 - out0) res[s] = ZL_ERR(ZL_E_FALLBACK);
     });
     for (size_t s = 0; s < nruns; s++) if (ZL_IS_ERR(res[s])) return res[s];
     d->last_slots = slots;
+    if (tail && !d->ignore_checksum) {  // the runs regenerate pieces; the checksum covers the whole
+        const size_t v = verify_frame_checksum_on_host(src, t.data_bytes, dst, (size_t)t.content);
+        if (ZL_IS_ERR(v)) return v;
+    }
     return (size_t)t.content;
 }
 
@@ -820,7 +871,9 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
             out += cs;
         }
     }
+    d->host_verify = true;
     size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
+    d->host_verify = false;
     d->chunk_off.clear();
     if (ZL_IS_ERR(e)) return e;
     if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -833,6 +886,10 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
     }
     if (total != t.content) return ZL_ERR(ZL_E_FALLBACK);
     if (hipMemcpyAsync(dst, d->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (t.one_frame && !d->run_headerless && !d->run_not_last && !d->ignore_checksum && !d->took_big.empty() && d->took_big[0]) {
+        const size_t v = verify_frame_checksum_on_host(src, t.data_bytes, dst, (size_t)total);
+        if (ZL_IS_ERR(v)) return v;
+    }
     return (size_t)total;
 }
 }  // namespace
@@ -922,6 +979,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     if (!d->d_src.ensure(n + 16) || !d->d_dst.ensure(cap + 16)) return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     size_t total = 0, i = 0;
+    std::vector<u8> big(table.size(), 0);  // frames the large-frame pipeline decoded: their content checksum is verified below, on the host
     while (i < table.size()) {
         size_t j = i;
         u64 off = total;
@@ -938,10 +996,13 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         d->host_walk.assign(std::make_move_iterator(walks.begin() + i), std::make_move_iterator(walks.begin() + j));
         d->sink_host = (table.size() == 1 && known[0] && d->pipeline) ? (u8*)dst : nullptr;
         d->sunk = 0;
+        d->host_verify = true;
         size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
+        d->host_verify = false;
         d->host_walk.clear();
         d->sink_host = nullptr;
         if (ZL_IS_ERR(e)) return e;
+        for (size_t k = 0; k < cnt && k < d->took_big.size(); k++) big[i + k] = d->took_big[k];
         if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         const u64* r = (const u64*)d->h_results.p;
@@ -956,6 +1017,14 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     if (total > have) {
         if (hipMemcpyAsync((u8*)dst + have, (const u8*)d->d_dst.p + have, total - have, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    if (!d->ignore_checksum) {
+        for (size_t k = 0; k < table.size(); k++) {
+            if (!big[k]) continue;
+            const u64 end = k + 1 < table.size() ? table[k + 1].dst_off : (u64)total;
+            const size_t v = verify_frame_checksum_on_host(src + table[k].src_off, (size_t)table[k].src_size, (const u8*)dst + table[k].dst_off, (size_t)(end - table[k].dst_off));
+            if (ZL_IS_ERR(v)) return v;
+        }
     }
     return total;
 }

@@ -15,6 +15,7 @@
 #include "zl_format.h"
 #include "zl_host.h"
 #include "zl_kernels.h"
+#include "zl_xxh64.h"
 
 #define ZL_GROUP_CHUNKS 8192u  // chunks encoded per launch group (1 GiB of input); bounds the scratch
 
@@ -50,6 +51,10 @@ struct zl_cctx_s {
     bool pending = false;
     hipStream_t pending_stream = nullptr;
     size_t pending_chunks = 0, pending_groups = 0;
+    bool pending_hash = false;        // the pending call writes ONE frame with a content checksum: XXH64 of the whole input goes behind the last block
+    const u8* pending_src = nullptr;  // ... the input (device) and its size, where the frame is being written
+    u8* pending_dst = nullptr;
+    size_t pending_n = 0;
     // diagnostics
     int profile = 0;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -69,6 +74,8 @@ struct zl_cctx_s {
         bool started = false;   // input has been taken in this session
         bool emitted = false;   // a frame has been written in this session
         bool finishing = false; // ZL_e_end has compressed the rest; only handing out remains
+        bool joined = false;    // the session's jobs are consecutive runs of blocks of ONE frame (decided when the first input arrives)
+        zlx::Xxh64 hash;        // joined session with ZL_c_checksumFlag: the content checksum runs through all jobs
     } cs;
 };
 
@@ -165,7 +172,23 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         m.stats = (u64*)c->d_stats.p;
     }
     if (prof) (void)hipEventRecord(c->ev[0], st);
-    if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (joined && c->dict_use) {
+        // ONE frame with a dictionary (zstd.c:27550: the dictionary's content is history in front of the frame's first byte):
+        // the frame's first chunk is searched with the dictionary in front of it, exactly as a dictionary frame of its own
+        // would be; the chunks behind it see the frame (far matches reach into chunk 0, not into the dictionary).
+        u32 skip = 0;
+        if (frame_chunk0 + first == 0) {
+            zl_match_args m0 = m;
+            m0.far_hints = nullptr;
+            if (zl_launch_match(&m0, 1, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            skip = 1;
+        }
+        zl_match_args m1 = m;
+        m1.chunks += skip; m1.lits += (size_t)skip * m.lit_stride; m1.seqs += (size_t)skip * m.seq_stride; m1.meta += skip;
+        m1.far_hints += (size_t)skip * ZL_FAR_HINT_WORDS;
+        m1.dict = nullptr; m1.dict_len = 0; m1.dict_hash = nullptr;
+        if (zl_launch_match(&m1, cnt - skip, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    } else if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) (void)hipEventRecord(c->ev[1], st);
     zl_entropy_args e;
     e.chunks = m.chunks;
@@ -186,7 +209,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.total_chunks = (u32)nchunks;
     e.wlog = ZL_FAR_WLOG;
     e.total_size = joined_total;
-    e.cdict = (c->dict_use && c->dict_formatted) ? c->d_cdict.p : nullptr;
+    e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.stats = m.stats ? m.stats + 8 : nullptr;
     if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) (void)hipEventRecord(c->ev[2], st);
@@ -237,13 +260,14 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     return 0;
 }
 
-// Which layout a call over n bytes of ONE input takes.  One frame (windowed) needs what only it can have: no
-// dictionary (dictionary frames are small and their own), no checksum (XXH64 over the whole content is one
-// serial chain, zstd.c:11708; per-chunk frames check their 128 KiB each in parallel), more than one chunk, and
-// 32-bit positions per launch group.  host_entry: the calls that stand in for ZSTD_compress2 / ZSTD_compressStream2,
-// whose readers take the FIRST frame only (src/raw-file.c:150-155) -- there one frame is the default.
+// Which layout a call over n bytes of ONE input takes.  host_entry: the calls that stand in for ZSTD_compress2 /
+// ZSTD_compressStream2, whose readers take the FIRST frame only (src/raw-file.c:150-155) -- there one frame is the
+// default, with or without a checksum or a dictionary (round 2 wrote independent frames for those two: a first-frame
+// reader then got 128 KiB back, silently).  The content checksum of one frame is one XXH64 over all of it
+// (zstd.c:27733): computed on the host beside the upload (zl_xxh64.h).  A dictionary is history in front of the frame's
+// first chunk (cctx_enqueue_group).
 bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
-    if (n <= ZL_CHUNK || !c->dict.empty() || c->checksum) return false;
+    if (n <= ZL_CHUNK) return false;
     if (c->layout == 1) return false;
     if (c->layout == 2) return true;
     return host_entry;
@@ -265,6 +289,13 @@ size_t append_seek_table(const zl_cctx* c, u8* dst, size_t cap, size_t total, si
     w32(one_frame ? 1u : 0u);
     w32(ZL_INDEX_TAG);
     return total + need;
+}
+
+// the frame's content checksum behind its last block (zstd.c:27733 ZSTD_writeEpilogue): low 32 bits of XXH64, little-endian
+inline size_t append_checksum(u8* dst, size_t cap, size_t total, u32 x) {
+    if (total + 4 > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    dst[total] = (u8)x; dst[total + 1] = (u8)(x >> 8); dst[total + 2] = (u8)(x >> 16); dst[total + 3] = (u8)(x >> 24);
+    return total + 4;
 }
 
 size_t fill_chunk_table(zl_cctx* c, size_t n) {
@@ -400,10 +431,15 @@ size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void*
     hipStream_t st = cctx_stream(c, stream);
     const size_t nchunks = fill_chunk_table(c, n);
     if (ZL_IS_ERR(nchunks)) return nchunks;
-    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, use_one_frame(c, n, false) ? (u64)n : 0);
+    const bool one = use_one_frame(c, n, false);
+    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, one ? (u64)n : 0);
     if (ZL_IS_ERR(e)) return e;
     c->pending = true;
     c->pending_stream = st;
+    c->pending_hash = one && c->checksum;
+    c->pending_src = (const u8*)d_src;
+    c->pending_dst = (u8*)d_dst;
+    c->pending_n = n;
     return 0;
 }
 
@@ -421,11 +457,39 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
         if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->far_ms = ms; }
         if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
+    size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    if (c->pending_hash) {
+        // ONE frame with a content checksum, content in device memory: the XXH64 chain runs on the host (zl_xxh64.h says why),
+        // over pieces brought down through two pinned buffers so that the copy of one piece hides behind the hashing of the
+        // one before.  Rare on this entry (its default layout is independent frames, each checked on the device).
+        const size_t piece = (size_t)16 << 20;
+        if (!c->h_stage_in.ensure(2 * piece)) return kGpuUnavailable;
+        zlx::Xxh64 h;
+        hipStream_t st = c->pending_stream;
+        const size_t n = c->pending_n;
+        size_t sent = 0, k = 0;
+        auto fetch = [&](size_t slot) { const size_t len = std::min(piece, n - sent); const bool ok = hipMemcpyAsync((u8*)c->h_stage_in.p + slot * piece, c->pending_src + sent, len, hipMemcpyDeviceToHost, st) == hipSuccess; sent += len; return ok ? len : (size_t)0; };
+        size_t len_cur = n ? fetch(0) : 0;
+        while (len_cur) {
+            if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            const size_t len_next = sent < n ? fetch((k + 1) & 1) : 0;
+            h.update((const u8*)c->h_stage_in.p + (k & 1) * piece, len_cur);
+            len_cur = len_next;
+            k++;
+        }
+        if (h.total != n) return ZL_ERR(ZL_E_GENERIC);
+        const u32 x = h.low32();
+        u8 le[4] = {(u8)x, (u8)(x >> 8), (u8)(x >> 16), (u8)(x >> 24)};
+        if (hipMemcpyAsync(c->pending_dst + total, le, 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);  // (the bound leaves room)
+        total += 4;
+        ((u32*)c->h_fsize.p)[c->pending_chunks - 1] += 4;  // (the last chunk's size covers the frame's footer: what the decoder's chunk hint expects)
+        c->pending_hash = false;
+    }
     if (frame_sizes) {
         const u32* fs = (const u32*)c->h_fsize.p;
         for (size_t i = 0; i < c->pending_chunks; i++) frame_sizes[i] = fs[i];
     }
-    return (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    return total;
 }
 
 size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
@@ -463,7 +527,9 @@ namespace {
 // multiple of the section size) -- the whole input, or one device's shard of it (compress2_sharded).  src points at the
 // range's first byte.  With dst: the range's frames are brought down there as they are packed (cap bytes) and the byte
 // count is returned; without: they are left packed in c->d_dst and the count is returned.
-size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n_total, bool one_frame, size_t chunk0 = 0, size_t nchunks_range = 0, size_t total_chunks = 0) {
+// hs: ONE frame with a content checksum whose ranges arrive call by call (a pledged stream): the running XXH64.  The range's
+// bytes are added to it here; the range that holds the frame's last chunk appends the digest.
+size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t n_total, bool one_frame, size_t chunk0 = 0, size_t nchunks_range = 0, size_t total_chunks = 0, zlx::Xxh64* hs = nullptr) {
     { const size_t pd = cctx_prepare_dict(c, cctx_stream(c, nullptr)); if (ZL_IS_ERR(pd)) return pd; }
     const bool whole = nchunks_range == 0;
     const size_t all_chunks = whole ? chunks_of(n_total) : total_chunks;
@@ -511,6 +577,13 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     std::atomic<size_t> enqueued{0};
     std::atomic<bool> failed{false};
     size_t down_result = 0, down_total = 0;
+    // the content checksum of ONE frame (zstd.c:27733): a third thread runs XXH64 over the range's bytes where they lie, in host
+    // memory, beside the upload.  (A shard -- no dst -- leaves it to the caller, who sees the whole input.)
+    const bool hashing = one_frame && c->checksum && dst;
+    zlx::Xxh64 local_hash;
+    zlx::Xxh64* const hash = hs ? hs : &local_hash;
+    std::thread hasher;
+    if (hashing) hasher = std::thread([&]() { hash->update(src, n); });
     std::thread down([&]() {
         (void)hipSetDevice(dev);
         u64 have = 0;
@@ -541,6 +614,7 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     }
     if (err) failed.store(true);
     down.join();
+    if (hashing) hasher.join();
     for (int k = 0; k < ZL_PIPE_SETS; k++) (void)hipStreamSynchronize(c->sets[k].st);
     (void)hipStreamSynchronize(c->copy_stream);
     if (err) return err;
@@ -552,8 +626,14 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         if (hipMemcpy(&upto, (const u64*)c->d_totals.p + ngroups, 8, hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         return (size_t)upto;
     }
+    const bool footer = hashing && chunk0 + nchunks == all_chunks;  // this range ends the frame
+    if (footer) {
+        down_total = append_checksum(dst, cap, down_total, hash->low32());
+        if (ZL_IS_ERR(down_total)) return down_total;
+    }
     if (c->seek_table && nchunks > 1 && whole) {
         if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || hipMemcpy(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (footer) ((u32*)c->h_fsize.p)[nchunks - 1] += 4;  // (the table's sizes add up to the bytes in front of it)
         return append_seek_table(c, dst, cap, down_total, nchunks, n, one_frame);
     }
     return down_total;
@@ -584,6 +664,11 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
         for (int s = 0; s < slots; s++) th.emplace_back([&, s]() { (void)hipSetDevice(s % ndev); fn(s); });
         for (auto& t : th) t.join();
     };
+    const bool hashing = one_frame && c->checksum;  // ONE frame's content checksum covers every slot's bytes: hashed here, beside the slots' work
+    zlx::Xxh64 hash;
+    std::thread hasher;
+    if (hashing) hasher = std::thread([&]() { hash.update(src, n); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{hasher};
     run([&](int s) {
         zl_cctx* p = c->peers[s];
         p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict;
@@ -601,6 +686,11 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
     });
     (void)hipSetDevice(home);
     for (int s = 0; s < slots; s++) if (res[s]) return res[s];
+    if (hashing) {
+        hasher.join();
+        total = append_checksum(dst, cap, total, hash.low32());
+        if (ZL_IS_ERR(total)) return total;
+    }
     if (c->seek_table && nchunks > 1) {  // every slot's per-chunk sizes, in order
         if (!c->h_fsize.ensure(nchunks * sizeof(u32))) return kGpuUnavailable;
         size_t err = 0;
@@ -610,6 +700,7 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
         });
         (void)hipSetDevice(home);
         if (err) return err;
+        if (hashing) ((u32*)c->h_fsize.p)[nchunks - 1] += 4;
         return append_seek_table(c, dst, cap, total, nchunks, n, one_frame);
     }
     return total;
@@ -637,14 +728,23 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
     if (n && hipMemcpyAsync(c->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const size_t nchunks = fill_chunk_table(c, n);
     if (ZL_IS_ERR(nchunks)) return nchunks;
-    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st, use_one_frame(c, n, true) ? (u64)n : 0);
+    const bool one = use_one_frame(c, n, true);
+    const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st, one ? (u64)n : 0);
     if (ZL_IS_ERR(e)) return e;
+    const bool hashing = one && c->checksum;  // ONE frame's content checksum: XXH64 on this thread while the kernels run
+    zlx::Xxh64 hash;
+    if (hashing) hash.update(src, n);
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    const size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
     if (total > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
     if (hipMemcpyAsync(dst, c->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (c->seek_table && nchunks > 1) return append_seek_table(c, (u8*)dst, cap, total, nchunks, n, use_one_frame(c, n, true));
+    if (hashing) {
+        total = append_checksum((u8*)dst, cap, total, hash.low32());
+        if (ZL_IS_ERR(total)) return total;
+        ((u32*)c->h_fsize.p)[nchunks - 1] += 4;
+    }
+    if (c->seek_table && nchunks > 1) return append_seek_table(c, (u8*)dst, cap, total, nchunks, n, one);
     return total;
 }
 
@@ -726,7 +826,7 @@ size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
         c->cs.out_pos = 0;
         c->cs.pledged = ZL_CONTENTSIZE_UNKNOWN;
         c->cs.consumed = 0;
-        c->cs.started = c->cs.emitted = c->cs.finishing = false;
+        c->cs.started = c->cs.emitted = c->cs.finishing = c->cs.joined = false;
     }
     if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
         if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:22790
@@ -761,12 +861,15 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         // jobs are consecutive runs of ONE frame -- the bytes zl_compress2 writes for the whole input, so that a reader that
         // takes the first frame gets all of it.  Jobs are whole sections (64 MiB), the unit the far search never crosses.
         // Without a pledge every job is a frame of its own (the total is not known when the first header is written).
+        // A joined session stays joined: its jobs are only ever cut at section boundaries and at the pledged end (a flush
+        // elsewhere hands out what is complete, see below) -- a frame of its own in the middle of the unterminated one would
+        // be an invalid stream.
         const u64 pledged = S.pledged;
         size_t r;
-        if (pledged != ZL_CONTENTSIZE_UNKNOWN && pledged > ZL_STREAM_JOB && use_one_frame(c, (size_t)pledged, true) && S.consumed <= pledged &&
-            (S.consumed - n) % ZL_STREAM_JOB == 0 && (n == ZL_STREAM_JOB || S.consumed == pledged))
-            r = compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged));
-        else
+        if (S.joined) {
+            if ((S.consumed - n) % ZL_STREAM_JOB != 0 || !(n == ZL_STREAM_JOB || S.consumed == pledged)) { S.out.n = old; return ZL_ERR(ZL_E_STAGE_WRONG); }
+            r = compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &S.hash);
+        } else
             r = zl_compress2(c, at, bound, S.stage.p, n);
         S.out.n = old + (ZL_IS_ERR(r) ? 0 : r);
         if (ZL_IS_ERR(r)) return r;
@@ -778,9 +881,13 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
     while (!S.finishing && input->pos < input->size && S.out.empty()) {
         const size_t take = std::min(input->size - input->pos, ZL_STREAM_JOB - S.stage.size());
         if (!S.stage.append((const u8*)input->src + input->pos, take)) return ZL_ERR(ZL_E_MEMORY);
+        if (!S.started) S.hash.reset();
+        if (!S.started)  // with the size pledged and more than one job of it, the jobs are runs of ONE frame
+            S.joined = S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.pledged > ZL_STREAM_JOB && use_one_frame(c, (size_t)S.pledged, true);
         input->pos += take;
         S.consumed += take;
         S.started = true;
+        if (S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.consumed > S.pledged) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140: more than was pledged
         if (S.stage.size() == ZL_STREAM_JOB) {
             const size_t e = run_job();
             if (ZL_IS_ERR(e)) return e;
@@ -789,8 +896,11 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
     }
     if (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && !S.finishing) {
         if (end_op == ZL_e_end && S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.pledged != S.consumed) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140
-        // the rest of the input; at the end of a session that has written nothing, the frame of an empty input
-        if (!S.stage.empty() || (end_op == ZL_e_end && !S.emitted)) {
+        // the rest of the input; at the end of a session that has written nothing, the frame of an empty input.
+        // ZL_e_flush inside a joined session cuts no job: the frame's runs end at 64 MiB boundaries and at the pledged end only,
+        // so a flush hands out the jobs that are complete and keeps the rest collected (include/zl_hip.h).
+        const bool cut = !(S.joined && end_op == ZL_e_flush && S.consumed != S.pledged);
+        if (cut && (!S.stage.empty() || (end_op == ZL_e_end && !S.emitted))) {
             const size_t e = run_job();
             if (ZL_IS_ERR(e)) return e;
         }
@@ -802,7 +912,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
     if (S.finishing && S.out.empty()) {  // session complete: the next call starts a new one
         S.pledged = ZL_CONTENTSIZE_UNKNOWN;
         S.consumed = 0;
-        S.started = S.emitted = S.finishing = false;
+        S.started = S.emitted = S.finishing = S.joined = false;
         return 0;
     }
     return S.out.size() - S.out_pos;

@@ -1356,6 +1356,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         return false;
     }
     u32* const glink = BIG ? a.big->link : nullptr;
+    const u32 dict_len = BIG ? a.big->dict_len : 0u;  // uniform
     const zl_frame_desc fd = a.frames[f];
     const u8* src = a.src + fd.src_off;
     u8* dst = a.dst + fd.dst_off;
@@ -1438,7 +1439,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                 const u32 off = S.b_off[i];
                 if (S.b_out[i + 1] < my_out + ll || S.b_lit[i + 1] < my_lit) S.err = ZL_E_CORRUPTION;  // positions never decrease
                 if ((u64)my_lit + ll > lit_size) S.err = ZL_E_CORRUPTION;   // zstd.c:44030
-                if (off == 0 || (u64)off > op + my_out + ll) S.err = ZL_E_CORRUPTION;  // zstd.c:44045 (no dictionary on this path)
+                if (off == 0 || (u64)off > op + my_out + ll + dict_len) S.err = ZL_E_CORRUPTION;  // zstd.c:44045 (a dictionary's content lies in front of a large frame's first byte)
             }
             if (batch_end > ZL_BLOCK_MAX || batch_end < batch_start || S.b_out[0] != batch_start || S.b_lit[0] != lit_pos) { if (t == 0) S.err = ZL_E_CORRUPTION; }
             else if ((u64)batch_end > cap_left) { if (t == 0) S.err = ZL_E_DSTSIZE_TOO_SMALL; }
@@ -1509,12 +1510,14 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                         const i64 q = (m < o) ? (i64)p - (i64)o : (i64)mstart - (i64)o + (i64)(m % o);
                         if (q < (i64)batch_start) {
                             u32 defer = ZL3_ROOT;
+                            const u8* from = bdst + q;  // an earlier batch or an earlier block: already in memory
                             if (BIG) {
-                                const u64 fp = (u64)((i64)op + q);  // frame position of the source
-                                defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);  // (another segment | this segment: final, or waiting itself)
+                                const i64 fpi = (i64)op + q;  // frame position of the source
+                                if (fpi < 0) from = a.big->dict_end + fpi;  // in front of the frame: the dictionary's content
+                                else { const u64 fp = (u64)fpi; defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp); }  // (another segment | this segment: final, or waiting itself)
                             }
                             if (defer == ZL3_ROOT) {
-                                S.img[p + ibase] = bdst[q];  // an earlier batch or an earlier block: already in memory
+                                S.img[p + ibase] = *from;
                                 S.link[p - batch_start] = EX_FINAL;
                             } else {
                                 S.far[p - batch_start] = defer;
@@ -1596,7 +1599,9 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                     // byte by byte: a source in front of the segment, or one that is itself waiting, defers the byte
                     const u64 fm = op + mstart;  // frame position of the match
                     for (u32 m = t; m < ml; m += EX_THREADS) {
-                        const u64 fp = fm - o + (m % o);
+                        const i64 fpi = (i64)fm - (i64)o + (i64)(m % o);
+                        if (fpi < 0) { to[m] = a.big->dict_end[fpi]; continue; }  // the dictionary's content
+                        const u64 fp = (u64)fpi;
                         const u32 defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);
                         if (defer == ZL3_ROOT) to[m] = dst[fp];
                         else { a.big->tile_flag[(fm + m) >> ZL3_TILE_LOG] = 1; glink[fm + m] = defer; }

@@ -56,12 +56,15 @@ struct zl3_dev {  // device pointers of one large-frame decode
     u32* seg_tmp;   // per segment 16 words (zl3_plan_kernel): [0..5] its own numbers, [6..13] the scanned ones
     u32* max_blocks;
     u32 cap_blocks;
+    u32 dict_id;        // id of the dictionary loaded into the context (0: none, or raw content)
+    u32 dict_tables;    // the context holds a formatted dictionary: blocks may ride on ITS entropy tables (-> general kernel)
+    u32 have_dict;      // the context holds a dictionary of any kind
 };
 
 __device__ __forceinline__ void info_err(zl3_info* info, u32 code) { atomicCAS(&info->err, 0u, code); }
 
 // frame header (zstd.c:41050-41148) -> info; returns the header size or 0 after recording an error
-__device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_desc& fd, const u8* src, bool whole = true) {
+__device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_desc& fd, const u8* src, bool whole = true, u32 ctx_dict_id = 0) {
     const u64 n = fd.src_size;
     if (n < 5) { info->err = ZL_E_SRCSIZE_WRONG; return 0; }
     if (zl_rd_le(src, 4) != ZL_MAGIC) { info->err = ZL_E_PREFIX_UNKNOWN; return 0; }
@@ -84,7 +87,7 @@ __device__ __forceinline__ u32 zl3_frame_header(zl3_info* info, const zl_frame_d
     else if (fflag == 1) fcs = (u64)zl_rd_le(src + pos, 2) + 256;
     else if (fflag == 2) fcs = zl_rd_le(src + pos, 4);
     else fcs = (u64)zl_rd_le(src + pos, 4) | ((u64)zl_rd_le(src + pos + 4, 4) << 32);
-    if (did) { info->err = ZL_E_DICT_WRONG; return 0; }  // this path never has a dictionary (zstd.c:41318)
+    if (did && did != ctx_dict_id) { info->err = ZL_E_DICT_WRONG; return 0; }  // zstd.c:41318: the frame names a dictionary the context does not hold
     // (a frame that does not record its size -- what ZSTD_compressStream2 writes when nothing is pledged -- is
     // bounded by its block count: the host sizes the links from that)
     if (!whole) { info->fcs = fd.dst_cap; info->has_checksum = 0; return hs; }  // the first run of a frame dealt out over several devices: it regenerates what its share of the output holds
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
     zl3_info* info = d.info;
     const u8* src = src_base + fd.src_off;
     const u64 n = fd.src_size;
-    u32 pos = zl3_frame_header(info, fd, src);
+    u32 pos = zl3_frame_header(info, fd, src, true, d.dict_id);
     if (!pos) return;
     u32 nb = 0;
     for (;;) {
@@ -132,17 +135,23 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
 // of the block counts.  The hint is only a hint: every chunk must end exactly where the next one starts, the frame's
 // last block must be the last chunk's last block and no other -- otherwise ZL_E_FALLBACK_WALK sends the frame to (1).
 #define ZL3_CHUNK_BLOCKS_MAX 64u
-__global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, const u64* chunk_off, u32 nchunks, u32* cnt, const u32* first, u32 pass, u32 headerless, u32 not_last) {
+// (the last chunk's listed size covers the frame's footer too -- 4 bytes of content checksum when the header says so)
+__device__ __forceinline__ u32 zl3_tail(const u8* src, u32 tail, u32 headerless) { return tail != ZL3_TAIL_FROM_HEADER ? tail : ((!headerless && ((src[4] >> 2) & 1)) ? 4u : 0u); }
+__global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, const u64* chunk_off, u32 nchunks, u32* cnt, const u32* first, u32 pass, u32 headerless, u32 not_last, u32 tail) {
     const u32 c = blockIdx.x * 256 + threadIdx.x;
     zl3_info* info = d.info;
     if (c >= nchunks) return;
+    // pass 1 stores through first[], which the scan kernel only fills when pass 0 found every chunk sound AND the blocks fit the
+    // table (cap_blocks): after any error there is nothing to store, and what first[] holds is stale
+    if (pass == 1 && info->err) return;
     const u8* src = src_base + fd.src_off;
     u64 pos = chunk_off[c];
-    const u64 end = chunk_off[c + 1];
+    u64 end = chunk_off[c + 1];
+    if (c + 1 == nchunks) { const u32 tl = fd.src_size >= 5 ? zl3_tail(src, tail, headerless) : 0u; end = end >= tl ? end - tl : 0; }
     if (c == 0) {
         if (pass == 0) {
             if (headerless) { info->fcs = fd.dst_cap; info->has_checksum = 0; info->hdr_size = 0; }
-            else { const u32 hs = zl3_frame_header(info, fd, src, !not_last); if (!hs) return; info->hdr_size = hs; }
+            else { const u32 hs = zl3_frame_header(info, fd, src, !not_last, d.dict_id); if (!hs) return; info->hdr_size = hs; }
         }
         pos = info->hdr_size;
     }
@@ -155,7 +164,11 @@ __global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame
         pos += 3;
         const u32 csize = (type == 1) ? 1 : bsize;
         if (type == 3 || end - pos < csize || (type != 2 && bsize > ZL_BLOCK_MAX)) { bad = true; break; }
-        if (pass == 1) { d.hblk[first[c] + nb].src_off = (u32)pos; d.hblk[first[c] + nb].hdr = bh; }
+        if (pass == 1) {
+            const u32 slot = first[c] + nb;
+            if (slot >= d.cap_blocks) { bad = true; break; }  // (cannot happen behind a sound scan; a guard for the table's bounds)
+            d.hblk[slot].src_off = (u32)pos; d.hblk[slot].hdr = bh;
+        }
         nb++;
         pos += csize;
         if (last != ((!not_last && c + 1 == nchunks && pos == end) ? 1u : 0u)) { bad = true; break; }  // Last_Block: the last chunk's last block, and only that one
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void zl3_chunk_walk_kernel(zl3_dev d, zl_frame
     if (bad || nb == 0) { info_err(info, ZL_E_FALLBACK_WALK); return; }
     if (pass == 0) cnt[c] = nb;
 }
-__global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_frame_desc fd, const u32* cnt, u32* first, u32 nchunks, const u64* chunk_off) {
+__global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_frame_desc fd, const u32* cnt, u32* first, u32 nchunks, const u64* chunk_off, const u8* src_base, u32 headerless, u32 tail) {
     __shared__ u32 part[1024];
     zl3_info* info = d.info;
     if (info->err) return;
@@ -178,7 +191,8 @@ __global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_fram
         for (u32 i = 0; i < 1024; i++) { const u32 v = part[i]; part[i] = run; run += v; }
         if (run > d.cap_blocks) info->err = ZL_E_FALLBACK;
         info->nblocks = run;
-        const u64 end = chunk_off[nchunks];
+        const u32 tl = fd.src_size >= 5 ? zl3_tail(src_base + fd.src_off, tail, headerless) : 0u;
+        const u64 end = chunk_off[nchunks] >= tl ? chunk_off[nchunks] - tl : 0;
         info->end_pos = (u32)end;
         if (info->has_checksum && fd.src_size - end < 4) info->err = ZL_E_CHECKSUM_WRONG;
     }
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_fram
 __global__ __launch_bounds__(64) void zl3_host_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nblocks, u32 end_pos) {
     if (threadIdx.x != 0) return;
     zl3_info* info = d.info;
-    if (!zl3_frame_header(info, fd, src_base + fd.src_off)) return;
+    if (!zl3_frame_header(info, fd, src_base + fd.src_off, true, d.dict_id)) return;
     if (nblocks > d.cap_blocks) { info->err = ZL_E_FALLBACK; return; }
     if (info->has_checksum && fd.src_size - end_pos < 4) { info->err = ZL_E_CHECKSUM_WRONG; return; }
     info->nblocks = nblocks;
@@ -399,13 +413,15 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
         for (u32 b = b0; b < b1; b++) {
             const zl2_blk_rec* r = d.braw + b;
             if (r->type != 2) continue;
-            if (r->lit_mode == 3 && cur[0] == ZL3_NONE) info_err(info, ZL_E_DICT_CORRUPTED);
+            // (with a formatted dictionary in the context such a block rides on the DICTIONARY's tables, zstd.c:42053: the general
+            // kernel knows those; this pipeline's lanes do not)
+            if (r->lit_mode == 3 && cur[0] == ZL3_NONE) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_DICT_CORRUPTED);
             if (r->lit_mode == 2) cur[0] = b;
             if (r->nseq > 0 && r->seq_modes != 0x100u) {
                 const u32 m = r->seq_modes;
                 const u32 mk[3] = {m >> 6, (m >> 4) & 3, (m >> 2) & 3};
                 for (int q = 0; q < 3; q++) {
-                    if (mk[q] == 3) { if (cur[1 + q] == ZL3_NONE) info_err(info, ZL_E_CORRUPTION); }
+                    if (mk[q] == 3) { if (cur[1 + q] == ZL3_NONE) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_CORRUPTION); }
                     else cur[1 + q] = b;
                 }
             }
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(256) void zl3_totals_kernel(zl3_dev d, const u32* s
     blk_tot[b] = o;
 }
 
-__global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const uint4* blk_tot) {
+__global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const uint4* blk_tot, u32 rep_a, u32 rep_b, u32 rep_c) {
     zl3_info* info = d.info;
     const u32 lane = threadIdx.x, nb = info->nblocks, ns = info->nsegs;
     if (info->err) return;
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
         if (first != ZL3_NONE) { if (lane == 0) info->err = d.frec[first].err; return; }
     }
     u64 op = 0;                    // uniform: output bytes in front of this batch
-    u32 r0 = 1, r1 = 4, r2 = 8;    // uniform: history in front of this batch (zstd.c:41433)
+    u32 r0 = rep_a, r1 = rep_b, r2 = rep_c;    // uniform: history in front of this batch (1, 4, 8 at the start of a frame, zstd.c:41433; a dictionary brings its own, zstd.c:42053)
     u32 bad = 0;
     for (u32 b0 = 0; b0 < nb; b0 += 64) {
         const u32 b = b0 + lane;
@@ -622,6 +638,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     zl3_dev d;
     d.info = (zl3_info*)s->info.p; d.hblk = (zl3_hblk*)s->hblk.p; d.braw = (zl2_blk_rec*)s->braw.p; d.seg_first = (u32*)s->seg_first.p; d.blk_slot = (u32*)s->blk_slot.p;
     d.blk_dst = (u32*)s->blk_dst.p; d.rep_start = (u32*)s->rep_start.p; d.max_blocks = (u32*)s->word.p; d.cap_blocks = cap_blocks;
+    const bool have_dict = hint && hint->dict_len != 0;
+    d.have_dict = have_dict ? 1u : 0u;
+    d.dict_id = have_dict ? hint->dict_id : 0u;
+    d.dict_tables = (have_dict && hint->dict_formatted) ? 1u : 0u;
     d.brec = nullptr; d.frec = nullptr; d.plan = nullptr; d.frames = nullptr; d.ext = nullptr; d.seg_tmp = nullptr;
     if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     // ---- the block table: uploaded from the host's walk, walked per chunk with the caller's chunk offsets, or walked by one lane
@@ -633,9 +653,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     } else if (hint && hint->d_chunk_off && hint->nchunks) {
         const u32 nc = hint->nchunks;
         if (!s->cnt.ensure((size_t)nc * 4) || !s->first.ensure((size_t)nc * 4)) return kGpuUnavailable;
-        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u, hint->headerless, hint->not_last);
-        hipLaunchKernelGGL(zl3_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d, fd, (const u32*)s->cnt.p, (u32*)s->first.p, nc, hint->d_chunk_off);
-        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 1u, hint->headerless, hint->not_last);
+        if (hipMemsetAsync(s->cnt.p, 0, (size_t)nc * 4, st) != hipSuccess || hipMemsetAsync(s->first.p, 0, (size_t)nc * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u, hint->headerless, hint->not_last, hint->tail);
+        hipLaunchKernelGGL(zl3_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d, fd, (const u32*)s->cnt.p, (u32*)s->first.p, nc, hint->d_chunk_off, d_src, hint->headerless, hint->tail);
+        hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 1u, hint->headerless, hint->not_last, hint->tail);
         zl3_info probe;
         if (hipMemcpyAsync(&probe, d.info, sizeof(probe), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (probe.err == ZL_E_FALLBACK_WALK) { if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC); }  // the hint does not describe this frame: walk it
@@ -659,6 +680,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         hipLaunchKernelGGL(zl3_plan_kernel, dim3(1), dim3(1024), 0, st, d, fd);
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("plan");
+        if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);  // (blocks that ride on a dictionary's entropy tables)
     }
 #ifdef ZL_DEV_SWITCHES
     if (dbg) fprintf(stderr, "[zl3] blocks %u segments %u literals %llu sequences %llu err %u\n", info.nblocks, info.nsegs, (unsigned long long)info.lit_total, (unsigned long long)info.seq_total, info.err);
@@ -671,7 +693,8 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
             return kGpuUnavailable;
         zl3_big big;
-        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = ZL3_EXEC_RUN; big.pad = 0;
+        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = ZL3_EXEC_RUN;
+        big.dict_len = have_dict ? hint->dict_len : 0u; big.dict_end = have_dict ? hint->dict_end : nullptr;
         if (hipMemcpyAsync(s->big.p, &big, sizeof(big), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemsetAsync(s->tile_flag.p, 0, ntiles * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         // every byte starts out final; the exec kernel writes the links of the waiting ones only (a plain fill at memory speed
@@ -688,7 +711,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         stamp("entropy");
         if (!s->tot.ensure((size_t)cap_blocks * 16)) return kGpuUnavailable;
         hipLaunchKernelGGL(zl3_totals_kernel, dim3((info.nblocks + 255) / 256), dim3(256), 0, st, d, (const u32*)s->seq.p, (uint4*)s->tot.p);
-        hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const uint4*)s->tot.p);
+        {   // the history the frame starts with: a formatted dictionary's three offsets, else 1, 4, 8
+            const bool dr = have_dict && hint->dict_formatted;
+            hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const uint4*)s->tot.p, dr ? hint->dict_rep[0] : 1u, dr ? hint->dict_rep[1] : 4u, dr ? hint->dict_rep[2] : 8u);
+        }
         stamp("offsets");
         if (zl2_launch_segments_exec(&a, ZL3_EXEC_RUN, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("exec");

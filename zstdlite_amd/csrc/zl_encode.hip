@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
     u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
     if (back > ZL_FAR_GROUP - 1) back = ZL_FAR_GROUP - 1;
+    if (back > c) back = c;  // (columns exist for the launch's own chunks only)
     if (back == 0) return;
     const u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
     const u32 count = list[0];
@@ -1596,19 +1597,23 @@ __device__ __noinline__ u32 write_frame_header(u8* p, u32 n, u32 checksum, u32 d
 
 // zstd.c:27089 ZSTD_writeFrameHeader for the single-frame layout: a frame of `total` bytes whose blocks are written by
 // many chunks.  Single_Segment when the content fits the window (zstd.c:27100), else a Window_Descriptor of 2^wlog.
-__device__ __forceinline__ u32 joined_header_size(u64 total, u32 wlog) {
+__device__ __forceinline__ u32 dict_id_bytes(u32 dict_id) { return dict_id == 0 ? 0u : (dict_id < 256 ? 1u : (dict_id < 65536 ? 2u : 4u)); }
+__device__ __forceinline__ u32 joined_header_size(u64 total, u32 wlog, u32 dict_id) {
     const bool single = total <= (1ull << wlog);
     const u32 fcs = total < 256 ? (single ? 1u : 2u) : (total < 65536 + 256 ? 2u : (total < 0xFFFFFFFFull ? 4u : 8u));
-    return 5 + (single ? 0u : 1u) + fcs;
+    return 5 + (single ? 0u : 1u) + dict_id_bytes(dict_id) + fcs;
 }
-__device__ __noinline__ u32 write_frame_header_joined(u8* p, u64 total, u32 wlog) {
+__device__ __noinline__ u32 write_frame_header_joined(u8* p, u64 total, u32 wlog, u32 checksum, u32 dict_id) {
     wr_le(p, ZL_MAGIC, 4);
     const bool single = total <= (1ull << wlog);
-    const u32 fcs = joined_header_size(total, wlog) - 5 - (single ? 0u : 1u);
+    const u32 dbytes = dict_id_bytes(dict_id);
+    const u32 fcs = joined_header_size(total, wlog, dict_id) - 5 - (single ? 0u : 1u) - dbytes;
     const u32 fcs_flag = fcs == 1 ? 0u : (fcs == 2 ? 1u : (fcs == 4 ? 2u : 3u));
-    p[4] = (u8)((fcs_flag << 6) | (single ? (1u << 5) : 0u));
+    p[4] = (u8)((fcs_flag << 6) | (single ? (1u << 5) : 0u) | (checksum ? 4u : 0u) | (dbytes == 4 ? 3u : dbytes));
     u32 pos = 5;
     if (!single) p[pos++] = (u8)((wlog - 10) << 3);
+    wr_le(p + pos, dict_id, dbytes);
+    pos += dbytes;
     wr_le(p + pos, fcs == 2 ? total - 256 : total, fcs);
     return pos + fcs;
 }
@@ -1753,15 +1758,15 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     // (single-frame layout: only the frame's first chunk carries a header, only its last one ends the frame)
     const bool joined = a.joined != 0;
     const bool frame_first = !joined || a.chunk_base + c == 0, frame_last = !joined || a.chunk_base + c + 1 == a.total_chunks;
-    const u32 fh = joined ? (frame_first ? joined_header_size(a.total_size, a.wlog) : 0u)
-                          : (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + (a.dict_id == 0 ? 0u : (a.dict_id < 256 ? 1u : (a.dict_id < 65536 ? 2u : 4u)));
+    const u32 fh = joined ? (frame_first ? joined_header_size(a.total_size, a.wlog, a.dict_id) : 0u)
+                          : (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + dict_id_bytes(a.dict_id);
     for (u32 i = t; i < 4 * 256; i += ENC_THREADS) (&S.hist[0][0])[i] = 0;
     for (u32 i = t; i < 3 * 64; i += ENC_THREADS) (&S.seq_hist[0][0])[i] = 0;
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     if (t == 0) {
         S.fail = 0;
         if (!joined) write_frame_header(out, n, a.checksum, a.dict_id);
-        else if (frame_first) write_frame_header_joined(out, a.total_size, a.wlog);
+        else if (frame_first) write_frame_header_joined(out, a.total_size, a.wlog, a.checksum, a.dict_id);  // (the checksum itself: one XXH64 over the whole content, appended by the host -- zl_xxh64.h)
     }
     // ---- blocks: up to ZL_ENC_BLOCKS per chunk, cut at sequence boundaries near equal byte counts.
     // They share one set of entropy tables (the first block describes them, the others use the

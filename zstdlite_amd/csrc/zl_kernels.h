@@ -141,7 +141,8 @@ struct zl3_big {
     const u32* rep_start;         // per block: repcode history it starts with (3 words)
     const u32* seg_first;         // per segment: its first block
     u32 exec_run;                 // consecutive segments one exec workgroup works through
-    u32 pad;
+    u32 dict_len;                 // bytes of dictionary content that sit, as history, in front of the frame's first byte (0: none)
+    const u8* dict_end;           // one past the last of them: frame position -k is dict_end[-k]
 };
 
 struct zl2_side {           // owned by the decompression context: lets the two entropy kernels run side by side
