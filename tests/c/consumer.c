@@ -54,16 +54,28 @@ int main(void) {
         CHECK(fcs == n, "the frame records the whole content size");
         total = zl_decompressDCtx(dctx, back, (size_t)fcs, dst, fsize);  /* raw-file.c:189 */
         CHECK(total == n && memcmp(src, back, n) == 0, "one-shot round trip through the first-frame helpers");
-        /* a checksum context writes one independent frame per 128 KiB chunk: the whole-buffer twins size those */
+        /* a checksum context writes ONE frame too (zstd.c:27733: one XXH64 over the whole content, four bytes behind the last
+         * block); the independent-frames layout, on request, is what the whole-buffer twins size */
         CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 201 /* ZSTD_c_checksumFlag */, 1)), "checksum flag");
         CHECK(!zl_isError(zl_CCtx_getParameter(cctx, 201, &value)) && value == 1, "get parameter");
         csize2 = zl_compress2(cctx, dst2, bound, src, n);
         CHECK(!zl_isError(csize2), zl_getErrorName(csize2));
-        CHECK(zl_getFrameContentSize(dst2, csize2) == 131072, "checksum: one frame per 128 KiB chunk");
+        CHECK(csize2 == csize + 4 && zl_findFrameCompressedSize(dst2, csize2) == csize2 && zl_getFrameContentSize(dst2, csize2) == n, "checksum: still one frame, four bytes longer");
+        memset(back, 0, n);
+        total = zl_decompressDCtx(dctx, back, n, dst2, csize2);
+        CHECK(total == n && memcmp(src, back, n) == 0, "round trip of the checksummed frame");
+        dst2[csize2 - 1] ^= 1;
+        total = zl_decompressDCtx(dctx, back, n, dst2, csize2);
+        CHECK(zl_isError(total) && strcmp(zl_getErrorName(total), "Restored data doesn't match checksum") == 0, "a damaged checksum is reported (tests/testthat/test-checksums.R:24-27)");
+        CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 9003 /* ZL_c_frameLayout */, 1 /* ZL_layout_frames */)), "frame layout");
+        csize2 = zl_compress2(cctx, dst2, bound, src, n);
+        CHECK(!zl_isError(csize2), zl_getErrorName(csize2));
+        CHECK(zl_getFrameContentSize(dst2, csize2) == 131072, "independent frames on request: one per 128 KiB chunk");
         CHECK(zl_findDecompressedSize(dst2, csize2) == n && zl_findAllFramesCompressedSize(dst2, csize2) == csize2, "whole-buffer size twins");
         memset(back, 0, n);
         total = zl_decompressDCtx(dctx, back, n, dst2, csize2);
         CHECK(total == n && memcmp(src, back, n) == 0, "round trip of concatenated checksummed frames");
+        CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 9003, 0)), "frame layout back to the default");
         CHECK(!zl_isError(zl_CCtx_setParameter(cctx, 201, 0)), "checksum flag off");
         free(dst2);
         /* streaming out (raw-file-out.c:74-123): pledge, whole buffer as input, output in pieces */
