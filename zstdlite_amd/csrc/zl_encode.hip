@@ -145,6 +145,9 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #ifndef ZL_DENSE_SEQS_FAR
 #define ZL_DENSE_SEQS_FAR 8  // the same for the windowed layout, whose callers sit behind PCIe and asked for the reference's ratio
 #endif
+#ifndef ZL_DENSE_LIT_PCT_FAR
+#define ZL_DENSE_LIT_PCT_FAR 65  // windowed layout: 0 = by sequence count (above); else the dense body while literals are at most this percentage of a window
+#endif
 // DICT: a dictionary's content sits in front of every chunk.  A template parameter: without it the
 // position arithmetic, the pointer selects and the straddle tests of the dictionary fold away (5.93 -> 5.80 ms).
 // PROF: the in-kernel phase stamps of ZL_c_profile = 2 (compiled out otherwise: 0.7 %).
@@ -202,7 +205,11 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // candidates are nearer (mean age = table size), so their gathers hit closer caches -- 1 GiB mix: match 5.74 -> 4.98 ms
     // for 0.1 % of ratio (text -1.2 %, python sources -2.4 %; a distance cap on the short candidates bought the same time
     // for twice the ratio: DESIGN.md 3.3).  The other instantiations keep 2^12 entries.
-    constexpr int SLOG = HI ? SHORT_LOG_HI : ((DICT || FAR || INTRA) ? SHORT_LOG : SHORT_LOG_BULK);
+    // One frame at level 3: 2^13 + 2^13 entries (34 KiB of LDS: four workgroups per CU).  Round 2 ran this layout with the level >= 5
+    // tables (2^14 + 2^13: three per CU) at every level; measured on the 1 GiB mix: match 10.3 -> 7.9 ms, python sources 4.396 ->
+    // 4.368 (1.014x the reference's size), text 4.604 -> 4.533 (reference 4.512).  2^14 + 2^11 ran as fast and cost the sources
+    // twice as much.
+    constexpr int SLOG = HI ? SHORT_LOG_HI : (FAR ? SHORT_LOG_FAR : ((DICT || INTRA) ? SHORT_LOG : SHORT_LOG_BULK));
     __shared__ MatchSharedT<LLOG, SLOG> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
@@ -239,7 +246,6 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // in the independent-frames layout, whose measure is GB/s: there it cost 6.7 % of match time (5.09 -> 5.43 ms) for 0.4 %
     // of the mix's ratio (text +4.0 %, python sources +1.2 %).  Uniform.
     const bool back_on = ZL_BACK_MAX != 0 && (ZL_BACK_BULK || FAR || HI || DICT || intra_on);
-    if (INTRA) S.jump[1][t] = 0;  // the intra-window table (see the dense body): whatever the last workgroup left there would name candidates of its own
     lds_barrier();
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     const bool prof = PROF && a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     for (u32 ip = 0; ip < n;) {
-        u32 win, win_seqs = 0;
+        u32 win, win_seqs = 0, win_lits = 0;
         if (dense) {
             win = WIN;
             const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -290,13 +296,34 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 w_f[j] = 0;
                 const u32 V = D + p;  // virtual position
                 q_r[j] = q_l[j] = q_s[j] = V;
+                u32 el = 0, es = 0;
                 if (can_match[j]) {
                     hl[j] = hash_long(v[j], lshift);
                     hs[j] = hash_short<FAR>(v[j], sshift);
+                }
+                if (INTRA && intra_on) {
+                    // LOOK UP AND INSERT, wave after wave: wave k reads its entries and puts its own positions in their place before
+                    // wave k + 1 reads, so a lookup sees every position up to the start of its own wave's 64 -- the window's own
+                    // included (the next line of a listing, the next record) -- and the tables end up exactly as the insert phases
+                    // at the end of the window left them (the last wave's positions win).  Round 2 kept the window's own positions
+                    // in a third table of 256 slots (3 barriers + a gather of its own) AND ran the insert phases (3 more).
+                    unsigned short* const tl = (unsigned short*)S.tbl_long;
+                    unsigned short* const ts = (unsigned short*)S.tbl_short;
+                    for (u32 ph = 0; ph < 4; ph++) {
+                        if (ph == (t >> 6) && can_match[j]) {
+                            el = tl[hl[j]]; es = ts[hs[j]];
+                            const unsigned short val = (unsigned short)(V + 1);
+                            tl[hl[j]] = val; ts[hs[j]] = val;  // (a wave's LDS accesses execute in program order: every lane has read before any lane writes)
+                        }
+                        if (ph < 3) lds_barrier();
+                    }
+                } else if (can_match[j]) {
                     word_l[j] = S.tbl_long[hl[j] >> 1];
                     word_s[j] = S.tbl_short[hs[j] >> 1];
+                    el = (word_l[j] >> ((hl[j] & 1) * 16)) & 0xFFFF; es = (word_s[j] >> ((hs[j] & 1) * 16)) & 0xFFFF;
+                }
+                if (can_match[j]) {
                     if (search) {
-                        const u32 el = (word_l[j] >> ((hl[j] & 1) * 16)) & 0xFFFF, es = (word_s[j] >> ((hs[j] & 1) * 16)) & 0xFFFF;
                         const u32 dl = (V + 1 - el) & 0xFFFF, ds = (V + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
                         have_r[j] = rep && V + reach >= rep;
                         have_f[j] = FAR && far_off[j] != 0 && far_off[j] != rep && p + reach >= far_off[j];
@@ -330,29 +357,6 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     else if (same_sl) w_s[j] = w_l[j];
                 }
             }
-            // FAR: what the window itself holds.  The match tables know positions in front of the window only (the
-            // window's own are inserted at its end), so a repeat at a distance below 256 -- the next line of a
-            // listing, the next record -- would go unseen.  A small third table is filled AS the window is looked
-            // up, wave after wave: wave k sees the positions of waves 0..k-1 (and whatever earlier windows left).
-            // It shares LDS with an array of the stride-2 body; its candidates are verified like all others.
-            u64 w_i = 0;
-            u32 q_i = 0;
-            bool have_i = false;
-            if (INTRA && intra_on) {
-                unsigned short* const intra = (unsigned short*)S.jump[1];
-                const u32 slot = hs[0] & (WIN - 1);
-                const u32 pw = ip + t;
-                u32 e_i = 0;
-                for (u32 ph = 0; ph < 4; ph++) {
-                    if (ph == (t >> 6) && can_match[0]) { e_i = intra[slot]; intra[slot] = (unsigned short)(pw + 1); }
-                    if (ph < 3) lds_barrier();
-                }
-                const u32 d_i = (pw + 1 - e_i) & 0xFFFF;
-                have_i = search && can_match[0] && e_i != 0 && d_i != 0 && d_i <= pw;
-                q_i = pw - d_i;
-                if (have_i && ((have_l[0] && q_i == q_l[0]) || (have_s[0] && q_i == q_s[0]) || (have_r[0] && q_i == q_r[0]))) have_i = false;  // (already among the others)
-                if (have_i) w_i = ld64(src + q_i);
-            }
             {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN + t;
                 pref_ip = ip + WIN;
@@ -369,10 +373,6 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
                     if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
                     if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
-                    if (INTRA && have_i) {  // (nearer than anything the tables can name: wins ties)
-                        const u32 l_i = common_bytes(v[j], w_i);
-                        if (l_i >= MIN_MATCH + 1 && l_i >= best_len[j] && !(best_len[j] == l_i && best_off[j] == rep)) { best_len[j] = l_i; best_off[j] = p - q_i; q_best[j] = D + q_i; }  // (q_best is a virtual position; q_i a chunk position)
-                    }
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (ZL_INSERT_CAS) insert16_pair(S.tbl_long, hl[j], word_l[j], S.tbl_short, hs[j], word_s[j], D + p, D + ip, WIN);
                 }
             }
-            if (!ZL_INSERT_CAS) {
+            if (!ZL_INSERT_CAS && !(INTRA && intra_on)) {  // (the look-up-and-insert phases above have done it)
                 for (u32 ph = 0; ph < 4; ph++) {
                     if (ph == (t >> 6) && can_match[0]) {
                         const unsigned short val = (unsigned short)(D + ip + t + 1);
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
+            win_lits = tot_l;
             lds_barrier();
             if (prof) {
                 const u64 s4 = __builtin_amdgcn_s_memtime();
@@ -592,11 +593,26 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 q_r = p, q_l = p, q_s = p;
             u32 far_off2 = 0;
             if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
+            u32 el = 0, es = 0;
+            if (can0) { hl0 = hash_long(v0, lshift); hs0 = hash_short<FAR>(v0, sshift); }
+            if (can1) { hl1 = hash_long(v1, lshift); hs1 = hash_short<FAR>(v1, sshift); }
+            if (INTRA && intra_on) {  // look up and insert, wave after wave (see the dense body); both positions of every lane go in
+                unsigned short* const tl = (unsigned short*)S.tbl_long;
+                unsigned short* const ts = (unsigned short*)S.tbl_short;
+                for (u32 ph = 0; ph < 4; ph++) {
+                    if (ph == wave) {
+                        if (can0) { el = tl[hl0]; es = ts[hs0]; }
+                        if (can0) { tl[hl0] = (unsigned short)(p + 1); ts[hs0] = (unsigned short)(p + 1); }
+                        if (can1) { tl[hl1] = (unsigned short)(p + 2); ts[hs1] = (unsigned short)(p + 2); }
+                    }
+                    if (ph < 3) lds_barrier();
+                }
+            } else {
+                if (can0) { wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1]; el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF; es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF; }
+                if (can1) { wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1]; }  // the odd position is only inserted: its table words are read here, next to the others
+            }
             if (can0) {
-                hl0 = hash_long(v0, lshift); hs0 = hash_short<FAR>(v0, sshift);
-                wl0 = S.tbl_long[hl0 >> 1]; ws0 = S.tbl_short[hs0 >> 1];
                 if (search) {
-                    const u32 el = (wl0 >> ((hl0 & 1) * 16)) & 0xFFFF, es = (ws0 >> ((hs0 & 1) * 16)) & 0xFFFF;
                     const u32 dl = (p + 1 - el) & 0xFFFF, ds = (p + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
                     have_r = rep && p + reach >= rep;
                     have_f = FAR && far_off2 != 0 && far_off2 != rep && p + reach >= far_off2;
@@ -606,10 +622,6 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     if (have_l) q_l = p - dl;
                     if (have_s) q_s = p - ds;
                 }
-            }
-            if (can1) {  // the odd position is only inserted: its table words are read here, next to the others
-                hl1 = hash_long(v1, lshift); hs1 = hash_short<FAR>(v1, sshift);
-                wl1 = S.tbl_long[hl1 >> 1]; ws1 = S.tbl_short[hs1 >> 1];
             }
             u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
             if (can0 && search) {  // (as in the stride-1 body: candidates are fetched by the lanes that have one, each position once)
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             if (ZL_INSERT_CAS) {
                 if (can0) insert16_pair(S.tbl_long, hl0, wl0, S.tbl_short, hs0, ws0, p, ip, WIN2);
                 if (can1) insert16_pair(S.tbl_long, hl1, wl1, S.tbl_short, hs1, ws1, p + 1, ip, WIN2);
-            } else {
+            } else if (!(INTRA && intra_on)) {
                 for (u32 ph = 0; ph < 4; ph++) {
                     if (ph == wave) {
                         if (can0) { ((unsigned short*)S.tbl_long)[hl0] = (unsigned short)(p + 1); ((unsigned short*)S.tbl_short)[hs0] = (unsigned short)(p + 1); }
@@ -793,6 +805,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
+            win_lits = tot_l;
             lds_barrier();
             if (prof) {
                 const u64 s4 = __builtin_amdgcn_s_memtime();
@@ -821,7 +834,15 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             nlit += to - ip;
             ip = to;
         }
+#if ZL_DENSE_LIT_PCT_FAR
+        // windowed layout: the dense body where MATCHES COVER the data (literals at most this share of the window), not where
+        // sequences are many: i.i.d. bytes over a small alphabet yield twenty 5-byte matches per 512 bytes that are worth
+        // little (iid10 in one frame: 5.7 ms per 256 MiB in the dense body for a WORSE ratio than the sparse one's)
+        if (FAR) dense = !a.sparse_only && win_lits * 100u <= win * (u32)ZL_DENSE_LIT_PCT_FAR;
+        else
+#endif
         dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= (FAR ? ZL_DENSE_SEQS_FAR : ZL_DENSE_SEQS));
+        (void)win_lits;
     }
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
@@ -947,7 +968,10 @@ static_assert(ZL_FAR_BUCKET_LOG + 15 <= 32 - 3, "a list key holds bucket and tag
 // each thread keeps in flight, not the number of waves.  Every thread takes 8 consecutive positions from ONE 16-byte
 // load, four such loads per trip.)
 #define FAR_SPAN 8u                     // positions per thread and load
-__global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
+// (1024 threads per chunk: a streaming kernel whose 64 KiB column allows two workgroups per CU wants every wave slot of them;
+// with 256 threads it ran at 1.8 TB/s)
+#define FAR_BUILD_THREADS 1024u
+__global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
     __shared__ u32 col[FAR_COL];
     __shared__ u32 count;
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
@@ -956,25 +980,25 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
     const u32 sl = a.sample_log;
     u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
-    for (u32 i = t; i < FAR_COL; i += ENC_THREADS) col[i] = 0;
+    for (u32 i = t; i < FAR_COL; i += FAR_BUILD_THREADS) col[i] = 0;
     if (t == 0) count = 0;
     {   // the chunk's hint words start out empty (the probe kernel raises them with atomicMax)
         uint4* h4 = (uint4*)(a.hints + (size_t)c * ZL_FAR_HINT_WORDS);
-        for (u32 i = t; i < ZL_FAR_HINT_WORDS / 4; i += ENC_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
+        for (u32 i = t; i < ZL_FAR_HINT_WORDS / 4; i += FAR_BUILD_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (u32 ip = 0; ip < lim; ip += ENC_THREADS * FAR_SPAN * FAR_UNROLL) {
+    for (u32 ip = 0; ip < lim; ip += FAR_BUILD_THREADS * FAR_SPAN * FAR_UNROLL) {
         uint4 w[FAR_UNROLL];
 #pragma unroll
         for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p0 = ip + (k * ENC_THREADS + t) * FAR_SPAN;
+            const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
             w[k] = make_uint4(0, 0, 0, 0);
             if (p0 + 16 <= lim + 7) w[k] = ld128(src + p0);               // 16 bytes from p0 lie inside what far_limit guards (lim + 7 bytes are readable)
             else for (u32 i = 0; i < 16 && p0 + i < lim + 7; i++) ((u32*)&w[k])[i >> 2] |= (u32)src[p0 + i] << (8 * (i & 3));
         }
 #pragma unroll
         for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p0 = ip + (k * ENC_THREADS + t) * FAR_SPAN;
+            const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
             const u64 lo = (u64)w[k].x | ((u64)w[k].y << 32), hi = (u64)w[k].z | ((u64)w[k].w << 32);
             u32 mine = 0, keys[FAR_SPAN];
 #pragma unroll
@@ -1010,13 +1034,36 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_build_kernel(zl_far_args a
     if (t == 0) list[0] = count < ZL_FAR_LIST_CAP ? count : ZL_FAR_LIST_CAP;
     uint4* out = (uint4*)(a.table + (size_t)c * FAR_COL);
     const uint4* in = (const uint4*)col;
-    for (u32 i = t; i < FAR_COL / 4; i += ENC_THREADS) out[i] = in[i];
+    for (u32 i = t; i < FAR_COL / 4; i += FAR_BUILD_THREADS) out[i] = in[i];
 }
 
-#define FAR_PER_THREAD 64u   // listed positions a thread holds in registers at a time
-__global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
-    __shared__ u32 col[FAR_COL];
-    const u32 c = blockIdx.x, t = threadIdx.x;
+// The probe kernel: 1024 threads per chunk, sixteen listed positions per thread in registers (round 2 held 64 per thread in a
+// 256-thread workgroup: 256 VGPRs + 13 AGPRs, ONE wave per SIMD, so that nothing overlapped the column loads -- 4.4 ms per GiB at
+// 1.8 TB/s of column traffic).  Two workgroups share a CU (64 KiB of LDS each): one streams its next column while the other looks
+// its entries up.
+#define FAR_PROBE_THREADS 1024u
+#define FAR_PER_THREAD 16u   // listed positions a thread holds in registers at a time
+// Workgroup b of a launch tends to run on XCD b mod 8 (dispatch is round-robin over the XCDs; nothing depends on it).  Runs of
+// FAR_XCD_RUN consecutive chunks go to one XCD: the workgroups resident there at one time then stream the SAME columns (chunk c
+// wants those of c-1 .. c-15), and the XCD's L2 serves most of the fifteen-fold re-read that otherwise goes out to the fabric.
+// (Runs, not one contiguous share per XCD: the chunks' costs differ with the data, and a share per XCD left most of the device
+// idle while the two XCDs that held the text quarter of the bench vector worked: 6.0 -> 8.9 ms.)
+#define FAR_XCDS 8u
+#ifndef FAR_XCD_RUN
+#define FAR_XCD_RUN 32u
+#endif
+__device__ __forceinline__ u32 far_xcd_chunk(u32 b) {
+#if FAR_XCD_RUN
+    const u32 x = b % FAR_XCDS, i = b / FAR_XCDS;
+    return ((i / FAR_XCD_RUN) * FAR_XCDS + x) * FAR_XCD_RUN + i % FAR_XCD_RUN;  // (>= nchunks at the ragged end: those workgroups leave)
+#else
+    return b;
+#endif
+}
+__global__ __launch_bounds__(FAR_PROBE_THREADS, 8) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
+    __shared__ __align__(16) u32 col[FAR_COL];
+    const u32 c = far_xcd_chunk(blockIdx.x), t = threadIdx.x;
+    if (c >= nchunks) return;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
@@ -1027,22 +1074,26 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
     const u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
     const u32 count = list[0];
     u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
-    for (u32 seg = 0; seg < count; seg += ENC_THREADS * FAR_PER_THREAD) {
+    for (u32 seg = 0; seg < count; seg += FAR_PROBE_THREADS * FAR_PER_THREAD) {
         // key[e]: bucket | tag << 14 while the entry is looking; the offset it found once it has (bit e of `found`)
         u32 key[FAR_PER_THREAD], pos[FAR_PER_THREAD];
-        u64 open = 0, found = 0;
+        u32 open = 0, found = 0;
 #pragma unroll
         for (u32 e = 0; e < FAR_PER_THREAD; e++) {
-            const u32 i = seg + e * ENC_THREADS + t;  // (consecutive threads read consecutive pairs)
+            const u32 i = seg + e * FAR_PROBE_THREADS + t;  // (consecutive threads read consecutive pairs)
             key[e] = 0; pos[e] = 0;
-            if (i < count) { const uint2 kp = *(const uint2*)(list + 16 + 2 * (size_t)i); key[e] = kp.x; pos[e] = kp.y; open |= 1ull << e; }
+            if (i < count) { const uint2 kp = *(const uint2*)(list + 16 + 2 * (size_t)i); key[e] = kp.x; pos[e] = kp.y; open |= 1u << e; }
         }
         // ---- the columns of the chunks in front, nearest first: an entry stops at the first one that carries its tag
         for (u32 k = 1; k <= back; k++) {
-            {
+            {   // the column goes straight from memory into LDS (global_load_lds_dwordx4: no registers in between, every load of
+                // the workgroup in flight at once; a wave's 64 x 16 bytes land in lane order, which is the column's own order)
                 const uint4* in = (const uint4*)(a.table + (size_t)(c - k) * FAR_COL);
                 uint4* out = (uint4*)col;
-                for (u32 i = t; i < FAR_COL / 4; i += ENC_THREADS) out[i] = in[i];
+#pragma unroll
+                for (u32 i = 0; i < FAR_COL / 4 / FAR_PROBE_THREADS; i++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + t + FAR_PROBE_THREADS * i), (__attribute__((address_space(3))) void*)(out + t + FAR_PROBE_THREADS * i), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
             u32 x[FAR_PER_THREAD];
@@ -1051,24 +1102,24 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
 #pragma unroll
             for (u32 e = 0; e < FAR_PER_THREAD; e++) {
                 const bool hit = ((open >> e) & 1) && x[e] != 0 && (x[e] & 0x7FFFu) == (key[e] >> ZL_FAR_BUCKET_LOG);
-                if (hit) { key[e] = k * ZL_CHUNK + pos[e] - (x[e] >> 15); open &= ~(1ull << e); found |= 1ull << e; }
+                if (hit) { key[e] = k * ZL_CHUNK + pos[e] - (x[e] >> 15); open &= ~(1u << e); found |= 1u << e; }
             }
             __syncthreads();
         }
-        // ---- check the hits against the bytes (eight at a time, so that their loads travel together), measure them (up to
+        // ---- check the hits against the bytes (four at a time, so that their loads travel together), measure them (up to
         // 32 bytes) and raise the hint word of their neighbourhood: the longest hit wins (ties: the larger offset)
 #pragma unroll
-        for (u32 e0 = 0; e0 < FAR_PER_THREAD; e0 += 8) {
-            if (!((found >> e0) & 0xFF)) continue;
-            u64 va[8], vb[8];
+        for (u32 e0 = 0; e0 < FAR_PER_THREAD; e0 += 4) {
+            if (!((found >> e0) & 0xF)) continue;
+            u64 va[4], vb[4];
 #pragma unroll
-            for (u32 j = 0; j < 8; j++) {
+            for (u32 j = 0; j < 4; j++) {
                 const bool on = (found >> (e0 + j)) & 1;
                 va[j] = on ? ld64(src + pos[e0 + j]) : 0;
                 vb[j] = on ? ld64(src + pos[e0 + j] - key[e0 + j]) : 1;
             }
 #pragma unroll
-            for (u32 j = 0; j < 8; j++) {
+            for (u32 j = 0; j < 4; j++) {
                 if (va[j] != vb[j]) continue;
                 const u32 p = pos[e0 + j], off = key[e0 + j];
                 const u8* q = src + p - off;
@@ -1086,12 +1137,14 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_far_probe_kernel(zl_far_args a
 
 extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_far_build_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    hipLaunchKernelGGL(zl_far_build_kernel, dim3(nchunks), dim3(FAR_BUILD_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_far_probe_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    static_assert((FAR_COL / 4) % FAR_PROBE_THREADS == 0, "a column is a whole number of 16-byte loads per thread");
+    const u32 round_to = FAR_XCD_RUN ? FAR_XCDS * FAR_XCD_RUN : 1u;
+    hipLaunchKernelGGL(zl_far_probe_kernel, dim3(((nchunks + round_to - 1) / round_to) * round_to), dim3(FAR_PROBE_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -1106,9 +1159,8 @@ extern "C" hipError_t zl_launch_match_wide(const zl_match_args* a, u32 nchunks, 
 #endif
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    // levels >= 5, and the one-frame layout at every level: its callers sit behind PCIe (host entries: 34 GB/s of link against
-    // 50-60 GB/s of kernels) and asked for the reference's ratio, so it always takes the larger tables
-    if ((a->hi || a->far_hints) && !a->dict_len) {
+    // levels >= 5: the larger tables
+    if (a->hi && !a->dict_len) {
         if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);

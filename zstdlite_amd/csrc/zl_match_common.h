@@ -50,6 +50,9 @@ __device__ __forceinline__ u32 hash5(u64 v) { return (u32)(((v << (64 - 8 * ZL_S
 #define SHORT_LOG_HI 13
 #endif
 __device__ __forceinline__ u32 hash_long(u64 v, u32 shift /* 64 - log2 of the table's entries */) { return (u32)(((v << (64 - 8 * ZL_LONG_BYTES)) * 0x9E3779B185EBCA87ULL) >> shift); }
+#ifndef SHORT_LOG_FAR
+#define SHORT_LOG_FAR 13   // the one-frame layout at level 3 (zl_encode.hip says why)
+#endif
 #ifndef SHORT_LOG_BULK
 #define SHORT_LOG_BULK 11  // the bulk instantiation of the match kernel (zl_encode.hip says why)
 #endif
