@@ -45,6 +45,7 @@ struct zl_cctx_s {
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    int copy_pair_duplex = -1;  // -1: not bound yet; 1 / 0: the pair's copies overlap / take turns (zl_bind_copy_pair)
     std::vector<hipEvent_t> pipe_events;  // grow-only pool for the pipeline
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
     // pending device-resident call
@@ -498,6 +499,8 @@ size_t zl_cctx_kernel_ms(const zl_cctx* c, double* ms) {
     return 0;
 }
 size_t zl_cctx_last_slots(const zl_cctx* c) { return c ? (size_t)c->last_slots : 0; }
+// not part of the public header: 1 when the context's upload and download streams sit on two copy engines, 0 when they take turns, -1 before the first large host call
+int zl_cctx_copy_duplex(const zl_cctx* c) { return c ? c->copy_pair_duplex : -1; }
 size_t zl_cctx_far_ms(const zl_cctx* c, double* ms) {
     if (!c || !ms || !c->profile || !c->ev_valid) return ZL_ERR(ZL_E_STAGE_WRONG);
     *ms = c->far_ms;
@@ -555,6 +558,23 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         return kGpuUnavailable;
     if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
     if (!c->down_stream && hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
+    if (c->copy_pair_duplex < 0 && dst) {
+        // the upload and the download stream on two copy engines (zl_host.h): bound once per context, a new download stream tried
+        // a few times when the first falls onto the upload stream's engine
+        const size_t probe = (size_t)16 << 20;
+        c->copy_pair_duplex = 0;
+        if (c->h_stage_in.ensure(2 * probe) && c->d_src.cap >= 2 * probe) {
+            for (int attempt = 0; attempt < 8 && !c->copy_pair_duplex; attempt++) {
+                if (attempt) {  // a fresh stream in place of one of the two, in turn
+                    hipStream_t& again = (attempt & 1) ? c->down_stream : c->copy_stream;
+                    (void)hipStreamDestroy(again);
+                    again = nullptr;
+                    if (hipStreamCreateWithFlags(&again, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
+                }
+                c->copy_pair_duplex = zl_bind_copy_pair(c->copy_stream, c->down_stream, c->h_stage_in.p, c->d_src.p, probe) ? 1 : 0;
+            }
+        }
+    }
     for (int k = 0; k < ZL_PIPE_SETS; k++)
         if (!c->sets[k].st && hipStreamCreateWithFlags(&c->sets[k].st, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
     while (c->pipe_events.size() < 3 * ngroups + 1) {
@@ -599,6 +619,11 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         down_total = (size_t)have;
     });
     size_t err = 0;
+#ifdef ZL_DEV_SWITCHES
+    static const bool dbg_pipe = getenv("ZL_DEBUG_PIPE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_start = now_ms();
+#endif
     for (size_t g = 0; g < ngroups && !err; g++) {
         const size_t first = g * ZL_PIPE_CHUNKS;
         const u32 cnt = (u32)std::min<size_t>(ZL_PIPE_CHUNKS, nchunks - first);
@@ -613,7 +638,15 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         enqueued.store(g + 1, std::memory_order_release);
     }
     if (err) failed.store(true);
+#ifdef ZL_DEV_SWITCHES
+    const double t_enq = now_ms();
+    if (dbg_pipe) { (void)hipStreamSynchronize(c->copy_stream); }
+    const double t_up = now_ms();
+#endif
     down.join();
+#ifdef ZL_DEV_SWITCHES
+    if (dbg_pipe) fprintf(stderr, "[zl pipe] enqueued (uploads handed over) %.2f ms, uploads done %.2f ms, downloads done %.2f ms\n", t_enq - t_start, t_up - t_start, now_ms() - t_start);
+#endif
     if (hashing) hasher.join();
     for (int k = 0; k < ZL_PIPE_SETS; k++) (void)hipStreamSynchronize(c->sets[k].st);
     (void)hipStreamSynchronize(c->copy_stream);

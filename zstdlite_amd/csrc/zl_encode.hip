@@ -145,6 +145,9 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 #ifndef ZL_DENSE_SEQS_FAR
 #define ZL_DENSE_SEQS_FAR 8  // the same for the windowed layout, whose callers sit behind PCIe and asked for the reference's ratio
 #endif
+#ifndef ZL_SUB_LANES
+#define ZL_SUB_LANES 8   // dense body, look-up-and-insert phases: lanes of a wave that read and insert together (64: the whole wave at once)
+#endif
 #ifndef ZL_DENSE_LIT_PCT_FAR
 #define ZL_DENSE_LIT_PCT_FAR 65  // windowed layout: 0 = by sequence count (above); else the dense body while literals are at most this percentage of a window
 #endif
@@ -310,10 +313,21 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     unsigned short* const tl = (unsigned short*)S.tbl_long;
                     unsigned short* const ts = (unsigned short*)S.tbl_short;
                     for (u32 ph = 0; ph < 4; ph++) {
-                        if (ph == (t >> 6) && can_match[j]) {
-                            el = tl[hl[j]]; es = ts[hs[j]];
-                            const unsigned short val = (unsigned short)(V + 1);
-                            tl[hl[j]] = val; ts[hs[j]] = val;  // (a wave's LDS accesses execute in program order: every lane has read before any lane writes)
+                        if (ph == (t >> 6)) {
+                            // ... and inside a wave, eight lanes after eight lanes (a wave's LDS accesses execute in program order: no
+                            // barrier needed): a lookup sees everything up to 8 positions in front of it.  What that buys is the
+                            // NEAREST repeat of records of 8 or 16 bytes -- a column of doubles, R's numeric vector -- whose
+                            // neighbours differ in one or two bytes: seq(0, by = 0.25) matched its ninth-last value and paid a full byte
+                            // per literal where the last value leaves 2 to 4 bits (1.57x the reference's size; tests/ratio_inputs.py).
+#pragma unroll
+                            for (u32 sub = 0; sub < 64 / ZL_SUB_LANES; sub++) {
+                                if (((t & 63) / ZL_SUB_LANES) == sub && can_match[j]) {
+                                    el = tl[hl[j]]; es = ts[hs[j]];
+                                    const unsigned short val = (unsigned short)(V + 1);
+                                    tl[hl[j]] = val; ts[hs[j]] = val;
+                                }
+                                asm volatile("" ::: "memory");
+                            }
                         }
                         if (ph < 3) lds_barrier();
                     }

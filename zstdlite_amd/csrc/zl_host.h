@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "zl_format.h"
 
@@ -109,6 +110,37 @@ struct ByteBuf {
     bool empty() const { return n == 0; }
     size_t size() const { return n; }
 };
+
+// Two copy streams that use the link in BOTH directions at once.  Measured on this platform (round 2, scripts/dev/exp_duplex*):
+// a stream is tied to a copy engine by its first copy of a MiB or more -- the engine that is idle at that moment -- and keeps it;
+// an upload stream and a download stream whose first large copies followed each other share ONE engine and take turns for good
+// (1 GiB up + 0.65 GiB down: 31 ms instead of 21).  So the pair is bound on purpose: first copies from pinned memory, overlapping
+// in time; then checked by timing (together against one after the other).  Returns true when the pair overlaps.
+// pin / dev: scratch of at least 2 * bytes each (pinned host, device).
+static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin, void* dev, size_t bytes) {
+    u8* hp = (u8*)pin;
+    u8* dp = (u8*)dev;
+    auto both = [&]() {
+        (void)hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, up);
+        (void)hipMemcpyAsync(hp + bytes, dp + bytes, bytes, hipMemcpyDeviceToHost, down);
+        (void)hipStreamSynchronize(up);
+        (void)hipStreamSynchronize(down);
+    };
+    both();  // the binding copies
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_up = 1e9, t_dn = 1e9, t_both = 1e9;
+    for (int k = 0; k < 2; k++) {
+        double t0 = now();
+        (void)hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, up); (void)hipStreamSynchronize(up);
+        double t1 = now();
+        (void)hipMemcpyAsync(hp + bytes, dp + bytes, bytes, hipMemcpyDeviceToHost, down); (void)hipStreamSynchronize(down);
+        double t2 = now();
+        both();
+        double t3 = now();
+        t_up = t1 - t0 < t_up ? t1 - t0 : t_up; t_dn = t2 - t1 < t_dn ? t2 - t1 : t_dn; t_both = t3 - t2 < t_both ? t3 - t2 : t_both;
+    }
+    return t_both < 0.75 * (t_up + t_dn);
+}
 
 static int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
 static int g_num_cu = 256;
