@@ -245,6 +245,13 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // (a launch that mixes small inputs with chunks of large ones -- a batch -- must write for every chunk what a launch of
     // its own would: the chunks of large inputs hash as the bulk instantiation does)
     const u32 sshift = (INTRA && !DICT && !FAR && !HI && !intra_on) ? 64u - SHORT_LOG_BULK : 64u - (u32)SLOG;
+    // Inputs of at most 16 KiB (no dictionary): the short table hashes FOUR bytes and a table candidate of four bytes is a match, as
+    // the reference's level 3 does for such inputs (zstd.c:29607: minMatch 4 up to 16 KiB); other single-chunk inputs hash five
+    // (zstd.c:29581).  A pickled data frame of 1 KiB held 9 sequences against the reference's 56 (1.29x its size): its repeats are
+    // 4 and 5 bytes long, 12 bytes apart.  Uniform; folds to the constants of the layout where the instantiation knows them.
+    const bool tiny = INTRA && !DICT && !FAR && !HI && intra_on && n <= 16384u;
+    const u32 sbsh = FAR ? 64u - 8u * ZL_SHORT_BYTES_FAR : (tiny ? 32u : ((INTRA && !DICT && !HI && intra_on) ? 24u : 64u - 8u * ZL_SHORT_BYTES));
+    const u32 tmin = tiny ? MIN_MATCH : MIN_MATCH + 1;  // shortest match a table candidate may be (a repeat offset: MIN_MATCH)
     // backward extension of matches (stride-1 body): everywhere but on the bulk path -- the chunks of large inputs at level 3
     // in the independent-frames layout, whose measure is GB/s: there it cost 6.7 % of match time (5.09 -> 5.43 ms) for 0.4 %
     // of the mix's ratio (text +4.0 %, python sources +1.2 %).  Uniform.
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 u32 el = 0, es = 0;
                 if (can_match[j]) {
                     hl[j] = hash_long(v[j], lshift);
-                    hs[j] = hash_short<FAR>(v[j], sshift);
+                    hs[j] = hash_short_rt(v[j], sbsh, sshift);
                 }
                 if (INTRA && intra_on) {
                     // LOOK UP AND INSERT, wave after wave: wave k reads its entries and puts its own positions in their place before
@@ -385,8 +392,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (can_match[j] && search) {
                     const u32 l_r = common_bytes(v[j], w_r[j]), l_l = common_bytes(v[j], w_l[j]), l_s = common_bytes(v[j], w_s[j]);
                     if (have_r[j] && l_r >= MIN_MATCH) { best_len[j] = l_r; best_off[j] = rep; q_best[j] = q_r[j]; }
-                    if (have_l[j] && l_l >= MIN_MATCH + 1 && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
-                    if (have_s[j] && best_len[j] < 8 && l_s >= MIN_MATCH + 1 && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
+                    if (have_l[j] && l_l >= tmin && l_l > best_len[j]) { best_len[j] = l_l; best_off[j] = D + p - q_l[j]; q_best[j] = q_l[j]; }
+                    if (have_s[j] && best_len[j] < 8 && l_s >= tmin && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
@@ -608,8 +615,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u32 far_off2 = 0;
             if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
             u32 el = 0, es = 0;
-            if (can0) { hl0 = hash_long(v0, lshift); hs0 = hash_short<FAR>(v0, sshift); }
-            if (can1) { hl1 = hash_long(v1, lshift); hs1 = hash_short<FAR>(v1, sshift); }
+            if (can0) { hl0 = hash_long(v0, lshift); hs0 = hash_short_rt(v0, sbsh, sshift); }
+            if (can1) { hl1 = hash_long(v1, lshift); hs1 = hash_short_rt(v1, sbsh, sshift); }
             if (INTRA && intra_on) {  // look up and insert, wave after wave (see the dense body); both positions of every lane go in
                 unsigned short* const tl = (unsigned short*)S.tbl_long;
                 unsigned short* const ts = (unsigned short*)S.tbl_short;
@@ -1838,7 +1845,14 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     // They share one set of entropy tables (the first block describes them, the others use the
     // repeat modes, zstd.c:20745 / :21059), which keeps the format overhead at ~12 bytes per block
     // and lets a decoder run the blocks' Huffman streams and FSE chains side by side.
-    const u32 nbk = (n >> 13) < 1 ? 1u : ((n >> 13) > ZL_ENC_BLOCKS ? (u32)ZL_ENC_BLOCKS : (n >> 13));
+    // (... and no more blocks than the chunk's content is worth: every block costs a header, two section headers and a stream
+    // split, about 20 bytes, which a chunk that is a few hundred sequences of long matches -- records that repeat, ratio 100 and
+    // more -- cannot carry eight times: one block per 4 KiB of sequences (counted at 4 bytes) and literals)
+    u32 nbk = (n >> 13) < 1 ? 1u : ((n >> 13) > ZL_ENC_BLOCKS ? (u32)ZL_ENC_BLOCKS : (n >> 13));
+    {
+        const u32 worth = (nseq * 4u + nlit) >> 12;
+        if (worth < nbk) nbk = worth ? worth : 1u;
+    }
     if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
     __syncthreads();
 

@@ -60,6 +60,8 @@ template <bool FAR>
 __device__ __forceinline__ u32 hash_short(u64 v, u32 shift /* 64 - log2 of the table's entries */) {
     return (u32)(((v << (64 - 8 * (FAR ? ZL_SHORT_BYTES_FAR : ZL_SHORT_BYTES))) * 0xC2B2AE3D27D4EB4FULL) >> shift);
 }
+// (the byte count as a shift that the caller holds in a register: 64 - 8 * bytes)
+__device__ __forceinline__ u32 hash_short_rt(u64 v, u32 byte_shift, u32 shift) { return (u32)(((v << byte_shift) * 0xC2B2AE3D27D4EB4FULL) >> shift); }
 __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
     const u64 x = a ^ b;
     return x ? (u32)(__builtin_ctzll(x) >> 3) : 8u;
