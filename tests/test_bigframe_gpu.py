@@ -236,3 +236,66 @@ def test_chunk_hints_that_do_not_fit_on_a_fresh_context(ref):
     want_r, _ = ref.decompress_code(crafted, content)
     assert ref.L.ZSTD_isError(want_r)  # the reference rejects it too (content size mismatch)
     assert z.zstd_decompress(z.zstd_compress(data), dctx=dctx) == data  # the context survives
+
+
+@needs_ref
+def test_speculative_block_walk_on_the_device(ref, oracle):
+    """Device entries that bring neither chunk sizes nor a host copy find a large frame's blocks with the speculative parallel
+    walk (zl_decode3.hip: a lane per candidate offset in every 2 MiB part, the parts linked on the host) -- the reference's
+    128 KiB blocks and this library's own 16 KiB ones --; a frame whose chain does not link up (damaged headers, truncation)
+    goes to the one-lane walk and gets the error the oracle gives."""
+    import torch
+    from zstdlite_amd.device import DeviceCodec, gen_mixed
+    n = 48 << 20
+    src = gen_mixed(n, torch.device("cuda", 0))[0]
+    data = src.cpu().numpy().tobytes()
+    codec = DeviceCodec()
+    frames = {"reference": ref.compress(data, level=3), "own": z.zstd_compress(data), "reference_checksum": ref.compress(data, level=1, checksum=True)}
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for name, comp in frames.items():
+        assert len(comp) > (4 << 20) and z.zstd_info(comp)["compressed_size"] == len(comp)
+        d_src = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+        before = large_frames_codec(codec)
+        out.zero_()
+        got, _ = codec.decompress(d_src, codec.frame_table([len(comp)], [n]), out)
+        assert got == n and torch.equal(out, src), name
+        assert large_frames_codec(codec) == before + 1, name
+    comp = frames["reference"]
+    rng = np.random.default_rng(5)
+    # damage: block headers (found through the oracle's own walk of the frame), a truncated tail, one flipped payload byte
+    hdrs = []
+    fhd = comp[4]
+    pos = 5 + (0 if (fhd >> 5) & 1 else 1) + (1 << (fhd >> 6) if fhd >> 6 else (1 if (fhd >> 5) & 1 else 0))
+    while True:
+        bh = int.from_bytes(comp[pos:pos + 3], "little")
+        hdrs.append(pos)
+        pos += 3 + (1 if (bh >> 1) & 3 == 1 else bh >> 3)
+        if bh & 1:
+            break
+    assert pos == len(comp) and len(hdrs) == n // 131072
+    cases = []
+    for h in rng.choice(hdrs[1:], 6, replace=False):
+        bad = bytearray(comp); bad[int(h) + int(rng.integers(0, 3))] ^= 1 << int(rng.integers(0, 8)); cases.append(bytes(bad))
+    cases.append(comp[:len(comp) - 100000])
+    bad = bytearray(comp); bad[len(comp) // 3] ^= 0x20; cases.append(bytes(bad))
+    for bad in cases:
+        want_r, want = ref.decompress_code(bad, n)
+        d_src = torch.frombuffer(bytearray(bad), dtype=torch.uint8).cuda()
+        out.zero_()
+        try:
+            got, _ = codec.decompress(d_src, codec.frame_table([len(bad)], [n]), out)
+            ok = True
+        except z.ZstdError:
+            ok = False
+        try:
+            o = oracle.decompress(bad, cap=n)
+        except Exception:
+            o = None
+        assert ok == (o is not None), "verdict differs from the oracle's"
+        if ok:
+            assert bytes(out.cpu().numpy()) == o
+    codec.close()
+
+
+def large_frames_codec(codec):
+    return int(_lib.lib().zl_dctx_large_frames(codec.dctx))

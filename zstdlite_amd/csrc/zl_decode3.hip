@@ -130,6 +130,82 @@ __global__ __launch_bounds__(64) void zl3_walk_kernel(zl3_dev d, zl_frame_desc f
     info->end_pos = pos;
 }
 
+// (1b) the same walk, SPECULATIVELY in parallel (round 3; one lane took 5.0 ms for the 8192 blocks of a 1 GiB reference frame,
+// 46 ms for the 65 536 of this library's own).  The frame is cut into parts of ZL3_SPEC_PART bytes.  The first block header inside
+// a part lies within its first 128 KiB + 3 bytes (the block that straddles the part's start is at most that long), so every
+// byte offset there is a CANDIDATE: a lane per candidate follows headers from it until the chain leaves the part, and dies at the
+// first header that cannot be one (reserved type, a size above the block maximum, past the end of the frame) -- garbage
+// survives one step in twenty.  The few survivors per part (the true chain, and whatever happened to fall onto it: chains
+// self-synchronise) are listed with where they started, where they left the part and how many blocks they saw.  The host then
+// links the parts -- part 0's chain starts behind the frame header, the next part's true chain starts where this one's left --
+// and a lane per part walks its true chain once more to fill the block table.  Anything that does not link up (a damaged
+// frame, a part with more survivors than its list holds) goes to the one-lane walk, which also names the error.
+#define ZL3_SPEC_PART (2u << 20)
+#define ZL3_SPEC_CANDS (ZL_BLOCK_MAX + 3u)
+#define ZL3_SPEC_LIST 16u
+struct zl3_spec_rec { u32 start, exit, count, last; };
+// follows block headers from `pos` until the chain leaves [.., part_end) or ends the frame; false: not a chain
+__device__ __forceinline__ bool zl3_spec_follow(const u8* src, u64 n, u64 pos, u64 part_end, zl3_spec_rec& r, zl3_hblk* out /* or null */, u32 out_cap) {
+    u32 count = 0;
+    r.start = (u32)pos; r.last = 0;
+    for (;;) {
+        if (n - pos < 3) return false;
+        const u32 bh = zl_rd_le(src + pos, 3);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
+        if (type == 3 || bsize > ZL_BLOCK_MAX) return false;  // (a compressed block above the maximum is an error of the frame: the one-lane walk reports it)
+        pos += 3;
+        const u32 csize = (type == 1) ? 1 : bsize;
+        if (n - pos < csize) return false;
+        if (out) { if (count >= out_cap) return false; out[count].src_off = (u32)pos; out[count].hdr = bh; }
+        count++;
+        pos += csize;
+        if (last) { r.last = 1; break; }
+        if (pos >= part_end) break;
+    }
+    r.exit = (u32)pos; r.count = count;
+    return true;
+}
+__global__ __launch_bounds__(256) void zl3_spec_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nparts, u32* counts, zl3_spec_rec* lists) {
+    const u32 k = blockIdx.y, cand = blockIdx.x * 256 + threadIdx.x;
+    const u8* src = src_base + fd.src_off;
+    const u64 n = fd.src_size;
+    const u64 part_start = (u64)k * ZL3_SPEC_PART, part_end = part_start + ZL3_SPEC_PART;
+    u64 pos;
+    if (k == 0) {  // the one candidate of part 0: behind the frame header
+        if (cand != 0) return;
+        const u32 hs = zl3_frame_header(d.info, fd, src, true, d.dict_id);
+        if (!hs) return;
+        d.info->hdr_size = hs;
+        pos = hs;
+    } else {
+        if (cand >= ZL3_SPEC_CANDS) return;
+        pos = part_start + cand;
+    }
+    zl3_spec_rec r;
+    if (pos >= n || !zl3_spec_follow(src, n, pos, part_end, r, nullptr, 0)) return;
+    if (!r.last && r.exit >= part_end + ZL3_SPEC_CANDS) return;  // (cannot happen: a block is shorter than that)
+    // a chain that meets a Last_Block must end where the frame does (half of all headers that garbage spells carry the bit:
+    // thousands of "frames" of one block per part otherwise); a frame table with slack behind the frame goes to the one-lane walk
+    if (r.last && (u64)r.exit + (((src[4] >> 2) & 1) ? 4u : 0u) != n) return;
+    const u32 slot = atomicAdd(&counts[k], 1u);
+    if (slot < ZL3_SPEC_LIST) lists[(size_t)k * ZL3_SPEC_LIST + slot] = r;
+}
+// lane per part: the part's true chain (start[k]; ZL3_NONE: no block starts in this part) into the block table
+__global__ __launch_bounds__(64) void zl3_spec_fill_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nparts, const u32* start, const u32* first, u32 nblocks, u32 end_pos) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    zl3_info* info = d.info;
+    if (k == 0) {
+        if (nblocks > d.cap_blocks) info_err(info, ZL_E_FALLBACK);  // more, smaller blocks than planned for: the general kernel takes the frame
+        else if (info->has_checksum && fd.src_size - end_pos < 4) info_err(info, ZL_E_CHECKSUM_WRONG);
+        info->nblocks = nblocks;
+        info->end_pos = end_pos;
+    }
+    if (k >= nparts || start[k] == 0xFFFFFFFFu || nblocks > d.cap_blocks) return;
+    zl3_spec_rec r;
+    const u64 part_end = ((u64)k + 1) * ZL3_SPEC_PART;
+    if (!zl3_spec_follow(src_base + fd.src_off, fd.src_size, start[k], part_end, r, d.hblk + first[k], d.cap_blocks - first[k])) info_err(info, ZL_E_CORRUPTION);  // (the same bytes gave a chain a moment ago)
+}
+
 // (2) the frame was written by this library's one-frame layout and the caller knows where every chunk's run of blocks
 // starts (zl_decompress_device_hint): a lane per chunk follows the few headers of its chunk.  Two passes around a scan
 // of the block counts.  The hint is only a hint: every chunk must end exactly where the next one starts, the frame's
@@ -599,7 +675,8 @@ __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_fram
 #define ZL3_SINK_LOG 26      // host entries: the output is downloaded in pieces of 64 MiB behind the copy stage (zl3_hint::sink_host)
 #define ZL3_SINK_EVENTS 64
 struct zl3_state_s {
-    DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot;
+    DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec;
+    PinBuf h_spec;
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
 };
 
@@ -607,7 +684,8 @@ extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s()
 extern "C" void zl3_free(zl3_state* s) {
     if (!s) return;
     for (DevBuf* b : {&s->info, &s->hblk, &s->braw, &s->seg_first, &s->blk_slot, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word,
-                      &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot}) b->release();
+                      &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot, &s->spec}) b->release();
+    s->h_spec.release();
     for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
@@ -663,6 +741,51 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         else walked = true;
     }
     if (!walked && hint && hint->headerless) return ZL_ERR(ZL_E_FALLBACK);  // (a run of blocks without a header has no other way in)
+    if (!walked && fd.src_size >= 2ull * ZL3_SPEC_PART) {
+        // the speculative parallel walk (above); whatever it cannot link up is walked by one lane below
+        const u32 nparts = (u32)((fd.src_size + ZL3_SPEC_PART - 1) / ZL3_SPEC_PART);
+        const size_t list_bytes = (size_t)nparts * ZL3_SPEC_LIST * sizeof(zl3_spec_rec), cnt_bytes = (size_t)nparts * 4;
+        const size_t total = cnt_bytes + list_bytes + 2 * cnt_bytes;  // counts | lists | start | first
+        if (!s->spec.ensure(total + 64) || !s->h_spec.ensure(total + sizeof(zl3_info) + 64)) return kGpuUnavailable;
+        u32* d_counts = (u32*)s->spec.p;
+        zl3_spec_rec* d_lists = (zl3_spec_rec*)((u8*)s->spec.p + cnt_bytes);
+        u32* d_start = (u32*)((u8*)s->spec.p + cnt_bytes + list_bytes);
+        u32* d_first = d_start + nparts;
+        u8* h = (u8*)s->h_spec.p;
+        if (hipMemsetAsync(d_counts, 0, cnt_bytes, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        hipLaunchKernelGGL(zl3_spec_walk_kernel, dim3((ZL3_SPEC_CANDS + 255) / 256, nparts), dim3(256), 0, st, d, fd, d_src, nparts, d_counts, d_lists);
+        if (hipMemcpyAsync(h, s->spec.p, cnt_bytes + list_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(h + total, d.info, sizeof(zl3_info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        const u32* counts = (const u32*)h;
+        const zl3_spec_rec* lists = (const zl3_spec_rec*)(h + cnt_bytes);
+        u32* start = (u32*)(h + cnt_bytes + list_bytes);
+        u32* first = start + nparts;
+        zl3_info hi;
+        memcpy(&hi, h + total, sizeof(hi));
+        bool ok = hi.err == 0 && hi.hdr_size != 0;
+        u64 cur = hi.hdr_size;
+        u32 nb = 0, end_pos = 0;
+        bool ended = false;
+        for (u32 k = 0; k < nparts && ok; k++) {
+            start[k] = 0xFFFFFFFFu; first[k] = 0;
+            if (ended || cur >= ((u64)k + 1) * ZL3_SPEC_PART) continue;  // no block starts inside this part
+            const u32 cnt = counts[k];
+            if (cnt > ZL3_SPEC_LIST) { ok = false; break; }
+            const zl3_spec_rec* hit = nullptr;
+            for (u32 i = 0; i < cnt; i++) if (lists[(size_t)k * ZL3_SPEC_LIST + i].start == (u32)cur) { hit = &lists[(size_t)k * ZL3_SPEC_LIST + i]; break; }
+            if (!hit) { ok = false; break; }
+            start[k] = hit->start; first[k] = nb;
+            nb += hit->count;
+            cur = hit->exit;
+            if (hit->last) { ended = true; end_pos = hit->exit; }
+        }
+        ok = ok && ended;
+        if (ok) {
+            if (hipMemcpyAsync(d_start, start, 2 * cnt_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            hipLaunchKernelGGL(zl3_spec_fill_kernel, dim3((nparts + 63) / 64), dim3(64), 0, st, d, fd, d_src, nparts, (const u32*)d_start, (const u32*)d_first, nb, end_pos);
+            walked = true;
+        } else if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);  // start over: the one-lane walk
+    }
     if (!walked) hipLaunchKernelGGL(zl3_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_parse_kernel, dim3((cap_blocks + 255) / 256), dim3(256), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_segment_kernel, dim3(1), dim3(1024), 0, st, d);
