@@ -1,5 +1,5 @@
 """N1 under the profiler: the reference's single frame of the bench mix decoded device-resident by the
-large-frame pipeline.  usage: exp_n1.py [MiB]   (rocprofv3 --kernel-trace --stats -- python3 scripts/exp_n1.py 512)"""
+large-frame pipeline.  usage: n1_prof.py [MiB]   (rocprofv3 --kernel-trace --stats -- python3 scripts/n1_prof.py 512)"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch

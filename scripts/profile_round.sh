@@ -15,7 +15,7 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpu
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-c2 --no-extra > /dev/null 2>&1
 # the large-frame pipeline under the same profiler: only the stats table travels back
 rm -rf /tmp/prof_n1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_n1 -- python3 scripts/dev/exp_n1.py 1024 > gpurun_out/n1_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_n1 -- python3 scripts/n1_prof.py 1024 > gpurun_out/n1_run.log 2>&1
 cp "$(ls /tmp/prof_n1/*/*kernel_stats.csv | head -1)" gpurun_out/n1_kernel_stats.csv 2>/dev/null
 # keep what travels back small: csv summaries only
 find gpurun_out -name "*.db" -delete 2>/dev/null

@@ -28,7 +28,7 @@ trace = one("prof_bench/*/*kernel_trace.csv")
 if stats:
     shutil.copy(stats, os.path.join(P, f"{rnd}_kernel_stats.csv"))
 n1 = os.path.join(G, "n1_kernel_stats.csv")
-if os.path.exists(n1):  # the large-frame pipeline's kernels (scripts/exp_n1.py 1024: three decodes of the 1 GiB single frame)
+if os.path.exists(n1):  # the large-frame pipeline's kernels (scripts/n1_prof.py 1024: three decodes of the 1 GiB single frame)
     rows = [r for r in csv.DictReader(open(n1)) if "zl" in r["Name"]]
     with open(os.path.join(P, f"{rnd}_n1_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["Name"])

@@ -29,8 +29,6 @@ def build_variant(name, defines, verbose=False):
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, f"libzl_hip.{name}.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if "-DZL_MATCH_WIDE=1" in defines:  # the LDS-resident match kernel (an experiment that lost: DESIGN.md 3.3) is built on request only
-        srcs.append(os.path.join(CSRC, "experiments", "zl_match_wide.hip"))
     cmd = [hipcc] + FLAGS + ["-I" + CSRC] + list(defines) + ["-shared", "-o", out] + srcs
     if verbose:
         print(" ".join(cmd))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -206,6 +207,7 @@ struct zl_dctx_s {
     bool ev_valid = false;
     double kernel_ms = 0;
     double stage_ms[4] = {0, 0, 0, 0};
+    double batch_ms[5] = {0, 0, 0, 0, 0};  // ZL_d_profile: the last zl_decompress_batch call: {pack, upload, kernels, download, unpack}
     DevBuf d_stats;
     u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -1037,6 +1039,9 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     if (n == 0) return 0;
     // Each item must be exactly one data frame with a recorded content size (what
     // zl_compress_batch / ZSTD_compress2 produce); pack inputs into one pinned staging buffer.
+    const bool prof = d->profile != 0;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double tp[6] = {now_ms(), 0, 0, 0, 0, 0};
     std::vector<zl_frame_desc> table(n);
     std::vector<size_t> pre(n, 0);
     size_t in_total = 0, out_total = 0;
@@ -1061,19 +1066,31 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         return kGpuUnavailable;
     for (size_t i = 0; i < n; i++)
         if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, srcs[i], table[i].src_size);
+    tp[1] = now_ms();
     if (hipMemcpyAsync(d->d_src.p, d->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
     memcpy(d->h_frames.p, table.data(), n * sizeof(zl_frame_desc));
     size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, n, st);
     if (ZL_IS_ERR(e)) return e;
+    if (prof) { (void)hipStreamSynchronize(st); tp[3] = now_ms(); }
     if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (out_total && hipMemcpyAsync(d->h_stage_out.p, d->d_dst.p, out_total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    tp[4] = now_ms();
     const u64* r = (const u64*)d->h_results.p;
     for (size_t i = 0; i < n; i++) {
         if (pre[i]) { results[i] = pre[i]; continue; }
         results[i] = (size_t)r[i];
         if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
     }
+    if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) d->batch_ms[k] = tp[k + 1] - tp[k]; }
+    return 0;
+}
+
+// not part of the public header (diagnostics, ZL_d_profile): the phases of the last zl_decompress_batch call in milliseconds
+size_t zl_dctx_batch_ms(const zl_dctx* d, double* ms) {
+    if (!d || !ms || !d->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int k = 0; k < 5; k++) ms[k] = d->batch_ms[k];
     return 0;
 }
 

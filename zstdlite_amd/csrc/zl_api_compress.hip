@@ -45,6 +45,7 @@ struct zl_cctx_s {
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    double batch_ms[5] = {0, 0, 0, 0, 0};  // ZL_c_profile: the last zl_compress_batch call: {pack on the host, upload, kernels, download, unpack on the host}
     int copy_pair_duplex = -1;  // -1: not bound yet; 1 / 0: the pair's copies overlap / take turns (zl_bind_copy_pair)
     std::vector<hipEvent_t> pipe_events;  // grow-only pool for the pipeline
     PinBuf h_chunks, h_fsize, h_totals, h_stage_in, h_stage_out;
@@ -790,6 +791,10 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (n == 0) return 0;
     hipStream_t st = cctx_stream(c, nullptr);
+    // (ZL_c_profile: the call's phases by the host clock, the stream drained between them -- a diagnostic, the drains cost a little)
+    const bool prof = c->profile != 0;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double tp[6] = {now_ms(), 0, 0, 0, 0, 0};
     size_t nchunks = 0, in_total = 0, bound_total = 0;
     std::vector<size_t> first_chunk(n + 1), in_off(n);
     for (size_t i = 0; i < n; i++) {
@@ -816,13 +821,17 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
             if (k == 1) c->any_small = true;
         }
     }
+    tp[1] = now_ms();
     if (in_total && hipMemcpyAsync(c->d_src.p, c->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
     const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
     if (ZL_IS_ERR(e)) return e;
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    tp[3] = now_ms();
     const size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
     if (hipMemcpyAsync(c->h_stage_out.p, c->d_dst.p, total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    tp[4] = now_ms();
     const u32* fs = (const u32*)c->h_fsize.p;
     size_t off = 0;
     for (size_t i = 0; i < n; i++) {
@@ -832,6 +841,15 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         else { memcpy(dsts[i], (const u8*)c->h_stage_out.p + off, sz); results[i] = sz; }
         off += sz;
     }
+    if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) c->batch_ms[k] = tp[k + 1] - tp[k]; }
+    return 0;
+}
+
+// not part of the public header (diagnostics, ZL_c_profile): the phases of the last zl_compress_batch call in milliseconds:
+// {pack into pinned memory, upload, kernels, download, unpack into the caller's buffers}
+size_t zl_cctx_batch_ms(const zl_cctx* c, double* ms) {
+    if (!c || !ms || !c->profile) return ZL_ERR(ZL_E_STAGE_WRONG);
+    for (int k = 0; k < 5; k++) ms[k] = c->batch_ms[k];
     return 0;
 }
 

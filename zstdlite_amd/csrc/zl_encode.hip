@@ -1169,15 +1169,6 @@ extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hip
     return hipGetLastError();
 }
 
-// -DZL_MATCH_WIDE=1 (variant builds only, `python -m zstdlite_amd.build --variant wide -DZL_MATCH_WIDE=1`) sends the bulk path to
-// csrc/experiments/zl_match_wide.hip: one 1024-thread workgroup per CU with the search window in LDS.  Measured slower
-// (DESIGN.md 3.3), kept as the record of the experiment.
-#ifndef ZL_MATCH_WIDE
-#define ZL_MATCH_WIDE 0
-#endif
-#if ZL_MATCH_WIDE
-extern "C" hipError_t zl_launch_match_wide(const zl_match_args* a, u32 nchunks, hipStream_t stream);
-#endif
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
     // levels >= 5: the larger tables
@@ -1191,9 +1182,6 @@ extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipSt
     else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-#if ZL_MATCH_WIDE
-    else return zl_launch_match_wide(a, nchunks, stream);
-#endif
     else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();

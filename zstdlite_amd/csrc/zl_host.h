@@ -111,7 +111,7 @@ struct ByteBuf {
     size_t size() const { return n; }
 };
 
-// Two copy streams that use the link in BOTH directions at once.  Measured on this platform (round 2, scripts/dev/exp_duplex*):
+// Two copy streams that use the link in BOTH directions at once.  Measured on this platform (round 2):
 // a stream is tied to a copy engine by its first copy of a MiB or more -- the engine that is idle at that moment -- and keeps it;
 // an upload stream and a download stream whose first large copies followed each other share ONE engine and take turns for good
 // (1 GiB up + 0.65 GiB down: 31 ms instead of 21).  So the pair is bound on purpose: first copies from pinned memory, overlapping

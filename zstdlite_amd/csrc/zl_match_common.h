@@ -1,5 +1,4 @@
-// zl_match_common.h -- what the two match kernels (zl_encode.hip: 256 threads per chunk, global candidate gathers;
-// zl_match_wide.hip: 1024 threads per chunk, the search window resident in LDS) share: hashes, byte compares, the
+// zl_match_common.h -- constants and small helpers of the match kernel (zl_encode.hip): hashes, byte compares, the
 // LDS-only barrier.
 #pragma once
 #include "zl_device.h"
