@@ -1296,22 +1296,29 @@ __global__ __launch_bounds__(64) void zl2_entropy1_kernel(zl2_args a) {
 #define EX_GRAN_LOG 5
 #define EX_CAP 8192u     // output bytes per batch (links are 16-bit, relative to the batch start)
 #define EX_MAXSEQ 1023u  // sequences per batch (+1 look-ahead entry)
-#define EX_FINAL 0xFFFFu
-#define EX_DEFER 0xFFFEu  // large-frame pipeline: the byte's source lies in another segment (or is itself waiting); S.far holds where
+// A byte's link inside a batch: an index below EX_CAP = the byte of the batch it copies (pending); EX_FINAL = its value stands in
+// the image.  Large-frame pipeline (BIG) only: any other value v = the byte WAITS for frame position v - EX_CAP, which lies in
+// another run of segments (or is itself waiting).  Small frames keep 16-bit links (38 KiB of LDS, four frames per CU); the large-frame
+// instantiation has 32-bit ones -- round 2 kept 16-bit links PLUS a 32-bit position per byte there (71 KiB: two workgroups per CU;
+// now 53 KiB: three).
+template <bool BIG> struct ExLink { typedef u16 type; };
+template <> struct ExLink<true> { typedef u32 type; };
+#define EX_MAXSEQ_BIG 895u  // (sequences per batch of the large-frame instantiation: three workgroups' LDS must fit a CU)
 template <bool BIG>
 struct ExecSharedT {
+    typedef typename ExLink<BIG>::type link_t;
+    static constexpr u32 MAXSEQ = BIG ? EX_MAXSEQ_BIG : EX_MAXSEQ;
     u8 img[EX_CAP + 16];  // byte d of the block sits at img[d + ibase]; (img + d + ibase) and (destination + d) agree modulo 16
-    u16 link[EX_CAP];
-    u32 b_out[EX_MAXSEQ + 1];
-    u32 b_lit[EX_MAXSEQ + 1];
-    u32 b_off[EX_MAXSEQ + 1];
+    link_t link[EX_CAP];
+    u32 b_out[MAXSEQ + 1];
+    u32 b_lit[MAXSEQ + 1];
+    u32 b_off[MAXSEQ + 1];
     u16 own[(EX_CAP >> EX_GRAN_LOG) + 8];
     u64 xxh_acc[4];
     u32 bcast[8];  // [0] xxh result, [1] batch size, [4..6] rotating "still pending" flags
     u32 brec[ZL2_MAXB * 16];  // the frame's block records, fetched once
     int err;
     u32 pad3;
-    u32 far[BIG ? EX_CAP : 4];  // frame position a deferred byte of the batch copies
 };
 
 // sequence of the current batch that owns block-relative output position p
@@ -1357,6 +1364,9 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
     }
     u32* const glink = BIG ? a.big->link : nullptr;
     const u32 dict_len = BIG ? a.big->dict_len : 0u;  // uniform
+    typedef typename ExecSharedT<BIG>::link_t link_t;
+    constexpr link_t EX_FINAL = (link_t)~(link_t)0;
+    constexpr u32 EX_MAXSEQ_T = ExecSharedT<BIG>::MAXSEQ;
     const zl_frame_desc fd = a.frames[f];
     const u8* src = a.src + fd.src_off;
     u8* dst = a.dst + fd.dst_off;
@@ -1413,7 +1423,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
 #define ZL2_RESOLVE(v_) (((v_) >> 31) ? (((v_) & 3u) == 0 ? rep0 : (((v_) & 3u) == 1 ? rep1 : rep2)) - (((v_) & 0x7FFFFFFFu) >> 2) : (v_))
         for (u32 b0 = 0; b0 < nseq;) {
             const u64 st0 = prof ? __builtin_amdgcn_s_memtime() : 0;
-            const u32 window = (nseq - b0 < EX_MAXSEQ) ? (nseq - b0) : EX_MAXSEQ;
+            const u32 window = (nseq - b0 < EX_MAXSEQ_T) ? (nseq - b0) : EX_MAXSEQ_T;
             if (t == 0) S.bcast[1] = 1;
             for (u32 i = t; i <= window; i += EX_THREADS) {  // one extra entry: the next sequence (or the totals)
                 const uint4 e = sq[b0 + i];
@@ -1520,8 +1530,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                                 S.img[p + ibase] = *from;
                                 S.link[p - batch_start] = EX_FINAL;
                             } else {
-                                S.far[p - batch_start] = defer;
-                                S.link[p - batch_start] = EX_DEFER;
+                                S.link[p - batch_start] = (link_t)(defer + EX_CAP);  // waits for frame position `defer` (BIG only)
                             }
                         } else {
                             const u32 qq = (u32)q;
@@ -1530,7 +1539,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                                 S.img[p + ibase] = S.img[qq + ibase];
                                 S.link[p - batch_start] = EX_FINAL;
                             } else {
-                                S.link[p - batch_start] = (u16)(qq - batch_start);
+                                S.link[p - batch_start] = (link_t)(qq - batch_start);
                             }
                         }
                     }
@@ -1545,13 +1554,10 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                     u32 pending = 0;
                     for (u32 i = t; i < tot_o; i += EX_THREADS) {
                         const u32 l1 = S.link[i];
-                        if (l1 >= EX_DEFER) continue;
+                        if (l1 >= EX_CAP) continue;  // final, or waiting for another run
                         const u32 l2 = S.link[l1];
-                        if (BIG && l2 == EX_DEFER) {  // (same order rules as for the bytes)
-                            asm volatile("" ::: "memory");
-                            S.far[i] = S.far[l1];
-                            asm volatile("" ::: "memory");
-                            S.link[i] = EX_DEFER;
+                        if (BIG && l2 >= EX_CAP && l2 != EX_FINAL) {
+                            S.link[i] = (link_t)l2;  // what it copies is waiting: it waits for the same frame position
                         } else if (l2 == EX_FINAL) {
                             // (order matters against the other waves of this round: read the link before the byte, write the byte before the link)
                             asm volatile("" ::: "memory");
@@ -1559,7 +1565,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                             asm volatile("" ::: "memory");
                             S.link[i] = EX_FINAL;
                         } else {
-                            S.link[i] = (u16)l2;
+                            S.link[i] = (link_t)l2;
                             pending = 1;
                         }
                     }
@@ -1583,8 +1589,8 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                     if (BIG) {  // what each byte of the batch is: final, or waiting for a frame position
                         u32* gl = glink + op + batch_start;
                         for (u32 i = t; i < tot_o; i += EX_THREADS) {
-                            const bool fin = S.link[i] == EX_FINAL;
-                            if (!fin) { gl[i] = S.far[i]; a.big->tile_flag[(op + batch_start + i) >> ZL3_TILE_LOG] = 1; }
+                            const u32 lk = S.link[i];
+                            if (lk != EX_FINAL) { gl[i] = lk - EX_CAP; a.big->tile_flag[(op + batch_start + i) >> ZL3_TILE_LOG] = 1; }
                         }
                     }
                 }
@@ -1685,7 +1691,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
 }
 
 template <bool BIG, bool PROF>
-__global__ __launch_bounds__(EX_THREADS, BIG ? 4 : 8) void zl2_exec_kernel(zl2_args a) {
+__global__ __launch_bounds__(EX_THREADS, BIG ? 6 : 8) void zl2_exec_kernel(zl2_args a) {
     __shared__ __align__(16) ExecSharedT<BIG> S;
     ZL_POISON(S, 2);
     u64 seg_start = 0;

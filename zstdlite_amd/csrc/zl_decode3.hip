@@ -678,6 +678,7 @@ struct zl3_state_s {
     DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec;
     PinBuf h_spec;
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
+    hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
 };
 
 extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s(); }
@@ -687,6 +688,8 @@ extern "C" void zl3_free(zl3_state* s) {
                       &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot, &s->spec}) b->release();
     s->h_spec.release();
     for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
+    if (s->fill_fork) (void)hipEventDestroy(s->fill_fork);
+    if (s->fill_join) (void)hipEventDestroy(s->fill_join);
     delete s;
 }
 
@@ -703,6 +706,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     auto stamp = [](const char*) {};
 #endif
     if (fd.src_size >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // block records are 32-bit
+    if (!s->fill_fork && (hipEventCreateWithFlags(&s->fill_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->fill_join, hipEventDisableTiming) != hipSuccess)) { s->fill_fork = s->fill_join = nullptr; }
     // (dst_cap may be the room left in the caller's buffer rather than the frame's size: what the frame can produce is bounded by its input too)
     const u64 out_bound = std::min<u64>(fd.dst_cap, fd.src_size * 1024 + ((u64)1 << 20));
     // blocks planned for: full blocks plus a generous allowance for encoders that split blocks (this library's own cut 16 KiB blocks)
@@ -810,7 +814,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
 #endif
     // output positions the links must cover: the recorded size, else what the blocks can produce at most (and the caller has room for)
     const u64 span = info.fcs != ZL_CONTENTSIZE_UNKNOWN ? info.fcs : std::min<u64>(fd.dst_cap, (u64)info.nblocks * ZL_BLOCK_MAX);
-    if (span >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // links are 32-bit
+    if (span >= 0xFFFFD000ull) return ZL_ERR(ZL_E_FALLBACK);  // links are 32-bit (and the exec kernel's in-batch form of one adds its batch size to a position)
     const u64 ntiles = (span >> ZL3_TILE_LOG) + 1;
     if (!info.err) {
         if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
@@ -822,7 +826,12 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (hipMemsetAsync(s->tile_flag.p, 0, ntiles * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         // every byte starts out final; the exec kernel writes the links of the waiting ones only (a plain fill at memory speed
         // instead of one more 4-byte store per output byte from the exec kernel's flush loops)
-        if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        // (on a stream of its own beside the entropy stage, whose serial chains leave the memory system idle: 4 GiB for a 1 GiB
+        // frame, 1.2 ms that used to stand in front of it; joined again in front of the exec kernel)
+        hipStream_t fill_st = (side && side->part_stream[2] && s->fill_fork && s->fill_join) ? side->part_stream[2] : st;
+        if (fill_st != st && (hipEventRecord(s->fill_fork, st) != hipSuccess || hipStreamWaitEvent(fill_st, s->fill_fork, 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
+        if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (fill_st != st && hipEventRecord(s->fill_join, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         zl2_args a;
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
@@ -839,6 +848,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
             hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const uint4*)s->tot.p, dr ? hint->dict_rep[0] : 1u, dr ? hint->dict_rep[1] : 4u, dr ? hint->dict_rep[2] : 8u);
         }
         stamp("offsets");
+        if (fill_st != st && hipStreamWaitEvent(st, s->fill_join, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (zl2_launch_segments_exec(&a, ZL3_EXEC_RUN, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("exec");
         // the deferred bytes: one launch per group of output, in order (the first group has nothing in front of it to wait for,
