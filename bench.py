@@ -167,8 +167,18 @@ def one_frame_leg(device, src, log):
     assert got == n and torch.equal(back, src), "one-frame round trip is not bit-exact"
     km = codec.kernel_ms()
     codec.close()
+    ckm = {k: km[k] for k in ("far", "match", "entropy", "scan", "gather") if k in km}
+    # roofline of this layout's dominant kernel, as the headline's: algorithmic bytes (input read once + frame written once) over
+    # the kernel's HIP-event duration ("far" = the two far-table passes together; the PMC traffic of these kernels is under
+    # profiles/, taken by scripts/profile_round.sh with the same one-frame round trip)
+    dom = max(ckm, key=ckm.get)
+    alg = n + total
+    ach = alg / (ckm[dom] / 1e3) / 1e9
     return {"ratio": n / total, "compressed_bytes": int(total), "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9,
-            "compress_kernel_ms": {k: km[k] for k in ("far", "match", "entropy", "scan", "gather") if k in km}, "bit_exact": True}
+            "compress_kernel_ms": ckm, "bit_exact": True,
+            "roofline": {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false, true, true, false>", "far": "zl_far_build_kernel + zl_far_probe_kernel",
+                                                    "entropy": "zl_entropy_kernel", "gather": "zl_gather_kernel", "scan": "zl_scan_sizes_kernel"}[dom],
+                         "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": ckm[dom]}}
 
 
 def long_range_leg(device, log):
@@ -836,6 +846,9 @@ def main():
                     out[name] = leg()
                 except Exception as e:  # informative legs; never lose the headline line to them
                     out[name] = {"error": repr(e)}
+            # the DEFAULT layout of the host entries (what an R caller gets) has its own roofline entry next to the headline's
+            if isinstance(out.get("one_frame_layout"), dict) and "roofline" in out["one_frame_layout"]:
+                out["roofline_one_frame"] = out["one_frame_layout"].pop("roofline")
         if world == 1 and not args.no_cpu:
             # ---- cpu_baseline leg: the only place bench.py touches oracle/ (the reference libzstd
             # built into oracle/_ref): timed on the host cores, and -- for BASELINE config C2 -- used

@@ -1431,6 +1431,101 @@ __device__ __noinline__ void fse_build_ctable(u16* state, i32* dnb, i32* dfs, u8
     }
 }
 
+// ---- the same two steps by ALL 64 LANES OF ONE WAVE, lane = symbol (at most 53 symbols): the results are those of the one-thread
+// versions above, cell for cell (which the Huffman-weight table still uses); what changes is the time -- a chunk's three sequence
+// tables used to cost 300 000 cycles of one lane each (a division and several dependent LDS round trips per symbol and per cell),
+// while the other 63 lanes of their waves waited.
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_excl_scan_u32(u32 v, u32 lane) {
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+    return inc - v;
+}
+#define ZL_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // one wave's LDS accesses execute in program order: this keeps the compiler to it
+// fse_normalize by one wave.  count[s] < 2^16 and log <= 9, so the scaled count fits 32 bits.
+__device__ __noinline__ void fse_normalize_wave(short* norm, const u32* count, u32 total, int max_sym, int log, u32 lane) {
+    const u32 size = 1u << log;
+    const bool on = (int)lane <= max_sym;
+    const u32 c = on ? count[lane] : 0u;
+    int n = 0;
+    u32 used_l = 0;
+    if (c) {
+        const u32 scaled = c << log;
+        u32 q = scaled / total;
+        const u32 rem = scaled - q * total;
+        if (q == 0) { n = -1; used_l = 1; }
+        else { if (rem * 2 >= total && q < 8) q++; n = (int)q; used_l = q; }  // round small probabilities to nearest
+    }
+    const u32 used = wave_sum_u32(used_l);
+    const int largest = 63 - (int)(wave_max_u32(c ? ((c << 6) | (63u - lane)) : 0u) & 63u);  // the largest count; the first symbol of several
+    if (used <= size) {
+        if (used < size && (int)lane == largest) n = n < 0 ? (int)(1 + (size - used)) : n + (int)(size - used);
+    } else {
+        u32 excess = used - size;  // uniform
+        while (excess) {  // take from the biggest cells first, never below one slot
+            const u32 b = wave_max_u32(n > 1 ? (((u32)n << 6) | (63u - lane)) : 0u);
+            const int big = 63 - (int)(b & 63u);
+            const u32 nb = b >> 6;
+            u32 take = nb - 1;
+            if (take > excess) take = excess;
+            const u32 soft = nb / 4 + 1;  // spread the correction over several symbols
+            if (take > soft) take = soft;
+            if ((int)lane == big) n -= (int)take;
+            excess -= take;
+        }
+    }
+    if (on) norm[lane] = (short)n;
+    ZL_WAVE_FENCE();
+}
+// fse_build_ctable by one wave.  symk: scratch of at least the table's size in bytes.
+__device__ __noinline__ void fse_build_ctable_wave(u16* state, i32* dnb, i32* dfs, u8* tsym, u8* symk, const short* norm, int max_sym, int log, u32 lane) {
+    const int size = 1 << log;
+    const bool on = (int)lane <= max_sym;
+    const int n = on ? (int)norm[lane] : 0;
+    const u32 cnt = n == -1 ? 1u : (n > 0 ? (u32)n : 0u), pos_cnt = n > 0 ? (u32)n : 0u;
+    const u32 cum = wave_excl_scan_u32(cnt, lane), pcum = wave_excl_scan_u32(pos_cnt, lane);
+    // symbols rarer than one slot take the top cells, in symbol order from the top down
+    const u64 low = __ballot(n == -1);
+    const int high = size - 1 - (int)__popcll(low);
+    if (n == -1) tsym[size - 1 - (int)__popcll(low & ((1ull << lane) - 1))] = (u8)lane;
+    for (u32 i = 0; i < pos_cnt; i++) symk[pcum + i] = (u8)lane;  // whose cell the k-th spread cell is
+    ZL_WAVE_FENCE();
+    // the spread visits (j * step) & mask for j = 0, 1, ... and takes the positions at or below `high` in that order
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    const u32 per = size >= 64 ? (u32)size / 64u : 1u, j0 = lane * per;
+    u32 mine = 0;
+    if ((int)j0 < size) for (u32 i = 0; i < per; i++) mine += ((int)(((j0 + i) * (u32)step) & (u32)mask) <= high) ? 1u : 0u;
+    u32 k = wave_excl_scan_u32(mine, lane);
+    if ((int)j0 < size)
+        for (u32 i = 0; i < per; i++) {
+            const int p = (int)(((j0 + i) * (u32)step) & (u32)mask);
+            if (p <= high) tsym[p] = symk[k++];
+        }
+    ZL_WAVE_FENCE();
+    // a symbol's states: its cells in increasing table position (every lane walks the table; the reads are broadcasts)
+    if (cnt) { u32 r = cum; for (int u = 0; u < size; u++) if (tsym[u] == (u8)lane) state[r++] = (u16)(size + u); }
+    if (on) {
+        if (n == 0) { dnb[lane] = ((log + 1) << 16) - size; dfs[lane] = 0; }
+        else if (n == -1 || n == 1) { dnb[lane] = (log << 16) - size; dfs[lane] = (i32)cum - 1; }
+        else {
+            const int max_bits_out = log - (int)hb32((u32)(n - 1));
+            dnb[lane] = (max_bits_out << 16) - (n << max_bits_out);
+            dfs[lane] = (i32)cum - n;
+        }
+    }
+    ZL_WAVE_FENCE();
+}
+
 // FSE encoder primitives (zstd.c:2060-2110 FSE_initCState2 / FSE_encodeSymbol)
 __device__ __forceinline__ u32 fse_init_state(const u16* state, i32 dnb, i32 dfs) {
     const u32 nb = (u32)(dnb + (1 << 15)) >> 16;
@@ -1925,32 +2020,36 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         while (S.hist[0][maxsym] == 0) maxsym--;
         S.huf_maxsym = maxsym;
     }
-    // table choice + construction (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059)
-    if (nseq && lane == 0 && wave < 3) {
+    // table choice + construction (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059): waves 0..2 build one
+    // table each, all 64 lanes at it (lane = symbol)
+    if (nseq && wave < 3) {
         const int k = (int)wave;
         const int max_code = k == T_LL ? 35 : (k == T_ML ? 52 : 31);
         const int def_log = k == T_OF ? 5 : 6, max_log = k == T_OF ? 8 : 9;
         const u32* h = S.seq_hist[k];
-        int max_sym = 0;
-        u32 most = 0;
-        for (int s = 0; s <= max_code; s++) if (h[s]) { max_sym = s; if (h[s] > most) most = h[s]; }
+        const u32 hc = (int)lane <= max_code ? h[lane] : 0u;
+        const u64 present = __ballot(hc != 0);
+        const int max_sym = present ? 63 - (int)__builtin_clzll(present) : 0;
+        const u32 most = wave_max_u32(hc);
         FseCTable& ct = S.ct[k];
         short* norm = S.tnorm[k];
         u8* tsym = S.ttsym[k];
+        u8* symk = (u8*)S.hist[1 + k];  // (the per-wave literal histograms are dead since their sum went into hist[0])
         u32 mode;
         if (most == nseq) mode = (nseq <= 2) ? 0 : 1;
         else if (nseq < ((1u << def_log) * 8u >> 3) || most < (nseq >> (def_log - 1))) mode = 0;
         else mode = 2;
         if (k == T_OF && mode == 0 && max_sym > 28) mode = 2;  // default offset table stops at code 28
-        ct.max_sym = max_sym;
+        if (lane == 0) ct.max_sym = max_sym;
         if (mode == 0) {
             const short* def = k == T_LL ? e_LL_default : (k == T_ML ? e_ML_default : e_OF_default);
             const int dmax = k == T_LL ? 35 : (k == T_ML ? 52 : 28);
-            for (int s = 0; s <= dmax; s++) norm[s] = def[s];
-            fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, dmax, def_log);
-            ct.log = (u32)def_log;
+            if ((int)lane <= dmax) norm[lane] = def[lane];
+            ZL_WAVE_FENCE();
+            fse_build_ctable_wave(ct.state, ct.dnb, ct.dfs, tsym, symk, norm, dmax, def_log, lane);
+            if (lane == 0) ct.log = (u32)def_log;
         } else if (mode == 1) {
-            ct.log = 0;
+            if (lane == 0) ct.log = 0;
         } else {
             int log = (int)hb32(nseq - 1) - 2;  // zstd.c:16220 FSE_optimalTableLog idea
             if (log > max_log) log = max_log;
@@ -1958,10 +2057,12 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             if (log < min_log) log = min_log;
             if (log < 5) log = 5;
             if (log > max_log) log = max_log;
-            fse_normalize(norm, h, nseq, max_sym, log);
-            fse_build_ctable(ct.state, ct.dnb, ct.dfs, tsym, S.cumul[k], norm, max_sym, log);
-            ct.log = (u32)log;
+            fse_normalize_wave(norm, h, nseq, max_sym, log, lane);
+            fse_build_ctable_wave(ct.state, ct.dnb, ct.dfs, tsym, symk, norm, max_sym, log, lane);
+            if (lane == 0) ct.log = (u32)log;
         }
+        ZL_WAVE_FENCE();
+      if (lane == 0) {
         if (dict_tables && mode != 1) {
             // Repeat_Mode against the table just built (zstd.c:21060-21110 weighs the same three costs):
             // every code that occurs must have a cell in the dictionary's table, and the bits it
@@ -1983,6 +2084,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             }
         }
         S.seq_mode[k] = mode;
+      }
     }
     __syncthreads();
     ENT_STAMP(1)
