@@ -1595,6 +1595,84 @@ __device__ __noinline__ u32 huf_build_lengths(EntShared& S, u32 m) {
     return maxlen;
 }
 
+// The same construction by one WAVE (wave 3 of the entropy kernel), lane 0 for what is a chain by nature and all 64 lanes for the
+// rest; the lengths are those of huf_build_lengths above.  Where the one-lane version spent its time, per phase: the two-queue
+// merge re-read both queue heads from LDS several times per step (here: both heads and their successors sit in registers, one
+// LDS round trip per step refills them); depths by walking every node's parent chain in index order, two dependent reads per node
+// (here: level by level, all nodes at once, eleven rounds -- deeper nodes are clamped to eleven anyway); the code lengths handed
+// out symbol by symbol (here: every rank looks its length up in the per-length counts).
+__device__ __noinline__ u32 huf_build_lengths_wave(EntShared& S, u32 m, u32 lane) {
+    for (u32 i = lane; i < m; i += 64) S.node_w[i] = S.hist[0][S.sorted[i]];
+    ZL_WAVE_FENCE();
+    const u32 root = 2 * m - 2;
+    if (lane == 0) {
+        const u32 INF = 0xFFFFFFFFu;
+        u32 q1 = 0, q2 = m, next = m;
+        u32 a0 = S.node_w[0], a1 = m > 1 ? S.node_w[1] : INF, b0 = INF, b1 = INF;
+        for (u32 k = 0; k + 1 < m; k++) {
+            u32 x, y, xi, yi;
+            if (a0 <= b0) { x = a0; xi = q1++; a0 = a1; } else { x = b0; xi = q2++; b0 = b1; }
+            if (a0 <= b0) { y = a0; yi = q1++; } else { y = b0; yi = q2++; }
+            S.node_w[next] = x + y;
+            S.node_parent[xi] = (u16)next;
+            S.node_parent[yi] = (u16)next;
+            next++;
+            a0 = q1 < m ? S.node_w[q1] : INF;          // (four independent reads behind the write: one round trip per step)
+            a1 = q1 + 1 < m ? S.node_w[q1 + 1] : INF;
+            b0 = q2 < next ? S.node_w[q2] : INF;
+            b1 = q2 + 1 < next ? S.node_w[q2 + 1] : INF;
+        }
+    }
+    ZL_WAVE_FENCE();
+    // depths, level by level from the root; what is deeper than HUF_MAX_BITS is clamped to it
+    for (u32 i = lane; i < root; i += 64) S.node_depth[i] = 0xFF;
+    if (lane == 0) S.node_depth[root] = 0;
+    ZL_WAVE_FENCE();
+    for (u32 r = 1; r <= HUF_MAX_BITS; r++) {
+        for (u32 i = lane; i < root; i += 64)
+            if (S.node_depth[i] == 0xFF && S.node_depth[S.node_parent[i]] == r - 1) S.node_depth[i] = (u8)r;
+        ZL_WAVE_FENCE();
+    }
+    u32* const bl = S.small;  // HUF_MAX_BITS + 2 counters
+    if (lane <= HUF_MAX_BITS + 1) bl[lane] = 0;
+    ZL_WAVE_FENCE();
+    u32 kraft_l = 0;
+    for (u32 i = lane; i < m; i += 64) {
+        u32 d = S.node_depth[i];
+        if (d > HUF_MAX_BITS) d = HUF_MAX_BITS;
+        atomicAdd(&bl[d], 1u);
+        kraft_l += 1u << (HUF_MAX_BITS - d);
+    }
+    u32 kraft = wave_sum_u32(kraft_l);  // in units of 2^-HUF_MAX_BITS
+    ZL_WAVE_FENCE();
+    if (lane == 0) {
+        while (kraft > (1u << HUF_MAX_BITS)) {
+            u32 bits = HUF_MAX_BITS - 1;
+            while (bl[bits] == 0) bits--;
+            bl[bits]--;
+            bl[bits + 1] += 2;
+            bl[HUF_MAX_BITS]--;
+            kraft--;
+        }
+    }
+    ZL_WAVE_FENCE();
+    // least frequent symbols take the longest codes: rank i (ascending count) gets the longest length whose counts reach past i
+    u32 cnt_b[HUF_MAX_BITS + 1];
+#pragma unroll
+    for (u32 b = 1; b <= HUF_MAX_BITS; b++) cnt_b[b] = bl[b];
+    u32 maxlen = 0;
+#pragma unroll
+    for (u32 b = 1; b <= HUF_MAX_BITS; b++) if (cnt_b[b]) maxlen = b;
+    for (u32 i = lane; i < m; i += 64) {
+        u32 acc = 0, len = 1;
+#pragma unroll
+        for (u32 b = HUF_MAX_BITS; b >= 1; b--) { if (i >= acc && i < acc + cnt_b[b]) len = b; acc += cnt_b[b]; }
+        S.hlen[S.sorted[i]] = (u8)len;
+    }
+    ZL_WAVE_FENCE();
+    return maxlen;
+}
+
 // Huffman tree description (zstd.c:16907 HUF_writeCTable_wksp): weights of symbols
 // 0..maxsym-1, FSE-compressed when that is smaller (zstd.c:16840 HUF_compressWeights),
 // else 4 bits each.  One thread.  Returns bytes written, 0 if the table cannot be described.
@@ -2010,15 +2088,19 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     if (t == 0) S.lit_from_dict = 0;
     ENT_STAMP(0)
     // ---- wave 3: the Huffman tree  |  waves 0..2: one FSE table each
-    if (t == 3 * 64 && S.lit_mode == 2) {
+    if (wave == 3) {  // (uniform inside the wave: every lane reads the same words)
+        bool go = S.lit_mode == 2;
         // zstd.c:18076 (HUF_compress_internal): "heuristic: probably not compressible enough"
-        if (S.hist[0][S.sorted[S.huf_present - 1]] <= (nlit >> 7) + 4) S.lit_mode = 0;
-    }
-    if (t == 3 * 64 && S.lit_mode == 2) {
-        S.huf_log = huf_build_lengths(S, S.huf_present);
-        u32 maxsym = 255;
-        while (S.hist[0][maxsym] == 0) maxsym--;
-        S.huf_maxsym = maxsym;
+        if (go && S.hist[0][S.sorted[S.huf_present - 1]] <= (nlit >> 7) + 4) { go = false; if (lane == 0) S.lit_mode = 0; }
+        if (go) {
+            const u32 log = huf_build_lengths_wave(S, S.huf_present, lane);
+            const u32 hc = S.hist[0][4 * lane] | S.hist[0][4 * lane + 1] | S.hist[0][4 * lane + 2] | S.hist[0][4 * lane + 3];
+            const u64 any = __ballot(hc != 0);  // the largest symbol present: in the four of the highest lane that holds one
+            const u32 top = 63u - (u32)__builtin_clzll(any);
+            u32 maxsym = 4 * top + 3;
+            while (S.hist[0][maxsym] == 0) maxsym--;
+            if (lane == 0) { S.huf_log = log; S.huf_maxsym = maxsym; }
+        }
     }
     // table choice + construction (zstd.c:21012 ZSTD_selectEncodingType, strategy < lazy branch :21034-21059): waves 0..2 build one
     // table each, all 64 lanes at it (lane = symbol)
