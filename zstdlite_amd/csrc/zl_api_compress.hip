@@ -134,7 +134,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
                           u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned, size_t frame_chunk0 = 0) {
     const bool joined = joined_total != 0;
     if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * ZL_LIT_STRIDE_ENC) || !es.seqs.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(zl_seq)) ||
-        !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(ushort4)) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
+        !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
         return kGpuUnavailable;
     if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
     c->far_valid = false;
@@ -198,7 +198,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.lits = m.lits;
     e.seqs = m.seqs;
     e.meta = m.meta;
-    e.seq_states = (ushort4*)es.sst.p;
+    e.seq_states = (u8*)es.sst.p;
     e.out = (u8*)es.staged.p;
     e.frame_size = (u32*)c->d_fsize.p + first;
     e.lit_stride = ZL_LIT_STRIDE_ENC;

@@ -12,6 +12,7 @@
 #define ZL_ENC_BLOCKS 8                          // blocks per frame (they share one set of entropy tables)
 #define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
 #define ZL_LIT_STRIDE_ENC (ZL_CHUNK + 64)
+#define ZL_SST_BYTES 9                          // per sequence slot of the FSE-chain scratch: 3 code bytes + 3 16-bit states
 #define ZL_FRAME_OVERHEAD 24                     // magic 4 + FHD 1 + dictID 4 + FCS 4 + block header 3 + checksum 4 (+ slack)
 #define ZL_OUT_STRIDE (ZL_CHUNK + ZL_FRAME_OVERHEAD + 8)
 
@@ -91,7 +92,7 @@ struct zl_entropy_args {
     const u8* lits;
     const zl_seq* seqs;
     const zl_chunk_meta* meta;
-    ushort4* seq_states;  // scratch, per chunk seq_stride records: FSE codes, then states (see zl_entropy_kernel)
+    u8* seq_states;       // scratch, per chunk seq_stride * ZL_SST_BYTES bytes: per table the sequences' codes (bytes) and FSE states (16-bit), see zl_entropy_kernel
     u8* out;           // per chunk out_stride bytes: the finished frame
     u32* frame_size;   // per chunk: bytes of the frame
     u32 lit_stride;

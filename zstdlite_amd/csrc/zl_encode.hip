@@ -1980,7 +1980,14 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     const u8* lit = a.lits + (size_t)c * a.lit_stride;
     const zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
     const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
-    ushort4* sst = a.seq_states + (size_t)c * a.seq_stride;  // per sequence: {LL|ML codes, OF code -> OF state, LL state, ML state}
+    // per-sequence scratch of the FSE chains, one array per table (ZL_SST_BYTES per sequence slot): the three codes as bytes,
+    // the three states BEFORE each sequence as 16-bit words.  (Round 2 kept one 8-byte record per sequence; a chain lane then
+    // needed a record per step, and its loop ran at the latency of those loads: one memory round trip per eight steps.  Now
+    // eight steps' codes are ONE 8-byte load, fetched four loads ahead.)
+    u8* const sst_base = (u8*)a.seq_states + (size_t)c * a.seq_stride * ZL_SST_BYTES;
+    u8* const code_k[3] = {sst_base, sst_base + a.seq_stride, sst_base + 2 * (size_t)a.seq_stride};                    // T_LL, T_OF, T_ML
+    unsigned short* const state_k[3] = {(unsigned short*)(sst_base + 3 * (size_t)a.seq_stride), (unsigned short*)(sst_base + 5 * (size_t)a.seq_stride),
+                                        (unsigned short*)(sst_base + 7 * (size_t)a.seq_stride)};
     u8* out = a.out + (size_t)c * a.out_stride;
     const u32 out_limit = a.out_stride - 16;  // what a frame may occupy while it is being built
     const bool prof = a.stats != nullptr && t == 0;
@@ -2048,7 +2055,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 atomicAdd(&S.seq_hist[T_LL][cl], 1u);
                 atomicAdd(&S.seq_hist[T_OF][co], 1u);
                 atomicAdd(&S.seq_hist[T_ML][cm], 1u);
-                sst[i] = make_ushort4((unsigned short)(cl | (cm << 8)), (unsigned short)co, 0, 0);
+                code_k[T_LL][i] = (u8)cl; code_k[T_OF][i] = (u8)co; code_k[T_ML][i] = (u8)cm;
             }
         }
     }
@@ -2257,33 +2264,45 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(max_ns, d, 64); max_ns = o > max_ns ? o : max_ns; }
         const FseCTable& ct = S.ct[k];
         const u32 log = ct.log;
-        unsigned short* slot = (unsigned short*)sst + (k == T_LL ? 2 : (k == T_ML ? 3 : 1));
+        const u8* const codes = code_k[k];
+        unsigned short* const states = state_k[k];
         u32 st = 0;
-        const u32 sym_shift = k == T_LL ? 0u : (k == T_ML ? 8u : 16u);  // where this lane's code sits in {LL | ML << 8, OF}
-        // Eight records are fetched while the previous eight are being coded: the chain itself only
-        // touches LDS, and a load that is needed right away would cost a memory round trip per step.
-        ushort4 cur[8], nxt[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) { nxt[q] = make_ushort4(0, 0, 0, 0); if ((u32)q < ns) nxt[q] = sst[e_seq - 1 - q]; }
+        // Step e of a chain codes sequence e_seq - 1 - e; the eight steps of a trip read the eight code bytes at
+        // [e_seq - 8 - e0, e_seq - e0): one load.  Four trips' loads are in flight: the chain itself only touches LDS, and the loop
+        // used to wait for memory once per trip.
+        auto fetch = [&](u32 e0) -> u64 {  // (bytes below the block's first sequence belong to its neighbour: read, never used)
+            if (e0 >= ns) return 0;
+            const int b = (int)e_seq - 8 - (int)e0;
+            return b >= 0 ? ld64(codes + b) : (ld64(codes) << (8 * (u32)(-b)));  // (the array's first bytes, moved up to where a full trip would have them)
+        };
+        u64 pre0 = fetch(0), pre1 = fetch(8), pre2 = fetch(16), pre3 = fetch(24);
         for (u32 e0 = 0; e0 < max_ns; e0 += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; q++) cur[q] = nxt[q];
-#pragma unroll
-            for (int q = 0; q < 8; q++) if (e0 + 8 + q < ns) nxt[q] = sst[e_seq - 1 - (e0 + 8 + q)];
+            const u64 cur = pre0;
+            pre0 = pre1; pre1 = pre2; pre2 = pre3; pre3 = fetch(e0 + 32);
             u32 before[8];
+            i32 dn[8], df[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
+            for (int q = 0; q < 8; q++) {  // the eight symbols' transforms first: sixteen LDS reads that do not depend on the state
+                const u32 sym = (u32)(cur >> (8 * (7 - q))) & 0xFFu;
+                dn[q] = ct.dnb[sym]; df[q] = ct.dfs[sym];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {  // then the eight steps, each one dependent table read
                 const u32 e = e0 + q;
                 before[q] = 0;
                 if (e < ns && log) {
-                    const ushort4 rec = cur[q];
-                    const u32 sym = (((u32)rec.x | ((u32)rec.y << 16)) >> sym_shift) & 0xFFu;  // (a shift per lane, not a ?: per table: no branches)
-                    if (e == 0) st = fse_init_state(ct.state, ct.dnb[sym], ct.dfs[sym]);
-                    else { before[q] = st; (void)fse_encode(ct.state, ct.dnb[sym], ct.dfs[sym], st); }
+                    if (e == 0) st = fse_init_state(ct.state, dn[q], df[q]);
+                    else { before[q] = st; (void)fse_encode(ct.state, dn[q], df[q], st); }
                 }
             }
+            if (e0 + 8 <= ns && e_seq >= e0 + 8) {  // a full trip: eight states, one 16-byte store (step q's sequence is the (7 - q)-th of them)
+                uint4 w;
+                w.x = before[7] | (before[6] << 16); w.y = before[5] | (before[4] << 16); w.z = before[3] | (before[2] << 16); w.w = before[1] | (before[0] << 16);
+                __builtin_memcpy(states + (e_seq - 8 - e0), &w, 16);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; q++) if (e0 + q < ns) slot[4 * (size_t)(e_seq - 1 - (e0 + q))] = (unsigned short)before[q];
+                for (int q = 0; q < 8; q++) if (e0 + q < ns) states[e_seq - 1 - (e0 + q)] = (unsigned short)before[q];
+            }
         }
         if (on) S.final_state[j][k] = st;
     }
@@ -2421,8 +2440,8 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 u64 lo = 0;
                 u32 nlo = 0;
                 if (e < ns && e > 0) {
-                    const ushort4 rec = sst[e_seq - 1 - e];
-                    const u32 bo = rec.y, bl = rec.z, bm = rec.w;  // states before this sequence
+                    const u32 si = e_seq - 1 - e;
+                    const u32 bo = state_k[T_OF][si], bl = state_k[T_LL][si], bm = state_k[T_ML][si];  // states before this sequence
                     const u32 no = S.ct[T_OF].log ? (u32)((i32)bo + S.ct[T_OF].dnb[co]) >> 16 : 0u;
                     const u32 nm_ = S.ct[T_ML].log ? (u32)((i32)bm + S.ct[T_ML].dnb[cm]) >> 16 : 0u;
                     const u32 nl2 = S.ct[T_LL].log ? (u32)((i32)bl + S.ct[T_LL].dnb[cl]) >> 16 : 0u;
