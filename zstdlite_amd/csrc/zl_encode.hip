@@ -2021,7 +2021,49 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         const u32 worth = (nseq * 4u + nlit) >> 12;
         if (worth < nbk) nbk = worth ? worth : 1u;
     }
-    if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
+    // The boundaries: for each, the first sequence whose match ends behind its byte target.  Searched WIDE: 256 threads sample the
+    // sequences' ends at equal strides, every boundary then names its stride from the samples in LDS, and the threads test that
+    // stride's sequences at once -- three memory round trips where a binary search per boundary made fifteen in a row while the
+    // other 247 threads waited.  Same boundaries as block_boundary() finds.
+    if (nbk > 1 && nseq) {
+        u32* const samp = S.stage;          // [256] the sampled ends (the staging words are zeroed again below)
+        u32* const lo_of = S.stage + 256;   // [nbk] per boundary: the first sequence that ends behind the target (minimum over the candidates)
+        const u32 stride = (nseq + ENC_THREADS - 1) / ENC_THREADS;
+        {
+            const u32 i = t * stride;
+            u32 e = 0xFFFFFFFFu;
+            if (i < nseq) { const zl_seq q = seqs[i]; e = q.pos + q.match_len; }
+            samp[t] = e;
+            if (t < ZL_ENC_BLOCKS + 1) lo_of[t] = nseq;
+        }
+        __syncthreads();
+        // candidates of boundary j: the stride behind the last sample that does not end behind the target (or the first stride)
+        for (u32 item = t; item < (nbk - 1) * (stride + 1); item += ENC_THREADS) {
+            const u32 j = 1 + item / (stride + 1), off = item % (stride + 1);
+            const u32 target = (u32)(((u64)j * n) / nbk);
+            u32 lo = 0, hi = ENC_THREADS;  // the samples are ascending: first sample that ends behind the target
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (samp[mid] > target) hi = mid; else lo = mid + 1; }
+            const u32 base = lo ? (lo - 1) * stride : 0u, i = base + off;  // the answer lies in [base, base + stride]
+            if (i < nseq) { const zl_seq q = seqs[i]; if (q.pos + q.match_len > target) atomicMin(&lo_of[j], i); }
+        }
+        __syncthreads();
+        if (t <= ZL_ENC_BLOCKS) {
+            u32 fs = 0, fl = 0;
+            if (t >= nbk) { fs = nseq; fl = nlit; }
+            else if (t > 0) {
+                const u32 target = (u32)(((u64)t * n) / nbk), lo = lo_of[t];
+                if (lo == nseq) { fs = nseq; fl = nlit - (n - target); }  // inside the trailing literals
+                else {
+                    const zl_seq q = seqs[lo];
+                    if (target <= q.pos) { fs = lo; fl = q.lit_cum - (q.pos - target); }  // inside the literal run in front of match lo
+                    else { fs = lo + 1; fl = q.lit_cum; }                                  // inside match lo: the block ends with it
+                }
+            }
+            S.blk_seq[t] = fs; S.blk_lit[t] = fl;
+        }
+        __syncthreads();
+        for (u32 i = t; i < 256 + ZL_ENC_BLOCKS + 1; i += ENC_THREADS) S.stage[i] = 0;
+    } else if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
     __syncthreads();
 
     // =========================== statistics of the whole chunk: literal histogram, sequence codes and their histograms
@@ -2030,32 +2072,53 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     // tables, the tree description next to the FSE state chains.
     {   // 16 literals per thread and trip (one byte per trip leaves a single load in flight per thread);
         // four histogram copies, one per wave, keep the atomics apart
+        // ZERO bytes are counted in a register and added once: lanes that hit one bin in one instruction are served one after the
+        // other, and zero is the byte that binary data is full of (a quarter of the literals of 20-bit integers stored in 32:
+        // the pass took three times as long as on random bytes)
         const u32 body = nlit & ~15u;
+        u32 zeros = 0;
         for (u32 i = t * 16; i < body; i += ENC_THREADS * 16) {
             const uint4 v = ld128(lit + i);
             const u32 w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                atomicAdd(&S.hist[wave][w4[k] & 0xFF], 1u);
-                atomicAdd(&S.hist[wave][(w4[k] >> 8) & 0xFF], 1u);
-                atomicAdd(&S.hist[wave][(w4[k] >> 16) & 0xFF], 1u);
-                atomicAdd(&S.hist[wave][w4[k] >> 24], 1u);
+                const u32 b0 = w4[k] & 0xFF, b1 = (w4[k] >> 8) & 0xFF, b2 = (w4[k] >> 16) & 0xFF, b3 = w4[k] >> 24;
+                if (b0) atomicAdd(&S.hist[wave][b0], 1u);
+                if (b1) atomicAdd(&S.hist[wave][b1], 1u);
+                if (b2) atomicAdd(&S.hist[wave][b2], 1u);
+                if (b3) atomicAdd(&S.hist[wave][b3], 1u);
+                zeros += (b0 == 0) + (b1 == 0) + (b2 == 0) + (b3 == 0);
             }
         }
+        if (zeros) atomicAdd(&S.hist[wave][0], zeros);
         if (t < nlit - body) atomicAdd(&S.hist[wave][lit[body + t]], 1u);
     }
     if (nseq) {
         for (u32 j = 0; j < nbk; j++) {
             const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
-            for (u32 i = f_seq + t; i < e_seq; i += ENC_THREADS) {
-                const zl_seq s = seqs[i];
-                u32 ll, ob;
-                seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
-                const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(s.match_len);
-                atomicAdd(&S.seq_hist[T_LL][cl], 1u);
-                atomicAdd(&S.seq_hist[T_OF][co], 1u);
-                atomicAdd(&S.seq_hist[T_ML][cm], 1u);
-                code_k[T_LL][i] = (u8)cl; code_k[T_OF][i] = (u8)co; code_k[T_ML][i] = (u8)cm;
+            // two consecutive sequences per thread and trip: the second's predecessor is the first, so three loads -- all in flight
+            // together -- serve two sequences (one sequence per trip made two dependent trips to memory for each)
+            for (u32 i = f_seq + 2 * t; i < e_seq; i += 2 * ENC_THREADS) {
+                const bool two = i + 1 < e_seq, first = i == f_seq;
+                const zl_seq s0 = seqs[i];
+                zl_seq s1 = s0, sp = s0;
+                if (two) s1 = seqs[i + 1];
+                if (!first) sp = seqs[i - 1];
+                const u32 prev_cum = first ? f_lit : sp.lit_cum, prev_off = first ? 0u : sp.offset;  // (seq_fields: a block's first sequence spells its offset out)
+                const u32 ll0 = s0.lit_cum - prev_cum, ob0 = (ll0 > 0 && s0.offset == prev_off) ? 1u : s0.offset + 3;
+                const u32 cl0 = ll_code(ll0), co0 = hb32(ob0), cm0 = ml_code(s0.match_len);
+                atomicAdd(&S.seq_hist[T_LL][cl0], 1u);
+                atomicAdd(&S.seq_hist[T_OF][co0], 1u);
+                atomicAdd(&S.seq_hist[T_ML][cm0], 1u);
+                code_k[T_LL][i] = (u8)cl0; code_k[T_OF][i] = (u8)co0; code_k[T_ML][i] = (u8)cm0;
+                if (two) {
+                    const u32 ll1 = s1.lit_cum - s0.lit_cum, ob1 = (ll1 > 0 && s1.offset == s0.offset) ? 1u : s1.offset + 3;
+                    const u32 cl1 = ll_code(ll1), co1 = hb32(ob1), cm1 = ml_code(s1.match_len);
+                    atomicAdd(&S.seq_hist[T_LL][cl1], 1u);
+                    atomicAdd(&S.seq_hist[T_OF][co1], 1u);
+                    atomicAdd(&S.seq_hist[T_ML][cm1], 1u);
+                    code_k[T_LL][i + 1] = (u8)cl1; code_k[T_OF][i + 1] = (u8)co1; code_k[T_ML][i + 1] = (u8)cm1;
+                }
             }
         }
     }
