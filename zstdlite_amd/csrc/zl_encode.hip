@@ -2075,6 +2075,10 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         // ZERO bytes are counted in a register and added once: lanes that hit one bin in one instruction are served one after the
         // other, and zero is the byte that binary data is full of (a quarter of the literals of 20-bit integers stored in 32:
         // the pass took three times as long as on random bytes)
+        // Four copies of every bin, side by side, one per lane modulo four (round 2: one copy per WAVE, which keeps waves apart
+        // but not the lanes of one instruction -- and those are what the LDS serialises: literals over a ten-letter alphabet put
+        // six lanes on every bin): the lanes that hit one byte value spread over four neighbouring banks.
+        u32* const H = &S.hist[0][0] + (lane & 3);
         const u32 body = nlit & ~15u;
         u32 zeros = 0;
         for (u32 i = t * 16; i < body; i += ENC_THREADS * 16) {
@@ -2083,16 +2087,19 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const u32 b0 = w4[k] & 0xFF, b1 = (w4[k] >> 8) & 0xFF, b2 = (w4[k] >> 16) & 0xFF, b3 = w4[k] >> 24;
-                if (b0) atomicAdd(&S.hist[wave][b0], 1u);
-                if (b1) atomicAdd(&S.hist[wave][b1], 1u);
-                if (b2) atomicAdd(&S.hist[wave][b2], 1u);
-                if (b3) atomicAdd(&S.hist[wave][b3], 1u);
+                if (b0) atomicAdd(&H[4 * b0], 1u);
+                if (b1) atomicAdd(&H[4 * b1], 1u);
+                if (b2) atomicAdd(&H[4 * b2], 1u);
+                if (b3) atomicAdd(&H[4 * b3], 1u);
                 zeros += (b0 == 0) + (b1 == 0) + (b2 == 0) + (b3 == 0);
             }
         }
-        if (zeros) atomicAdd(&S.hist[wave][0], zeros);
-        if (t < nlit - body) atomicAdd(&S.hist[wave][lit[body + t]], 1u);
+        if (zeros) atomicAdd(&H[0], zeros);
+        if (t < nlit - body) atomicAdd(&H[4 * (u32)lit[body + t]], 1u);
     }
+    // (the three code histograms likewise in four copies per bin, in the staging words -- 3 KiB that nothing else uses during this
+    // pass --, summed into seq_hist behind the barrier: a text chunk's 18 000 sequences share a handful of codes)
+    u32* const SH = S.stage + (lane & 3);
     if (nseq) {
         for (u32 j = 0; j < nbk; j++) {
             const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
@@ -2107,23 +2114,24 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 const u32 prev_cum = first ? f_lit : sp.lit_cum, prev_off = first ? 0u : sp.offset;  // (seq_fields: a block's first sequence spells its offset out)
                 const u32 ll0 = s0.lit_cum - prev_cum, ob0 = (ll0 > 0 && s0.offset == prev_off) ? 1u : s0.offset + 3;
                 const u32 cl0 = ll_code(ll0), co0 = hb32(ob0), cm0 = ml_code(s0.match_len);
-                atomicAdd(&S.seq_hist[T_LL][cl0], 1u);
-                atomicAdd(&S.seq_hist[T_OF][co0], 1u);
-                atomicAdd(&S.seq_hist[T_ML][cm0], 1u);
+                atomicAdd(&SH[4 * (64 * T_LL + cl0)], 1u);
+                atomicAdd(&SH[4 * (64 * T_OF + co0)], 1u);
+                atomicAdd(&SH[4 * (64 * T_ML + cm0)], 1u);
                 code_k[T_LL][i] = (u8)cl0; code_k[T_OF][i] = (u8)co0; code_k[T_ML][i] = (u8)cm0;
                 if (two) {
                     const u32 ll1 = s1.lit_cum - s0.lit_cum, ob1 = (ll1 > 0 && s1.offset == s0.offset) ? 1u : s1.offset + 3;
                     const u32 cl1 = ll_code(ll1), co1 = hb32(ob1), cm1 = ml_code(s1.match_len);
-                    atomicAdd(&S.seq_hist[T_LL][cl1], 1u);
-                    atomicAdd(&S.seq_hist[T_OF][co1], 1u);
-                    atomicAdd(&S.seq_hist[T_ML][cm1], 1u);
+                    atomicAdd(&SH[4 * (64 * T_LL + cl1)], 1u);
+                    atomicAdd(&SH[4 * (64 * T_OF + co1)], 1u);
+                    atomicAdd(&SH[4 * (64 * T_ML + cm1)], 1u);
                     code_k[T_LL][i + 1] = (u8)cl1; code_k[T_OF][i + 1] = (u8)co1; code_k[T_ML][i + 1] = (u8)cm1;
                 }
             }
         }
     }
     zl_sync_global();  // (the codes travel to the chain lanes through memory)
-    const u32 cnt_t = S.hist[0][t] + S.hist[1][t] + S.hist[2][t] + S.hist[3][t];
+    if (t < 3 * 64) (&S.seq_hist[0][0])[t] = S.stage[4 * t] + S.stage[4 * t + 1] + S.stage[4 * t + 2] + S.stage[4 * t + 3];
+    const u32 cnt_t = (&S.hist[0][0])[4 * t] + (&S.hist[0][0])[4 * t + 1] + (&S.hist[0][0])[4 * t + 2] + (&S.hist[0][0])[4 * t + 3];
     __syncthreads();
     S.hist[0][t] = cnt_t;
     __syncthreads();
