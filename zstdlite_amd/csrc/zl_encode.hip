@@ -2489,20 +2489,36 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             u8* bs = sq + S.seq_hdr_size;
             const u32 bs_pos = cur + 3 + lit_sec + S.seq_hdr_size;
             u32 written = 0, carry_bits = 0;
+            // (a tile's records -- the sequence, its predecessor's literal count and offset, the three saved states -- are asked for
+            // one tile AHEAD: the loop used to wait for memory once per tile, 72 times per text chunk)
+            struct TileRec { u32 lit_cum, match_len, offset, prev_cum, prev_off, bo, bl, bm; };
+            auto fetch_tile = [&](u32 e) -> TileRec {
+                TileRec r = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (e < ns) {
+                    const u32 i = e_seq - 1 - e;
+                    const zl_seq sq_ = seqs[i];
+                    r.lit_cum = sq_.lit_cum; r.match_len = sq_.match_len; r.offset = sq_.offset;
+                    if (i == f_seq) { r.prev_cum = f_lit; r.prev_off = 0; }  // (seq_fields: a block's first sequence counts its literals from the block start and spells its offset out)
+                    else { const zl_seq pq = seqs[i - 1]; r.prev_cum = pq.lit_cum; r.prev_off = pq.offset; }
+                    if (e > 0) { r.bo = state_k[T_OF][i]; r.bl = state_k[T_LL][i]; r.bm = state_k[T_ML][i]; }  // states before this sequence
+                }
+                return r;
+            };
+            TileRec nxt_rec = fetch_tile(t);
             for (u32 e0 = 0; e0 < ns; e0 += SEQ_TILE) {
                 const u32 e = e0 + t;  // emission index; sequence index = e_seq-1-e
+                const TileRec rec = nxt_rec;
+                nxt_rec = fetch_tile(e + SEQ_TILE);
                 u64 extra = 0;   // LL extra | ML extra | OF extra (in stream order)
                 u32 nextra = 0;
                 u32 cl = 0, cm = 0, co = 0;
                 if (e < ns) {
-                    const u32 i = e_seq - 1 - e;
-                    const zl_seq s = seqs[i];
-                    u32 ll, ob;
-                    seq_fields(seqs, i, f_seq, f_lit, s, ll, ob);
-                    cl = ll_code(ll); cm = ml_code(s.match_len); co = hb32(ob);
+                    const u32 ll = rec.lit_cum - rec.prev_cum;
+                    const u32 ob = (ll > 0 && rec.offset == rec.prev_off) ? 1u : rec.offset + 3;
+                    cl = ll_code(ll); cm = ml_code(rec.match_len); co = hb32(ob);
                     const u32 nl_ = e_LL_bits[cl], nm = e_ML_bits[cm];
                     extra = (u64)(ll - e_LL_base[cl]);
-                    extra |= (u64)(s.match_len - e_ML_base[cm]) << nl_;
+                    extra |= (u64)(rec.match_len - e_ML_base[cm]) << nl_;
                     extra |= (u64)(ob - (1u << co)) << (nl_ + nm);
                     nextra = nl_ + nm + co;
                 }
@@ -2511,8 +2527,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 u64 lo = 0;
                 u32 nlo = 0;
                 if (e < ns && e > 0) {
-                    const u32 si = e_seq - 1 - e;
-                    const u32 bo = state_k[T_OF][si], bl = state_k[T_LL][si], bm = state_k[T_ML][si];  // states before this sequence
+                    const u32 bo = rec.bo, bl = rec.bl, bm = rec.bm;
                     const u32 no = S.ct[T_OF].log ? (u32)((i32)bo + S.ct[T_OF].dnb[co]) >> 16 : 0u;
                     const u32 nm_ = S.ct[T_ML].log ? (u32)((i32)bm + S.ct[T_ML].dnb[cm]) >> 16 : 0u;
                     const u32 nl2 = S.ct[T_LL].log ? (u32)((i32)bl + S.ct[T_LL].dnb[cl]) >> 16 : 0u;
@@ -2533,10 +2548,15 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 const u32 nbytes = total >> 3;
                 if (bs_pos + written + nbytes + 32 > out_limit) fail = true;  // uniform
                 const u8* sb = (const u8*)S.stage;
-                if (!fail) for (u32 i = t; i < nbytes; i += ENC_THREADS) bs[written + i] = sb[i];
+                if (!fail) {  // whole dwords (global memory takes unaligned dword stores), then the odd bytes
+                    const u32 nd = nbytes >> 2;
+                    for (u32 i = t; i < nd; i += ENC_THREADS) { const u32 x = S.stage[i]; __builtin_memcpy(bs + written + 4 * i, &x, 4); }
+                    if (t < (nbytes & 3)) bs[written + 4 * nd + t] = sb[4 * nd + t];
+                }
                 const u32 keep = (total & 7) ? sb[nbytes] : 0;
                 __syncthreads();
-                for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = (i == 0) ? keep : 0;
+                const u32 used = (total >> 5) + 3 < 1024u ? (total >> 5) + 3 : 1024u;  // (only the words this tile touched)
+                for (u32 i = t; i < used; i += ENC_THREADS) S.stage[i] = (i == 0) ? keep : 0;
                 __syncthreads();
                 if (fail) break;
                 written += nbytes;
