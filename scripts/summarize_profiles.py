@@ -74,7 +74,7 @@ def pmc(path):
 fetch = pmc(one("pmc_fetch/*/*counter_collection.csv"))
 write = pmc(one("pmc_write/*/*counter_collection.csv"))
 summary, short = {}, {}
-names = {"zl_match_auto_kernel": "match", "zl_match_auto_kernel<false, false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true, false>": "match_small", "zl_match_auto_kernel<false, false, false, false, true>": "match_level5", "zl_match_auto_kernel<false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true>": "match_small", "zl_far_build_kernel": "far_build", "zl_far_probe_kernel": "far_probe", "zl_match_auto_kernel<false, false>": "match", "zl_match_auto_kernel<false, true>": "match", "zl_match_auto_kernel<true, false>": "match_dict", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
+names = {"zl_match_auto_kernel<false, false, true, true, false>": "match_windowed", "zl_match_auto_kernel": "match", "zl_match_auto_kernel<false, false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true, false>": "match_small", "zl_match_auto_kernel<false, false, false, false, true>": "match_level5", "zl_match_auto_kernel<false, false, false, false>": "match", "zl_match_auto_kernel<false, false, true, true>": "match_windowed", "zl_match_auto_kernel<false, false, false, true>": "match_small", "zl_far_build_kernel": "far_build", "zl_far_probe_kernel": "far_probe", "zl_match_auto_kernel<false, false>": "match", "zl_match_auto_kernel<false, true>": "match", "zl_match_auto_kernel<true, false>": "match_dict", "zl_entropy_kernel": "entropy", "zl_scan_sizes_kernel": "scan", "zl_gather_kernel": "gather",
          "zl_decode_kernel": "d_general", "zl2_index_kernel": "d_index", "zl2_entropy_kernel": "d_entropy", "zl2_seq_kernel": "d_entropy", "zl2_entropy1_kernel": "d_entropy1", "zl2_lit_kernel": "d_entropy_lit", "zl2_lit_kernel<8>": "d_entropy_lit", "zl2_lit_kernel<1>": "d_entropy_lit1", "zl2_order_kernel": "d_order", "zl2_exec_kernel": "d_exec", "zl2_exec_kernel<false>": "d_exec", "zl2_exec_kernel<true>": "d_exec_large", "zl2_exec_kernel<false, false>": "d_exec", "zl2_exec_kernel<false, true>": "d_exec", "zl2_exec_kernel<true, false>": "d_exec_large"}
 for k in sorted(set(dur) | set(fetch) | set(write)):
     base = k.split("(")[0].replace("void ", "")
@@ -98,3 +98,50 @@ short["_kernel_sources_sha256"] = h.hexdigest()
 json.dump(summary, open(os.path.join(P, f"{rnd}_kernel_summary.json"), "w"), indent=1)
 json.dump(short, open(os.path.join(P, f"{rnd}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
+
+# ---- the DEFAULT (one-frame) layout: scripts/one_frame_prof.py under the profiler (kernel stats, FETCH_SIZE / WRITE_SIZE passes)
+of_stats = one("prof_one_frame/*/*kernel_stats.csv")
+if of_stats:
+    rows = [r for r in csv.DictReader(open(of_stats)) if "zl" in r["Name"]]
+    with open(os.path.join(P, f"{rnd}_one_frame_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["Name"])
+        w.writeheader()
+        w.writerows(rows)
+    of_fetch = pmc(one("pmc_of_fetch/*/*counter_collection.csv"))
+    of_write = pmc(one("pmc_of_write/*/*counter_collection.csv"))
+    avg = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e6 for r in rows}
+    of = {}
+    for k in sorted(set(of_fetch) | set(of_write)):
+        base = k.split("(")[0].replace("void ", "")
+        f_kb = sum(of_fetch[k]) / len(of_fetch[k]) if of_fetch.get(k) else None
+        w_kb = sum(of_write[k]) / len(of_write[k]) if of_write.get(k) else None
+        of[base] = {"avg_ms_all_launches": avg.get(base), "FETCH_SIZE_KB_per_full_launch": f_kb, "WRITE_SIZE_KB_per_full_launch": w_kb,
+                    "hbm_bytes_per_launch_raw": (f_kb + w_kb) * 1024 if f_kb is not None and w_kb is not None else None,
+                    "hbm_bytes_per_launch_fetch_doubled": (2 * f_kb + w_kb) * 1024 if f_kb is not None and w_kb is not None else None}
+    of["_note"] = "compress + decompress of the 1 GiB bench mix in the one-frame layout, device-resident (scripts/one_frame_prof.py); FETCH_SIZE / WRITE_SIZE from separate rocprofv3 --pmc passes, largest-grid launches only; MI355X_MICROARCH.md: FETCH_SIZE halves wide streaming reads on gfx950 (both bounds given)"
+    json.dump(of, open(os.path.join(P, f"{rnd}_one_frame_pmc.json"), "w"), indent=1)
+
+# ---- L2 and fabric counters of the headline command (what the match kernel's candidate gathers do to the memory system)
+l2csv = one("pmc_l2/*/*counter_collection.csv")
+if l2csv:
+    rows = list(csv.DictReader(open(l2csv)))
+    for r in rows:
+        r["Grid_Size"] = r.get("Grid_Size") or r.get("Grid_Size_X") or "0"
+    big = collections.defaultdict(int)
+    for r in rows:
+        if "zl" in r["Kernel_Name"]:
+            big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        k = r["Kernel_Name"]
+        if "zl" in k and int(r["Grid_Size"]) == big[k]:
+            acc[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    l2 = {}
+    for k, cs in acc.items():
+        e = {c: sum(v) / len(v) for c, v in cs.items()}
+        if e.get("TCC_HIT_sum") is not None and e.get("TCC_MISS_sum") is not None and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
+            e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
+        l2[k] = e
+    l2["_note"] = ("per full-grid launch of the headline command.  TCC_EA0_RDREQ counts the L2's read requests to the fabric; whether the fabric serves them from the "
+                   "Infinity Cache or from HBM is decided behind the TCC block and is not visible to these counters (MI355X_MICROARCH.md: Infinity-Cache hits appear to be counted, not excluded)")
+    json.dump(l2, open(os.path.join(P, f"{rnd}_l2_counters.json"), "w"), indent=1)
