@@ -39,7 +39,7 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 /* parameter ids: numerically identical to ZSTD_cParameter / ZSTD_dParameter so that
  * src/cctx.c:265-284 and src/dctx.c:99,163 compile unchanged against the twins */
 #define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel.  Three operating points: < 3 (every other position
-                                   * probed), 3-4 (the double-hash parse), >= 5 (match tables four times the size, longer
+                                   * probed), 3-4 (the double-hash parse), >= 5 (larger match tables, longer
                                    * verification, denser far search: slower, smaller output).  zl_CCtx_getParameter reports
                                    * the point a context runs at (as given below 3; 3 or 5 above). */
 #define ZL_c_checksumFlag 201     /* zstd.h:440  ZSTD_c_checksumFlag     */
@@ -54,8 +54,10 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  *   ZL_layout_frames (1): one independent frame per chunk, concatenated: decodes fastest (no chunk depends on
  *     another), but a first-frame reader sees 128 KiB, and nothing further back than the chunk is matched.
  *   ZL_layout_auto (0, default): one frame for zl_compress2 / zl_compressStream2, independent frames for the
- *     device-resident and batch entries.  A context with a dictionary or with ZL_c_checksumFlag always writes
- *     independent frames (a dictionary frame is small by nature; XXH64 over one huge frame is a serial chain). */
+ *     device-resident and batch entries.  Contexts with ZL_c_checksumFlag or a dictionary follow the same rule (round 3):
+ *     one frame carries ONE content checksum over all of it (zstd.c:27733; XXH64 is a single dependency chain, so it is
+ *     computed on a host thread beside the upload and checked on the host beside the download), and a dictionary's
+ *     content is history in front of the frame's first chunk (zstd.c:27550). */
 #define ZL_c_frameLayout 9003
 #define ZL_layout_auto 0
 #define ZL_layout_frames 1
@@ -67,7 +69,9 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * zstd.c:41722-41733, and by a reader that takes the first frame only) listing the compressed size of every 128 KiB
  * chunk.  zl_decompressDCtx and zl_index_frames find it from the end of the buffer and skip the serial walk over
  * every block header of the data in front of it; the table is checked against the data, never trusted.  Off by default:
- * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written. */
+ * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written.
+ * The table's layout is PRIVATE to this library (zl_format.h: magic 0x184D2A5E, trailer tag "ZLIX"), not the seekable
+ * format of zstd's contrib tools (footer magic 0x8F92EAB1): other tools skip it, they cannot use it. */
 #define ZL_c_seekTable 9006
 /* Devices behind one call: zl_compress2 / zl_decompressDCtx of a large host buffer deal its 64 MiB sections out
  * over this many device slots -- slot s on device s mod hipGetDeviceCount() --, each with its own host thread, upload and
@@ -101,7 +105,7 @@ size_t zl_findFrameCompressedSize(const void *src, size_t srcSize);
 unsigned long long zl_getFrameContentSize(const void *src, size_t srcSize);
 
 /* Whole-buffer helpers for concatenated frames (what the independent-frames layout produces for inputs
- * larger than one chunk: device-resident and batch entries, checksum and dictionary contexts).
+ * larger than one chunk: device-resident and batch entries, or ZL_c_frameLayout = ZL_layout_frames).
  * zl_findDecompressedSize is the twin of
  * ZSTD_findDecompressedSize (zstd.h:1484): sum of the content sizes of all frames.
  * zl_findAllFramesCompressedSize: total bytes covered by complete frames from src[0]. */
@@ -118,8 +122,8 @@ size_t zl_CCtx_getParameter(const zl_cctx *cctx, int param, int *value);
 size_t zl_CCtx_loadDictionary(zl_cctx *cctx, const void *dict, size_t dictSize); /* copied, as zstd.c:23826-23830 */
 
 /* replaces ZSTD_compress2 (zstd.h:599; call sites src/raw-file.c:74, src/serialize.c:91):
- * host src -> host dst.  ONE complete zstd frame with the content size recorded, as the reference writes
- * (ZL_c_frameLayout; a checksum or dictionary context writes one frame per 128 KiB chunk instead).  Large
+ * host src -> host dst.  ONE complete zstd frame with the content size recorded, as the reference writes, whatever the
+ * context holds -- level, checksum flag, dictionary (ZL_c_frameLayout selects independent frames instead).  Large
  * inputs are uploaded, compressed and downloaded in overlapping 64 MiB sections (ZL_c_pipeline), optionally
  * on several devices (ZL_c_devices); the bytes written depend on neither. */
 size_t zl_compress2(zl_cctx *cctx, void *dst, size_t dstCapacity, const void *src, size_t srcSize);

@@ -197,7 +197,7 @@ __device__ __forceinline__ bool worth_it(u32 len, u32 off, u32 rep) {
 }
 // HI: the operating point of levels >= 5 (no dictionary): tables of 2^14 + 2^13 entries (48 KiB of LDS: three workgroups per
 // CU instead of seven) and verification up to 72 bytes per lane.  The CPU model of the parse (scripts/dev/sim/sim.c) gives
-// text +3.2 %, python sources +5.3 % of ratio for it; what the device gives and costs is in DESIGN.md 3.4.
+// text +3.2 %, python sources +5.3 % of ratio for it; what the device gives and costs is in DESIGN.md 3.3.
 template <bool DICT, bool PROF, bool FAR, bool INTRA, bool HI = false>
 __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     static_assert(!(DICT && HI), "the dictionary's table image has the base sizes");
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // The bulk path (no dictionary, independent frames, inputs larger than a chunk) runs with half the short table: its
     // candidates are nearer (mean age = table size), so their gathers hit closer caches -- 1 GiB mix: match 5.74 -> 4.98 ms
     // for 0.1 % of ratio (text -1.2 %, python sources -2.4 %; a distance cap on the short candidates bought the same time
-    // for twice the ratio: DESIGN.md 3.3).  The other instantiations keep 2^12 entries.
+    // for twice the ratio: DESIGN.md appendix A.1).  The other instantiations keep 2^12 entries.
     // One frame at level 3: 2^13 + 2^13 entries (34 KiB of LDS: four workgroups per CU).  Round 2 ran this layout with the level >= 5
     // tables (2^14 + 2^13: three per CU) at every level; measured on the 1 GiB mix: match 10.3 -> 7.9 ms, python sources 4.396 ->
     // 4.368 (1.014x the reference's size), text 4.604 -> 4.533 (reference 4.512).  2^14 + 2^11 ran as fast and cost the sources
