@@ -413,3 +413,33 @@ def test_ratio_sweep_small_sizes(ref):
             if r > 1.05:
                 over[(name, n)] = round(r, 3)
     assert len(over) <= 6, over  # (the table's own count of cells above 1.05)
+
+
+def test_device_entry_one_frame_with_checksum_and_dictionary(ref):
+    """The device-resident entry in the one-frame layout (on request there; its default is independent frames): with
+    ZL_c_checksumFlag the frame's XXH64 is computed on the host over pieces brought down from the device and appended on the
+    device; the last chunk's reported size covers those four bytes, which is what the decoder's chunk hint expects.  Same bytes
+    as the host entry writes for the same input."""
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    data = GENERATORS["text"](700001, seed=21) + GENERATORS["iid10"](300000, seed=22) + GENERATORS["rand"](100000, seed=23)
+    n = len(data)
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    codec = DeviceCodec(include_checksum=True, frame_layout="one_frame")
+    dst, total, sizes = codec.compress(src)
+    comp = bytes(dst[:total].cpu().numpy())
+    assert int(sizes.sum()) == total
+    assert comp == z.zstd_compress(data, include_checksum=True)
+    assert ref.L.ZSTD_findFrameCompressedSize(comp, len(comp)) == len(comp)
+    assert ref.decompress(comp, n) == data
+    back = torch.zeros_like(src)
+    tbl = codec.frame_table([total], [n])
+    for hint in (sizes, None):
+        back.zero_()
+        got, _ = codec.decompress(dst, tbl, back, chunk_sizes=hint)
+        assert got == n and torch.equal(back, src)
+    bad = dst.clone()
+    bad[total - 2] ^= 0x21
+    with pytest.raises(z.ZstdError, match="doesn't match checksum"):
+        codec.decompress(bad, tbl, back, chunk_sizes=sizes)
+    codec.close()

@@ -1045,18 +1045,22 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     std::vector<zl_frame_desc> table(n);
     std::vector<size_t> pre(n, 0);
     size_t in_total = 0, out_total = 0;
+    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            FrameHeader h;
+            const u8* s = (const u8*)srcs[i];
+            const size_t fs = find_frame_size(s, sizes[i], &h);
+            if (ZL_IS_ERR(fs)) { pre[i] = fs; }
+            else if (h.skippable || fs != sizes[i]) { pre[i] = ZL_ERR(ZL_E_SRCSIZE_WRONG); }
+            else if (h.content_size == ZL_CONTENTSIZE_UNKNOWN) { pre[i] = ZL_ERR(ZL_E_FRAMEPARAM_UNSUPPORTED); }
+            else if (h.content_size > caps[i]) { pre[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL); }
+            table[i].src_size = pre[i] ? 0 : sizes[i];
+            table[i].dst_cap = pre[i] ? 0 : h.content_size;
+        }
+    });
     for (size_t i = 0; i < n; i++) {
-        FrameHeader h;
-        const u8* s = (const u8*)srcs[i];
-        size_t fs = find_frame_size(s, sizes[i], &h);
-        if (ZL_IS_ERR(fs)) { pre[i] = fs; fs = 0; }
-        else if (h.skippable || fs != sizes[i]) { pre[i] = ZL_ERR(ZL_E_SRCSIZE_WRONG); }
-        else if (h.content_size == ZL_CONTENTSIZE_UNKNOWN) { pre[i] = ZL_ERR(ZL_E_FRAMEPARAM_UNSUPPORTED); }
-        else if (h.content_size > caps[i]) { pre[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL); }
         table[i].src_off = in_total;
-        table[i].src_size = pre[i] ? 0 : sizes[i];
         table[i].dst_off = out_total;
-        table[i].dst_cap = pre[i] ? 0 : h.content_size;
         in_total += (table[i].src_size + 15) & ~(size_t)15;
         out_total += (table[i].dst_cap + 15) & ~(size_t)15;
     }
@@ -1064,8 +1068,10 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     if (!d->h_stage_in.ensure(in_total + 16) || !d->h_stage_out.ensure(out_total + 16) || !d->d_src.ensure(in_total + 16) ||
         !d->d_dst.ensure(out_total + 16) || !d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64)))
         return kGpuUnavailable;
-    for (size_t i = 0; i < n; i++)
-        if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, srcs[i], table[i].src_size);
+    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++)
+            if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, srcs[i], table[i].src_size);
+    });
     tp[1] = now_ms();
     if (hipMemcpyAsync(d->d_src.p, d->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
@@ -1078,11 +1084,13 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     tp[4] = now_ms();
     const u64* r = (const u64*)d->h_results.p;
-    for (size_t i = 0; i < n; i++) {
-        if (pre[i]) { results[i] = pre[i]; continue; }
-        results[i] = (size_t)r[i];
-        if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
-    }
+    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            if (pre[i]) { results[i] = pre[i]; continue; }
+            results[i] = (size_t)r[i];
+            if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
+        }
+    });
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) d->batch_ms[k] = tp[k + 1] - tp[k]; }
     return 0;
 }

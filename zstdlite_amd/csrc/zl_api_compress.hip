@@ -25,6 +25,7 @@ struct zl_cctx_s {
     int nb_workers = 0;
     int layout = 0;  // ZL_c_frameLayout: 0 auto, 1 independent frames, 2 one frame
     int pipeline = 1;  // ZL_c_pipeline: host entries overlap upload, kernels and download for large inputs
+    u32 chunk_cap = ZL_CHUNK;  // the largest src_size in the chunk table being enqueued, if the caller knows it (zl_compress_batch): sizes the per-chunk scratch
     bool any_small = false;  // the chunk table being enqueued holds inputs of at most one chunk (zl_chunk_desc::flags bit 0)
     int last_slots = 1;  // device slots the last zl_compress2 call used
     int devices = 1;     // ZL_c_devices: device slots zl_compress2 spreads a large input over (0: every visible device)
@@ -125,6 +126,22 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
     return 0;
 }
 
+// The per-chunk scratch strides for a chunk table whose largest entry holds `cap` bytes.  Full chunks: the constants of
+// zl_encode.h.  A batch of small objects (config C4: 100k objects of a few hundred bytes) gets strides to match, so that
+// the whole batch is ONE launch group instead of thirteen (each group's four kernels and its size scan drain the device).
+struct EncStrides { u32 lit, seq, out, group; };
+inline EncStrides enc_strides(u32 cap) {
+    EncStrides s;
+    if (cap >= ZL_CHUNK) { s.lit = ZL_LIT_STRIDE_ENC; s.seq = ZL_SEQ_STRIDE; s.out = ZL_OUT_STRIDE; s.group = ZL_GROUP_CHUNKS; return s; }
+    cap = std::max<u32>(cap, 1024u);
+    s.lit = (cap + 64 + 15) & ~15u;
+    s.seq = (cap / 4 + 8 + 7) & ~7u;                      // (min match 4; the code arrays of zl_entropy_kernel want a multiple of 8)
+    s.out = (cap + 1024 + 15) & ~15u;                     // (the entropy kernel keeps 512 bytes of headroom for a sequences header while it builds a frame)
+    const size_t per = (size_t)s.lit + (size_t)s.seq * (sizeof(zl_seq) + ZL_SST_BYTES) + s.out;
+    s.group = (u32)std::max<size_t>(ZL_GROUP_CHUNKS, std::min<size_t>(((size_t)8 << 30) / per, 1u << 20));  // scratch of a group: at most what 8192 full chunks take
+    return s;
+}
+
 // One launch group: far passes (windowed layout) -> E1 -> E2 -> size scan -> gather for chunks [first, first + cnt) on
 // stream st, with scratch set `es`.  The group's frames land behind those of group g - 1 in d_dst: its size scan starts
 // from d_totals[g] (wait_prev: an event behind which that word is valid, when the groups run on different streams) and
@@ -133,8 +150,9 @@ size_t cctx_prepare_dict(zl_cctx* c, hipStream_t st) {
 size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8* d_src, size_t first, u32 cnt, size_t nchunks, size_t g, hipStream_t st,
                           u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned, size_t frame_chunk0 = 0) {
     const bool joined = joined_total != 0;
-    if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * ZL_LIT_STRIDE_ENC) || !es.seqs.ensure((size_t)cnt * ZL_SEQ_STRIDE * sizeof(zl_seq)) ||
-        !es.sst.ensure((size_t)cnt * ZL_SEQ_STRIDE * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * ZL_OUT_STRIDE))
+    const EncStrides sd = enc_strides(c->chunk_cap);
+    if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * sd.lit) || !es.seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) ||
+        !es.sst.ensure((size_t)cnt * sd.seq * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * sd.out))
         return kGpuUnavailable;
     if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
     c->far_valid = false;
@@ -158,8 +176,8 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.lits = (u8*)es.lits.p;
     m.seqs = (zl_seq*)es.seqs.p;
     m.meta = (zl_chunk_meta*)es.meta.p;
-    m.lit_stride = ZL_LIT_STRIDE_ENC;
-    m.seq_stride = ZL_SEQ_STRIDE;
+    m.lit_stride = sd.lit;
+    m.seq_stride = sd.seq;
     m.stats = nullptr;
     m.sparse_only = c->level < 3 ? 1u : 0u;
     m.hi = c->level >= 5 ? 1u : 0u;
@@ -201,9 +219,9 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.seq_states = (u8*)es.sst.p;
     e.out = (u8*)es.staged.p;
     e.frame_size = (u32*)c->d_fsize.p + first;
-    e.lit_stride = ZL_LIT_STRIDE_ENC;
-    e.seq_stride = ZL_SEQ_STRIDE;
-    e.out_stride = ZL_OUT_STRIDE;
+    e.lit_stride = sd.lit;
+    e.seq_stride = sd.seq;
+    e.out_stride = sd.out;
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
     e.joined = joined ? 1u : 0u;
@@ -225,7 +243,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     ga.frame_size = e.frame_size;
     ga.frame_off = (const u64*)c->d_foff.p + first;
     ga.dst = d_dst;
-    ga.out_stride = ZL_OUT_STRIDE;
+    ga.out_stride = sd.out;
     if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) { (void)hipEventRecord(c->ev[4], st); c->ev_valid = true; }
     return 0;
@@ -238,7 +256,8 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
 size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st, u64 joined_total = 0) {
     { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
     const bool joined = joined_total != 0;
-    const size_t ngroups = (nchunks + ZL_GROUP_CHUNKS - 1) / ZL_GROUP_CHUNKS;
+    const size_t group = enc_strides(c->chunk_cap).group;
+    const size_t ngroups = (nchunks + group - 1) / group;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)))
         return kGpuUnavailable;
@@ -249,8 +268,8 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     if (prof && joined && !c->ev_far) (void)hipEventCreate(&c->ev_far);
     c->ev_valid = false;
     for (size_t g = 0; g < ngroups; g++) {
-        const size_t first = g * ZL_GROUP_CHUNKS;
-        const u32 cnt = (u32)std::min<size_t>(ZL_GROUP_CHUNKS, nchunks - first);
+        const size_t first = g * group;
+        const u32 cnt = (u32)std::min<size_t>(group, nchunks - first);
         const size_t e = cctx_enqueue_group(c, c->sets[0], d_dst, d_src, first, cnt, nchunks, g, st, joined_total, prof, nullptr, nullptr);
         if (ZL_IS_ERR(e)) return e;
     }
@@ -810,21 +829,29 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         return kGpuUnavailable;
     zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
     c->any_small = false;
+    size_t largest = 0;
     for (size_t i = 0; i < n; i++) {
-        if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
-        const size_t k = chunks_of(sizes[i]);
-        for (size_t j = 0; j < k; j++) {
-            zl_chunk_desc& d = t[first_chunk[i] + j];
-            d.src_off = in_off[i] + j * (size_t)ZL_CHUNK;
-            d.src_size = (u32)std::min<size_t>(ZL_CHUNK, sizes[i] - j * (size_t)ZL_CHUNK);
-            d.flags = k == 1 ? 1u : 0u;
-            if (k == 1) c->any_small = true;
-        }
+        largest = std::max(largest, sizes[i]);
+        if (chunks_of(sizes[i]) == 1) c->any_small = true;
     }
+    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
+            const size_t k = chunks_of(sizes[i]);
+            for (size_t j = 0; j < k; j++) {
+                zl_chunk_desc& d = t[first_chunk[i] + j];
+                d.src_off = in_off[i] + j * (size_t)ZL_CHUNK;
+                d.src_size = (u32)std::min<size_t>(ZL_CHUNK, sizes[i] - j * (size_t)ZL_CHUNK);
+                d.flags = k == 1 ? 1u : 0u;
+            }
+        }
+    });
     tp[1] = now_ms();
     if (in_total && hipMemcpyAsync(c->d_src.p, c->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
+    c->chunk_cap = (u32)std::min<size_t>(largest, ZL_CHUNK);  // small objects: small scratch per object, one launch group (enc_strides)
     const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
+    c->chunk_cap = ZL_CHUNK;
     if (ZL_IS_ERR(e)) return e;
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     tp[3] = now_ms();
@@ -833,15 +860,23 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     tp[4] = now_ms();
     const u32* fs = (const u32*)c->h_fsize.p;
+    std::vector<size_t>& out_off = in_off;  // (reused: where each object's frames start in the packed output)
     size_t off = 0;
     for (size_t i = 0; i < n; i++) {
         size_t sz = 0;
         for (size_t j = first_chunk[i]; j < first_chunk[i + 1]; j++) sz += fs[j];
-        if (sz > caps[i]) results[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
-        else { memcpy(dsts[i], (const u8*)c->h_stage_out.p + off, sz); results[i] = sz; }
+        out_off[i] = off;
+        results[i] = sz;
         off += sz;
     }
+    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+            if (results[i] > caps[i]) results[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+            else memcpy(dsts[i], (const u8*)c->h_stage_out.p + out_off[i], results[i]);
+        }
+    });
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) c->batch_ms[k] = tp[k + 1] - tp[k]; }
+    if (c->profile >= 2 && c->ev_valid && c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     return 0;
 }
 

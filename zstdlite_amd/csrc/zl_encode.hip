@@ -2222,29 +2222,27 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
             if (lane == 0) ct.log = (u32)log;
         }
         ZL_WAVE_FENCE();
-      if (lane == 0) {
         if (dict_tables && mode != 1) {
             // Repeat_Mode against the table just built (zstd.c:21060-21110 weighs the same three costs):
             // every code that occurs must have a cell in the dictionary's table, and the bits it
-            // spends there must not exceed ours plus our table's description
-            u64 need = 0;
-            for (int s = 0; s <= max_code; s++) if (h[s]) need |= 1ull << s;
+            // spends there must not exceed ours plus our table's description.  All 64 lanes at it (lane = symbol):
+            // a batch of small objects with a dictionary spends its time here otherwise.
             const FseCTable& dct = dtab->ct[k];
-            if ((need & ~dtab->sym_mask[k]) == 0) {
-                u32 cost_dict = 0, cost_own = 0;
-                for (int s = 0; s <= max_sym; s++) if (h[s]) { cost_dict += h[s] * fse_bit_cost(dct.dnb[s], dct.log); cost_own += h[s] * fse_bit_cost(ct.dnb[s], ct.log); }
+            if ((present & ~dtab->sym_mask[k]) == 0) {
+                const u32 dlog = dct.log;
+                const bool mine = hc != 0;  // (present: lanes <= max_code <= 52 < 56)
+                const u32 cost_dict = wave_sum_u32(mine ? hc * fse_bit_cost(dct.dnb[lane], dlog) : 0u);
+                u32 cost_own = wave_sum_u32(mine ? hc * fse_bit_cost(ct.dnb[lane], ct.log) : 0u);
                 if (mode == 2) cost_own += 256u * 8u * (((u32)max_sym + 1) * 5 / 8 + 1);
                 if (cost_dict <= cost_own) {
                     mode = 3;
-                    for (u32 q = 0; q < (1u << dct.log); q++) ct.state[q] = dct.state[q];
-                    for (int q = 0; q < 56; q++) { ct.dnb[q] = dct.dnb[q]; ct.dfs[q] = dct.dfs[q]; }
-                    ct.log = dct.log;
-                    ct.max_sym = dct.max_sym;
+                    for (u32 q = lane; q < (1u << dlog); q += 64) ct.state[q] = dct.state[q];
+                    if (lane < 56) { ct.dnb[lane] = dct.dnb[lane]; ct.dfs[lane] = dct.dfs[lane]; }
+                    if (lane == 0) { ct.log = dlog; ct.max_sym = dct.max_sym; }
                 }
             }
         }
-        S.seq_mode[k] = mode;
-      }
+        if (lane == 0) S.seq_mode[k] = mode;
     }
     __syncthreads();
     ENT_STAMP(1)

@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "zl_format.h"
 
@@ -140,6 +143,24 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
         t_up = t1 - t0 < t_up ? t1 - t0 : t_up; t_dn = t2 - t1 < t_dn ? t2 - t1 : t_dn; t_both = t3 - t2 < t_both ? t3 - t2 : t_both;
     }
     return t_both < 0.75 * (t_up + t_dn);
+}
+
+// f(begin, end) over [0, n) on up to 8 host threads (the calling one takes the first range); ranges of at least `grain`
+// items, so small batches stay on the caller.  For the per-object loops of the batch entries (pack, header parse, unpack).
+template <class F>
+static inline void zl_parallel_for(size_t n, size_t grain, F f) {
+    size_t hw = std::thread::hardware_concurrency();
+    size_t t = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), grain ? n / grain : 1);
+    if (t <= 1) { f((size_t)0, n); return; }
+    const size_t per = (n + t - 1) / t;
+    std::vector<std::thread> th;
+    th.reserve(t - 1);
+    for (size_t k = 1; k < t; k++) {
+        const size_t b = k * per, e = std::min(n, b + per);
+        if (b < e) th.emplace_back([=]() { f(b, e); });
+    }
+    f((size_t)0, std::min(n, per));
+    for (auto& x : th) x.join();
 }
 
 static int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
