@@ -41,3 +41,22 @@ if ct[14]:
     nc = ct[14]
     print(f"entropy phases, kcycles/object: statistics {ct[8]/nc/1e3:.1f}  tree|tables {ct[9]/nc/1e3:.1f}  codes+bits {ct[10]/nc/1e3:.1f}  chains|tree description (+tail) {ct[13]/nc/1e3:.1f}  blk literals {ct[11]/nc/1e3:.1f}  blk sequences {ct[12]/nc/1e3:.1f}")
 print("ratio", B.sizes.sum() / B.csize.sum())
+
+# the decoder's side: the general kernel's phase counters (ZL_d_profile 2)
+dctx = L.zl_createDCtx()
+if use_dict:
+    L.zl_DCtx_loadDictionary(dctx, d, len(d))
+L.zl_DCtx_setParameter(dctx, 9002, 2)
+L.zl_dctx_batch_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+for it in range(3):
+    r = L.zl_decompress_batch(dctx, B.n, B.p_back.ctypes.data_as(vp), B.sizes.ctypes.data_as(sp), B.p_comp.ctypes.data_as(vp), B.csize.ctypes.data_as(sp), B.bsize.ctypes.data_as(sp))
+    assert not _lib.is_error(r)
+L.zl_dctx_batch_ms(dctx, ms)
+print("decode call phases ms", [round(x, 3) for x in ms])
+st = (C.c_ulonglong * 16)()
+L.zl_dctx_phase_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+if L.zl_dctx_phase_stats(dctx, st) == 0 and st[5]:
+    nb = st[5]
+    print(f"decode phases, kcycles/block: H {st[0]/nb/1e3:.1f}  B {st[1]/nb/1e3:.1f}  A {st[2]/nb/1e3:.1f}  A||B {st[3]/nb/1e3:.1f}  C {st[4]/nb/1e3:.1f}   blocks {nb}  seq/block {st[6]/nb:.0f}  huflits/block {st[7]/nb:.0f}")
+else:
+    print("no decode phase stats", list(st))

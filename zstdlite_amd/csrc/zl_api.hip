@@ -1092,6 +1092,7 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         }
     });
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) d->batch_ms[k] = tp[k + 1] - tp[k]; }
+    if (d->profile >= 2 && d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 128, hipMemcpyDeviceToHost);
     return 0;
 }
 

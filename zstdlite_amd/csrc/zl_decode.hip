@@ -99,6 +99,7 @@ struct DecShared {
     u32 nseq;
     u32 seq_off, seq_len;  // FSE bitstream inside the block
     u64 stamp_a;           // profiling: cycles the literal lanes spent (max over lanes)
+    u32 dict_live;         // which of this workgroup's tables still hold the dictionary's: bit 0 fse_ll, 1 fse_ml, 2 fse_of, 3 huf
 };
 
 // ---------------------------------------------------------------------------------------
@@ -593,6 +594,9 @@ __device__ void parse_seq_header(DecShared& S, const u8* p, u32 n) {
     if (pos + 1 > n) { S.err = ZL_E_SRCSIZE_WRONG; return; }
     const u32 modes = p[pos++];
     if (modes & 3) { S.err = ZL_E_CORRUPTION; return; }
+    if ((modes >> 6) != 3) S.dict_live &= ~1u;  // (anything but Repeat_Mode writes the table)
+    if (((modes >> 2) & 3) != 3) S.dict_live &= ~2u;
+    if (((modes >> 4) & 3) != 3) S.dict_live &= ~4u;
     u32 r = read_seq_table(S, K_LL, modes >> 6, p + pos, n - pos);
     if (r == 0xFFFFFFFFu) { S.err = ZL_E_CORRUPTION; return; }
     pos += r;
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
 
     // behind the lane pipeline: nothing to do unless it has counted frames for this kernel (word 9 of the counter block)
     if (a.plan && a.counter[9] == 0) return;
+    if (t == 0) S.dict_live = 0;
     for (;;) {
         zl_sync_global();
         if (t == 0) S.frame = atomicAdd(a.counter, 1u);
@@ -719,10 +724,15 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
             continue;
         }
         if (DT) {
-            for (u32 i = t; i < 512; i += DEC_THREADS) { S.fse_ll[i] = DT->fse_ll[i]; S.fse_ml[i] = DT->fse_ml[i]; }
-            for (u32 i = t; i < 256; i += DEC_THREADS) S.fse_of[i] = DT->fse_of[i];
-            for (u32 i = t; i < 4096; i += DEC_THREADS) S.huf[i] = DT->huf[i];
+            // (only the tables that a frame since the last copy has replaced: a batch of small frames that all ride on the
+            // dictionary's tables -- what a dictionary is for -- copies them once per workgroup, not 18 KiB per frame)
+            const u32 live = S.dict_live;
+            if (!(live & 1)) for (u32 i = t; i < 512; i += DEC_THREADS) S.fse_ll[i] = DT->fse_ll[i];
+            if (!(live & 2)) for (u32 i = t; i < 512; i += DEC_THREADS) S.fse_ml[i] = DT->fse_ml[i];
+            if (!(live & 4)) for (u32 i = t; i < 256; i += DEC_THREADS) S.fse_of[i] = DT->fse_of[i];
+            if (!(live & 8)) for (u32 i = t; i < 4096; i += DEC_THREADS) S.huf[i] = DT->huf[i];
             zl_sync_global();
+            if (t == 0) S.dict_live = 15u;
         }
         u64 pos = S.hdr_size, op = 0;
         bool done = false;
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
                 if (S.err) break;
                 if (S.lit_mode == 2) {
                     fill_huf_table(S);
-                    if (t == 0) S.huf_valid = 1;
+                    if (t == 0) { S.huf_valid = 1; S.dict_live &= ~8u; }
                     zl_sync_global();
                 }
                 // ---- stages A + B, concurrently on different waves
@@ -833,6 +843,7 @@ __global__ __launch_bounds__(DEC_THREADS, 4) void zl_decode_kernel(zl_decode_arg
             zl_sync_global();
             if (!S.err && S.has_checksum && !a.ignore_checksum) {
                 const u32 got = zl_xxh64_low32((u8*)S.huf, S.xxh_acc, S.scan_a, out, op);
+                if (t == 0) S.dict_live &= ~8u;  // (the Huffman table was the staging tile)
                 if (t == 0 && got != zl_rd_le(src + pos, 4)) S.err = ZL_E_CHECKSUM_WRONG;  // zstd.c:41655
             }
             zl_sync_global();

@@ -8,8 +8,12 @@
 #include <cstring>
 #include <ctime>
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
+#include <pthread.h>
 
 #include "zl_format.h"
 
@@ -145,22 +149,75 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
     return t_both < 0.75 * (t_up + t_dn);
 }
 
-// f(begin, end) over [0, n) on up to 8 host threads (the calling one takes the first range); ranges of at least `grain`
-// items, so small batches stay on the caller.  For the per-object loops of the batch entries (pack, header parse, unpack).
+// A few host threads that stay around between calls, for the per-object loops of the batch entries (pack, header parse,
+// unpack: 100k memcpys of a few hundred bytes).  Starting seven threads costs 0.2-0.5 ms, which is what such a loop takes
+// on one thread; waking sleeping ones costs a tenth of that.  One user at a time (a second caller runs its loop itself);
+// the workers are never joined (the object is leaked on purpose: they sleep on it until the process ends); a forked child
+// starts its own.
+struct ZlPool {
+    static const size_t kWorkers = 7;
+    std::mutex m, user;
+    std::condition_variable cv_work, cv_done;
+    void (*fn)(void*, size_t) = nullptr;
+    void* ctx = nullptr;
+    size_t gen = 0, want = 0, done = 0;
+    void worker(size_t k) {
+        size_t seen = 0;
+        std::unique_lock<std::mutex> l(m);
+        for (;;) {
+            cv_work.wait(l, [&] { return gen != seen; });
+            seen = gen;
+            if (k >= want) continue;
+            void (*f)(void*, size_t) = fn;
+            void* c = ctx;
+            l.unlock();
+            f(c, k);
+            l.lock();
+            if (++done == want) cv_done.notify_one();
+        }
+    }
+    // f(ctx, k) for k in [0, parts): part 0 on the caller, the others on the workers
+    void run(void (*f)(void*, size_t), void* c, size_t parts) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            fn = f; ctx = c; want = parts - 1; done = 0; gen++;
+        }
+        cv_work.notify_all();
+        f(c, parts - 1);
+        std::unique_lock<std::mutex> l(m);
+        cv_done.wait(l, [&] { return done == want; });
+    }
+};
+inline ZlPool* g_pool = nullptr;  // (this header sits inside each API file's anonymous namespace: one pool for the compression entries, one for the decompression entries)
+inline std::once_flag g_pool_once;
+inline ZlPool* zl_pool() {
+    std::call_once(g_pool_once, []() {
+        pthread_atfork(nullptr, nullptr, []() { g_pool = nullptr; });  // (the child has none of the workers: it runs its loops itself)
+        ZlPool* p = new (std::nothrow) ZlPool();
+        if (!p) return;
+        for (size_t k = 0; k < ZlPool::kWorkers; k++) {
+            try { std::thread(&ZlPool::worker, p, k).detach(); } catch (...) { return; }  // (no threads to be had: stay serial)
+        }
+        g_pool = p;
+    });
+    return g_pool;
+}
+
+// f(begin, end) over [0, n) on up to 8 host threads (the calling one among them); ranges of at least `grain` items, so
+// small batches stay on the caller.
 template <class F>
 static inline void zl_parallel_for(size_t n, size_t grain, F f) {
-    size_t hw = std::thread::hardware_concurrency();
-    size_t t = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), grain ? n / grain : 1);
-    if (t <= 1) { f((size_t)0, n); return; }
-    const size_t per = (n + t - 1) / t;
-    std::vector<std::thread> th;
-    th.reserve(t - 1);
-    for (size_t k = 1; k < t; k++) {
-        const size_t b = k * per, e = std::min(n, b + per);
-        if (b < e) th.emplace_back([=]() { f(b, e); });
-    }
-    f((size_t)0, std::min(n, per));
-    for (auto& x : th) x.join();
+    const size_t hw = std::thread::hardware_concurrency();
+    const size_t t = std::min<size_t>(std::min<size_t>(ZlPool::kWorkers + 1, hw ? hw : 1), grain ? n / grain : 1);
+    ZlPool* pool = t > 1 ? zl_pool() : nullptr;
+    if (!pool || !pool->user.try_lock()) { f((size_t)0, n); return; }
+    struct Ctx { F* f; size_t n, per; } cx{&f, n, (n + t - 1) / t};
+    pool->run([](void* v, size_t k) {
+        Ctx* c = (Ctx*)v;
+        const size_t b = k * c->per, e = std::min(c->n, b + c->per);
+        if (b < e) (*c->f)(b, e);
+    }, &cx, t);
+    pool->user.unlock();
 }
 
 static int g_device_state = 0;  // 0 unknown, 1 ok, -1 unavailable
