@@ -1058,20 +1058,19 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
     for (u32 i = t; i < FAR_COL / 4; i += FAR_BUILD_THREADS) out[i] = in[i];
 }
 
-// The probe kernel: 1024 threads per chunk, sixteen listed positions per thread in registers (round 2 held 64 per thread in a
-// 256-thread workgroup: 256 VGPRs + 13 AGPRs, ONE wave per SIMD, so that nothing overlapped the column loads -- 4.4 ms per GiB at
-// 1.8 TB/s of column traffic).  Two workgroups share a CU (64 KiB of LDS each): one streams its next column while the other looks
-// its entries up.
+// The probe kernel: 1024 threads per PAIR of chunks, sixteen listed positions of each per thread in registers (round 2 held 64
+// per thread in a 256-thread workgroup: 256 VGPRs + 13 AGPRs, ONE wave per SIMD, so that nothing overlapped the column loads --
+// 4.4 ms per GiB at 1.8 TB/s of column traffic).  One workgroup per CU, two column buffers (128 KiB of LDS).
 #define FAR_PROBE_THREADS 1024u
 #define FAR_PER_THREAD 16u   // listed positions a thread holds in registers at a time
 // Workgroup b of a launch tends to run on XCD b mod 8 (dispatch is round-robin over the XCDs; nothing depends on it).  Runs of
-// FAR_XCD_RUN consecutive chunks go to one XCD: the workgroups resident there at one time then stream the SAME columns (chunk c
+// FAR_XCD_RUN consecutive pairs of chunks go to one XCD: the workgroups resident there at one time then stream the SAME columns (chunk c
 // wants those of c-1 .. c-15), and the XCD's L2 serves most of the fifteen-fold re-read that otherwise goes out to the fabric.
 // (Runs, not one contiguous share per XCD: the chunks' costs differ with the data, and a share per XCD left most of the device
 // idle while the two XCDs that held the text quarter of the bench vector worked: 6.0 -> 8.9 ms.)
 #define FAR_XCDS 8u
 #ifndef FAR_XCD_RUN
-#define FAR_XCD_RUN 32u
+#define FAR_XCD_RUN 16u
 #endif
 __device__ __forceinline__ u32 far_xcd_chunk(u32 b) {
 #if FAR_XCD_RUN
@@ -1081,76 +1080,176 @@ __device__ __forceinline__ u32 far_xcd_chunk(u32 b) {
     return b;
 #endif
 }
-__global__ __launch_bounds__(FAR_PROBE_THREADS, 8) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
-    __shared__ __align__(16) u32 col[FAR_COL];
-    const u32 c = far_xcd_chunk(blockIdx.x), t = threadIdx.x;
-    if (c >= nchunks) return;
-    const zl_chunk_desc cd = a.chunks[c];
-    const u8* src = a.src + cd.src_off;
-    const u32 lim = far_limit(a, cd, a.chunk_base + c);
-    u32 back = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
-    if (back > ZL_FAR_GROUP - 1) back = ZL_FAR_GROUP - 1;
-    if (back > c) back = c;  // (columns exist for the launch's own chunks only)
-    if (back == 0) return;
-    const u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
-    const u32 count = list[0];
-    u32* hints = a.hints + (size_t)c * ZL_FAR_HINT_WORDS;
-    for (u32 seg = 0; seg < count; seg += FAR_PROBE_THREADS * FAR_PER_THREAD) {
-        // key[e]: bucket | tag << 14 while the entry is looking; the offset it found once it has (bit e of `found`)
-        u32 key[FAR_PER_THREAD], pos[FAR_PER_THREAD];
-        u32 open = 0, found = 0;
+__global__ __launch_bounds__(FAR_PROBE_THREADS, 4) void zl_far_probe_kernel(zl_far_args a, u32 nchunks) {
+    // A workgroup serves TWO neighbouring chunks: chunk c wants the columns of c-1 .. c-15, chunk c+1 those of c .. c-14, so a
+    // column that is in LDS for one is there for the other and the kernel's column traffic (what it is bound by) halves.  The
+    // entries' positions are not held in registers any more (two chunks' keys take their place): a hit keeps offset - position
+    // and reads the position again from the list when it is checked.  Thirty-two keys per thread want 128 registers, which is
+    // one workgroup per CU; the overlap that two resident workgroups gave each other (one streams while the other looks up)
+    // now happens inside the one: two column buffers, the next column's LDS-DMA in flight during the lookups in this one.
+    __shared__ __align__(16) u32 colbuf[2][FAR_COL];
+    __shared__ u32 still_open[ZL_FAR_GROUP + 2];  // per column step: does any wave hold an entry that is still looking
+    const u32 c0 = 2 * far_xcd_chunk(blockIdx.x), t = threadIdx.x;
+    if (c0 >= nchunks) return;
+    u32 back[2], count[2], lim[2];
+    const u32* list[2];
+    const u8* src[2];
 #pragma unroll
-        for (u32 e = 0; e < FAR_PER_THREAD; e++) {
-            const u32 i = seg + e * FAR_PROBE_THREADS + t;  // (consecutive threads read consecutive pairs)
-            key[e] = 0; pos[e] = 0;
-            if (i < count) { const uint2 kp = *(const uint2*)(list + 16 + 2 * (size_t)i); key[e] = kp.x; pos[e] = kp.y; open |= 1u << e; }
+    for (u32 h = 0; h < 2; h++) {
+        const u32 c = c0 + h;
+        back[h] = 0; count[h] = 0; lim[h] = 0; list[h] = a.lists; src[h] = a.src;
+        if (c < nchunks) {
+            const zl_chunk_desc cd = a.chunks[c];
+            src[h] = a.src + cd.src_off;
+            lim[h] = far_limit(a, cd, a.chunk_base + c);
+            u32 b = (a.chunk_base + c) & ((1u << ZL_FAR_SECTION_LOG) - 1);  // chunks of this section in front of ours
+            if (b > ZL_FAR_GROUP - 1) b = ZL_FAR_GROUP - 1;
+            if (b > c) b = c;  // (columns exist for the launch's own chunks only)
+            back[h] = b;
+            list[h] = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
+            count[h] = b ? list[h][0] : 0u;
         }
-        // ---- the columns of the chunks in front, nearest first: an entry stops at the first one that carries its tag
-        for (u32 k = 1; k <= back; k++) {
-            {   // the column goes straight from memory into LDS (global_load_lds_dwordx4: no registers in between, every load of
-                // the workgroup in flight at once; a wave's 64 x 16 bytes land in lane order, which is the column's own order)
-                const uint4* in = (const uint4*)(a.table + (size_t)(c - k) * FAR_COL);
-                uint4* out = (uint4*)col;
+    }
+    if (back[0] == 0 && back[1] == 0) return;
+    // the columns the pair wants: from the nearest one (c0 itself for chunk c0 + 1, else c0 - 1) down to the farthest
+    const u32 j_hi = back[1] ? c0 : c0 - 1;
+    u32 j_lo = j_hi;
+    if (back[0] && c0 - back[0] < j_lo) j_lo = c0 - back[0];
+    if (back[1] && c0 + 1 - back[1] < j_lo) j_lo = c0 + 1 - back[1];
+    const u32 most = count[0] > count[1] ? count[0] : count[1];
+    for (u32 seg = 0; seg < most; seg += FAR_PROBE_THREADS * FAR_PER_THREAD) {
+        // key[h][e]: bucket | tag << 14 while the entry is looking; bit 31 | (offset - position) once it has found -- a value whose
+        // tag field no column word can equal, so that the lookup below needs no mask of who is still looking (bit 31 alone: no entry)
+        u32 key[2][FAR_PER_THREAD];
+        u32 nopen[2] = {0, 0};  // entries of this thread that are still looking
 #pragma unroll
-                for (u32 i = 0; i < FAR_COL / 4 / FAR_PROBE_THREADS; i++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + t + FAR_PROBE_THREADS * i), (__attribute__((address_space(3))) void*)(out + t + FAR_PROBE_THREADS * i), 16, 0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            u32 x[FAR_PER_THREAD];
-#pragma unroll
-            for (u32 e = 0; e < FAR_PER_THREAD; e++) x[e] = col[key[e] & (FAR_COL - 1)];  // (found entries read a harmless word)
+        for (u32 h = 0; h < 2; h++) {
 #pragma unroll
             for (u32 e = 0; e < FAR_PER_THREAD; e++) {
-                const bool hit = ((open >> e) & 1) && x[e] != 0 && (x[e] & 0x7FFFu) == (key[e] >> ZL_FAR_BUCKET_LOG);
-                if (hit) { key[e] = k * ZL_CHUNK + pos[e] - (x[e] >> 15); open &= ~(1u << e); found |= 1u << e; }
+                const u32 i = seg + e * FAR_PROBE_THREADS + t;  // (consecutive threads read consecutive pairs)
+                key[h][e] = 0x80000000u;
+                if (i < count[h]) { key[h][e] = list[h][16 + 2 * (size_t)i]; nopen[h]++; }
             }
-            __syncthreads();
         }
-        // ---- check the hits against the bytes (four at a time, so that their loads travel together), measure them (up to
-        // 32 bytes) and raise the hint word of their neighbourhood: the longest hit wins (ties: the larger offset)
+        // ---- the columns, nearest first: an entry stops at the first one that carries its tag
+        auto stream_column = [&](u32 j, u32 b) {
+            // straight from memory into LDS (global_load_lds_dwordx4: no registers in between, every load of the workgroup in
+            // flight at once; a wave's 64 x 16 bytes land in lane order, which is the column's own order)
+            const uint4* in = (const uint4*)(a.table + (size_t)j * FAR_COL);
+            uint4* out = (uint4*)colbuf[b];
 #pragma unroll
-        for (u32 e0 = 0; e0 < FAR_PER_THREAD; e0 += 4) {
-            if (!((found >> e0) & 0xF)) continue;
-            u64 va[4], vb[4];
+            for (u32 i = 0; i < FAR_COL / 4 / FAR_PROBE_THREADS; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in + t + FAR_PROBE_THREADS * i), (__attribute__((address_space(3))) void*)(out + t + FAR_PROBE_THREADS * i), 16, 0, 0);
+        };
+        __syncthreads();  // (the last segment's lookups are done with buffer 0)
+        if (t < ZL_FAR_GROUP + 2) still_open[t] = 0;
+        stream_column(j_hi, 0);
+        u32 cur = 0;
+        for (u32 j = j_hi;; j--) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // column j has landed in colbuf[cur]; nobody reads the other buffer any more
+            // (text: every listed position finds its tag in the nearest column or two -- once no wave has an entry left looking,
+            // the columns further back are neither streamed nor searched)
+            if (j != j_hi && still_open[j_hi - j - 1] == 0) break;
+            if (j > j_lo) stream_column(j - 1, cur ^ 1);
+            const u32* col = colbuf[cur];
 #pragma unroll
-            for (u32 j = 0; j < 4; j++) {
-                const bool on = (found >> (e0 + j)) & 1;
-                va[j] = on ? ld64(src + pos[e0 + j]) : 0;
-                vb[j] = on ? ld64(src + pos[e0 + j] - key[e0 + j]) : 1;
-            }
+            for (u32 h = 0; h < 2; h++) {
+                const u32 k = c0 + h - j;  // how many chunks in front of chunk c0 + h this column lies (uniform)
+                if (k < 1 || k > back[h]) continue;
+                if (__ballot(nopen[h] != 0) == 0) continue;  // (this wave's entries of the chunk have all found)
+                u32 x[FAR_PER_THREAD];
 #pragma unroll
-            for (u32 j = 0; j < 4; j++) {
-                if (va[j] != vb[j]) continue;
-                const u32 p = pos[e0 + j], off = key[e0 + j];
-                const u8* q = src + p - off;
-                u32 len = 8;
-                while (len < 32 && p + len < lim) {
-                    const u32 l = common_bytes(ld64(src + p + len), ld64(q + len));
-                    len += l;
-                    if (l < 8) break;
+                for (u32 e = 0; e < FAR_PER_THREAD; e++) x[e] = col[key[h][e] & (FAR_COL - 1)];  // (found entries read a harmless word)
+                const u32 base = 0x80000000u | (k * ZL_CHUNK);
+#pragma unroll
+                for (u32 e = 0; e < FAR_PER_THREAD; e++) {
+                    const bool hit = x[e] != 0 && (x[e] & 0x7FFFu) == (key[h][e] >> ZL_FAR_BUCKET_LOG);
+                    if (hit) { key[h][e] = base - (x[e] >> 15); nopen[h]--; }
                 }
-                atomicMax(hints + (p >> ZL_FAR_HINT_LOG), (len << 26) | off);
+            }
+            const bool wave_open = __ballot((nopen[0] | nopen[1]) != 0) != 0;  // (all lanes vote; one writes)
+            if (wave_open && (t & 63) == 0) still_open[j_hi - j] = 1;
+            cur ^= 1;
+            if (j == j_lo) break;
+        }
+        u32 found[2] = {0, 0};
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+#pragma unroll
+            for (u32 e = 0; e < FAR_PER_THREAD; e++) {
+                if (key[h][e] > 0x80000000u) found[h] |= 1u << e;
+                key[h][e] &= 0x7FFFFFFFu;  // (entries still looking are not read again)
+            }
+        }
+        // ---- check the hits against the bytes, measure them (up to 32 bytes) and raise the hint word of their neighbourhood: the
+        // longest hit wins (ties: the larger offset).  ALL 32 bytes of both sides are asked for at once (two hits at a time):
+        // one trip to memory per pair of hits instead of up to four dependent ones per hit (the sources lie up to 2 MiB back).
+        // (the hint words are raised in LDS -- the column buffers are free now -- and go out to memory once, whole, instead of a
+        // global atomicMax per hit, 16 000 of them per chunk of text scattered over 32 KiB: text 1.59 -> 1.17 ms per 256 MiB)
+        static_assert(ZL_FAR_HINT_WORDS <= FAR_COL, "a chunk's hint words fit a column buffer");
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++)
+            for (u32 i = t; i < ZL_FAR_HINT_WORDS; i += FAR_PROBE_THREADS) colbuf[h][i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            u32* hints = colbuf[h];
+#pragma unroll
+            for (u32 e0 = 0; e0 < FAR_PER_THREAD; e0 += 2) {
+                if (!((found[h] >> e0) & 3)) continue;
+                u32 ps[2];
+#pragma unroll
+                for (u32 j = 0; j < 2; j++) {
+                    const bool on = (found[h] >> (e0 + j)) & 1;
+                    ps[j] = on ? list[h][16 + 2 * (size_t)(seg + (e0 + j) * FAR_PROBE_THREADS + t) + 1] : 0u;
+                }
+                uint4 a0[2], a1[2], b0[2], b1[2];
+                bool wide[2];
+#pragma unroll
+                for (u32 j = 0; j < 2; j++) {
+                    const bool on = (found[h] >> (e0 + j)) & 1;
+                    const u8* pp = src[h] + ps[j];
+                    const u8* qq = pp - (key[h][e0 + j] + ps[j]);
+                    wide[j] = on && ps[j] + 32 <= lim[h] + 7;  // (lim + 7 bytes are readable, see far_limit)
+                    a0[j] = a1[j] = b0[j] = b1[j] = make_uint4(0, 0, 0, 0);
+                    b0[j].x = 1;  // (an entry that is off compares unequal)
+                    if (wide[j]) { a0[j] = ld128(pp); a1[j] = ld128(pp + 16); b0[j] = ld128(qq); b1[j] = ld128(qq + 16); }
+                    else if (on) { const u64 va = ld64(pp), vb = ld64(qq); a0[j].x = (u32)va; a0[j].y = (u32)(va >> 32); b0[j].x = (u32)vb; b0[j].y = (u32)(vb >> 32); }
+                }
+#pragma unroll
+                for (u32 j = 0; j < 2; j++) {
+                    if (a0[j].x != b0[j].x || a0[j].y != b0[j].y) continue;
+                    const u32 p = ps[j], off = key[h][e0 + j] + ps[j];
+                    u32 len = 8;
+                    if (wide[j]) {  // the same steps as the loop below, from registers
+                        const u64 wa[3] = {(u64)a0[j].z | ((u64)a0[j].w << 32), (u64)a1[j].x | ((u64)a1[j].y << 32), (u64)a1[j].z | ((u64)a1[j].w << 32)};
+                        const u64 wb[3] = {(u64)b0[j].z | ((u64)b0[j].w << 32), (u64)b1[j].x | ((u64)b1[j].y << 32), (u64)b1[j].z | ((u64)b1[j].w << 32)};
+#pragma unroll
+                        for (u32 k = 0; k < 3; k++) {
+                            if (len == 8 * (k + 1) && p + len < lim[h]) len += common_bytes(wa[k], wb[k]);
+                        }
+                    } else {
+                        const u8* q = src[h] + p - off;
+                        while (len < 32 && p + len < lim[h]) {
+                            const u32 l = common_bytes(ld64(src[h] + p + len), ld64(q + len));
+                            len += l;
+                            if (l < 8) break;
+                        }
+                    }
+                    atomicMax(hints + (p >> ZL_FAR_HINT_LOG), (len << 26) | off);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            if (c0 + h >= nchunks) continue;
+            u32* g = a.hints + (size_t)(c0 + h) * ZL_FAR_HINT_WORDS;  // (zeroed by the build kernel; this workgroup alone writes them)
+            for (u32 i = t; i < ZL_FAR_HINT_WORDS; i += FAR_PROBE_THREADS) {
+                const u32 v = colbuf[h][i];
+                if (v && (seg == 0 || v > g[i])) g[i] = v;
             }
         }
     }
@@ -1165,7 +1264,8 @@ extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hip
     if (nchunks == 0) return hipSuccess;
     static_assert((FAR_COL / 4) % FAR_PROBE_THREADS == 0, "a column is a whole number of 16-byte loads per thread");
     const u32 round_to = FAR_XCD_RUN ? FAR_XCDS * FAR_XCD_RUN : 1u;
-    hipLaunchKernelGGL(zl_far_probe_kernel, dim3(((nchunks + round_to - 1) / round_to) * round_to), dim3(FAR_PROBE_THREADS), 0, stream, *a, nchunks);
+    const u32 pairs = (nchunks + 1) / 2;  // a workgroup per two chunks
+    hipLaunchKernelGGL(zl_far_probe_kernel, dim3(((pairs + round_to - 1) / round_to) * round_to), dim3(FAR_PROBE_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
