@@ -6,7 +6,8 @@ from zstdlite_amd.device import DeviceCodec, gen_device
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (256 << 20)
 kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rand", "iid10", "text", "int20"]
-codec = DeviceCodec(profile=2)
+import os
+codec = DeviceCodec(profile=2, frame_layout=os.environ.get("ZL_LAYOUT", "frames"))  # ZL_LAYOUT=one_frame: the windowed layout's kernels
 for kind in kinds:
     src = gen_device(kind, n, dev)
     comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=dev)
@@ -14,8 +15,9 @@ for kind in kinds:
     best = {}
     for it in range(4):
         _, total, fs = codec.compress(src, comp)
-        tbl = codec.frame_table(fs, codec.chunk_content_sizes(n))
-        codec.decompress(comp, tbl, back)
+        one = os.environ.get("ZL_LAYOUT") == "one_frame"
+        tbl = codec.frame_table([total], [n]) if one else codec.frame_table(fs, codec.chunk_content_sizes(n))
+        codec.decompress(comp, tbl, back, chunk_sizes=fs if one else None)
         for k, v in codec.kernel_ms().items():
             best[k] = min(best.get(k, 1e9), v)
     assert torch.equal(back, src)
