@@ -70,8 +70,10 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * chunk.  zl_decompressDCtx and zl_index_frames find it from the end of the buffer and skip the serial walk over
  * every block header of the data in front of it; the table is checked against the data, never trusted.  Off by default:
  * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written.
- * The table's layout is PRIVATE to this library (zl_format.h: magic 0x184D2A5E, trailer tag "ZLIX"), not the seekable
- * format of zstd's contrib tools (footer magic 0x8F92EAB1): other tools skip it, they cannot use it. */
+ * Independent frames (ZL_layout_frames): the table is zstd's published SEEKABLE FORMAT (contrib/seekable_format of the zstd
+ * distribution: skippable magic 0x184D2A5E, {compressed size, decompressed size} per frame, footer magic 0x8F92EAB1), which
+ * that format's other readers use as well.  ONE frame: the published format lists frames, not the runs of blocks inside
+ * one, so the table there is private to this library (zl_format.h: trailer tag "ZLIX"): other tools skip it. */
 #define ZL_c_seekTable 9006
 /* Devices behind one call: zl_compress2 / zl_decompressDCtx of a large host buffer deal its 64 MiB sections out
  * over this many device slots -- slot s on device s mod hipGetDeviceCount() --, each with its own host thread, upload and

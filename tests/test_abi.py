@@ -138,3 +138,19 @@ def test_seek_table_is_read_from_the_end_of_the_buffer(golden):
     lying = data + table([len(a["comp"]) + 1, len(b["comp"])], content)
     assert L.zl_index_frames(lying, len(lying), frames, 4) == 2               # sizes do not add up: ignored, walked instead
     assert frames[0].src_size == len(a["comp"])
+
+    # zstd's published seekable format (contrib/seekable_format; what this library writes behind independent frames):
+    # {compressed size, decompressed size} per frame, footer {number of frames, descriptor, 0x8F92EAB1}
+    def seekable(entries, descriptor=0):
+        payload = b"".join(struct.pack("<II", c, d) for c, d in entries) + struct.pack("<IBI", len(entries), descriptor, 0x8F92EAB1)
+        return struct.pack("<II", 0x184D2A5E, len(payload)) + payload
+    std = bytes(broken[: len(data)]) + seekable([(len(a["comp"]), a["n"]), (len(b["comp"]), b["n"])])
+    assert L.zl_index_frames(std, len(std), frames, 4) == 2                   # (the damaged walk again: the table answers)
+    assert [(f.src_off, f.src_size, f.dst_off, f.dst_cap) for f in frames[:2]] == [(0, len(a["comp"]), 0, 131072), (len(a["comp"]), len(b["comp"]), 131072, 65536)]
+    ok_std = data + seekable([(len(a["comp"]), a["n"]), (len(b["comp"]), b["n"])])
+    assert L.zl_findDecompressedSize(ok_std, len(ok_std)) == content          # skippable for everybody else
+    # a seekable file whose frames are not this library's 128 KiB chunks, or with reserved descriptor bits, is walked instead
+    other = data + seekable([(len(a["comp"]), a["n"] - 1), (len(b["comp"]), b["n"] + 1)])
+    assert L.zl_index_frames(other, len(other), frames, 4) == 2 and frames[0].dst_cap == 131072
+    reserved = bytes(broken[: len(data)]) + seekable([(len(a["comp"]), a["n"]), (len(b["comp"]), b["n"])], descriptor=0x04)
+    assert _lib.is_error(L.zl_index_frames(reserved, len(reserved), frames, 4))

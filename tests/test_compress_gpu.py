@@ -345,8 +345,14 @@ def test_seek_table_is_skippable_and_spares_the_walk(layout, ref):
     plain = z.zstd_compress(data, frame_layout=layout)
     comp = z.zstd_compress(data, frame_layout=layout, seek_table=True)
     nchunks = -(-len(data) // 131072)
-    assert comp[:len(plain)] == plain and len(comp) == len(plain) + 8 + 4 * nchunks + 20
+    # one frame: the private trailer; independent frames: zstd's seekable format (zl_format.h)
+    assert comp[:len(plain)] == plain and len(comp) == len(plain) + (8 + 4 * nchunks + 20 if layout == "auto" else 8 + 8 * nchunks + 9)
     assert int.from_bytes(comp[len(plain):len(plain) + 4], "little") == 0x184D2A5E
+    if layout == "frames":
+        assert comp[-4:] == (0x8F92EAB1).to_bytes(4, "little") and comp[-5] == 0 and int.from_bytes(comp[-9:-5], "little") == nchunks
+        ent = comp[len(plain) + 8:-9]
+        assert sum(int.from_bytes(ent[8 * i:8 * i + 4], "little") for i in range(nchunks)) == len(plain)
+        assert sum(int.from_bytes(ent[8 * i + 4:8 * i + 8], "little") for i in range(nchunks)) == len(data)
     assert ref.decompress(comp, len(data)) == data           # the whole buffer: the table is skipped
     assert z.zstd_decompress(comp) == data                   # through the table
     L = _lib.lib()
@@ -357,9 +363,9 @@ def test_seek_table_is_skippable_and_spares_the_walk(layout, ref):
     # a table that lies about one size still sums up only if another lies too: both chunks then fail to decode from where
     # the table says they start, and the decoder goes back to walking the data
     bad = bytearray(comp)
-    t0 = len(plain) + 8
-    a = int.from_bytes(bad[t0:t0 + 4], "little"); b = int.from_bytes(bad[t0 + 4:t0 + 8], "little")
-    bad[t0:t0 + 4] = (a + 1).to_bytes(4, "little"); bad[t0 + 4:t0 + 8] = (b - 1).to_bytes(4, "little")
+    t0, step = len(plain) + 8, (4 if layout == "auto" else 8)
+    a = int.from_bytes(bad[t0:t0 + 4], "little"); b = int.from_bytes(bad[t0 + step:t0 + step + 4], "little")
+    bad[t0:t0 + 4] = (a + 1).to_bytes(4, "little"); bad[t0 + step:t0 + step + 4] = (b - 1).to_bytes(4, "little")
     assert z.zstd_decompress(bytes(bad)) == data
 
 

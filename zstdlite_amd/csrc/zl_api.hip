@@ -128,10 +128,38 @@ struct SeekTable {
     u64 content = 0;
     u32 nchunks = 0;
     bool one_frame = false;
-    const u8* sizes = nullptr;  // nchunks little-endian u32
+    const u8* sizes = nullptr;  // nchunks little-endian u32 compressed sizes, `stride` bytes apart
+    u32 stride = 4;
     size_t data_bytes = 0;      // bytes in front of the table
+    u32 size_of(size_t i) const { return rd_le(sizes + stride * i, 4); }
 };
+// zstd's seekable format (zl_format.h): taken only when its frames are this library's chunks -- 128 KiB of content each, the
+// last one the rest -- because that is what the decoder's chunk table assumes; any other seekable file is walked like any
+// other buffer of frames.
+bool read_seekable_table(const u8* src, size_t n, SeekTable& t) {
+    if (n < ZL_SEEKABLE_BYTES(2)) return false;
+    const u8* f = src + n - ZL_SEEKABLE_FOOTER;
+    if (rd_le(f + 5, 4) != ZL_SEEKABLE_MAGIC) return false;
+    const u32 nframes = rd_le(f, 4), desc = f[4];
+    if (nframes < 2 || nframes > 0x1FFFFFFFu || (desc & 0x7C)) return false;  // (reserved bits must be zero)
+    const u32 entry = (desc & 0x80) ? 12u : 8u;
+    const size_t need = 8 + (size_t)entry * nframes + ZL_SEEKABLE_FOOTER;
+    if (need > n) return false;
+    const u8* idx = src + n - need;
+    if (rd_le(idx, 4) != ZL_MAGIC_INDEX || rd_le(idx + 4, 4) != need - 8) return false;
+    u64 csum = 0, content = 0;
+    for (u32 i = 0; i < nframes; i++) {
+        const u32 dsz = rd_le(idx + 8 + (size_t)entry * i + 4, 4);
+        if (i + 1 < nframes ? dsz != ZL_BLOCK_MAX : (dsz == 0 || dsz > ZL_BLOCK_MAX)) return false;
+        csum += rd_le(idx + 8 + (size_t)entry * i, 4);
+        content += dsz;
+    }
+    if (csum != n - need) return false;
+    t.content = content; t.nchunks = nframes; t.one_frame = false; t.sizes = idx + 8; t.stride = entry; t.data_bytes = n - need;
+    return true;
+}
 bool read_seek_table(const u8* src, size_t n, SeekTable& t) {
+    if (read_seekable_table(src, n, t)) return true;
     if (n < ZL_INDEX_BYTES(2)) return false;
     const u8* f = src + n - ZL_INDEX_FOOTER;
     if (rd_le(f + 16, 4) != ZL_INDEX_TAG) return false;
@@ -145,9 +173,10 @@ bool read_seek_table(const u8* src, size_t n, SeekTable& t) {
     if (rd_le(idx, 4) != ZL_MAGIC_INDEX || rd_le(idx + 4, 4) != need - 8) return false;
     if (t.content == 0 || (t.content + ZL_BLOCK_MAX - 1) / ZL_BLOCK_MAX != t.nchunks) return false;
     t.sizes = idx + 8;
+    t.stride = 4;
     t.data_bytes = n - need;
     u64 sum = 0;
-    for (u32 i = 0; i < t.nchunks; i++) sum += rd_le(t.sizes + 4 * (size_t)i, 4);
+    for (u32 i = 0; i < t.nchunks; i++) sum += t.size_of(i);
     return sum == t.data_bytes;
 }
 
@@ -318,7 +347,7 @@ size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t ca
     if (listed) {  // what the table says is untrusted input: every listed frame must at least start like one and record the size its chunk has
         u64 at = 0;
         for (u32 i = 0; i < st.nchunks && listed; i++) {
-            const u32 fs = rd_le(st.sizes + 4 * (size_t)i, 4);
+            const u32 fs = st.size_of(i);
             const u64 cs = i + 1 < st.nchunks ? ZL_BLOCK_MAX : st.content - (u64)i * ZL_BLOCK_MAX;
             FrameHeader h;
             if (fs < 6 || at + fs > st.data_bytes || ZL_IS_ERR(parse_frame_header(h, src + at, fs)) || h.skippable || h.content_size != cs) listed = false;
@@ -327,7 +356,7 @@ size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t ca
     }
     if (listed) {  // one frame per chunk, sizes listed: no walk over block headers (the frames' contents are checked when they are decoded)
         for (u32 i = 0; i < st.nchunks; i++) {
-            const u32 fs = rd_le(st.sizes + 4 * (size_t)i, 4);
+            const u32 fs = st.size_of(i);
             const u64 cs = i + 1 < st.nchunks ? ZL_BLOCK_MAX : st.content - (u64)i * ZL_BLOCK_MAX;
             if (i < cap) { frames[i].src_off = pos; frames[i].src_size = fs; frames[i].dst_off = dst_off; frames[i].dst_cap = cs; }
             pos += fs;
@@ -805,7 +834,7 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
     const size_t nruns = runs_for(plan, nsec);
     std::vector<u64> off((size_t)t.nchunks + 1);
     u64 run = 0;
-    for (u32 i = 0; i < t.nchunks; i++) { off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
+    for (u32 i = 0; i < t.nchunks; i++) { off[i] = run; run += t.size_of(i); }
     off[t.nchunks] = run;
     std::vector<size_t> res(nruns, 0);
     u32 tail = 0;  // ONE frame with a content checksum: its 4 bytes are covered by the last chunk's listed size
@@ -817,7 +846,7 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
         zl_dctx* p = d->peers[w];
         SeekTable sub = t;
         sub.nchunks = (u32)(c1 - c0);
-        sub.sizes = t.sizes + 4 * c0;
+        sub.sizes = t.sizes + (size_t)t.stride * c0;
         sub.data_bytes = (size_t)(off[c1] - off[c0]);
         sub.content = out1 - out0;
         p->run_headerless = t.one_frame && c0 != 0;
@@ -861,12 +890,12 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
         tbl[0].src_off = 0; tbl[0].src_size = t.data_bytes; tbl[0].dst_off = 0; tbl[0].dst_cap = t.content;
         d->chunk_off.resize((size_t)t.nchunks + 1);
         u64 run = 0;
-        for (u32 i = 0; i < t.nchunks; i++) { d->chunk_off[i] = run; run += rd_le(t.sizes + 4 * (size_t)i, 4); }
+        for (u32 i = 0; i < t.nchunks; i++) { d->chunk_off[i] = run; run += t.size_of(i); }
         d->chunk_off[t.nchunks] = run;
     } else {
         u64 pos = 0, out = 0;
         for (u32 i = 0; i < t.nchunks; i++) {
-            const u32 fs = rd_le(t.sizes + 4 * (size_t)i, 4);
+            const u32 fs = t.size_of(i);
             const u64 cs = i + 1 < t.nchunks ? ZL_BLOCK_MAX : t.content - (u64)i * ZL_BLOCK_MAX;
             tbl[i].src_off = pos; tbl[i].src_size = fs; tbl[i].dst_off = out; tbl[i].dst_cap = cs;
             pos += fs;

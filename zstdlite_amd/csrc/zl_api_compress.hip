@@ -294,20 +294,31 @@ bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
     return host_entry;
 }
 
-// the seek table behind `total` bytes of output (zl_format.h), from the per-chunk sizes in c->h_fsize
+// the seek table behind `total` bytes of output (zl_format.h), from the per-chunk sizes in c->h_fsize: zstd's seekable format
+// for independent frames, the private trailer for the runs of blocks of one frame
 size_t append_seek_table(const zl_cctx* c, u8* dst, size_t cap, size_t total, size_t nchunks, u64 content, bool one_frame) {
-    const size_t need = ZL_INDEX_BYTES(nchunks);
-    if (nchunks > 0x3FFFFFFFu) return total;
+    const size_t need = one_frame ? ZL_INDEX_BYTES(nchunks) : ZL_SEEKABLE_BYTES(nchunks);
+    if (nchunks > 0x1FFFFFFFu) return total;
     if (total + need > cap) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
     u8* p = dst + total;
     auto w32 = [&](u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); p += 4; };
     w32(ZL_MAGIC_INDEX);
     w32((u32)(need - 8));
     const u32* fs = (const u32*)c->h_fsize.p;
+    if (!one_frame) {
+        for (size_t i = 0; i < nchunks; i++) {
+            w32(fs[i]);
+            w32((u32)std::min<u64>(ZL_CHUNK, content - (u64)i * ZL_CHUNK));
+        }
+        w32((u32)nchunks);
+        *p++ = 0;  // Seek_Table_Descriptor: no per-frame checksums
+        w32(ZL_SEEKABLE_MAGIC);
+        return total + need;
+    }
     for (size_t i = 0; i < nchunks; i++) w32(fs[i]);
     w32((u32)content); w32((u32)(content >> 32));
     w32((u32)nchunks);
-    w32(one_frame ? 1u : 0u);
+    w32(1u);
     w32(ZL_INDEX_TAG);
     return total + need;
 }
@@ -341,7 +352,7 @@ extern "C" {
 // this bound is also large enough for what the reference would have produced.
 size_t zl_compressBound(size_t n) {
     const size_t zb = n + (n >> 8) + (n < ZL_BLOCK_MAX ? ((ZL_BLOCK_MAX - n) >> 11) : 0);
-    return zb + chunks_of(n) * ZL_FRAME_OVERHEAD + ZL_INDEX_BYTES(chunks_of(n));  // (room for the optional seek table, ZL_c_seekTable)
+    return zb + chunks_of(n) * ZL_FRAME_OVERHEAD + ZL_SEEK_ROOM(chunks_of(n));  // (room for the optional seek table, ZL_c_seekTable)
 }
 
 size_t zl_compress_device_nframes(size_t n) { return chunks_of(n); }
