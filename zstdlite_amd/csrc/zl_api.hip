@@ -533,9 +533,6 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         seq_total += (u64)p.seq_cap;  // 16-byte records
         if (!fast) nslow++;
     }
-#ifndef ZL_DEC_WGS_PER_CU
-#define ZL_DEC_WGS_PER_CU 6  // general kernel: resident workgroups per CU (80 VGPRs; 4 at 128: 64 KiB dictionary frames 25.9 -> 19.6 ms per 4000, 100 000 small ones 4.9 -> 4.1; 7 and 8 spill too much: 8.3)
-#endif
     const u32 max_slots = (u32)g_num_cu * ZL_DEC_WGS_PER_CU;
     // scratch of the general kernel: one slot per resident workgroup.  Frames routed to it on the host are counted;
     // the lane pipeline may hand a few more back on the device (12-bit Huffman tables, long table descriptions), so

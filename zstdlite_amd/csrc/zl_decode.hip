@@ -682,9 +682,6 @@ __device__ u32 execute_block(DecShared& S, u8* blk_out, u64 cap_left, i64 blk_ab
     return out_pos + rest;
 }
 
-#ifndef ZL_DEC_WGS_PER_CU
-#define ZL_DEC_WGS_PER_CU 6  // general kernel: resident workgroups per CU (80 VGPRs; 4 at 128: 64 KiB dictionary frames 25.9 -> 19.6 ms per 4000, 100 000 small ones 4.9 -> 4.1; 7 and 8 spill too much: 8.3)
-#endif
 __global__ __launch_bounds__(DEC_THREADS, ZL_DEC_WGS_PER_CU) void zl_decode_kernel(zl_decode_args a) {
     __shared__ DecShared S;
     const u32 t = threadIdx.x;

@@ -44,6 +44,9 @@ struct zl2_frame_rec {
     u32 pad2;
 };
 
+// general kernel: resident workgroups per CU = scratch slots per CU (80 VGPRs; at 4 and 128 VGPRs dictionary frames of 64 KiB
+// took 25.9 instead of 19.6 ms per 4000 and 100 000 small ones 4.9 instead of 4.1; 7 and 8 spill too much: 8.3)
+#define ZL_DEC_WGS_PER_CU 6
 struct zl_decode_args {
     const zl_frame_desc* frames;
     u32 nframes;
