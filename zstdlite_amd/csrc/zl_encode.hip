@@ -1775,57 +1775,77 @@ __device__ __noinline__ u32 huf_build_lengths_wave(EntShared& S, u32 m, u32 lane
 
 // Huffman tree description (zstd.c:16907 HUF_writeCTable_wksp): weights of symbols
 // 0..maxsym-1, FSE-compressed when that is smaller (zstd.c:16840 HUF_compressWeights),
-// else 4 bits each.  One thread.  Returns bytes written, 0 if the table cannot be described.
-__device__ __noinline__ u32 huf_write_tree(EntShared& S, u8* dst) {
+// else 4 bits each.  By one WAVE (wave 3 of the entropy kernel): the weights, their histogram, the normalised counts and the
+// encoding table on all lanes (lane = symbol / weight; the same cells as the one-thread functions above), the bit stream of
+// the weights -- a chain by nature -- on lane 0.  A full chunk hides this behind its FSE state chains; a batch of small
+// objects has nothing to hide it behind, and one thread took 173 000 cycles per object for it.
+// Returns bytes written (the same in all lanes), 0 if the table cannot be described.
+__device__ __noinline__ u32 huf_write_tree_wave(EntShared& S, u8* dst, u32 lane) {
     const u32 maxsym = S.huf_maxsym, log = S.huf_log;
-    for (u32 s = 0; s < maxsym; s++) S.weights[s] = S.hlen[s] ? (u8)(log + 1 - S.hlen[s]) : 0;
-    // ---- try FSE
     u32* const wc = S.small;
-    for (u32 w = 0; w < 16; w++) wc[w] = 0;
-    u32 maxw = 0, maxcount = 0;
-    for (u32 s = 0; s < maxsym; s++) { const u32 w = S.weights[s]; wc[w]++; if (w > maxw) maxw = w; }
-    for (u32 w = 0; w <= maxw; w++) if (wc[w] > maxcount) maxcount = wc[w];
+    if (lane < 16) wc[lane] = 0;
+    ZL_WAVE_FENCE();
+    u32 maxw_l = 0;
+    for (u32 sy = lane; sy < maxsym; sy += 64) {
+        const u32 w = S.hlen[sy] ? log + 1 - S.hlen[sy] : 0u;
+        S.weights[sy] = (u8)w;
+        atomicAdd(&wc[w], 1u);
+        maxw_l = w > maxw_l ? w : maxw_l;
+    }
+    ZL_WAVE_FENCE();
+    const u32 maxw = wave_max_u32(maxw_l);
+    const u32 maxcount = wave_max_u32(lane <= maxw ? wc[lane] : 0u);
     u32 fse_size = 0;
-    if (maxsym > 1 && maxcount != maxsym && maxcount != 1) {
+    if (maxsym > 1 && maxcount != maxsym && maxcount != 1) {  // (uniform)
         int wlog = (int)hb32(maxsym - 1) - 1;  // a little below log2(#weights)
         if (wlog > 6) wlog = 6;
         if (wlog < 5) wlog = 5;
-        fse_normalize(S.norm, wc, maxsym, (int)maxw, wlog);
-        u8* p = dst + 1;
-        const u32 hs = fse_write_ncount(p, S.norm, (int)maxw, wlog);
-        fse_build_ctable(S.wstate, S.wdnb, S.wdfs, S.tsym, S.cumul[3], S.norm, (int)maxw, wlog);
-        // two interleaved states, last weight first (zstd.c:16090 FSE_compress_usingCTable_generic)
-        BitW w;
-        bw_init(w, p + hs);
-        int ip = (int)maxsym;
-        u32 s1, s2;
-        if (maxsym & 1) {
-            ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
-            ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
-            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
-        } else {
-            ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
-            ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+        fse_normalize_wave(S.norm, wc, maxsym, (int)maxw, wlog, lane);
+        ZL_WAVE_FENCE();
+        fse_build_ctable_wave(S.wstate, S.wdnb, S.wdfs, S.tsym, (u8*)S.cumul[3], S.norm, (int)maxw, wlog, lane);
+        ZL_WAVE_FENCE();
+        if (lane == 0) {
+            u8* p = dst + 1;
+            const u32 hs = fse_write_ncount(p, S.norm, (int)maxw, wlog);
+            // two interleaved states, last weight first (zstd.c:16090 FSE_compress_usingCTable_generic)
+            BitW w;
+            bw_init(w, p + hs);
+            int ip = (int)maxsym;
+            u32 s1, s2;
+            if (maxsym & 1) {
+                ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+                ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+                ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
+            } else {
+                ip--; s2 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+                ip--; s1 = fse_init_state(S.wstate, S.wdnb[S.weights[ip]], S.wdfs[S.weights[ip]]);
+            }
+            while (ip > 0) {
+                ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s2); bw_add(w, o & 0xFFFF, o >> 16); }
+                ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
+            }
+            bw_add(w, s2, (u32)wlog);
+            bw_add(w, s1, (u32)wlog);
+            bw_add(w, 1, 1);
+            fse_size = hs + bw_finish(w);
         }
-        while (ip > 0) {
-            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s2); bw_add(w, o & 0xFFFF, o >> 16); }
-            ip--; { const u32 c = S.weights[ip]; const u32 o = fse_encode(S.wstate, S.wdnb[c], S.wdfs[c], s1); bw_add(w, o & 0xFFFF, o >> 16); }
-        }
-        bw_add(w, s2, (u32)wlog);
-        bw_add(w, s1, (u32)wlog);
-        bw_add(w, 1, 1);
-        fse_size = hs + bw_finish(w);
+        fse_size = (u32)__shfl((int)fse_size, 0, 64);
     }
     if (fse_size > 1 && fse_size < maxsym / 2 && fse_size < 128) {
-        dst[0] = (u8)fse_size;
+        if (lane == 0) dst[0] = (u8)fse_size;
+        ZL_WAVE_FENCE();
         return 1 + fse_size;
     }
     if (maxsym > 128) return 0;
-    dst[0] = (u8)(127 + maxsym);
-    for (u32 s = 0; s < maxsym; s += 2) {
-        const u32 hi = S.weights[s], lo = (s + 1 < maxsym) ? S.weights[s + 1] : 0;
-        dst[1 + s / 2] = (u8)((hi << 4) | lo);
+    if (lane == 0) dst[0] = (u8)(127 + maxsym);
+    {   // (at most 128 weights: a byte of two per lane)
+        const u32 sy = 2 * lane;
+        if (sy < maxsym) {
+            const u32 hi = S.weights[sy], lo = (sy + 1 < maxsym) ? S.weights[sy + 1] : 0;
+            dst[1 + lane] = (u8)((hi << 4) | lo);
+        }
     }
+    ZL_WAVE_FENCE();
     return 1 + (maxsym + 1) / 2;
 }
 
@@ -2408,17 +2428,19 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     __syncthreads();
     ENT_STAMP(2)
     // ---- wave 3: the tree description and the literal decision  |  wave 0: the FSE state chains
-    if (t == 3 * 64 && S.lit_mode == 2) {
+    if (wave == 3 && S.lit_mode == 2) {  // (uniform inside the wave)
         const bool from_dict = S.lit_from_dict != 0;
-        u32 total = 0;
-        for (u32 j = 0; j < nbk; j++) {
-            const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
-            for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
-            total += four ? 6 : 0;
+        const u32 tree = from_dict ? 0u : huf_write_tree_wave(S, S.tree_buf, lane);
+        if (lane == 0) {
+            u32 total = 0;
+            for (u32 j = 0; j < nbk; j++) {
+                const bool four = S.blk_lit[j + 1] - S.blk_lit[j] >= 256;
+                for (u32 k = 0; k < (four ? 4u : 1u); k++) total += (S.sbits[j][k] + 8) >> 3;  // payload + end marker
+                total += four ? 6 : 0;
+            }
+            S.tree_size = tree;
+            if ((!from_dict && tree == 0) || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
         }
-        const u32 tree = from_dict ? 0u : huf_write_tree(S, S.tree_buf);
-        S.tree_size = tree;
-        if ((!from_dict && tree == 0) || tree + total >= nlit - min_gain(nlit)) S.lit_mode = 0;  // zstd.c:20770: not worth it -> raw
     }
     // The FSE state chains (zstd.c:21163-21222) are serial per table and per block -- and the blocks
     // are independent, so the 3 x nbk chains run side by side on the lanes of one wave.  Each lane
