@@ -421,7 +421,7 @@ def test_ratio_sweep_small_sizes(ref):
     assert len(over) <= 6, over  # (the table's own count of cells above 1.05)
 
 
-def test_device_entry_one_frame_with_checksum_and_dictionary(ref):
+def test_device_entry_one_frame_with_checksum(ref):
     """The device-resident entry in the one-frame layout (on request there; its default is independent frames): with
     ZL_c_checksumFlag the frame's XXH64 is computed on the host over pieces brought down from the device and appended on the
     device; the last chunk's reported size covers those four bytes, which is what the decoder's chunk hint expects.  Same bytes
