@@ -274,3 +274,47 @@ def test_damaged_single_block_frames_in_a_batch_that_is_cut_in_two(oracle):
             accepted += 1
             assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
     assert accepted >= m // 5
+
+
+@pytest.mark.gpu
+def test_dictionary_tables_survive_frames_that_bring_their_own(ref):
+    """The general kernel keeps the dictionary's entropy tables in LDS from one frame to the next and copies again only what a
+    frame in between has replaced (zl_decode.hip: DecShared::dict_live).  A batch that mixes, in one launch and in an order the
+    workgroups pick, frames that ride on the dictionary's tables (small objects: Repeat_Mode, treeless literals), frames that
+    describe tables of their own (larger texts), frames with a content checksum (whose check stages the output in the
+    Huffman table's LDS) and raw / RLE frames: every frame decodes to its input with the dictionary, made by the reference
+    library (zstd.c:42053 ZSTD_loadDEntropy, :43666 repeat modes)."""
+    import pickle
+    rng = np.random.default_rng(11)
+    names = [f"field_{i:02d}_{'y' * (i % 5)}" for i in range(40)]
+
+    def small():
+        perm = rng.permutation(40)[: int(rng.integers(8, 30))]
+        return pickle.dumps({names[j]: int(rng.integers(0, 500)) for j in perm}, protocol=4)
+    smalls = [small() for _ in range(1200)]
+    d = ref.train_dict(smalls[:600], 4000)
+    items = []
+    for i in range(900):
+        k = i % 9
+        if k in (0, 1, 2, 3, 4):
+            items.append((smalls[i], False))
+        elif k == 5:
+            items.append((GENERATORS["text"](int(rng.integers(20000, 60000)), seed=i), False))  # its own tables
+        elif k == 6:
+            items.append((smalls[i] * 2, True))                                                  # with a checksum
+        elif k == 7:
+            items.append((bytes(rng.integers(0, 256, int(rng.integers(50, 400)), dtype=np.uint8)), False))  # raw block
+        else:
+            items.append((GENERATORS["iid10"](int(rng.integers(3000, 9000)), seed=i), True))     # own tables + checksum
+    frames = [ref.compress(x, level=3, checksum=c, dict=d) for x, c in items]
+    modes = {f[5 + 4 + (1 if len(x) < 256 else (2 if len(x) < 65792 else 4)) + 3] & 3 for (x, _), f in zip(items, frames)}
+    assert 3 in modes and 2 in modes, modes  # treeless literals and literals with their own tree are both in the batch
+    for rep in range(3):  # (the order in which workgroups take the frames differs from launch to launch)
+        back = z.zstd_decompress_batch(frames, dict=d)
+        assert back == [x for x, _ in items]
+    # a damaged checksum is still caught in the middle of such a batch
+    i = next(k for k, (_, c) in enumerate(items) if c)
+    bad = list(frames)
+    bad[i] = frames[i][:-1] + bytes([frames[i][-1] ^ 0x5A])
+    with pytest.raises(z.ZstdError):
+        z.zstd_decompress_batch(bad, dict=d)
