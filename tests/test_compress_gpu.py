@@ -449,3 +449,67 @@ def test_device_entry_one_frame_with_checksum(ref):
     with pytest.raises(z.ZstdError, match="doesn't match checksum"):
         codec.decompress(bad, tbl, back, chunk_sizes=sizes)
     codec.close()
+
+
+def test_batch_entries_report_per_object_results_at_scale():
+    """zl_compress_batch / zl_decompress_batch with tens of thousands of objects: the per-object loops of the call's host side
+    run on several host threads (zl_host.h zl_parallel_for) and one launch group takes the whole batch (scratch strides sized
+    to the largest object).  Every object's result stands at its own index: sizes, an empty object, a destination that is too
+    small (zstd.h:1219 dstSize_tooSmall for that object only, the others unaffected), a source that is not a frame -- and the
+    same bytes come out as object by object through zl_compress2."""
+    import ctypes as C
+    from zstdlite_amd import _lib
+    rng = np.random.default_rng(5)
+    L = _lib.lib()
+    n = 40000
+    words = [bytes(rng.integers(97, 123, int(rng.integers(3, 9)), dtype=np.uint8)) for _ in range(200)]
+    items = [b" ".join(words[int(j)] for j in rng.integers(0, 200, int(rng.integers(0, 120)))) for _ in range(n)]
+    items[17] = b""
+    items[4242] = b"some words that repeat, some words that repeat"
+    items[n - 1] = bytes(3000)
+    sizes = np.array([len(x) for x in items], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    blob = np.frombuffer(b"".join(items), dtype=np.uint8).copy()
+    caps = np.array([L.zl_compressBound(int(s)) for s in sizes], dtype=np.uint64)
+    coff = np.concatenate([[0], np.cumsum(caps)]).astype(np.uint64)
+    comp = np.zeros(int(coff[-1]), dtype=np.uint8)
+    p_src = (blob.ctypes.data + off[:-1]).astype(np.uint64)
+    p_comp = (comp.ctypes.data + coff[:-1]).astype(np.uint64)
+    caps_c = caps.copy()
+    small = [5, 20001, n - 2]
+    for i in small:
+        caps_c[i] = 3  # too small for any frame of a non-empty object
+    assert all(sizes[i] > 0 for i in small)
+    csize = np.zeros(n, dtype=np.uint64)
+    vp, sp = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    try:
+        r = L.zl_compress_batch(cctx, n, p_comp.ctypes.data_as(vp), caps_c.ctypes.data_as(sp), p_src.ctypes.data_as(vp), sizes.ctypes.data_as(sp), csize.ctypes.data_as(sp))
+        assert not _lib.is_error(r)
+        for i in range(n):
+            if i in small:
+                assert _lib.is_error(int(csize[i])) and "too small" in _lib.error_name(int(csize[i])).lower(), i
+            else:
+                assert not _lib.is_error(int(csize[i])) and 0 < csize[i] <= caps[i], i
+        for i in (0, 17, 4242, 20000, 20002, n - 1):  # the same bytes as the one-object entry writes
+            one = z.zstd_compress(items[i], frame_layout="frames")
+            assert bytes(comp[int(coff[i]):int(coff[i]) + int(csize[i])]) == one, i
+        # decompress: the objects whose compression failed are handed garbage instead of a frame
+        dsizes = csize.copy()
+        for i in small:
+            dsizes[i] = 3
+        back = np.zeros(len(blob) + 16, dtype=np.uint8)
+        p_back = (back.ctypes.data + off[:-1]).astype(np.uint64)
+        dcap = sizes.copy()
+        dcap[4242] = max(int(sizes[4242]) - 1, 0)  # one destination too small
+        bsize = np.zeros(n, dtype=np.uint64)
+        r = L.zl_decompress_batch(dctx, n, p_back.ctypes.data_as(vp), dcap.ctypes.data_as(sp), p_comp.ctypes.data_as(vp), dsizes.ctypes.data_as(sp), bsize.ctypes.data_as(sp))
+        assert not _lib.is_error(r)
+        for i in range(n):
+            if i in small or i == 4242:
+                assert _lib.is_error(int(bsize[i])), i
+            else:
+                assert bsize[i] == sizes[i], i
+                assert bytes(back[int(off[i]):int(off[i + 1])]) == items[i], i
+    finally:
+        L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
