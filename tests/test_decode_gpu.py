@@ -318,3 +318,61 @@ def test_dictionary_tables_survive_frames_that_bring_their_own(ref):
     bad[i] = frames[i][:-1] + bytes([frames[i][-1] ^ 0x5A])
     with pytest.raises(z.ZstdError):
         z.zstd_decompress_batch(bad, dict=d)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (reference libzstd) to make the frames and the dictionary")
+def test_dictionary_frames_on_the_lane_pipeline_agree_with_the_oracle(ref, oracle):
+    """Frames of 2 KiB of content and more that start from a dictionary take the lane pipeline (zl_api.hip ZL_DICT_LANE_MIN):
+    its sequence and literal lanes inherit the dictionary's tables from a synthetic block (zl2_args::ext_shared), chains start
+    from a symbolic history that the exec kernel fills with the dictionary's repeat offsets, matches reach into the
+    dictionary's content in front of position 0.  Reference-made frames (zstd.c:42053 ZSTD_loadDEntropy, :43640 repeat modes,
+    :44030 ZSTD_execSequence with a dictionary) of one to five blocks, with and without checksum, from both a trained and a
+    raw-content dictionary -- intact: bit-exact; with flipped bits: accepted exactly when the oracle accepts them, and then the
+    same bytes."""
+    import ctypes as C
+    rng = np.random.default_rng(23)
+    text = GENERATORS["text"](3 << 20, seed=31)
+    trained = ref.train_dict([text[i * 4000:(i + 1) * 4000] for i in range(300)], 16000)
+    raw = text[100000:130000]  # no magic: content only
+    for d in (trained, raw):
+        items = []
+        for n in (2048, 3000, 9000, 40000, 131072, 131073, 300000, 600000):
+            x = text[(1 << 20) + 7 * n:(1 << 20) + 8 * n]
+            if n == 9000:
+                x = x[:4000] + text[100100:104100] + x[8000:]  # long matches into the dictionary's content
+            items.append(x)
+        items.append(GENERATORS["iid10"](50000, seed=2))
+        frames = [ref.compress(x, level=3, checksum=bool(i & 1), dict=d) for i, x in enumerate(items)]
+        assert z.zstd_decompress_batch(frames, dict=d) == items
+        assert [z.zstd_decompress(f, dict=d) for f in frames[:4]] == items[:4]
+        # without the dictionary: whatever the reference says (a frame that names a dictionary id is refused, zstd.c:41318)
+        for f, x in zip(frames[:3], items[:3]):
+            code, _ = ref.decompress_code(f, len(x))
+            if is_error(code):
+                with pytest.raises(z.ZstdError):
+                    z.zstd_decompress(f)
+        damaged = []
+        for f, x in zip(frames, items):
+            for _ in range(40):
+                b = bytearray(f)
+                for _ in range(int(rng.integers(1, 4))):
+                    b[int(rng.integers(4, len(b)))] ^= 1 << int(rng.integers(0, 8))
+                damaged.append((bytes(b), len(x)))
+        m = len(damaged)
+        outs = [np.zeros(max(n, 1), dtype=np.uint8) for _, n in damaged]
+        srcs = [np.frombuffer(f, dtype=np.uint8) for f, _ in damaged]
+        res = (C.c_size_t * m)()
+        dctx = z.zstd_dctx(dict=d)
+        r = _lib.lib().zl_decompress_batch(dctx._ptr, m, (C.c_void_p * m)(*[x.ctypes.data for x in outs]), (C.c_size_t * m)(*[n for _, n in damaged]),
+                                           (C.c_void_p * m)(*[x.ctypes.data for x in srcs]), (C.c_size_t * m)(*[len(f) for f, _ in damaged]), res)
+        assert not is_error(r)
+        accepted = 0
+        for i, (f, n) in enumerate(damaged):
+            code, out = oracle.decompress_code(f, n, dict=d)
+            if is_error(res[i]):
+                assert is_error(code), (i, _lib.error_name(res[i]), code)
+            else:
+                accepted += 1
+                assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
+        assert 0 < accepted < m

@@ -874,11 +874,14 @@ __global__ __launch_bounds__(DEC_THREADS) void zl_digest_dict_kernel(const u8* d
     if (t == 0 && !S.err) {
         u32 pos = S.hdr_size;
         const int kinds[3] = {K_OF, K_ML, K_LL};
+        out->sec[0] = 8;
         for (int i = 0; i < 3 && !S.err; i++) {
+            out->sec[1 + i] = pos;
             u32 r = read_seq_table(S, kinds[i], 2, dict + pos, n - pos);
             if (r == 0xFFFFFFFFu) S.err = ZL_E_DICT_CORRUPTED;
             else pos += r;
         }
+        out->sec[4] = pos;
         if (!S.err && pos + 12 > n) S.err = ZL_E_DICT_CORRUPTED;
         if (!S.err) {
             const u32 content = n - (pos + 12);

@@ -74,6 +74,13 @@ __device__ __forceinline__ void set_err(zl2_frame_rec* fr, u32 code) {
     if (fr->err == 0) fr->err = code;
 }
 
+// Inherited table descriptions (zl_kernels.h zl2_args::ext): four records per segment of a large frame, or ONE set of four for
+// every frame of a batch that starts from a dictionary (ext_shared), whose offsets count from ext_base.
+__device__ __forceinline__ const zl2_blk_rec& ext_rec(const zl2_args& a, u32 f, u32 k) { return a.ext[(a.ext_shared ? (size_t)0 : (size_t)f * 4) + k]; }
+__device__ __forceinline__ const u8* ext_src(const zl2_args& a, u32 f) { return a.ext_base ? a.ext_base : a.src + a.frames[f].src_off; }
+// does a chain of frame / segment f start from a history that the exec kernel fills in (symbols instead of numbers)?
+__device__ __forceinline__ bool starts_symbolic(const zl2_args& a, u32 f) { return a.ext != nullptr && (f != 0 || a.ext_shared != 0); }
+
 __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
     const u32 f = blockIdx.x * 64 + threadIdx.x;
     if (f >= a.nframes) return;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
     else if (fflag == 1) fcs = (u64)zl_rd_le(src + pos, 2) + 256;
     else if (fflag == 2) fcs = zl_rd_le(src + pos, 4);
     else fcs = (u64)zl_rd_le(src + pos, 4) | ((u64)zl_rd_le(src + pos + 4, 4) << 32);
-    if (did) { fr->err = ZL_E_DICT_WRONG; return; }  // this path never has a dictionary (zstd.c:41318)
+    if (did && did != a.dict_id) { fr->err = ZL_E_DICT_WRONG; return; }  // zstd.c:41318 (a frame that names no dictionary still starts from the context's)
     fr->fcs = fcs;
     fr->has_checksum = (fhd >> 2) & 1;
     // ---- blocks (zstd.c:43075) and their section headers
@@ -544,7 +551,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
     if (f < a.nframes) {
         fr = a.frec + f;
         const u32 nblocks = (fr->err == 0 && !fr->skippable) ? fr->nblocks : 0;
-        const bool have_ext = a.ext != nullptr && nblocks != 0 && a.ext[(size_t)f * 4].type == 2;
+        const bool have_ext = a.ext != nullptr && nblocks != 0 && ext_rec(a, f, 0).type == 2;
         ext_leader = have_ext && b == 0 && sub == 0;
         if (b < nblocks) {
             const zl2_blk_rec* br = a.brec + (size_t)f * ZL2_MAXB;
@@ -568,8 +575,8 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
         const bool mine = active && lb == round;
         if (ri == 0 ? ext_leader : (mine && (int)b == round && sub == 0)) {
             zl2_blk_rec lr = r;
-            if (ri == 0) lr = a.ext[(size_t)f * 4];
-            const u8* blk = src + lr.src_off;
+            if (ri == 0) lr = ext_rec(a, f, 0);
+            const u8* blk = (ri == 0 ? ext_src(a, f) : src) + lr.src_off;
             u32 tree = build_huf_table(g, blk + lr.lit_a, lr.lit_b);
             if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); atomicAdd(a.max_blocks + 1, 1u); tree = 0; g.ok = 0; }
             else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
@@ -1102,7 +1109,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
             r = br[b];
             active = (r.type == 2 && r.nseq > 0);
             if (active && r.seq_modes == 0x100u) { set_err(fr, ZL_E_SRCSIZE_WRONG); active = false; }
-            else if (active && lb < 0 && !(a.ext != nullptr && a.ext[(size_t)f * 4 + 1].type == 2)) { set_err(fr, ZL_E_CORRUPTION); active = false; }  // repeat mode with nothing to repeat (zstd.c:43666)
+            else if (active && lb < 0 && !(a.ext != nullptr && ext_rec(a, f, 1).type == 2)) { set_err(fr, ZL_E_CORRUPTION); active = false; }  // repeat mode with nothing to repeat (zstd.c:43666)
         }
     }
     // Rounds: 0..2 build the tables a segment of a large frame inherits from earlier blocks (large-frame
@@ -1110,7 +1117,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
     // block k of the frame (segment).
     u32 ext_n = 0;  // inherited table descriptions of this lane's segment (block 0's lane reads them)
     if (a.ext != nullptr && f < a.nframes && b == 0 && fr->err == 0 && !fr->skippable && fr->nblocks != 0)
-        for (u32 k = 1; k < 4; k++) if (a.ext[(size_t)f * 4 + k].type == 2) ext_n = k;
+        for (u32 k = 1; k < 4; k++) if (ext_rec(a, f, k).type == 2) ext_n = k;
     if (f < a.nframes && src == nullptr) src = a.src + a.frames[f].src_off;
     if (active) atomicOr(rounds, 1u << (lb + 4));
     if (ext_n) atomicOr(rounds, (1u << ext_n) - 1);
@@ -1132,8 +1139,8 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         wave_sync();
         if (ext_lead || (mine && b + 4 == ri)) {  // leader: copy the table descriptions out of the frame, then parse them
             zl2_blk_rec lr = r;
-            if (ext_lead) lr = a.ext[(size_t)f * 4 + 1 + ri];
-            const u8* sp = src + lr.src_off + lr.seq_off;
+            if (ext_lead) lr = ext_rec(a, f, 1 + ri);
+            const u8* sp = (ext_lead ? ext_src(a, f) : src) + lr.src_off + lr.seq_off;
             const u32 sn = lr.seq_len, hn = sn < sizeof(B.hdr) ? sn : (u32)sizeof(B.hdr);
             {   // whole 16-byte pieces in one round trip, the last few bytes one by one
                 const u32 full = hn >> 4;
@@ -1181,11 +1188,11 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
                 const zl2_blk_rec r4 = a.brec[(size_t)f4 * ZL2_MAXB];
                 const u8* sp4 = a.src + a.frames[f4].src_off + r4.src_off + r4.seq_off;
                 uint4* o4 = (uint4*)a.seq_scratch + a.plan[f4].seq_off + r4.seq_dst;
-                const u32 err = seq_chain_quad(S, S.L[fq], lane, r4, sp4, S.qpos[fq], S.logs[fq][0], S.logs[fq][1], S.logs[fq][2], a.ext != nullptr && f4 != 0, o4);
+                const u32 err = seq_chain_quad(S, S.L[fq], lane, r4, sp4, S.qpos[fq], S.logs[fq][0], S.logs[fq][1], S.logs[fq][2], starts_symbolic(a, f4), o4);
                 if (err) set_err(a.frec + f4, err);
             }
         } else if (mine && S.logs[fi][3] == 1 && fr->err == 0) {
-            const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0 || (a.ext != nullptr && f != 0),
+            const u32 err = seq_chain(S, L, lane, r, src + r.src_off + r.seq_off, pos, S.logs[fi][0], S.logs[fi][1], S.logs[fi][2], b != 0 || starts_symbolic(a, f),
                                       q_seq + r.seq_dst);
             if (err) set_err(fr, err);
         }
@@ -1363,7 +1370,8 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
         return false;
     }
     u32* const glink = BIG ? a.big->link : nullptr;
-    const u32 dict_len = BIG ? a.big->dict_len : 0u;  // uniform
+    const u32 dict_len = BIG ? a.big->dict_len : a.dict_len;  // uniform
+    const u8* const dict_end = BIG ? a.big->dict_end : a.dict_end;
     typedef typename ExecSharedT<BIG>::link_t link_t;
     constexpr link_t EX_FINAL = (link_t)~(link_t)0;
     constexpr u32 EX_MAXSEQ_T = ExecSharedT<BIG>::MAXSEQ;
@@ -1382,7 +1390,7 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
     const u32 seg_blk0 = BIG ? a.big->seg_first[f] : 0u;  // the segment's first block inside the frame
     u64 op = BIG ? (u64)a.big->blk_dst[seg_blk0] : 0;
     if (first) seg_start = op;
-    u32 rep0 = 1, rep1 = 4, rep2 = 8;  // repcode history at the start of the next block with sequences (zstd.c:41433)
+    u32 rep0 = a.dict_rep[0], rep1 = a.dict_rep[1], rep2 = a.dict_rep[2];  // repcode history at the start of the next block with sequences (zstd.c:41433; 1, 4, 8 unless a formatted dictionary says otherwise, zstd.c:42140)
     const u64 wg_t1 = wg_prof ? __builtin_amdgcn_s_memtime() : 0;
     // Output goes to memory with plain stores and is read back (by other waves) only in pass 2a of a
     // later batch, so the one place that drains the stores is the barrier in front of pass 2a:
@@ -1523,8 +1531,11 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                             const u8* from = bdst + q;  // an earlier batch or an earlier block: already in memory
                             if (BIG) {
                                 const i64 fpi = (i64)op + q;  // frame position of the source
-                                if (fpi < 0) from = a.big->dict_end + fpi;  // in front of the frame: the dictionary's content
+                                if (fpi < 0) from = dict_end + fpi;  // in front of the frame: the dictionary's content
                                 else { const u64 fp = (u64)fpi; defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp); }  // (another segment | this segment: final, or waiting itself)
+                            } else if (dict_len) {
+                                const i64 fpi = (i64)op + q;
+                                if (fpi < 0) from = dict_end + fpi;
                             }
                             if (defer == ZL3_ROOT) {
                                 S.img[p + ibase] = *from;
@@ -1606,11 +1617,19 @@ __device__ __forceinline__ bool exec_frame(const zl2_args& a, ExecSharedT<BIG>& 
                     const u64 fm = op + mstart;  // frame position of the match
                     for (u32 m = t; m < ml; m += EX_THREADS) {
                         const i64 fpi = (i64)fm - (i64)o + (i64)(m % o);
-                        if (fpi < 0) { to[m] = a.big->dict_end[fpi]; continue; }  // the dictionary's content
+                        if (fpi < 0) { to[m] = dict_end[fpi]; continue; }  // the dictionary's content
                         const u64 fp = (u64)fpi;
                         const u32 defer = fp < seg_start ? (u32)fp : ex_link_load(glink + fp);
                         if (defer == ZL3_ROOT) to[m] = dst[fp];
                         else { a.big->tile_flag[(fm + m) >> ZL3_TILE_LOG] = 1; glink[fm + m] = defer; }
+                    }
+                } else if (dict_len && (i64)op + (i64)mstart - (i64)o < 0) {
+                    // (a frame that starts from a dictionary, a match longer than a batch whose source begins inside the
+                    // dictionary's content: byte by byte, the bytes in front of position 0 from the dictionary)
+                    const i64 fm = (i64)op + (i64)mstart;
+                    for (u32 m = t; m < ml; m += EX_THREADS) {
+                        const i64 fpi = fm - (i64)o + (i64)(m % o);
+                        to[m] = fpi < 0 ? dict_end[fpi] : dst[fpi];
                     }
                 } else if (o >= 16) {
                     // whole 16-byte pieces while they do not wrap around the period

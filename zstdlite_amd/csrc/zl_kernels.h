@@ -75,6 +75,9 @@ struct zl_dict_tables {
     u32 rep[3];
     u32 content_off;  // first content byte inside the dictionary buffer
     u32 status;       // 0 ok, else error code
+    u32 sec[5];       // where the entropy section's pieces start inside the dictionary buffer: Huffman description, offset-code,
+                      // match-length and literal-length table descriptions, the three repeat offsets (zstd.c:42053-42150)
+    u32 pad;
 };
 
 struct zl2_args {
@@ -96,6 +99,16 @@ struct zl2_args {
     // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
     const zl2_blk_rec* ext;   // per segment 4 records of earlier blocks whose tables the segment inherits: [0] Huffman tree, [1..3] sequence tables in block order; type 0xFFFFFFFF: none.  Null on the ordinary path
     const struct zl3_big* big;  // execution state shared by the segments.  Null on the ordinary path
+    // ---- frames that start from a DICTIONARY (zl_api.hip, batches on the ordinary path): its entropy tables are inherited the
+    // way a segment inherits an earlier block's -- ext then holds ONE set of 4 records for every frame (ext_shared), describing a
+    // synthetic block at ext_base: the dictionary's Huffman description, and a sequences header that spells out its three FSE
+    // tables --, its content is history in front of position 0 of every frame, its repeat offsets are the history a frame starts with
+    u32 ext_shared;
+    const u8* ext_base;       // where the ext records' offsets count from (null: the frame's / segment's own source)
+    const u8* dict_end;       // one past the dictionary's content (null: none)
+    u32 dict_len;
+    u32 dict_id;              // what a frame's Dictionary_ID must be when it has one (0: the context has no dictionary)
+    u32 dict_rep[3];          // the history a frame starts with (1, 4, 8 without a formatted dictionary)
     // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there).
     // 0: all of it.  Otherwise the launch's ROLE in the two-part schedule; which groups a role covers depends on the mode
     // the order kernel chose on the device (max_blocks[2]: ZL2_MODE_*).
