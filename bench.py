@@ -326,7 +326,7 @@ def c4_leg(log, nitems=100000):
             "gpu_over_cpu_all_cores_decompress": gpu_d / cpu_d,
             "note": "; ".join(
                 (f"{what}: the batch entry on one GPU runs at {g / c:.2f}x the reference's per-object loop on {ncores} host threads" +
-                 ("" if g >= c else " (objects of 400 bytes: the decoder's general kernel takes them one per workgroup, 40 us each, and the call's host side -- a memcpy and a header parse per object -- is a third of the call)"))
+                 ("" if g >= c else " (objects of 400 bytes: the call's host side -- a memcpy and a header parse per object -- is half of the call)"))
                 for what, g, c in (("compress", gpu_c, cpu_c), ("decompress", gpu_d, cpu_d))),
             "checked": "every frame through our decoder; one in fifty through the reference decoder with the dictionary"}
 

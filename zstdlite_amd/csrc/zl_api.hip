@@ -223,7 +223,7 @@ struct zl_dctx_s {
     bool run_headerless = false, run_not_last = false;  // the "frame" of the call is one device's run of a frame's chunks (decompress sharding)
     u32 run_tail = 0;                  // ... and its last chunk's listed size covers this many footer bytes (the frame's content checksum)
     u32 dict_rep[3] = {1, 4, 8};       // a formatted dictionary's repeat offsets (zstd.c:42053)
-    DevBuf d_dict_ext;                 // lane pipeline: 4 zl2_blk_rec + the synthetic block they point into (dctx_prepare_dict)
+    DevBuf d_dict_ext, d_dict_pre;     // lane pipeline: 4 zl2_blk_rec + the synthetic block they point into; the tables built from it (dctx_prepare_dict)
     bool dict_ext_ok = false;
     bool host_verify = false;          // host entries: the content checksum of frames that take the large-frame pipeline is checked on the host, over the downloaded bytes (zl_xxh64.h)
     std::vector<u8> took_big;          // per frame of the last dctx_enqueue: 1 when the large-frame pipeline decoded it
@@ -396,7 +396,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
-                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off, &d->d_dict_ext};
+                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off, &d->d_dict_ext, &d->d_dict_pre};
     for (DevBuf* b : bufs) b->release();
     for (zl_dctx* p : d->peers) (void)zl_freeDCtx(p);
     d->peers.clear();
@@ -527,6 +527,11 @@ size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
             if (hipMemcpy(d->d_dict_ext.p, rec, sizeof(rec), hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy((u8*)d->d_dict_ext.p + sizeof(rec), pb.data(), pb.size(), hipMemcpyHostToDevice) != hipSuccess)
                 return ZL_ERR(ZL_E_GENERIC);
+            // ... and the tables themselves in the lanes' formats, once (the inheritance rounds copy them)
+            if (!d->d_dict_pre.ensure(sizeof(zl2_dict_pre))) return kGpuUnavailable;
+            if (zl2_launch_dict_prebuild((const zl2_blk_rec*)d->d_dict_ext.p, (const u8*)d->d_dict_ext.p + sizeof(rec), (zl2_dict_pre*)d->d_dict_pre.p, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return ZL_ERR(ZL_E_GENERIC);
             d->dict_ext_ok = true;
         }
     } else {
@@ -545,9 +550,6 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     const zl_frame_desc* tbl = (const zl_frame_desc*)d->h_frames.p;
     if (!d->h_plan.ensure(n * sizeof(zl2_frame_plan))) return kGpuUnavailable;
     zl2_frame_plan* plan = (zl2_frame_plan*)d->h_plan.p;
-#ifndef ZL_DICT_LANE_MIN
-#define ZL_DICT_LANE_MIN 2048u  // content bytes from which a frame that starts from a dictionary takes the lane pipeline
-#endif
     const bool has_dict = !d->dict.empty();
     const bool lane_dict = !has_dict || !d->dict_formatted || d->dict_ext_ok;  // can the lane pipeline start frames from this context's dictionary?
     const u64 route_max = (u64)ZL2_MAXB * ZL_BLOCK_MAX;
@@ -559,11 +561,11 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         // the lane pipeline takes frames of up to ZL2_MAXB blocks (it hands back on the device what has more)
         // (with a dictionary: its content rides as history in front of every frame; a formatted one's tables are inherited
         // through the synthetic block of dctx_prepare_dict -- without that block the general kernel takes the frames)
-        // (... and only frames of some size: the pipeline builds the dictionary's four tables once per group of eight frames,
-        // which frames of a few hundred bytes do not repay -- 100 000 of them: 8.6 ms against the general kernel's 4.1, which
-        // copies the digested tables; 4000 frames of 64 KiB: 2.7 ms against 19.6.  Per frame, general kernel / lane pipeline
-        // (scripts/dev/dict_sizes_bench.py): 1 KiB 80 / 97 ns, 2 KiB 145 / 112, 4 KiB 318 / 146, 8 KiB 711 / 226)
-        const bool fast = lane_dict && (!has_dict || tbl[i].dst_cap >= ZL_DICT_LANE_MIN) && tbl[i].dst_cap <= route_max && tbl[i].src_size < (1u << 30);
+        // (Every size: the inheritance rounds COPY the tables, which dctx_prepare_dict has built once in the lanes' formats.
+        // While they built them per group of eight frames, frames under 2 KiB were faster on the general kernel -- 100 000
+        // objects of config C4: 8.6 ms against 4.1; with the copy 3.3.  Per frame, general kernel / lanes
+        // (scripts/dev/dict_sizes_bench.py): 512 B 51 / 37 ns, 1 KiB 80 / 43, 2 KiB 145 / 59, 4 KiB 318 / 90, 8 KiB 711 / 171.)
+        const bool fast = lane_dict && tbl[i].dst_cap <= route_max && tbl[i].src_size < (1u << 30);
         p.route = fast ? 1u : 0u;
         p.lit_off = lit_total;
         p.seq_off = seq_total;
@@ -658,7 +660,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.fuse1 = 3u;  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
     f2.big = nullptr;
     f2.part = 0;
-    f2.ext_shared = 0; f2.ext_base = nullptr; f2.dict_end = nullptr; f2.dict_len = 0; f2.dict_id = d->dict_id;
+    f2.ext_shared = 0; f2.ext_base = nullptr; f2.dict_end = nullptr; f2.dict_len = 0; f2.dict_id = d->dict_id; f2.dict_pre = nullptr;
     f2.dict_rep[0] = 1; f2.dict_rep[1] = 4; f2.dict_rep[2] = 8;
     if (has_dict) {
         f2.dict_end = (const u8*)d->d_dict.p + d->dict.size();
@@ -667,6 +669,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             f2.ext = (const zl2_blk_rec*)d->d_dict_ext.p;
             f2.ext_shared = 1;
             f2.ext_base = (const u8*)d->d_dict_ext.p + 4 * sizeof(zl2_blk_rec);
+            f2.dict_pre = (const zl2_dict_pre*)d->d_dict_pre.p;
             for (int k = 0; k < 3; k++) f2.dict_rep[k] = d->dict_rep[k];
         }
     }

@@ -577,7 +577,23 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
             zl2_blk_rec lr = r;
             if (ri == 0) lr = ext_rec(a, f, 0);
             const u8* blk = (ri == 0 ? ext_src(a, f) : src) + lr.src_off;
-            u32 tree = build_huf_table(g, blk + lr.lit_a, lr.lit_b);
+            u32 tree;
+            if (ri == 0 && a.dict_pre != nullptr) {  // the dictionary's table, built once per context: copied
+                const zl2_dict_pre* P = a.dict_pre;
+                tree = P->huf_ok == 1 ? lr.lit_b : (P->huf_ok == 2 ? 0xFFFFFFFFu : 0u);
+                if (P->huf_ok == 1) {
+                    const uint4* from = (const uint4*)P->tab;
+                    uint4* to = (uint4*)g.tab;
+                    for (u32 i = 0; i < 2048 * 2 / 16; i += 8) {
+                        uint4 v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) v[q] = from[i + q];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) to[i + q] = v[q];
+                    }
+                    g.log = P->huf_log;
+                }
+            } else tree = build_huf_table(g, blk + lr.lit_a, lr.lit_b);
             if (tree == 0xFFFFFFFFu) { set_err(fr, ZL_E_FALLBACK); atomicAdd(a.max_blocks + 1, 1u); tree = 0; g.ok = 0; }
             else if (tree == 0) { set_err(fr, ZL_E_CORRUPTION); g.ok = 0; }
             else g.ok = 1;
@@ -1137,6 +1153,23 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         // the scratch shares LDS with the record ring: whatever the last chains left there must not look like a parsed header
         if (b == 0) B.stamp = 0;
         wave_sync();
+        if (ext_lead && a.dict_pre != nullptr) {
+            // the dictionary's three tables, built once per context (zl2_dict_prebuild_kernel): copied, nothing to parse or build
+            const zl2_dict_pre* P = a.dict_pre;
+            if (P->seq_ok == 1) {
+                const uint4* from = (const uint4*)P->ent;
+                uint4* to = (uint4*)L.ent;
+                for (u32 i = 0; i < 1280 * 4 / 16; i += 8) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = from[i + q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) to[i + q] = v[q];
+                }
+                S.logs[fi][0] = P->seq_log[0]; S.logs[fi][1] = P->seq_log[1]; S.logs[fi][2] = P->seq_log[2];
+                if (S.logs[fi][3] != 2) S.logs[fi][3] = 1;
+            } else { set_err(fr, ZL_E_DICT_CORRUPTED); S.logs[fi][3] = 2; }
+        } else
         if (ext_lead || (mine && b + 4 == ri)) {  // leader: copy the table descriptions out of the frame, then parse them
             zl2_blk_rec lr = r;
             if (ext_lead) lr = ext_rec(a, f, 1 + ri);
@@ -1238,6 +1271,55 @@ __global__ __launch_bounds__(LIT_FRAMES * MB * 4, 1) void zl2_lit_kernel(zl2_arg
     lit_role<MB>(a, G, &rounds, g0 + blockIdx.x);
     if (prof) atomicAdd((unsigned long long*)&a.stats[6], (unsigned long long)(clock64() - t0));  // profile: cycles per literal workgroup
 }
+// A dictionary's tables in the lanes' formats, once per context (zl_kernels.h zl2_dict_pre): lane 0 builds the Huffman table, then
+// parses the synthetic block's sequences header; lanes 0..2 build one FSE table each -- the same functions the inheritance
+// rounds run, so that a copy of the result is what they would have built.
+__global__ __launch_bounds__(64) void zl2_dict_prebuild_kernel(const zl2_blk_rec* ext, const u8* ext_base, zl2_dict_pre* out) {
+    __shared__ LitGroupT<1> G;
+    __shared__ SeqLane L;
+    __shared__ SeqBuild B;
+    __shared__ short defn[3][64];
+    __shared__ u32 logs[4];
+    const u32 lane = threadIdx.x;
+    if (lane < 36) defn[0][lane] = k_LL_default[lane];
+    if (lane < 29) defn[1][lane] = k_OF_default[lane];
+    if (lane < 53) defn[2][lane] = k_ML_default[lane];
+    if (lane < 4) logs[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        const zl2_blk_rec h = ext[0];
+        const u32 tree = h.type == 2 ? build_huf_table(G, ext_base + h.src_off + h.lit_a, h.lit_b) : 0u;
+        out->huf_ok = tree == 0xFFFFFFFFu ? 2u : (tree != 0 ? 1u : 0u);
+        out->huf_log = G.log;
+        const zl2_blk_rec q = ext[1];
+        bool ok = q.type == 2 && q.seq_len >= 1 && q.seq_len <= sizeof(B.hdr);
+        if (ok) {
+            const u8* sp = ext_base + q.src_off + q.seq_off;
+            for (u32 x = 0; x < q.seq_len; x++) B.hdr[x] = sp[x];
+            const u32 modes = B.hdr[0];
+            ok = modes == 0xA8u;
+            u32 pos = 1;
+            for (int k = 0; ok && k < 3; k++) {  // block order: LL, OF, ML (kinds 0, 1, 2)
+                const u32 used = parse_seq_table(B, k, 2, B.hdr + pos, q.seq_len - pos, false);
+                ok = used != 0xFFFFFFFFu;
+                pos += ok ? used : 0;
+            }
+            ok = ok && pos == q.seq_len;
+        }
+        logs[3] = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (lane < 3 && logs[3]) {
+        const u32 lg = make_seq_table(L, B, &defn[0][0], (int)lane, 0u);
+        if (lg == 0xFFFFFFFFu) atomicExch(&logs[3], 0u);
+        else logs[lane] = lg;
+    }
+    __syncthreads();
+    if (lane == 0) { out->seq_ok = logs[3]; out->seq_log[0] = logs[0]; out->seq_log[1] = logs[1]; out->seq_log[2] = logs[2]; }
+    for (u32 i = lane; i < 2048; i += 64) out->tab[i] = G.tab[i];
+    for (u32 i = lane; i < 1280; i += 64) out->ent[i] = L.ent[i];
+}
+
 __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
     __shared__ SeqShared S;
     __shared__ u32 rounds;
@@ -1801,6 +1883,10 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     return hipGetLastError();
 }
 
+extern "C" hipError_t zl2_launch_dict_prebuild(const zl2_blk_rec* ext, const u8* ext_base, zl2_dict_pre* out, hipStream_t stream) {
+    hipLaunchKernelGGL(zl2_dict_prebuild_kernel, dim3(1), dim3(64), 0, stream, ext, ext_base, out);
+    return hipGetLastError();
+}
 // Large-frame pipeline (zl_decode3.hip): the same kernels over the segments of one frame.  The caller has
 // filled frec / brec / plan / ext on the device.
 extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t stream, const zl2_side* side) {

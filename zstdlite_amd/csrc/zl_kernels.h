@@ -80,6 +80,17 @@ struct zl_dict_tables {
     u32 pad;
 };
 
+// A dictionary's tables as the lanes of zl_decode2.hip keep them in LDS (LitGroupT::tab, SeqLane::ent), built once per context by
+// zl2_dict_prebuild_kernel from the synthetic block: the inheritance rounds of a batch of SMALL frames then copy 9 KiB per frame
+// instead of building four tables per group of eight frames.
+struct zl2_dict_pre {
+    u32 huf_ok, huf_log;      // huf_ok: 1 usable, 0 the description is corrupt, 2 a 12-bit table (the general kernel's)
+    u32 seq_ok, seq_log[3];   // LL, OF, ML
+    u32 pad[2];
+    u16 tab[2048];
+    u32 ent[1280];
+};
+
 struct zl2_args {
     const zl_frame_desc* frames;
     const zl2_frame_plan* plan;
@@ -109,6 +120,7 @@ struct zl2_args {
     u32 dict_len;
     u32 dict_id;              // what a frame's Dictionary_ID must be when it has one (0: the context has no dictionary)
     u32 dict_rep[3];          // the history a frame starts with (1, 4, 8 without a formatted dictionary)
+    const struct zl2_dict_pre* dict_pre;  // the dictionary's tables in the lanes' own formats, built once per context (null: the inheritance rounds build them from the synthetic block)
     // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there).
     // 0: all of it.  Otherwise the launch's ROLE in the two-part schedule; which groups a role covers depends on the mode
     // the order kernel chose on the device (max_blocks[2]: ZL2_MODE_*).
@@ -173,4 +185,5 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
 extern "C" hipError_t zl2_launch_segments_exec(const zl2_args* a, u32 exec_run, hipStream_t stream);
 
 extern "C" hipError_t zl_launch_decode(const zl_decode_args* a, u32 nslots, hipStream_t stream);
+extern "C" hipError_t zl2_launch_dict_prebuild(const zl2_blk_rec* ext, const u8* ext_base, struct zl2_dict_pre* out, hipStream_t stream);
 extern "C" hipError_t zl_launch_digest_dict(const u8* d_dict, u32 n, void* d_tables, hipStream_t stream);
