@@ -1126,9 +1126,19 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     const bool prof = d->profile != 0;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double tp[6] = {now_ms(), 0, 0, 0, 0, 0};
-    std::vector<zl_frame_desc> table(n);
+    // (one pass over the sources: where an object's bytes go in the staging buffer follows from the sizes the caller gave, so
+    // its header can be parsed and its bytes copied while they are in the cache; the frame table is written where the upload
+    // takes it from)
     std::vector<size_t> pre(n, 0);
     size_t in_total = 0, out_total = 0;
+    hipStream_t st = dctx_stream(d, nullptr);
+    if (!d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64))) return kGpuUnavailable;
+    zl_frame_desc* const table = (zl_frame_desc*)d->h_frames.p;
+    for (size_t i = 0; i < n; i++) {
+        table[i].src_off = in_total;
+        in_total += (sizes[i] + 15) & ~(size_t)15;
+    }
+    if (!d->h_stage_in.ensure(in_total + 16) || !d->d_src.ensure(in_total + 16)) return kGpuUnavailable;
     zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
             FrameHeader h;
@@ -1140,26 +1150,17 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
             else if (h.content_size > caps[i]) { pre[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL); }
             table[i].src_size = pre[i] ? 0 : sizes[i];
             table[i].dst_cap = pre[i] ? 0 : h.content_size;
+            if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, s, table[i].src_size);
         }
     });
     for (size_t i = 0; i < n; i++) {
-        table[i].src_off = in_total;
         table[i].dst_off = out_total;
-        in_total += (table[i].src_size + 15) & ~(size_t)15;
         out_total += (table[i].dst_cap + 15) & ~(size_t)15;
     }
-    hipStream_t st = dctx_stream(d, nullptr);
-    if (!d->h_stage_in.ensure(in_total + 16) || !d->h_stage_out.ensure(out_total + 16) || !d->d_src.ensure(in_total + 16) ||
-        !d->d_dst.ensure(out_total + 16) || !d->h_frames.ensure(n * sizeof(zl_frame_desc)) || !d->h_results.ensure(n * sizeof(u64)))
-        return kGpuUnavailable;
-    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; i++)
-            if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, srcs[i], table[i].src_size);
-    });
+    if (!d->h_stage_out.ensure(out_total + 16) || !d->d_dst.ensure(out_total + 16)) return kGpuUnavailable;
     tp[1] = now_ms();
     if (hipMemcpyAsync(d->d_src.p, d->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
-    memcpy(d->h_frames.p, table.data(), n * sizeof(zl_frame_desc));
     size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, n, st);
     if (ZL_IS_ERR(e)) return e;
     if (prof) { (void)hipStreamSynchronize(st); tp[3] = now_ms(); }
