@@ -154,3 +154,40 @@ def test_seek_table_is_read_from_the_end_of_the_buffer(golden):
     assert L.zl_index_frames(other, len(other), frames, 4) == 2 and frames[0].dst_cap == 131072
     reserved = bytes(broken[: len(data)]) + seekable([(len(a["comp"]), a["n"]), (len(b["comp"]), b["n"])], descriptor=0x04)
     assert _lib.is_error(L.zl_index_frames(reserved, len(reserved), frames, 4))
+
+
+def test_batch_mirror_packs_and_reads_headers_like_the_library(golden):
+    """The Python mirror's batch entries hand the C-ABI ONE packed buffer with vectorised pointer / size arrays and read every
+    frame's Frame_Content_Size themselves (zstdlite_amd/__init__.py _pack_items, _content_sizes; zstd.c:41050-41148).  No GPU
+    needed: the sizes must be what zl_getFrameContentSize says for every golden frame -- all header shapes: single segment or
+    window descriptor, 1 / 2 / 4 / 8-byte size fields, dictionary ids -- and 0 for what is no data frame with a recorded size."""
+    import struct
+    import numpy as np
+    import zstdlite_amd as z
+    cases, _ = golden
+    L = _lib.lib()
+    frames = [bytes(c["comp"]) for c in cases]
+    # hand-made headers for the shapes the fixtures may not hold: 8-byte size field, window descriptor without a size, skippable
+    # frame, reserved bit, truncated header, garbage, empty
+    frames += [struct.pack("<IB", 0xFD2FB528, 0xC0 | 0x20) + struct.pack("<Q", 5_000_000_000) + b"\x01\x00\x00",
+               struct.pack("<IBB", 0xFD2FB528, 0x00, 0x50) + b"\x01\x00\x00",
+               struct.pack("<II", 0x184D2A50, 4) + b"abcd",
+               struct.pack("<IB", 0xFD2FB528, 0x28) + b"\x05\x01\x00\x00",
+               struct.pack("<IB", 0xFD2FB528, 0xE0) + b"\x01\x02",
+               b"\x00" * 9, b"", b"\x28\xb5\x2f"]
+    blob, sizes, off = z._pack_items(frames, "test")
+    assert int(sizes.sum()) == sum(map(len, frames)) and [int(x) for x in sizes] == [len(f) for f in frames]
+    for i in (0, 1, len(frames) // 2, len(frames) - 9):
+        assert bytes(blob[int(off[i]):int(off[i + 1])]) == frames[i]
+    got = z._content_sizes(blob, sizes, off)
+    unknown = (1 << 64) - 1
+    for i, f in enumerate(frames):
+        want = L.zl_getFrameContentSize(f, len(f))
+        want = 0 if want >= unknown - 1 else want  # CONTENTSIZE_UNKNOWN / _ERROR: the batch entry then reports the item itself
+        if len(f) >= 4 and struct.unpack("<I", f[:4])[0] & 0xFFFFFFF0 == 0x184D2A50:
+            want = 0  # (skippable: content size 0 by the helper's definition, not a data frame for the batch entry)
+        assert int(got[i]) == want, (i, f[:14].hex(), int(got[i]), want)
+    # mixed input kinds go through the generic path and give the same packing
+    mixed = [frames[0], bytearray(frames[1]), memoryview(frames[2]), np.frombuffer(frames[3], dtype=np.uint8)]
+    b2, s2, o2 = z._pack_items(mixed, "test")
+    assert bytes(b2[: int(o2[-1])]) == b"".join(frames[:4]) and [int(x) for x in s2] == [len(f) for f in frames[:4]]
