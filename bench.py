@@ -346,7 +346,7 @@ def end_to_end_leg(host, device, log):
         cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
         L.zl_CCtx_setParameter(cctx, 9003, code)
         tc = td = 1e9
-        for _ in range(3):
+        for _ in range(5):  # (best of 5, as the CPU baseline: the first calls of a context create its streams, peers and buffers)
             t0 = time.perf_counter(); r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n); t1 = time.perf_counter()
             assert not _lib.is_error(r), _lib.error_name(r)
             r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r); t2 = time.perf_counter()
