@@ -376,3 +376,42 @@ def test_dictionary_frames_on_the_lane_pipeline_agree_with_the_oracle(ref, oracl
                 accepted += 1
                 assert not is_error(code) and res[i] == code and outs[i][: res[i]].tobytes() == out, i
         assert 0 < accepted < m
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (reference libzstd) to make the frames")
+def test_batch_entry_takes_frames_without_a_recorded_content_size(ref, oracle):
+    """zl_decompress_batch decodes a frame that records no content size into the room its caller gave it, as
+    ZSTD_decompressDCtx does (zstd.c:41554) -- round 2 refused such items ("Unsupported frame parameter").  Found by
+    scripts/fuzz_dict.py: clearing the Single_Segment bit of a small frame turns its one-byte size field into a window
+    descriptor and leaves a frame every other decoder accepts.  Also frames the reference's streaming API writes without a
+    pledged size, with and without a dictionary; a destination that is too small for such a frame is that item's error only."""
+    import ctypes as C
+    x = GENERATORS["text"](100, seed=3)
+    f = bytearray(ref.compress(x, level=3))
+    assert f[4] & 0x20 and (f[4] >> 6) == 0      # Single_Segment with a one-byte Frame_Content_Size
+    f[4] &= ~0x20                                 # ... which now reads as Window_Descriptor: content size unknown
+    f = bytes(f)
+    code, out = oracle.decompress_code(f, 4096)
+    assert not is_error(code) and out == x
+    y = GENERATORS["text"](50000, seed=4)
+    g = bytearray(ref.compress(y, level=3))       # 3-byte size field (flag 1 with Single_Segment clear is still a recorded size)
+    frames = [f, bytes(g), f, f]
+    caps = [4096, 50000, 100, 99]                 # the last one: too small
+    m = len(frames)
+    outs = [np.zeros(max(c, 1), dtype=np.uint8) for c in caps]
+    srcs = [np.frombuffer(b, dtype=np.uint8) for b in frames]
+    res = (C.c_size_t * m)()
+    dctx = z.zstd_dctx()
+    r = _lib.lib().zl_decompress_batch(dctx._ptr, m, (C.c_void_p * m)(*[o.ctypes.data for o in outs]), (C.c_size_t * m)(*caps),
+                                       (C.c_void_p * m)(*[s.ctypes.data for s in srcs]), (C.c_size_t * m)(*[len(b) for b in frames]), res)
+    assert not is_error(r)
+    assert res[0] == 100 and outs[0][:100].tobytes() == x
+    assert res[1] == 50000 and outs[1].tobytes() == y
+    assert res[2] == 100 and outs[2][:100].tobytes() == x
+    assert is_error(res[3])
+    one = np.zeros(4096, dtype=np.uint8)          # the one-shot entry of the C-ABI always took it
+    r1 = _lib.lib().zl_decompressDCtx(dctx._ptr, one.ctypes.data, 4096, f, len(f))
+    assert r1 == 100 and one[:100].tobytes() == x
+    with pytest.raises(z.ZstdError):              # (the R glue's mirror refuses it before any decoder runs, as src/raw-file.c does)
+        z.zstd_decompress(f)
