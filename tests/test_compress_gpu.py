@@ -513,3 +513,20 @@ def test_batch_entries_report_per_object_results_at_scale():
                 assert bytes(back[int(off[i]):int(off[i + 1])]) == items[i], i
     finally:
         L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+
+
+def test_output_does_not_depend_on_scheduling_when_a_chunk_oversamples(ref):
+    """The far search lists a chunk's sampled positions (content-defined: the top bits of the hash of 8 bytes), at most
+    ZL_FAR_LIST_CAP of them.  A long run samples all of its positions or none, so a chunk of runs lists far more than the cap
+    -- and WHICH ones were kept used to depend on the order in which the waves of zl_far_build_kernel reached an atomic counter:
+    the same input compressed to different (valid) bytes from call to call (found by scripts/fuzz_encode.py at level 9, one
+    frame).  Now such a chunk is listed again in position order.  Runs of 64 KiB of 24 byte values (every chunk holds two; at
+    either sampling rate several of them are sampled) plus some text: ten calls, one output, at both operating points."""
+    import warnings
+    data = b"".join(bytes([b]) * 65536 for b in range(24)) + GENERATORS["text"](100000, seed=8)
+    for level in (3, 5):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs = {z.zstd_compress(data, level=level, frame_layout="one_frame") for _ in range(10)}
+        assert len(outs) == 1, (level, len(outs))
+        assert ref.decompress(next(iter(outs)), len(data)) == data

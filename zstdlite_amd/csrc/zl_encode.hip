@@ -994,7 +994,9 @@ static_assert(ZL_FAR_BUCKET_LOG + 15 <= 32 - 3, "a list key holds bucket and tag
 #define FAR_BUILD_THREADS 1024u
 __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
     __shared__ u32 col[FAR_COL];
+    __shared__ u32 wtot[2][FAR_BUILD_THREADS / 64];
     __shared__ u32 count;
+    u32 running = 0;  // ordered pass: sampled positions so far (uniform)
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
@@ -1008,39 +1010,59 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
         for (u32 i = t; i < ZL_FAR_HINT_WORDS / 4; i += FAR_BUILD_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
-    for (u32 ip = 0; ip < lim; ip += FAR_BUILD_THREADS * FAR_SPAN * FAR_UNROLL) {
-        uint4 w[FAR_UNROLL];
-#pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
-            w[k] = make_uint4(0, 0, 0, 0);
-            if (p0 + 16 <= lim + 7) w[k] = ld128(src + p0);               // 16 bytes from p0 lie inside what far_limit guards (lim + 7 bytes are readable)
-            else for (u32 i = 0; i < 16 && p0 + i < lim + 7; i++) ((u32*)&w[k])[i >> 2] |= (u32)src[p0 + i] << (8 * (i & 3));
+    // The list: one slot per sampled position.  First pass: slots handed out per wave from an atomic counter, in whatever order
+    // the waves reach it -- which positions share a slot range does not matter as long as ALL of them fit.  When a chunk samples
+    // more positions than the list holds (long runs, whose positions all hash alike: all of them are sampled or none), WHICH
+    // positions are kept must not depend on scheduling (until round 3 it did: the same input could compress to different
+    // bytes; scripts/fuzz_encode.py): such a chunk is listed again, in the order of its positions -- a scan over the waves'
+    // totals in wave order, one barrier per step -- and keeps the first ZL_FAR_LIST_CAP.  (The scan for every chunk: 3.2 -> 3.45 ms.)
+    for (u32 ordered = 0; ordered < 2; ordered++) {
+        if (ordered) {
+            __syncthreads();  // (count is final, every position is in the column)
+            if (count <= ZL_FAR_LIST_CAP) break;
         }
+        for (u32 ip = 0; ip < lim; ip += FAR_BUILD_THREADS * FAR_SPAN * FAR_UNROLL) {
+            uint4 w[FAR_UNROLL];
 #pragma unroll
-        for (int k = 0; k < FAR_UNROLL; k++) {
-            const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
-            const u64 lo = (u64)w[k].x | ((u64)w[k].y << 32), hi = (u64)w[k].z | ((u64)w[k].w << 32);
-            u32 mine = 0, keys[FAR_SPAN];
-#pragma unroll
-            for (u32 j = 0; j < FAR_SPAN; j++) {
-                const u64 v = j == 0 ? lo : ((lo >> (8 * j)) | (hi << (64 - 8 * j)));
-                const u64 h = far_hash(v);
-                const bool on = p0 + j < lim && far_sampled(h, sl);
-                const u32 bucket = far_bucket(h, sl), tag = far_tag(h, sl);
-                keys[j] = bucket | (tag << ZL_FAR_BUCKET_LOG);
-                if (on) { atomicMax(&col[bucket], ((p0 + j) << 15) | tag); mine |= 1u << j; }
+            for (int k = 0; k < FAR_UNROLL; k++) {
+                const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
+                w[k] = make_uint4(0, 0, 0, 0);
+                if (p0 + 16 <= lim + 7) w[k] = ld128(src + p0);               // 16 bytes from p0 lie inside what far_limit guards (lim + 7 bytes are readable)
+                else for (u32 i = 0; i < 16 && p0 + i < lim + 7; i++) ((u32*)&w[k])[i >> 2] |= (u32)src[p0 + i] << (8 * (i & 3));
             }
-            // the list: one slot per sampled position, handed out per wave
-            u32 cnt = (u32)__popc(mine), inc = cnt;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
-            const u32 wave_total = __shfl(inc, 63, 64);
-            if (wave_total) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(&count, wave_total);
-                base = __shfl(base, 0, 64);
-                u32 idx = base + inc - cnt;
+            for (int k = 0; k < FAR_UNROLL; k++) {
+                const u32 p0 = ip + (k * FAR_BUILD_THREADS + t) * FAR_SPAN;
+                const u64 lo = (u64)w[k].x | ((u64)w[k].y << 32), hi = (u64)w[k].z | ((u64)w[k].w << 32);
+                u32 mine = 0, keys[FAR_SPAN];
+#pragma unroll
+                for (u32 j = 0; j < FAR_SPAN; j++) {
+                    const u64 v = j == 0 ? lo : ((lo >> (8 * j)) | (hi << (64 - 8 * j)));
+                    const u64 h = far_hash(v);
+                    const bool on = p0 + j < lim && far_sampled(h, sl);
+                    const u32 bucket = far_bucket(h, sl), tag = far_tag(h, sl);
+                    keys[j] = bucket | (tag << ZL_FAR_BUCKET_LOG);
+                    if (on) { if (!ordered) atomicMax(&col[bucket], ((p0 + j) << 15) | tag); mine |= 1u << j; }
+                }
+                u32 cnt = (u32)__popc(mine), inc = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const u32 x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+                u32 idx;
+                if (!ordered) {
+                    const u32 wave_total = __shfl(inc, 63, 64);
+                    u32 base = 0;
+                    if (lane == 0 && wave_total) base = atomicAdd(&count, wave_total);
+                    idx = __shfl(base, 0, 64) + inc - cnt;
+                } else {
+                    u32* const wt = wtot[k & 1];  // (two sets of totals in turn: a step's totals are read before the step after next writes them again, and the next step's barrier lies in between)
+                    if (lane == 63) wt[t >> 6] = inc;
+                    __syncthreads();
+                    u32 pre = 0, tot = 0;
+#pragma unroll
+                    for (u32 w2 = 0; w2 < FAR_BUILD_THREADS / 64; w2++) { const u32 x = wt[w2]; pre += w2 < (t >> 6) ? x : 0u; tot += x; }
+                    idx = running + pre + inc - cnt;
+                    running += tot;
+                }
 #pragma unroll
                 for (u32 j = 0; j < FAR_SPAN; j++) {
                     if ((mine >> j) & 1) {
@@ -1051,7 +1073,7 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  // (every position is in the column)
     if (t == 0) list[0] = count < ZL_FAR_LIST_CAP ? count : ZL_FAR_LIST_CAP;
     uint4* out = (uint4*)(a.table + (size_t)c * FAR_COL);
     const uint4* in = (const uint4*)col;
