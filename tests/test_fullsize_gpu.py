@@ -271,3 +271,47 @@ def test_c4_hundred_thousand_objects_with_a_dictionary():
         theirs += len(ref.compress(items[i], level=3, dict=d))
     assert int(B.csize[::50].sum()) <= theirs * 1.03
     L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+
+
+def test_no_sequence_reaches_in_front_of_its_section():
+    """Sections of 64 MiB are self-contained (include/zl_hip.h): the far search never looks across them, and neither may the
+    one-byte backward extension of the stride-2 body -- which checked the bytes in front of the chunk in the FRAME, not in the
+    section, until round 3: a match whose source is a section's first byte could be extended onto the byte in front of the
+    section.  (A pledged stream's later jobs hold their own section only: the read faulted; scripts/fuzz_stream.py.)  The input
+    makes exactly that case -- the last byte of section 1 and the first 64 bytes of section 2 appear again, 1000 bytes into
+    section 2, on an even position, among random bytes -- and the frame is decoded section by section on two device slots, each
+    of which has nothing but its own section: both slots must be used and the bytes must come back."""
+    from zstdlite_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    sec = 64 << 20
+    host = rng.integers(0, 256, sec + (1 << 20), dtype=np.uint8)
+    host[sec - 1] = ord("Q")
+    head = host[sec:sec + 64].copy()
+    host[sec + 999] = ord("Q")
+    host[sec + 1000:sec + 1064] = head
+    n = host.size
+    cap = L.zl_compressBound(n)
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    try:
+        L.zl_CCtx_setParameter(cctx, 9003, 2); L.zl_CCtx_setParameter(cctx, 9006, 1)  # one frame, seek table
+        assert L.zl_DCtx_setParameter(dctx, 9008, 2) == 0                               # two device slots
+        buf = np.empty(cap, dtype=np.uint8)
+        r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+        assert not _lib.is_error(r), _lib.error_name(r)
+        back = np.zeros(n, dtype=np.uint8)
+        r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, buf.ctypes.data, r)
+        assert r2 == n, _lib.error_name(r2)
+        assert np.array_equal(back, host)
+        assert int(L.zl_dctx_last_slots(dctx)) == 2  # (a section that needed the one in front of it would have sent the call back to one slot)
+        # ... and as a pledged stream, whose second job has only section 2 on the device
+        import zstdlite_amd as z
+        from zstdlite_amd import stream
+        sc = z.zstd_cctx()
+        comp = stream.Compressor(sc._ptr, pledged=n)
+        raw = host.tobytes()
+        out = [comp.feed(raw[p:p + (8 << 20)]) for p in range(0, n, 8 << 20)]
+        out.append(comp.finish())
+        assert b"".join(out) == z.zstd_compress(raw)
+    finally:
+        L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)

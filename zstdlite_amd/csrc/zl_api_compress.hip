@@ -151,6 +151,12 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
                           u64 joined_total, bool prof, hipEvent_t wait_prev, hipEvent_t scanned, size_t frame_chunk0 = 0) {
     const bool joined = joined_total != 0;
     const EncStrides sd = enc_strides(c->chunk_cap);
+#ifdef ZL_DEV_SWITCHES
+    static const bool dbg_sync = getenv("ZL_DEBUG_SYNC") != nullptr;  // (development: drain the stream behind every kernel and say which one it was)
+    auto stage_ok = [&](const char* what) { if (dbg_sync) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[zl enc] group %zu first %zu cnt %u: %s -> %d\n", g, first, cnt, what, (int)e); } };
+#else
+    auto stage_ok = [](const char*) {};
+#endif
     if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * sd.lit) || !es.seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) ||
         !es.sst.ensure((size_t)cnt * sd.seq * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * sd.out))
         return kGpuUnavailable;
@@ -168,7 +174,10 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         f.table = (u32*)es.far_table.p;
         f.hints = (u32*)es.far_hints.p;
         f.lists = (u32*)es.far_lists.p;
-        if (zl_launch_far_build(&f, cnt, st) != hipSuccess || zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (zl_launch_far_build(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        stage_ok("far build");
+        if (zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        stage_ok("far probe");
     }
     zl_match_args m;
     m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
@@ -209,6 +218,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         m1.dict = nullptr; m1.dict_len = 0; m1.dict_hash = nullptr;
         if (zl_launch_match(&m1, cnt - skip, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     } else if (zl_launch_match(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    stage_ok("match");
     if (prof) (void)hipEventRecord(c->ev[1], st);
     zl_entropy_args e;
     e.chunks = m.chunks;
@@ -232,6 +242,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.stats = m.stats ? m.stats + 8 : nullptr;
     if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    stage_ok("entropy");
     if (prof) (void)hipEventRecord(c->ev[2], st);
     u64* totals = (u64*)c->d_totals.p;
     if (wait_prev && hipStreamWaitEvent(st, wait_prev, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -245,6 +256,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     ga.dst = d_dst;
     ga.out_stride = sd.out;
     if (zl_launch_gather(&ga, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    stage_ok("scan + gather");
     if (prof) { (void)hipEventRecord(c->ev[4], st); c->ev_valid = true; }
     return 0;
 }

@@ -230,9 +230,12 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     const u32 D = DICT ? a.dict_len : 0u;
     const u8* const dict = a.dict;
     static_assert(!(DICT && FAR), "a dictionary frame is a frame of its own");
-    // bytes of the frame in front of this chunk (clamped); a source position is a chunk position that may be "negative"
-    const u32 reach = FAR ? (u32)(cd.src_off < 0x7F000000ull ? cd.src_off : 0x7F000000ull) : 0u;
-    const u32 reach_sec = FAR ? (u32)(cd.src_off & (((u64)ZL_CHUNK << ZL_FAR_SECTION_LOG) - 1)) : 0u;  // ... of them inside the chunk's section
+    // bytes of the frame in front of this chunk INSIDE THE CHUNK'S SECTION: a source position is a chunk position that may be
+    // "negative", down to -reach_sec.  (Until round 3 the repeat-offset, far-hint and one-byte backward-extension checks used the
+    // bytes in front of the chunk in the whole FRAME: the stride-2 body's backward extension could read -- and make a sequence
+    // copy -- the byte in front of a section's first byte, which a pledged stream's later jobs do not even have on the device:
+    // a memory fault that scripts/fuzz_stream.py found.)
+    const u32 reach_sec = FAR ? (u32)(cd.src_off & (((u64)ZL_CHUNK << ZL_FAR_SECTION_LOG) - 1)) : 0u;
     const u32* const hints = FAR ? a.far_hints + (size_t)c * ZL_FAR_HINT_WORDS : nullptr;
     auto at = [&](u32 q) -> const u8* {  // where (virtual) position q lives
         if (FAR) return src + (ptrdiff_t)(i32)q;
@@ -346,8 +349,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (can_match[j]) {
                     if (search) {
                         const u32 dl = (V + 1 - el) & 0xFFFF, ds = (V + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
-                        have_r[j] = rep && V + reach >= rep;
-                        have_f[j] = FAR && far_off[j] != 0 && far_off[j] != rep && p + reach >= far_off[j];
+                        have_r[j] = rep && V + reach_sec >= rep;
+                        have_f[j] = FAR && far_off[j] != 0 && far_off[j] != rep && p + reach_sec >= far_off[j];
                         have_l[j] = el != 0 && dl != 0 && dl <= V;
                         have_s[j] = es != 0 && ds != 0 && ds <= V && short_in_reach<FAR>(ds);
                         if (have_r[j]) q_r[j] = V - rep;
@@ -635,8 +638,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             if (can0) {
                 if (search) {
                     const u32 dl = (p + 1 - el) & 0xFFFF, ds = (p + 1 - es) & 0xFFFF;  // distance to the nearest position the entry can mean
-                    have_r = rep && p + reach >= rep;
-                    have_f = FAR && far_off2 != 0 && far_off2 != rep && p + reach >= far_off2;
+                    have_r = rep && p + reach_sec >= rep;
+                    have_f = FAR && far_off2 != 0 && far_off2 != rep && p + reach_sec >= far_off2;
                     have_l = el != 0 && dl != 0 && dl <= p;
                     have_s = es != 0 && ds != 0 && ds <= p && short_in_reach<FAR>(ds);
                     if (have_r) q_r = p - rep;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             // front of the candidate is fetched now (it is needed when the sequence is written): if it
             // equals the byte in front of p and that byte is still a free literal, the match starts there.
             u32 cand_before = 0x100;
-            if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);
+            if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach_sec >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);  // (inside the chunk's SECTION: the byte in front of a section is not this launch's to read -- a pledged stream's second job holds its own section only, and sections are self-contained)
             const bool back_ok = cand_before == byte_before;
     #ifndef ZL_SPARSE_MIN
 #define ZL_SPARSE_MIN 5
