@@ -1,7 +1,7 @@
 """Fuzz the encoder: random inputs (mixtures of the generators, runs, copies from earlier in the input, lengths from 0 to a few
 chunks with the edges of chunks and blocks over-represented), random options (level, checksum, dictionary, layout, seek table):
 every output must be ONE or more standard frames that the REFERENCE decoder turns back into the input (and our decoder too),
-and the same call must write the same bytes twice.  usage: fuzz_encode.py [rounds=200] [seed=1]"""
+and the same call must write the same bytes twice.  usage: fuzz_encode.py [rounds=200] [seed=1] [largest input=400000]"""
 import sys
 import time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -10,6 +10,7 @@ import zstdlite_amd as z
 from zl_testlib import GENERATORS, Ref
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+maxn = int(sys.argv[3]) if len(sys.argv) > 3 else 400000  # (largest input; a few MiB exercise many chunks per frame)
 ref = Ref()
 kinds = ["text", "iid10", "int20", "rand"]
 pool = {k: GENERATORS[k](1 << 20, seed=9) for k in kinds}
@@ -22,11 +23,11 @@ def make():
     if rng.random() < 0.4:
         n = int(edges[int(rng.integers(0, len(edges)))])
     else:
-        n = int(rng.integers(0, 400000))
+        n = int(rng.integers(0, maxn))
     parts, have = [], 0
     while have < n:
         r = rng.random()
-        k = int(min(n - have, max(1, int(rng.integers(1, 60000)))))
+        k = int(min(n - have, max(1, int(rng.integers(1, max(60000, maxn // 20))))))
         if r < 0.55:
             src = pool[kinds[int(rng.integers(0, 4))]]
             o = int(rng.integers(0, len(src) - k))
