@@ -27,7 +27,7 @@ def make():
     parts, have = [], 0
     while have < n:
         r = rng.random()
-        k = int(min(n - have, max(1, int(rng.integers(1, max(60000, maxn // 20))))))
+        k = int(min(n - have, max(1, int(rng.integers(1, max(60000, maxn // 20)))), (1 << 20) - 1))  # (a pool holds 1 MiB)
         if r < 0.55:
             src = pool[kinds[int(rng.integers(0, 4))]]
             o = int(rng.integers(0, len(src) - k))
