@@ -530,3 +530,28 @@ def test_output_does_not_depend_on_scheduling_when_a_chunk_oversamples(ref):
             outs = {z.zstd_compress(data, level=level, frame_layout="one_frame") for _ in range(10)}
         assert len(outs) == 1, (level, len(outs))
         assert ref.decompress(next(iter(outs)), len(data)) == data
+
+
+@pytest.mark.parametrize("layout", ["one_frame", "frames"])
+def test_a_seek_table_with_a_damaged_content_field_is_not_believed(layout, ref):
+    """The seek table is a skippable frame: damage inside it must not change what the data in front of it decodes to
+    (include/zl_hip.h: checked against the data, never trusted).  Until round 3 a content field that grew by a byte -- still the
+    same number of chunks, so the table passed its own checks -- made zl_decompressDCtx fail with dstSize_tooSmall on a buffer the
+    reference reads (scripts/fuzz_seek.py); every failure on the table's word now sends the call to the header walk."""
+    import struct
+    data = GENERATORS["text"](700000, seed=12)
+    comp = bytearray(z.zstd_compress(data, frame_layout=layout, seek_table=True))
+    plain = z.zstd_compress(data, frame_layout=layout)
+    assert len(comp) > len(plain)
+    if layout == "one_frame":   # private trailer: ... u64 content | u32 nchunks | u32 flags | u32 tag
+        at = len(comp) - 20
+        (content,) = struct.unpack_from("<Q", comp, at)
+        assert content == len(data)
+        struct.pack_into("<Q", comp, at, content + 1)
+    else:                       # seekable format: the last frame's decompressed size sits 8 + 5 bytes in front of the end... entry {c, d}
+        at = len(comp) - 9 - 4
+        (dsz,) = struct.unpack_from("<I", comp, at)
+        assert dsz == len(data) - (len(data) // 131072) * 131072
+        struct.pack_into("<I", comp, at, dsz + 1)
+    assert ref.decompress(bytes(comp), len(data)) == data
+    assert z.zstd_decompress(bytes(comp)) == data

@@ -992,8 +992,12 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         SeekTable t;
         if (d->dict.empty() && read_seek_table(src, n, t)) {
             if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
+            // (never trusted: whatever goes wrong on the table's word -- a content size that does not fit, a chunk that does not
+            // decode from where the table says it starts -- the walk below decides.  Until round 3 only some failures came
+            // back here: a table whose content field was damaged made the call fail on data every other decoder reads;
+            // scripts/fuzz_seek.py)
             const size_t r = decompress_with_seek_table(d, (u8*)dst, cap, src, t);
-            if (r != ZL_ERR(ZL_E_FALLBACK)) return r;
+            if (!ZL_IS_ERR(r)) return r;
         }
     }
     // ---- index frames on the host (serial header walk, zstd.c:41335)
