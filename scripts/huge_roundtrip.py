@@ -1,0 +1,55 @@
+"""Inputs above 4 GiB (32-bit positions and sizes are the classic casualty): the host entries in both layouts, with a seek table
+and device slots, and the device entries, on N GiB of the bench mix: reference decode (one frame: as a whole; frames: all of
+them), our decode, bit-exact.  usage: huge_roundtrip.py [GiB=4.5]"""
+import ctypes as C
+import sys
+import time
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import torch
+from zstdlite_amd import _lib
+from zstdlite_amd.device import DeviceCodec, gen_mixed
+from zl_testlib import Ref
+gib = float(sys.argv[1]) if len(sys.argv) > 1 else 4.5
+n = int(gib * (1 << 30)) + 12345
+L = _lib.lib()
+ref = Ref()
+dev = torch.device("cuda", 0)
+t0 = time.time()
+src = gen_mixed(n, dev)[0]
+host = src.cpu().numpy()
+print(f"input {n} bytes ready in {time.time() - t0:.1f}s", flush=True)
+cap = L.zl_compressBound(n)
+comp = np.empty(cap, dtype=np.uint8)
+back = np.empty(n, dtype=np.uint8)
+for layout, seek, slots in ((0, 0, 1), (1, 0, 1), (2, 1, 3), (1, 1, 2)):
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    L.zl_CCtx_setParameter(cctx, 9003, layout); L.zl_CCtx_setParameter(cctx, 9006, seek); L.zl_CCtx_setParameter(cctx, 9007, slots)
+    L.zl_DCtx_setParameter(dctx, 9008, slots)
+    t1 = time.time()
+    r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
+    assert not _lib.is_error(r), _lib.error_name(r)
+    t2 = time.time()
+    back.fill(0)
+    r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+    t3 = time.time()
+    assert r2 == n, _lib.error_name(r2) if _lib.is_error(r2) else r2
+    assert np.array_equal(back, host), "our decoder: bytes differ"
+    ok_ref = ref.decompress(comp[:r].tobytes(), n) == host.tobytes()
+    assert ok_ref, "reference decoder: bytes differ"
+    print(f"layout {layout} seek {seek} slots {slots}: {r} bytes, compress {n / (t2 - t1) / 1e9:.1f} GB/s, decompress {n / (t3 - t2) / 1e9:.1f} GB/s, reference decode ok", flush=True)
+    L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+# device-resident entries
+for layout in ("frames", "one_frame"):
+    codec = DeviceCodec(frame_layout=layout)
+    dst, total, fs = codec.compress(src)
+    assert int(np.sum(fs, dtype=np.uint64)) == total
+    out = torch.zeros(n, dtype=torch.uint8, device=dev)
+    if layout == "frames":
+        codec.decompress(dst, codec.frame_table(fs, codec.chunk_content_sizes(n)), out)
+    else:
+        codec.decompress(dst, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+    assert torch.equal(out, src), "device decode differs"
+    print(f"device entries, {layout}: {total} bytes, round trip bit-exact", flush=True)
+    codec.close()
+print("ok")

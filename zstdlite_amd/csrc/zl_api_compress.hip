@@ -306,6 +306,15 @@ bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
     return host_entry;
 }
 
+// Does this call append the seek table?  On request (ZL_c_seekTable) -- and, unasked, behind ONE frame of 4 GiB or more: the
+// large-frame decoder plans frames below 4 GiB (32-bit positions, zl_decode3.hip), a larger one it could only hand to the
+// general kernel, one workgroup for the whole frame: 4.5 GiB decoded in 400 s (scripts/huge_roundtrip.py).  With the table
+// the same frame is decoded section by section (16 GB/s from host memory).  The table is a skippable frame behind the data
+// frame: a reader that takes the first frame gets all of the content, as without it.
+inline bool wants_seek_table(const zl_cctx* c, size_t n, bool one_frame) {
+    return c->seek_table || (one_frame && n >= (size_t)0xFFFFD000ull);
+}
+
 // the seek table behind `total` bytes of output (zl_format.h), from the per-chunk sizes in c->h_fsize: zstd's seekable format
 // for independent frames, the private trailer for the runs of blocks of one frame
 size_t append_seek_table(const zl_cctx* c, u8* dst, size_t cap, size_t total, size_t nchunks, u64 content, bool one_frame) {
@@ -707,7 +716,7 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
         down_total = append_checksum(dst, cap, down_total, hash->low32());
         if (ZL_IS_ERR(down_total)) return down_total;
     }
-    if (c->seek_table && nchunks > 1 && whole) {
+    if (wants_seek_table(c, n, one_frame) && nchunks > 1 && whole) {
         if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || hipMemcpy(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (footer) ((u32*)c->h_fsize.p)[nchunks - 1] += 4;  // (the table's sizes add up to the bytes in front of it)
         return append_seek_table(c, dst, cap, down_total, nchunks, n, one_frame);
@@ -767,7 +776,7 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
         total = append_checksum(dst, cap, total, hash.low32());
         if (ZL_IS_ERR(total)) return total;
     }
-    if (c->seek_table && nchunks > 1) {  // every slot's per-chunk sizes, in order
+    if (wants_seek_table(c, n, one_frame) && nchunks > 1) {  // every slot's per-chunk sizes, in order
         if (!c->h_fsize.ensure(nchunks * sizeof(u32))) return kGpuUnavailable;
         size_t err = 0;
         run([&](int s) {
@@ -820,7 +829,7 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
         if (ZL_IS_ERR(total)) return total;
         ((u32*)c->h_fsize.p)[nchunks - 1] += 4;
     }
-    if (c->seek_table && nchunks > 1) return append_seek_table(c, (u8*)dst, cap, total, nchunks, n, one);
+    if (wants_seek_table(c, n, one) && nchunks > 1) return append_seek_table(c, (u8*)dst, cap, total, nchunks, n, one);
     return total;
 }
 
