@@ -273,6 +273,74 @@ def test_c4_hundred_thousand_objects_with_a_dictionary():
     L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
 
 
+def test_one_frame_with_a_checksum_is_still_decoded_on_every_slot():
+    """One frame + content checksum + seek table, decoded on two device slots: the first slot's run starts with the frame's
+    header -- which says "checksum" -- but holds no footer; only the last run ends in the 4 bytes.  Until round 3 the first
+    run was walked as if its last chunk were 4 bytes shorter: the walk failed, the call fell back to ONE slot and the header
+    walk (same bytes, a third of the speed, and nothing said so).  Both slots must be used, the checksum must still be
+    verified over the whole: a flipped checksum byte is "doesn't match checksum", a flipped content byte is an error."""
+    from zstdlite_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = (200 << 20) + 4321
+    host = gen_mixed(n, dev)[0].cpu().numpy()
+    cap = L.zl_compressBound(n)
+    cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
+    try:
+        L.zl_CCtx_setParameter(cctx, 9003, 2); L.zl_CCtx_setParameter(cctx, 9006, 1); L.zl_CCtx_setParameter(cctx, 201, 1)
+        assert L.zl_DCtx_setParameter(dctx, 9008, 2) == 0
+        buf = np.empty(cap, dtype=np.uint8)
+        r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+        assert not _lib.is_error(r), _lib.error_name(r)
+        back = np.zeros(n, dtype=np.uint8)
+        assert L.zl_decompressDCtx(dctx, back.ctypes.data, n, buf.ctypes.data, r) == n
+        assert np.array_equal(back, host)
+        assert int(L.zl_dctx_last_slots(dctx)) == 2
+        first = int(L.zl_findFrameCompressedSize(buf.ctypes.data, r))  # the data frame; the seek table is a skippable frame behind it
+        assert 0 < first < r
+        bad = buf[:r].copy(); bad[first - 2] ^= 0x10
+        e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, bad.ctypes.data, r)
+        assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)
+        bad = buf[:r].copy(); bad[first // 2] ^= 0x01
+        assert _lib.is_error(L.zl_decompressDCtx(dctx, back.ctypes.data, n, bad.ctypes.data, r))
+    finally:
+        L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+
+
+def test_device_entry_decodes_one_frame_of_more_than_4_gib_in_runs():
+    """The device-resident entries on ONE frame of 4 GiB and more: the large-frame pipeline plans below 4 GiB and the general
+    kernel is one workgroup per frame -- 400 s for this input in round 2.  With the chunk hint (zl_decompress_device_hint) the
+    frame is decoded in runs of 16 sections (decode_hinted_frame_in_runs, zl_api.hip): seconds.  Bit-exact; with a content
+    checksum, which covers the whole and is checked behind the runs: a flipped footer byte must be reported."""
+    import time
+    from zstdlite_amd.device import DeviceCodec
+    dev = torch.device("cuda", 0)
+    n = (4 << 30) + (300 << 20) + 777
+    piece = gen_mixed(1 << 30, dev)[0]
+    src = torch.empty(n, dtype=torch.uint8, device=dev)
+    for off in range(0, n, piece.numel()):   # (sections are self-contained: repeating the GiB does not make far matches)
+        k = min(piece.numel(), n - off)
+        src[off:off + k] = piece[:k]
+        src[off:off + 4096] ^= (off >> 30) + 1
+    del piece
+    codec = DeviceCodec(frame_layout="one_frame", include_checksum=True)
+    try:
+        comp, total, fs = codec.compress(src)
+        out = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        got, _ = codec.decompress(comp, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+        dt = time.time() - t0
+        assert got == n and torch.equal(out, src)
+        assert dt < 30, f"{dt:.1f} s: the frame went to the general kernel"
+        bad = comp[:total].clone()
+        bad[total - 2] ^= 0x40
+        with pytest.raises(Exception, match="match checksum"):
+            codec.decompress(bad, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+    finally:
+        codec.close()
+
+
 def test_no_sequence_reaches_in_front_of_its_section():
     """Sections of 64 MiB are self-contained (include/zl_hip.h): the far search never looks across them, and neither may the
     one-byte backward extension of the stride-2 body -- which checked the bytes in front of the chunk in the FRAME, not in the

@@ -231,7 +231,7 @@ struct zl_dctx_s {
     bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
     std::vector<zl_dctx_s*> peers;
-    DevBuf d_chunk_off;
+    DevBuf d_chunk_off, d_run_off, d_run_results;  // (d_run_off, d_run_results: decode_hinted_frame_in_runs)
     size_t large_frames = 0;
     u8* sink_host = nullptr;   // host entries decoding one large frame: where its bytes go (zl3_hint::sink_host)
     u64 sunk = 0;              // ... and how many of them are there already
@@ -396,7 +396,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
-                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off, &d->d_dict_ext, &d->d_dict_pre};
+                      &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off, &d->d_run_off, &d->d_run_results, &d->d_dict_ext, &d->d_dict_pre};
     for (DevBuf* b : bufs) b->release();
     for (zl_dctx* p : d->peers) (void)zl_freeDCtx(p);
     d->peers.clear();
@@ -541,6 +541,63 @@ size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
     return 0;
 }
 
+// ONE frame of this library of 4 GiB or more, device-resident, with the caller's chunk hint (zl_decompress_device_hint): the
+// large-frame pipeline plans below 4 GiB (32-bit positions), the general kernel is one workgroup for the whole frame (400 s
+// for 4.5 GiB).  The hint says where every chunk's blocks start and sections of 512 chunks are self-contained (include/
+// zl_hip.h), so the frame goes through the pipeline in runs of 16 sections (1 GiB of content) -- the first with the header,
+// the others as headerless runs of blocks, only the last with the Last_Block and the footer: what the host entries do with a
+// seek table (decompress_sharded_with_seek_table).  The content checksum covers the whole: one more kernel behind the runs.
+// Returns 0 with the frame's result word written, or ZL_ERR(ZL_E_FALLBACK): hint and frame do not agree, or a run failed --
+// the general kernel then decides what the frame is.
+size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8* d_src, u8* d_dst, u64* d_result, hipStream_t st, zl3_hint hint) {
+    const size_t nchunks = d->chunk_off.size() - 1;
+    u8 head[18];  // (the longest frame header, zstd.h ZSTD_FRAMEHEADERSIZE_MAX)
+    if (fd.src_size < sizeof(head)) return ZL_ERR(ZL_E_FALLBACK);
+    if (hipMemcpyAsync(head, d_src + fd.src_off, sizeof(head), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    FrameHeader h;
+    if (ZL_IS_ERR(parse_frame_header(h, head, sizeof(head))) || h.skippable || h.dict_id || h.content_size == ZL_CONTENTSIZE_UNKNOWN || h.content_size > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
+    const u64 content = h.content_size;
+    if (nchunks != (content + ZL_BLOCK_MAX - 1) / ZL_BLOCK_MAX) return ZL_ERR(ZL_E_FALLBACK);
+    const size_t per = (size_t)16 << 9;  // chunks per run: 16 sections (ZL_FAR_SECTION_LOG, zl_encode.h)
+    const size_t nruns = (nchunks + per - 1) / per;
+    // every run's chunk offsets, relative to the run, in one upload
+    std::vector<u64> rel(nchunks + nruns);
+    for (size_t r = 0; r < nruns; r++) {
+        const size_t c0 = r * per, c1 = std::min(nchunks, c0 + per);
+        for (size_t c = c0; c <= c1; c++) rel[c + r] = d->chunk_off[c] - d->chunk_off[c0];
+    }
+    if (!d->d_run_off.ensure(rel.size() * 8) || !d->d_run_results.ensure(nruns * 8)) return kGpuUnavailable;
+    if (hipMemcpyAsync(d->d_run_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    hint.sink_host = nullptr;
+    for (size_t r = 0; r < nruns; r++) {
+        const size_t c0 = r * per, c1 = std::min(nchunks, c0 + per);
+        zl_frame_desc run;
+        run.src_off = fd.src_off + d->chunk_off[c0];
+        run.src_size = d->chunk_off[c1] - d->chunk_off[c0];
+        run.dst_off = fd.dst_off + (u64)c0 * ZL_BLOCK_MAX;
+        run.dst_cap = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, content) - (u64)c0 * ZL_BLOCK_MAX;
+        hint.d_chunk_off = (const u64*)d->d_run_off.p + c0 + r;
+        hint.nchunks = (u32)(c1 - c0);
+        hint.headerless = c0 != 0 ? 1u : 0u;
+        hint.not_last = c1 != nchunks ? 1u : 0u;
+        hint.tail = (c1 == nchunks && h.has_checksum) ? 4u : 0u;
+        const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p + r, 1, st, &d->side, &hint);
+        if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
+    }
+    std::vector<u64> got(nruns);
+    if (hipMemcpyAsync(got.data(), d->d_run_results.p, nruns * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    u64 total = 0;
+    for (size_t r = 0; r < nruns; r++) {
+        if (ZL_IS_ERR(got[r])) return ZL_ERR(ZL_E_FALLBACK);
+        total += got[r];
+    }
+    if (total != content) return ZL_ERR(ZL_E_FALLBACK);
+    const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
+    const u64 foot = d->chunk_off[nchunks] - 4;  // (has_checksum: the last chunk's listed size covers the 4 bytes)
+    if (zl3_check_content(d_dst + fd.dst_off, content, check ? d_src + fd.src_off + foot : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    return 0;
+}
+
 // enqueue the decode of `n` frames whose table sits in d->h_frames (pinned).  Frames of at most
 // one block size and without dictionary go through the lane-parallel pipeline (zl_decode2.hip);
 // the rest -- and whatever that pipeline hands back -- through the general kernel.
@@ -605,7 +662,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
         hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
-        hint.tail = d->run_headerless ? d->run_tail : ZL3_TAIL_FROM_HEADER;
+        hint.tail = (d->run_headerless || d->run_not_last) ? d->run_tail : ZL3_TAIL_FROM_HEADER;  // (a run that is not the frame's last has no footer, whatever the header says)
         hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0;
         hint.dict_rep[0] = 1; hint.dict_rep[1] = 4; hint.dict_rep[2] = 8;
         if (has_dict) {  // the dictionary's content is history in front of the frame; its tables stay with the general kernel (zl_decode3.h)
@@ -629,7 +686,14 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             hint.headerless = d->run_headerless ? 1u : 0u;
             hint.not_last = d->run_not_last ? 1u : 0u;
         }
-        const size_t e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
+        size_t e3 = ZL_ERR(ZL_E_FALLBACK);
+        if (i == 0 && tbl[i].dst_cap >= 0xFFFFD000ull && !has_dict && !d->run_headerless && !d->run_not_last && d->chunk_off.size() > 1 && d->chunk_off.back() <= tbl[i].src_size && d->chunk_off.back() >= 4) {
+            zl3_hint base = hint;
+            base.host_blocks = nullptr; base.nblocks = 0; base.end_pos = 0;
+            e3 = decode_hinted_frame_in_runs(d, tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, st, base);
+            if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
+        }
+        if (e3 != 0) e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
         if (e3 == 0) { plan[i].route = 3; d->large_frames++; d->took_big[i] = 1; }
         else if (e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
     }

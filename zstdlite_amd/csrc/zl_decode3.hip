@@ -687,7 +687,25 @@ __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_fram
     if (threadIdx.x == 0) *result = err ? ZL_ERR(err) : info->produced;
 }
 
+// the result word of a frame decoded in runs: its content checksum over the whole (zl3_check_content)
+__global__ __launch_bounds__(512) void zl3_check_kernel(const u8* content, u64 n, const u8* expect, u64* result) {
+    __shared__ __align__(16) u8 tile[8192];
+    __shared__ u64 acc[4];
+    __shared__ u32 bc[4];
+    u32 err = 0;
+    if (expect) {
+        const u32 got = zl_xxh64_low32(tile, acc, bc, content, n);
+        if (got != zl_rd_le(expect, 4)) err = ZL_E_CHECKSUM_WRONG;
+    }
+    if (threadIdx.x == 0) *result = err ? ZL_ERR(err) : n;
+}
+
 }  // namespace
+
+extern "C" hipError_t zl3_check_content(const u8* d_content, u64 n, const u8* d_expect, u64* d_result, hipStream_t st) {
+    hipLaunchKernelGGL(zl3_check_kernel, dim3(1), dim3(512), 0, st, d_content, n, d_expect, d_result);
+    return hipGetLastError();
+}
 
 #define ZL3_SINK_LOG 26      // host entries: the output is downloaded in pieces of 64 MiB behind the copy stage (zl3_hint::sink_host)
 #define ZL3_SINK_EVENTS 64
