@@ -87,6 +87,11 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 #define ZL_d_devices 9008
 #define ZL_c_pipeline 9004
 #define ZL_d_pipeline 9005
+/* Frames of 4 GiB and more that carry no chunk hint or seek table (what the reference writes for a large R object) are decoded
+ * in runs of at most 8192 blocks, each run with the output in front of it as its history (zl_api.hip
+ * decode_walked_frame_in_runs).  ZL_d_runBlocks = N (16 .. 8192; 0 = default) makes every frame of more than N blocks that a
+ * host entry decodes take that path, in runs of at most N blocks: how tests and fuzzers reach it with frames of a few MiB. */
+#define ZL_d_runBlocks 9009
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
 #define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
 
@@ -258,6 +263,8 @@ size_t zl_dctx_kernel_ms(const zl_dctx *dctx, double *ms);
  * the whole device: what ZSTD_compress2 writes for inputs above 128 KiB, src/raw-file.c:74) rather
  * than with one workgroup.  Lets tests and benchmarks assert which path ran. */
 size_t zl_dctx_large_frames(const zl_dctx *dctx);
+/* ... and the runs of blocks that frames of 4 GiB and more (or, with ZL_d_runBlocks, of more than N blocks) were decoded in. */
+size_t zl_dctx_frame_runs(const zl_dctx *dctx);
 /* Device slots the last zl_compress2 / zl_decompressDCtx call spread its work over (ZL_c_devices / ZL_d_devices): 1 when it ran on
  * the current device alone.  Lets tests assert that the sharded path ran. */
 size_t zl_cctx_last_slots(const zl_cctx *cctx);

@@ -60,6 +60,7 @@ SYMBOLS = [
     ("zl_cctx_far_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_kernel_ms", C.c_size_t, [C.c_void_p, C.POINTER(C.c_double)]),
     ("zl_dctx_large_frames", C.c_size_t, [C.c_void_p]),
+    ("zl_dctx_frame_runs", C.c_size_t, [C.c_void_p]),
     ("zl_cctx_last_slots", C.c_size_t, [C.c_void_p]),
     ("zl_dctx_last_slots", C.c_size_t, [C.c_void_p]),
     ("zl_compressStream2", C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

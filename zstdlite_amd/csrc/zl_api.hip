@@ -215,7 +215,7 @@ struct zl_dctx_s {
     } ds;
     zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
     // what is known about the large frames of the call being enqueued (either, or neither):
-    struct HostWalk { std::vector<zl3_hblk> blocks; u32 end_pos = 0; };
+    struct HostWalk { std::vector<zl3_hblk> blocks; u32 end_pos = 0; const u8* host_src = nullptr; };  // (host_src: the frame's bytes in host memory, for decode_walked_frame_in_runs)
     std::vector<HostWalk> host_walk;   // host entries: per frame of the current launch group, the blocks the host walked (empty: none)
     std::vector<u64> chunk_off;        // device entries: zl_decompress_device_hint, consumed by the next call
     const u8* host_copy = nullptr;     // device entries: zl_decompress_device_hint_host_copy, consumed by the next call
@@ -228,11 +228,13 @@ struct zl_dctx_s {
     bool host_verify = false;          // host entries: the content checksum of frames that take the large-frame pipeline is checked on the host, over the downloaded bytes (zl_xxh64.h)
     std::vector<u8> took_big;          // per frame of the last dctx_enqueue: 1 when the large-frame pipeline decoded it
     int devices = 1;                   // ZL_d_devices
+    int run_blocks = 0;                // ZL_d_runBlocks
     bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
     std::vector<zl_dctx_s*> peers;
     DevBuf d_chunk_off, d_run_off, d_run_results;  // (d_run_off, d_run_results: decode_hinted_frame_in_runs)
     size_t large_frames = 0;
+    size_t frame_runs = 0;             // runs of blocks decoded by decode_walked_frame_in_runs / decode_hinted_frame_in_runs so far
     u8* sink_host = nullptr;   // host entries decoding one large frame: where its bytes go (zl3_hint::sink_host)
     u64 sunk = 0;              // ... and how many of them are there already
     bool ev_valid = false;
@@ -423,6 +425,10 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     case ZL_d_stableOutBuffer: return 0;
     case ZL_d_profile: d->profile = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;
     case ZL_d_pipeline: d->pipeline = value ? 1 : 0; return 0;
+    case ZL_d_runBlocks:
+        if (value != 0 && (value < 16 || value > 8192)) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        d->run_blocks = value;
+        return 0;
     case ZL_d_devices:
         if (value < 0 || value > 64) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
         d->devices = value;
@@ -439,6 +445,7 @@ size_t zl_dctx_kernel_ms(const zl_dctx* d, double* ms) {
 }
 
 size_t zl_dctx_large_frames(const zl_dctx* d) { return d ? d->large_frames : 0; }
+size_t zl_dctx_frame_runs(const zl_dctx* d) { return d ? d->frame_runs : 0; }
 size_t zl_dctx_last_slots(const zl_dctx* d) { return d ? (size_t)d->last_slots : 0; }
 
 // not part of the public header: phase cycle sums.  [0..7] general kernel {H, B, A, A||B wall, C, blocks,
@@ -583,6 +590,7 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         hint.tail = (c1 == nchunks && h.has_checksum) ? 4u : 0u;
         const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p + r, 1, st, &d->side, &hint);
         if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
+        d->frame_runs++;
     }
     std::vector<u64> got(nruns);
     if (hipMemcpyAsync(got.data(), d->d_run_results.p, nruns * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -595,6 +603,145 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
     const u64 foot = d->chunk_off[nchunks] - 4;  // (has_checksum: the last chunk's listed size covers the 4 bytes)
     if (zl3_check_content(d_dst + fd.dst_off, content, check ? d_src + fd.src_off + foot : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    return 0;
+}
+
+// A frame of 4 GiB or more that someone else wrote (the reference's ZSTD_compress of a large R object) and whose bytes the
+// caller still holds in host memory.  No chunk hint, no self-contained sections: matches reach back as far as the window.  The
+// large-frame pipeline still takes it, in runs of at most 8192 blocks (1 GiB), each a headerless run of blocks that
+//   * starts from the repeat offsets the run in front of it left behind (zl3_info::rep_end, handed on as a "dictionary's"),
+//   * has everything in front of it as history: the output so far is where a dictionary's content would be,
+//   * takes the entropy tables in force at its start from the blocks that described them (treeless literals and Repeat_Mode
+//     ride on earlier blocks: zstd.c:43171, :43666): the host reads the section headers of all blocks (a few bytes each),
+//     knows for every run which block last described the Huffman tree and the LL, OF and ML table, and hands those -- at
+//     most four -- to the pipeline as DONORS behind the run's own blocks: parsed like them, never decoded; the segments
+//     inherit from them as they do from earlier blocks of a frame (zl3_plan_kernel).
+// The general kernel -- one workgroup, 11 MB/s on such a frame -- stays the fallback for whatever does not fit.
+namespace runs {
+struct BlockUse { u8 uses, defs; };  // bit 0 Huffman tree, 1 LL, 2 OF, 3 ML: rides on an earlier block's table / describes (or resets) it
+// literals and sequences section headers (zstd.c:43146-43230, :43707-43735), only as far as the table modes; false: malformed
+bool block_use(const u8* b, u32 n, BlockUse& u) {
+    u.uses = u.defs = 0;
+    if (n < 1) return false;
+    const u32 lt = b[0] & 3, sf = (b[0] >> 2) & 3;
+    u64 lsec;
+    if (lt < 2) {
+        u32 lh, regen;
+        if (sf == 0 || sf == 2) { lh = 1; regen = b[0] >> 3; }
+        else if (sf == 1) { if (n < 2) return false; lh = 2; regen = rd_le(b, 2) >> 4; }
+        else { if (n < 3) return false; lh = 3; regen = rd_le(b, 3) >> 4; }
+        lsec = lt == 0 ? (u64)lh + regen : (u64)lh + 1;
+    } else {
+        if (n < 5) return false;
+        const u32 h4 = rd_le(b, 4);
+        u32 lh, cs;
+        if (sf < 2) { lh = 3; cs = (h4 >> 14) & 0x3FF; }
+        else if (sf == 2) { lh = 4; cs = h4 >> 18; }
+        else { lh = 5; cs = (h4 >> 22) + ((u32)b[4] << 10); }
+        lsec = (u64)lh + cs;
+        if (lt == 2) u.defs |= 1; else u.uses |= 1;
+    }
+    if (lsec >= n) return false;
+    const u8* sp = b + lsec;
+    const u32 sn = (u32)(n - lsec);
+    u32 nseq = sp[0], sh = 1;
+    if (nseq > 0x7F) { if (nseq == 0xFF) { if (sn < 3) return false; nseq = rd_le(sp + 1, 2) + 0x7F00; sh = 3; } else { if (sn < 2) return false; nseq = ((nseq - 0x80) << 8) + sp[1]; sh = 2; } }
+    if (nseq == 0 || sn <= sh) return nseq == 0;
+    const u32 m = sp[sh];
+    const u32 mk[3] = {m >> 6, (m >> 4) & 3, (m >> 2) & 3};
+    for (int q = 0; q < 3; q++) { if (mk[q] == 3) u.uses |= (u8)(2u << q); else u.defs |= (u8)(2u << q); }
+    return true;
+}
+struct Block { u64 at; u32 hdr; BlockUse use; };  // at: where the block's content starts in the frame (behind its 3-byte header)
+}  // namespace runs
+
+size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8* host_src, const u8* d_src, u8* d_dst, u64* d_result, hipStream_t st, zl3_hint hint) {
+    using namespace runs;
+    const size_t n = (size_t)fd.src_size;
+    FrameHeader h;
+    if (ZL_IS_ERR(parse_frame_header(h, host_src, n)) || h.skippable || h.dict_id) return ZL_ERR(ZL_E_FALLBACK);
+    std::vector<Block> blk;
+    u64 pos = h.header_size;
+    for (;;) {  // (the walk of find_frame_size, with 64-bit positions and a look into every compressed block)
+        if (n - pos < 3) return ZL_ERR(ZL_E_FALLBACK);
+        Block b;
+        b.hdr = rd_le(host_src + pos, 3);
+        const u32 type = (b.hdr >> 1) & 3, bsize = b.hdr >> 3;
+        const u64 csize = type == 1 ? 1 : bsize;
+        pos += 3;
+        if (type == 3 || n - pos < csize || (type == 2 && bsize > ZL_BLOCK_MAX)) return ZL_ERR(ZL_E_FALLBACK);
+        b.at = pos;
+        b.use.uses = b.use.defs = 0;
+        if (type == 2 && !block_use(host_src + pos, bsize, b.use)) return ZL_ERR(ZL_E_FALLBACK);
+        blk.push_back(b);
+        pos += csize;
+        if (b.hdr & 1) break;
+        if (blk.size() > 0x7FFFFFFFu) return ZL_ERR(ZL_E_FALLBACK);
+    }
+    const u64 end_pos = pos;
+    if (h.has_checksum && n - pos < 4) return ZL_ERR(ZL_E_FALLBACK);
+    const size_t nb = blk.size();
+    const u64 bound = std::min<u64>(fd.dst_cap, (u64)nb * ZL_BLOCK_MAX);
+    const size_t per = d->run_blocks ? (size_t)d->run_blocks : 8192;
+    if (d->run_blocks ? nb <= per : (bound < 0xFFFFD000ull && fd.src_size < 0xFFFFFF00ull)) return ZL_ERR(ZL_E_FALLBACK);  // (the pipeline takes it as a whole)
+    if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && h.content_size > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
+    // ---- run by run
+    const size_t nruns = (nb + per - 1) / per;
+    std::vector<zl3_hblk> hb;
+    u64 out_pos = 0, left[4] = {0, 1, 4, 8};
+    u32 cur[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the latest block in front of the run that describes the Huffman tree, the LL, OF, ML table
+    hint.host_blocks = nullptr; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.sink_host = nullptr;
+    hint.headerless = 1; hint.not_last = 0; hint.tail = 0; hint.size_unknown = 1; hint.run_out = left;
+    hint.dict_id = 0;
+    for (size_t r = 0; r < nruns; r++) {
+        const size_t b0 = r * per, b1 = std::min(nb, b0 + per);
+        // which tables does the run take over from the blocks in front of it?
+        u32 need = 0, have = 0;
+        for (size_t b = b0; b < b1 && have != 15u; b++) { need |= blk[b].use.uses & ~have; have |= blk[b].use.defs; }
+        u32 dn[4], nd = 0;  // the donors: distinct, in frame order
+        for (int q = 0; q < 4; q++) {
+            if (!((need >> q) & 1)) continue;
+            if (cur[q] == 0xFFFFFFFFu) return ZL_ERR(ZL_E_FALLBACK);  // (repeats what nobody described: the general kernel names the error)
+            bool seen = false;
+            for (u32 k = 0; k < nd; k++) seen = seen || dn[k] == cur[q];
+            if (!seen) dn[nd++] = cur[q];
+        }
+        std::sort(dn, dn + nd);
+        u64 s0 = blk[b0].at - 3;
+        const u64 s1 = b1 < nb ? blk[b1].at - 3 : end_pos;
+        const u64 base = nd ? std::min<u64>(s0, blk[dn[0]].at - 3) : s0;
+        if (s1 - base >= 0xFFFFFF00ull || out_pos > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
+        hb.resize(b1 - b0 + nd);
+        for (size_t b = b0; b < b1; b++) { hb[b - b0].src_off = (u32)(blk[b].at - base); hb[b - b0].hdr = blk[b].hdr; }
+        for (u32 k = 0; k < nd; k++) { hb[b1 - b0 + k].src_off = (u32)(blk[dn[k]].at - base); hb[b1 - b0 + k].hdr = blk[dn[k]].hdr; }
+        hint.ndonors = nd;
+        for (int q = 0; q < 4; q++) {
+            hint.donor[q] = 0xFFFFFFFFu;
+            if ((need >> q) & 1) for (u32 k = 0; k < nd; k++) if (dn[k] == cur[q]) hint.donor[q] = k;
+        }
+        zl_frame_desc run;
+        run.src_off = fd.src_off + base;
+        run.src_size = s1 - base;
+        run.dst_off = fd.dst_off + out_pos;
+        run.dst_cap = std::min<u64>(fd.dst_cap - out_pos, (u64)(b1 - b0) * ZL_BLOCK_MAX);
+        hint.host_blocks = hb.data();
+        hint.nblocks = (u32)(b1 - b0);
+        hint.end_pos = (u32)(s1 - base);
+        hint.dict_end = d_dst + fd.dst_off + out_pos;
+        hint.dict_len = (u32)std::min<u64>(out_pos, 0x80000000ull);
+        hint.dict_formatted = r ? 1u : 0u;
+        for (int k = 0; k < 3; k++) hint.dict_rep[k] = (u32)left[1 + k];
+        left[0] = ~0ull;
+        const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p, 1, st, &d->side, &hint);
+        if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
+        if (left[0] == ~0ull) return ZL_ERR(ZL_E_FALLBACK);  // (the run reported an error: the general kernel names it)
+        out_pos += left[0];
+        d->frame_runs++;
+        for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
+    }
+    if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos != h.content_size) return ZL_ERR(ZL_E_FALLBACK);
+    const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
+    if (zl3_check_content(d_dst + fd.dst_off, out_pos, check ? d_src + fd.src_off + end_pos : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     return 0;
 }
 
@@ -665,6 +812,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         hint.tail = (d->run_headerless || d->run_not_last) ? d->run_tail : ZL3_TAIL_FROM_HEADER;  // (a run that is not the frame's last has no footer, whatever the header says)
         hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0;
         hint.dict_rep[0] = 1; hint.dict_rep[1] = 4; hint.dict_rep[2] = 8;
+        hint.size_unknown = 0; hint.run_out = nullptr; hint.ndonors = 0; hint.donor[0] = hint.donor[1] = hint.donor[2] = hint.donor[3] = 0xFFFFFFFFu;
         if (has_dict) {  // the dictionary's content is history in front of the frame; its tables stay with the general kernel (zl_decode3.h)
             hint.dict_len = (u32)(d->dict.size() - d->dict_content_off);
             hint.dict_end = (const u8*)d->d_dict.p + d->dict.size();
@@ -691,6 +839,12 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             zl3_hint base = hint;
             base.host_blocks = nullptr; base.nblocks = 0; base.end_pos = 0;
             e3 = decode_hinted_frame_in_runs(d, tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, st, base);
+            if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
+        }
+        if (e3 != 0 && i < d->host_walk.size() && d->host_walk[i].host_src && !has_dict && !d->run_headerless && !d->run_not_last &&
+            (tbl[i].dst_cap >= 0xFFFFD000ull || tbl[i].src_size >= 0xFFFFFF00ull || d->run_blocks)) {
+            if (!d->d_run_results.ensure(64)) return kGpuUnavailable;
+            e3 = decode_walked_frame_in_runs(d, tbl[i], d->host_walk[i].host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }
         if (e3 != 0) e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
@@ -724,6 +878,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.fuse1 = 3u;  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
     f2.big = nullptr;
     f2.part = 0;
+    f2.sym_first = 0;
     f2.ext_shared = 0; f2.ext_base = nullptr; f2.dict_end = nullptr; f2.dict_len = 0; f2.dict_id = d->dict_id; f2.dict_pre = nullptr;
     f2.dict_rep[0] = 1; f2.dict_rep[1] = 4; f2.dict_rep[2] = 8;
     if (has_dict) {
@@ -792,6 +947,7 @@ size_t zl_decompress_device_async(zl_dctx* d, void* d_dst, const void* d_src, co
             zl_dctx_s::HostWalk hw;
             const size_t fs = find_frame_size(d->host_copy + fd.src_off, (size_t)fd.src_size, &h, &hw.blocks, &hw.end_pos);
             if (!ZL_IS_ERR(fs) && !h.skippable && hw.blocks.size() == h.nblocks && hw.blocks.size() > ZL2_MAXB) d->host_walk[i] = std::move(hw);
+            if (!ZL_IS_ERR(fs) && !h.skippable && fs == fd.src_size) d->host_walk[i].host_src = d->host_copy + fd.src_off;
         }
         d->host_copy = nullptr;
     }
@@ -938,7 +1094,7 @@ bool ensure_peers(zl_dctx* d, int slots) {
         p->is_peer = true;
         d->peers.push_back(p);
     }
-    for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; }
+    for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; d->peers[s]->run_blocks = d->run_blocks; }
     return true;
 }
 
@@ -1088,6 +1244,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             table.push_back(fd);
             known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
             if (hw.blocks.size() <= ZL2_MAXB || hw.blocks.size() != h.nblocks) hw.blocks.clear();  // (small frames take the lane pipeline, which indexes on the device)
+            hw.host_src = src + pos;
             walks.push_back(std::move(hw));
         }
         any = true;

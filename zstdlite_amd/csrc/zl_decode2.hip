@@ -79,7 +79,7 @@ __device__ __forceinline__ void set_err(zl2_frame_rec* fr, u32 code) {
 __device__ __forceinline__ const zl2_blk_rec& ext_rec(const zl2_args& a, u32 f, u32 k) { return a.ext[(a.ext_shared ? (size_t)0 : (size_t)f * 4) + k]; }
 __device__ __forceinline__ const u8* ext_src(const zl2_args& a, u32 f) { return a.ext_base ? a.ext_base : a.src + a.frames[f].src_off; }
 // does a chain of frame / segment f start from a history that the exec kernel fills in (symbols instead of numbers)?
-__device__ __forceinline__ bool starts_symbolic(const zl2_args& a, u32 f) { return a.ext != nullptr && (f != 0 || a.ext_shared != 0); }
+__device__ __forceinline__ bool starts_symbolic(const zl2_args& a, u32 f) { return a.ext != nullptr && (f != 0 || a.ext_shared != 0 || a.sym_first != 0); }
 
 __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
     const u32 f = blockIdx.x * 64 + threadIdx.x;

@@ -279,14 +279,18 @@ __global__ __launch_bounds__(1024) void zl3_chunk_scan_kernel(zl3_dev d, zl_fram
 
 // (3) the host has walked the frame already (zl_findFrameCompressedSize does, src/raw-file.c:150) and uploads
 // what it saw: nothing to do on the device but the checks the walk would have made.
-__global__ __launch_bounds__(64) void zl3_host_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nblocks, u32 end_pos) {
+__global__ __launch_bounds__(64) void zl3_host_walk_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base, u32 nblocks, u32 end_pos, u32 headerless, u32 size_unknown, u32 ndonors, uint4 donor) {
     if (threadIdx.x != 0) return;
     zl3_info* info = d.info;
-    if (!zl3_frame_header(info, fd, src_base + fd.src_off, true, d.dict_id)) return;
-    if (nblocks > d.cap_blocks) { info->err = ZL_E_FALLBACK; return; }
+    if (headerless) { info->fcs = size_unknown ? ZL_CONTENTSIZE_UNKNOWN : fd.dst_cap; info->has_checksum = 0; info->hdr_size = 0; }  // (a run of a frame's blocks: the caller holds the header and the footer)
+    else if (!zl3_frame_header(info, fd, src_base + fd.src_off, true, d.dict_id)) return;
+    if (nblocks + ndonors > d.cap_blocks) { info->err = ZL_E_FALLBACK; return; }
     if (info->has_checksum && fd.src_size - end_pos < 4) { info->err = ZL_E_CHECKSUM_WRONG; return; }
     info->nblocks = nblocks;
     info->end_pos = end_pos;
+    info->ndonors = ndonors;
+    const u32 dn[4] = {donor.x, donor.y, donor.z, donor.w};
+    for (int q = 0; q < 4; q++) info->donor[q] = (ndonors && dn[q] < ndonors) ? nblocks + dn[q] : 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -295,8 +299,9 @@ __global__ __launch_bounds__(64) void zl3_host_walk_kernel(zl3_dev d, zl_frame_d
 __global__ __launch_bounds__(256) void zl3_parse_kernel(zl3_dev d, zl_frame_desc fd, const u8* src_base) {
     const u32 b = blockIdx.x * 256 + threadIdx.x;
     zl3_info* info = d.info;
-    if (info->err || (b & ~63u) >= info->nblocks) return;  // (whole waves stay: the count at the end is a ballot)
-    if (b >= info->nblocks) { (void)__ballot(false); return; }
+    const u32 nall = info->nblocks + info->ndonors;  // (the donors of a run of blocks are parsed like its own blocks)
+    if (info->err || (b & ~63u) >= nall) return;  // (whole waves stay: the count at the end is a ballot)
+    if (b >= nall) { (void)__ballot(false); return; }
     const zl3_hblk hb = d.hblk[b];
     bool dependent = false;
     zl2_blk_rec r;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) void zl3_parse_kernel(zl3_dev d, zl_frame_desc
     if (b == 0) r.pad[1] = 1;
     d.braw[b] = r;
     // how many blocks ride on earlier tables decides whether segments are formed at all (zl3_segment_kernel)
-    const u64 md = __ballot(dependent && r.pad[1] == 0);  // (blocks that ride and bring nothing of their own: the ones a segment would spare a table rebuild)
+    const u64 md = __ballot(b < info->nblocks && dependent && r.pad[1] == 0);  // (blocks that ride and bring nothing of their own: the ones a segment would spare a table rebuild)
     if ((threadIdx.x & 63) == 0 && md) atomicAdd(&info->ndependent, (u32)__popcll(md));
 }
 
@@ -388,7 +393,9 @@ __global__ __launch_bounds__(1024) void zl3_segment_kernel(zl3_dev d) {
 // segments: scratch offsets and inherited tables.  One workgroup.
 // ---------------------------------------------------------------------------------------
 #define ZL3_NONE 0xFFFFFFFFu
-__device__ __forceinline__ u32 max_def(u32 a, u32 b) { return (a == ZL3_NONE) ? b : ((b == ZL3_NONE) ? a : (a > b ? a : b)); }
+// the latest defining block: what the segments so far had (a), unless this segment has one of its own (b) -- which is later in the
+// frame than anything in front of it, the donors of a run of blocks (whose indices lie BEHIND the run's own) included
+__device__ __forceinline__ u32 max_def(u32 a, u32 b) { return (b == ZL3_NONE) ? a : b; }
 
 __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc fd) {
     __shared__ u32 tile[6][1024];
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
         u32* o = d.seg_tmp + (size_t)s * 16;
         o[0] = (lit + 15) & ~15u; o[1] = seq; o[2] = def[0]; o[3] = def[1]; o[4] = def[2]; o[5] = def[3];
     }
-    if (t == 0) { carry_sum[0] = 0; carry_sum[1] = 0; carry_def[0] = carry_def[1] = carry_def[2] = carry_def[3] = ZL3_NONE; }
+    if (t == 0) { carry_sum[0] = 0; carry_sum[1] = 0; for (int q = 0; q < 4; q++) carry_def[q] = info->ndonors ? info->donor[q] : ZL3_NONE; }
     zl_sync_global();  // (the segments' numbers travel through memory)
     // ---- B: across segments: exclusive sums of the scratch needs, exclusive running maximum of the defining blocks
     for (u32 s0 = 0; s0 < ns; s0 += 1024) {
@@ -478,9 +485,13 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
         if (cur[0] != ZL3_NONE) x[0] = d.braw[cur[0]];
         {   // the (up to three) distinct defining blocks of the sequence tables, in block order
             u32 a0 = cur[1], a1 = cur[2], a2 = cur[3];
-            if (a0 > a1) { const u32 q = a0; a0 = a1; a1 = q; }   // (ZL3_NONE sorts last)
-            if (a1 > a2) { const u32 q = a1; a1 = a2; a2 = q; }
-            if (a0 > a1) { const u32 q = a0; a0 = a1; a1 = q; }
+            const u32 nbk = info->nblocks;
+            // (frame order: a run's donors, indices nblocks .., come in front of its own blocks; ZL3_NONE sorts last)
+            #define ZL3_ORDER_KEY(i_) ((i_) == ZL3_NONE ? ZL3_NONE : ((i_) >= nbk ? (i_) - nbk : (i_) + 4u))
+            if (ZL3_ORDER_KEY(a0) > ZL3_ORDER_KEY(a1)) { const u32 q = a0; a0 = a1; a1 = q; }
+            if (ZL3_ORDER_KEY(a1) > ZL3_ORDER_KEY(a2)) { const u32 q = a1; a1 = a2; a2 = q; }
+            if (ZL3_ORDER_KEY(a0) > ZL3_ORDER_KEY(a1)) { const u32 q = a0; a0 = a1; a1 = q; }
+            #undef ZL3_ORDER_KEY
             u32 k = 1;
             if (a0 != ZL3_NONE) x[k++] = d.braw[a0];
             if (a1 != ZL3_NONE && a1 != a0) x[k++] = d.braw[a1];
@@ -598,6 +609,7 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
     if (lane == 0) {
         d.blk_dst[nb] = (u32)op;
         info->produced = op;
+        info->rep_end[0] = r0; info->rep_end[1] = r1; info->rep_end[2] = r2;
         if (bad) info->err = bad;
         else if (op > fd.dst_cap) info->err = ZL_E_DSTSIZE_TOO_SMALL;
         else if (info->fcs != ZL_CONTENTSIZE_UNKNOWN && op != info->fcs) info->err = ZL_E_CORRUPTION;  // zstd.c:41646
@@ -746,7 +758,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     const u64 out_bound = std::min<u64>(fd.dst_cap, fd.src_size * 1024 + ((u64)1 << 20));
     // blocks planned for: full blocks plus a generous allowance for encoders that split blocks (this library's own cut 16 KiB blocks)
     u32 cap_blocks = (u32)std::min<u64>((out_bound >> 13) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
-    if (hint && hint->host_blocks && hint->nblocks > cap_blocks) cap_blocks = (hint->nblocks + ZL2_MAXB) & ~(u32)(ZL2_MAXB - 1);
+    if (hint && hint->host_blocks && hint->nblocks + 4 > cap_blocks) cap_blocks = (hint->nblocks + 4 + ZL2_MAXB) & ~(u32)(ZL2_MAXB - 1);
     const u32 cap_segs = cap_blocks;  // (a segment holds at least one block)
     if (!s->info.ensure(sizeof(zl3_info)) || !s->hblk.ensure((size_t)cap_blocks * sizeof(zl3_hblk)) || !s->braw.ensure((size_t)cap_blocks * sizeof(zl2_blk_rec)) ||
         !s->seg_first.ensure(((size_t)cap_segs + 1) * 4) || !s->blk_slot.ensure((size_t)cap_blocks * 4) || !s->blk_dst.ensure(((size_t)cap_blocks + 1) * 4) ||
@@ -765,7 +777,9 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     bool walked = false;
     if (hint && hint->host_blocks && hint->nblocks) {
         if (hipMemcpyAsync(d.hblk, hint->host_blocks, (size_t)hint->nblocks * sizeof(zl3_hblk), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        hipLaunchKernelGGL(zl3_host_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src, hint->nblocks, hint->end_pos);
+        const u32 nd = hint->headerless ? std::min<u32>(hint->ndonors, 4u) : 0u;
+        if (nd && hipMemcpyAsync(d.hblk + hint->nblocks, hint->host_blocks + hint->nblocks, (size_t)nd * sizeof(zl3_hblk), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        hipLaunchKernelGGL(zl3_host_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src, hint->nblocks, hint->end_pos, hint->headerless, hint->size_unknown, nd, make_uint4(hint->donor[0], hint->donor[1], hint->donor[2], hint->donor[3]));
         walked = true;
     } else if (hint && hint->d_chunk_off && hint->nchunks) {
         const u32 nc = hint->nchunks;
@@ -874,6 +888,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         a.ext_shared = 0; a.ext_base = nullptr; a.dict_pre = nullptr; a.dict_end = nullptr; a.dict_len = 0; a.dict_id = 0; a.dict_rep[0] = 1; a.dict_rep[1] = 4; a.dict_rep[2] = 8;  // (the dictionary of a large frame travels in zl3_big)
         a.fuse1 = 3u;
         a.part = 0;
+        a.sym_first = (have_dict && hint->dict_formatted) ? 1u : 0u;
         stamp("alloc");
         if (zl2_launch_segments_entropy(&a, st, side) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("entropy");
@@ -914,6 +929,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         stamp("resolve");
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
         if (nsink && !info.err) *hint->sunk = (u64)nsink << ZL3_SINK_LOG;  // (a frame that failed or goes to the general kernel is downloaded as a whole, whatever was copied)
+        if (hint && hint->run_out && !info.err) { hint->run_out[0] = info.produced; for (int k = 0; k < 3; k++) hint->run_out[1 + k] = info.rep_end[k]; }
     }
     hipLaunchKernelGGL(zl3_finish_kernel, dim3(1), dim3(512), 0, st, d.info, fd, d_src, (const u8*)d_dst, d_result, (u32)ignore_checksum);
     stamp("finish");

@@ -125,6 +125,11 @@ struct zl2_args {
     // 0: all of it.  Otherwise the launch's ROLE in the two-part schedule; which groups a role covers depends on the mode
     // the order kernel chose on the device (max_blocks[2]: ZL2_MODE_*).
     u32 part;
+    // large-frame pipeline: the first block of segment 0 starts from a history other than 1, 4, 8 (a formatted dictionary's, or
+    // what the run in front of this run of blocks left behind): its chain writes symbols like every other block's, zl3_offsets_kernel
+    // resolves them.  (Until round 3 that chain resolved its repeat offsets against 1, 4, 8 whatever the dictionary said;
+    // dictionaries from ZDICT_trainFromBuffer say 1, 4, 8.)
+    u32 sym_first;
 };
 #define ZL2_ROLE_E1 1u   // entropy kernels, main stream
 #define ZL2_ROLE_ES 3u   // entropy kernels, second stream
@@ -160,6 +165,12 @@ struct zl3_info {                 // one per large frame, device memory
     u64 produced;                 // regenerated bytes (zl3_offsets_kernel)
     u32 pending;                  // (unused)
     u32 ndependent;               // blocks that ride on the tables of an earlier block (treeless literals, Repeat_Mode)
+    u32 rep_end[3];               // the repcode history behind the last block (zl3_offsets_kernel): what a following run of the same frame starts with
+    // a run of a frame's blocks (zl3_hint::ndonors): the blocks in front of the run whose table descriptions are in force at its
+    // start sit behind the run's own in the block table -- parsed like them, decoded never -- and donor[] says which of them
+    // (index into the table, or 0xFFFFFFFF) holds the Huffman tree, the LL, OF and ML table
+    u32 ndonors;
+    u32 donor[4];
 };
 struct zl3_big {
     zl3_info* info;
