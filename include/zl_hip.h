@@ -71,8 +71,8 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * every block header of the data in front of it; the table is checked against the data, never trusted.  Off by default:
  * the output is then exactly one frame (one-frame layout) and zl_findFrameCompressedSize(out) == bytes written -- except
  * for ONE frame of 4 GiB of content or more, which always carries the table: this library's large-frame decoder plans frames
- * below 4 GiB (32-bit positions); a larger one is decoded section by section from the table, and by ONE workgroup without it
- * (correct, and a thousand times slower; that is also what a reference-made frame of that size gets).
+ * below 4 GiB (32-bit positions); a larger one is decoded section by section from the table.  (Without it -- the device
+ * entries' chunk hint, or a frame another writer made -- such a frame is decoded in runs of blocks: ZL_d_runBlocks below.)
  * Independent frames (ZL_layout_frames): the table is zstd's published SEEKABLE FORMAT (contrib/seekable_format of the zstd
  * distribution: skippable magic 0x184D2A5E, {compressed size, decompressed size} per frame, footer magic 0x8F92EAB1), which
  * that format's other readers use as well.  ONE frame: the published format lists frames, not the runs of blocks inside

@@ -1,6 +1,6 @@
 """Inputs above 4 GiB (32-bit positions and sizes are the classic casualty): the host entries in both layouts, with a seek table
-and device slots, and the device entries, on N GiB of the bench mix: reference decode (one frame: as a whole; frames: all of
-them), our decode, bit-exact.  usage: huge_roundtrip.py [GiB=4.5]"""
+and device slots, the device entries, and a frame the reference wrote, on N GiB of the bench mix: reference decode (one frame: as a
+whole; frames: all of them), our decode, bit-exact.  usage: huge_roundtrip.py [GiB=4.5]"""
 import ctypes as C
 import sys
 import time
@@ -50,6 +50,41 @@ for layout in ("frames", "one_frame"):
     else:
         codec.decompress(dst, codec.frame_table([total], [n]), out, chunk_sizes=fs)
     assert torch.equal(out, src), "device decode differs"
-    print(f"device entries, {layout}: {total} bytes, round trip bit-exact", flush=True)
+    out.zero_()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    if layout == "frames":
+        codec.decompress(dst, codec.frame_table(fs, codec.chunk_content_sizes(n)), out)
+    else:
+        codec.decompress(dst, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+    t2 = time.time()
+    assert torch.equal(out, src), "device decode differs"
+    print(f"device entries, {layout}: {total} bytes, round trip bit-exact, decompress {n / (t2 - t1) / 1e9:.1f} GB/s", flush=True)
     codec.close()
+    del dst, out
+# a frame the REFERENCE wrote (ZSTD_compress2, level 3, checksum): one frame, no hint, no seek table -- decoded in runs of blocks
+rc = ref.L.ZSTD_createCCtx()
+ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_compressionLevel, 3); ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_checksumFlag, 1)
+t1 = time.time()
+r = ref.L.ZSTD_compress2(rc, comp.ctypes.data, cap, host.ctypes.data, n)
+t2 = time.time()
+ref.L.ZSTD_freeCCtx(rc)
+assert not ref.L.ZSTD_isError(r)
+dctx = L.zl_createDCtx()
+for rep in range(2):
+    back.fill(0)
+    t3 = time.time()
+    r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+    t4 = time.time()
+    assert r2 == n, _lib.error_name(r2) if _lib.is_error(r2) else r2
+    assert np.array_equal(back, host), "reference frame: bytes differ"
+    print(f"reference-made frame: {r} bytes (reference compress {n / (t2 - t1) / 1e9:.2f} GB/s), our decompress {n / (t4 - t3) / 1e9:.1f} GB/s in {int(L.zl_dctx_frame_runs(dctx))} runs so far", flush=True)
+rd = ref.L.ZSTD_createDCtx()
+t5 = time.time()
+r3 = ref.L.ZSTD_decompressDCtx(rd, back.ctypes.data, n, comp.ctypes.data, r)
+t6 = time.time()
+ref.L.ZSTD_freeDCtx(rd)
+assert r3 == n
+print(f"reference decompress of the same frame: {n / (t6 - t5) / 1e9:.2f} GB/s", flush=True)
+L.zl_freeDCtx(dctx)
 print("ok")

@@ -299,3 +299,52 @@ def test_speculative_block_walk_on_the_device(ref, oracle):
 
 def large_frames_codec(codec):
     return int(_lib.lib().zl_dctx_large_frames(codec.dctx))
+
+
+@needs_ref
+def test_frames_decoded_in_runs_of_blocks(ref, oracle):
+    """How frames of 4 GiB and more from other writers are decoded (zl_api.hip decode_walked_frame_in_runs), reached here with
+    frames of a few MiB: ZL_d_runBlocks = N cuts every frame of more than N blocks into runs of at most N, each a pass of the
+    large-frame pipeline that starts from the output so far (history), the repeat offsets the run before left behind and the
+    earlier blocks whose tables are still in force (donors).  Text at level 3 rides on repeated tables in almost every block;
+    the mix puts raw blocks and table changes on the run boundaries; level 19 brings long windows and split blocks.  The runs
+    must have been taken, the bytes must be the input; damaged frames get the oracle's verdict."""
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    text = GENERATORS["text"](5 << 20, seed=3)
+    ints = GENERATORS["int20"](2 << 20, seed=4)
+    mixed = b"".join((text, noise, ints, bytes(1 << 18))[k % 4][(k * 77777) % (1 << 19):][: 192 << 10] for k in range(28))
+    frames = [(ref.compress(text, level=3), text), (ref.compress(mixed, level=3, checksum=True), mixed),
+              (ref.compress(mixed, level=9), mixed), (ref.compress(text[: 3 << 20], level=19), text[: 3 << 20]),
+              (ref.compress(noise * 3, level=3), noise * 3)]
+    dctx = z.zstd_dctx()
+    for comp, data in frames:
+        for nrun in (16, 17, 33):
+            assert L.zl_DCtx_setParameter(dctx._ptr, 9009, nrun) == 0  # ZL_d_runBlocks
+            before = int(L.zl_dctx_frame_runs(dctx._ptr))
+            assert z.zstd_decompress(comp, dctx=dctx) == data, nrun
+            blocks = -(-len(data) // 131072)
+            if blocks > nrun:
+                assert int(L.zl_dctx_frame_runs(dctx._ptr)) - before >= -(-blocks // nrun), (len(data), nrun)
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9009, 20) == 0
+    comp, data = frames[1]
+    errs = 0
+    for _ in range(30):
+        bad = bytearray(comp)
+        for _ in range(int(rng.integers(1, 3))):
+            bad[int(rng.integers(4, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        try:
+            want = oracle.decompress(bad, cap=len(data))
+        except Exception:
+            want = None
+        try:
+            got = z.zstd_decompress(bad, dctx=dctx)
+        except z.ZstdError:
+            got = None
+        assert (got is None) == (want is None), "verdicts differ"
+        assert got == want
+        errs += got is None
+    assert errs >= 10
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9009, 5) != 0 and L.zl_DCtx_setParameter(dctx._ptr, 9009, 0) == 0

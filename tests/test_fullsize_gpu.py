@@ -341,6 +341,52 @@ def test_device_entry_decodes_one_frame_of_more_than_4_gib_in_runs():
         codec.close()
 
 
+def test_reference_frame_of_more_than_4_gib_is_decoded_in_runs():
+    """What the reference's zstd_serialize writes for an R object of 4 GiB and more: ONE frame, no seek table, no chunk hint,
+    matches as far back as the window.  The large-frame pipeline plans below 4 GiB and the general kernel is one workgroup --
+    11 MB/s, 400 s for this frame.  zl_decompressDCtx decodes it in runs of 8192 blocks (zl_api.hip
+    decode_walked_frame_in_runs): the runs must have been taken, the bytes must be the input, with a content checksum (checked
+    over the whole); a flipped byte in the middle is an error, as it is for the reference."""
+    import time
+    from zstdlite_amd import _lib
+    from zl_testlib import Ref
+    if not have_ref():
+        pytest.skip("needs the reference build (oracle/_ref)")
+    ref = Ref()
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = (4 << 30) + (200 << 20) + 4321
+    piece = gen_mixed(1 << 30, dev)[0].cpu().numpy()
+    host = np.empty(n, dtype=np.uint8)
+    for off in range(0, n, piece.size):   # (the window of level 3 is 2 MiB: repeating the GiB makes no matches)
+        k = min(piece.size, n - off)
+        host[off:off + k] = piece[:k]
+        host[off:off + 4096] ^= (off >> 30) + 1
+    del piece
+    cap = ref.L.ZSTD_compressBound(n)
+    comp = np.empty(cap, dtype=np.uint8)
+    cctx = ref.L.ZSTD_createCCtx()
+    ref.L.ZSTD_CCtx_setParameter(cctx, ref.ZSTD_c_compressionLevel, 3); ref.L.ZSTD_CCtx_setParameter(cctx, ref.ZSTD_c_checksumFlag, 1)
+    r = ref.L.ZSTD_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
+    ref.L.ZSTD_freeCCtx(cctx)
+    assert not ref.L.ZSTD_isError(r)
+    dctx = L.zl_createDCtx()
+    try:
+        back = np.zeros(n, dtype=np.uint8)
+        t0 = time.time()
+        got = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+        dt = time.time() - t0
+        assert got == n, _lib.error_name(got)
+        assert int(L.zl_dctx_frame_runs(dctx)) >= 5
+        assert np.array_equal(back, host)
+        assert dt < 60, f"{dt:.1f} s"
+        comp[r - 2] ^= 0x04   # the footer
+        e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+        assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)
+    finally:
+        L.zl_freeDCtx(dctx)
+
+
 def test_no_sequence_reaches_in_front_of_its_section():
     """Sections of 64 MiB are self-contained (include/zl_hip.h): the far search never looks across them, and neither may the
     one-byte backward extension of the stride-2 body -- which checked the bytes in front of the chunk in the FRAME, not in the
