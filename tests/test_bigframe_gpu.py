@@ -348,3 +348,25 @@ def test_frames_decoded_in_runs_of_blocks(ref, oracle):
         errs += got is None
     assert errs >= 10
     assert L.zl_DCtx_setParameter(dctx._ptr, 9009, 5) != 0 and L.zl_DCtx_setParameter(dctx._ptr, 9009, 0) == 0
+    # the device-resident entry takes the same path when the caller still holds the compressed bytes (host-copy hint); the
+    # content checksum is then checked on the device, over the whole, behind the runs
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    codec = DeviceCodec(level=3)
+    try:
+        assert L.zl_DCtx_setParameter(codec.dctx, 9009, 24) == 0
+        for comp, data in frames[:3]:
+            h = np.frombuffer(comp, dtype=np.uint8)
+            d_src = torch.from_numpy(h.copy()).cuda()
+            d_dst = torch.zeros(len(data), dtype=torch.uint8, device="cuda")
+            before = int(L.zl_dctx_frame_runs(codec.dctx))
+            total, _ = codec.decompress(d_src, codec.frame_table([len(comp)], [len(data)]), d_dst, host_copy=h)
+            assert total == len(data) and bytes(d_dst.cpu().numpy()) == data
+            assert int(L.zl_dctx_frame_runs(codec.dctx)) > before
+        comp, data = frames[1]
+        h = np.frombuffer(comp, dtype=np.uint8).copy()
+        h[-2] ^= 0x20  # the footer
+        with pytest.raises(z.ZstdError, match="match checksum"):
+            codec.decompress(torch.from_numpy(h).cuda(), codec.frame_table([len(comp)], [len(data)]), torch.zeros(len(data), dtype=torch.uint8, device="cuda"), host_copy=h)
+    finally:
+        codec.close()
