@@ -337,6 +337,19 @@ def test_device_entry_decodes_one_frame_of_more_than_4_gib_in_runs():
         bad[total - 2] ^= 0x40
         with pytest.raises(Exception, match="match checksum"):
             codec.decompress(bad, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+        bad[total - 2] ^= 0x40
+        bad[total // 2] ^= 0x01  # damage inside a chunk: reported by its run, at once
+        t0 = time.time()
+        with pytest.raises(Exception):
+            codec.decompress(bad, codec.frame_table([total], [n]), out, chunk_sizes=fs)
+        assert time.time() - t0 < 30
+        wrong = fs.copy(); wrong[5] += 1; wrong[6] -= 1   # a hint that does not describe the frame is ignored, not believed
+        small = DeviceCodec(frame_layout="one_frame")
+        c2, t2, f2 = small.compress(src[: 3 << 20])
+        o2 = torch.zeros(3 << 20, dtype=torch.uint8, device=dev)
+        w2 = f2.copy(); w2[5] += 1; w2[6] -= 1
+        assert small.decompress(c2, small.frame_table([t2], [3 << 20]), o2, chunk_sizes=w2)[0] == 3 << 20 and torch.equal(o2, src[: 3 << 20])
+        small.close()
     finally:
         codec.close()
 
@@ -383,6 +396,11 @@ def test_reference_frame_of_more_than_4_gib_is_decoded_in_runs():
         comp[r - 2] ^= 0x04   # the footer
         e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
         assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)
+        comp[r - 2] ^= 0x04
+        comp[r // 2] ^= 0x01  # inside a block of the third run: that run's error is the frame's, without a detour over the general kernel
+        t0 = time.time()
+        e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+        assert _lib.is_error(e) and time.time() - t0 < 60
     finally:
         L.zl_freeDCtx(dctx)
 

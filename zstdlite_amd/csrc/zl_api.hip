@@ -571,21 +571,27 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     std::vector<u64> rel(nchunks + nruns);
     for (size_t r = 0; r < nruns; r++) {
         const size_t c0 = r * per, c1 = std::min(nchunks, c0 + per);
-        for (size_t c = c0; c <= c1; c++) rel[c + r] = d->chunk_off[c] - d->chunk_off[c0];
+        // (every run is headerless, the first one too: it starts behind the frame header.  A hint that does not describe the
+        // frame then fails the chunk walk of its run -- the call goes back to the general kernel, "a hint that does not fit is
+        // ignored" -- while an error a run reports is an error in the data and is reported as the frame's, at once)
+        const u64 from = c0 ? d->chunk_off[c0] : (u64)h.header_size;
+        for (size_t c = c0; c <= c1; c++) rel[c + r] = c == c0 ? 0 : d->chunk_off[c] - from;
     }
+    if (d->chunk_off[std::min(nchunks, per)] < h.header_size) return ZL_ERR(ZL_E_FALLBACK);
     if (!d->d_run_off.ensure(rel.size() * 8) || !d->d_run_results.ensure(nruns * 8)) return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_run_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     hint.sink_host = nullptr;
     for (size_t r = 0; r < nruns; r++) {
         const size_t c0 = r * per, c1 = std::min(nchunks, c0 + per);
         zl_frame_desc run;
-        run.src_off = fd.src_off + d->chunk_off[c0];
-        run.src_size = d->chunk_off[c1] - d->chunk_off[c0];
+        const u64 from = c0 ? d->chunk_off[c0] : (u64)h.header_size;
+        run.src_off = fd.src_off + from;
+        run.src_size = d->chunk_off[c1] - from;
         run.dst_off = fd.dst_off + (u64)c0 * ZL_BLOCK_MAX;
         run.dst_cap = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, content) - (u64)c0 * ZL_BLOCK_MAX;
         hint.d_chunk_off = (const u64*)d->d_run_off.p + c0 + r;
         hint.nchunks = (u32)(c1 - c0);
-        hint.headerless = c0 != 0 ? 1u : 0u;
+        hint.headerless = 1u;
         hint.not_last = c1 != nchunks ? 1u : 0u;
         hint.tail = (c1 == nchunks && h.has_checksum) ? 4u : 0u;
         const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p + r, 1, st, &d->side, &hint);
@@ -596,7 +602,10 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     if (hipMemcpyAsync(got.data(), d->d_run_results.p, nruns * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     u64 total = 0;
     for (size_t r = 0; r < nruns; r++) {
-        if (ZL_IS_ERR(got[r])) return ZL_ERR(ZL_E_FALLBACK);
+        if (ZL_IS_ERR(got[r])) {  // the data of this run is damaged: that is the frame's result
+            if (hipMemcpyAsync(d_result, (const u64*)d->d_run_results.p + r, 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            return 0;
+        }
         total += got[r];
     }
     if (total != content) return ZL_ERR(ZL_E_FALLBACK);
@@ -616,7 +625,8 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
 //     knows for every run which block last described the Huffman tree and the LL, OF and ML table, and hands those -- at
 //     most four -- to the pipeline as DONORS behind the run's own blocks: parsed like them, never decoded; the segments
 //     inherit from them as they do from earlier blocks of a frame (zl3_plan_kernel).
-// The general kernel -- one workgroup, 11 MB/s on such a frame -- stays the fallback for whatever does not fit.
+// The general kernel -- one workgroup, 11 MB/s on such a frame -- stays the fallback for whatever does not fit; damage inside a
+// block that a run reports is the frame's error at once.
 namespace runs {
 struct BlockUse { u8 uses, defs; };  // bit 0 Huffman tree, 1 LL, 2 OF, 3 ML: rides on an earlier block's table / describes (or resets) it
 // literals and sequences section headers (zstd.c:43146-43230, :43707-43735), only as far as the table modes; false: malformed
@@ -734,7 +744,15 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         left[0] = ~0ull;
         const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p, 1, st, &d->side, &hint);
         if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
-        if (left[0] == ~0ull) return ZL_ERR(ZL_E_FALLBACK);  // (the run reported an error: the general kernel names it)
+        if (left[0] == ~0ull) {
+            // the run reported an error.  The host has walked every block and handed the run its tables: what is left is damage
+            // inside a block, and that is the frame's result -- not 400 s of the general kernel finding the same
+            u64 word = 0;
+            if (hipMemcpyAsync(&word, d->d_run_results.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            if (!ZL_IS_ERR(word) || word == ZL_ERR(ZL_E_FALLBACK)) return ZL_ERR(ZL_E_FALLBACK);
+            if (hipMemcpyAsync(d_result, d->d_run_results.p, 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            return 0;
+        }
         out_pos += left[0];
         d->frame_runs++;
         for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
