@@ -611,7 +611,7 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     if (total != content) return ZL_ERR(ZL_E_FALLBACK);
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
     const u64 foot = d->chunk_off[nchunks] - 4;  // (has_checksum: the last chunk's listed size covers the 4 bytes)
-    if (zl3_check_content(d_dst + fd.dst_off, content, check ? d_src + fd.src_off + foot : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (zl3_check_content(d->big, d_dst + fd.dst_off, content, check ? d_src + fd.src_off + foot : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     return 0;
 }
 
@@ -759,7 +759,7 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     }
     if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos != h.content_size) return ZL_ERR(ZL_E_FALLBACK);
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
-    if (zl3_check_content(d_dst + fd.dst_off, out_pos, check ? d_src + fd.src_off + end_pos : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (zl3_check_content(d->big, d_dst + fd.dst_off, out_pos, check ? d_src + fd.src_off + end_pos : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     return 0;
 }
 

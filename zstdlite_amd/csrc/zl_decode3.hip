@@ -37,6 +37,7 @@
 #include "zl_format.h"
 #include "zl_host.h"
 #include "zl_kernels.h"
+#include "zl_xxh64.h"
 
 namespace {
 
@@ -686,27 +687,28 @@ __global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* ds
 // ---------------------------------------------------------------------------------------
 // the frame's result: checksum and size (zstd.c:41646-41660)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_frame_desc fd, const u8* src_base, const u8* dst_base, u64* result, u32 ignore_checksum) {
+// (have_hash: the host has run the XXH64 chain over the regenerated bytes -- zl3_hash_on_host says why -- and hands its low 32 bits in)
+__global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_frame_desc fd, const u8* src_base, const u8* dst_base, u64* result, u32 ignore_checksum, u32 have_hash, u32 hash) {
     __shared__ __align__(16) u8 tile[8192];
     __shared__ u64 acc[4];
     __shared__ u32 bc[4];
     u32 err = info->err;
     if (!err && info->pending) err = ZL_E_CORRUPTION;  // (cannot happen for links that only point backwards; kept as a guard)
     if (!err && info->has_checksum && !ignore_checksum) {
-        const u32 got = zl_xxh64_low32(tile, acc, bc, dst_base + fd.dst_off, info->produced);
+        const u32 got = have_hash ? hash : zl_xxh64_low32(tile, acc, bc, dst_base + fd.dst_off, info->produced);
         if (got != zl_rd_le(src_base + fd.src_off + info->end_pos, 4)) err = ZL_E_CHECKSUM_WRONG;
     }
     if (threadIdx.x == 0) *result = err ? ZL_ERR(err) : info->produced;
 }
 
 // the result word of a frame decoded in runs: its content checksum over the whole (zl3_check_content)
-__global__ __launch_bounds__(512) void zl3_check_kernel(const u8* content, u64 n, const u8* expect, u64* result) {
+__global__ __launch_bounds__(512) void zl3_check_kernel(const u8* content, u64 n, const u8* expect, u64* result, u32 have_hash, u32 hash) {
     __shared__ __align__(16) u8 tile[8192];
     __shared__ u64 acc[4];
     __shared__ u32 bc[4];
     u32 err = 0;
     if (expect) {
-        const u32 got = zl_xxh64_low32(tile, acc, bc, content, n);
+        const u32 got = have_hash ? hash : zl_xxh64_low32(tile, acc, bc, content, n);
         if (got != zl_rd_le(expect, 4)) err = ZL_E_CHECKSUM_WRONG;
     }
     if (threadIdx.x == 0) *result = err ? ZL_ERR(err) : n;
@@ -714,16 +716,12 @@ __global__ __launch_bounds__(512) void zl3_check_kernel(const u8* content, u64 n
 
 }  // namespace
 
-extern "C" hipError_t zl3_check_content(const u8* d_content, u64 n, const u8* d_expect, u64* d_result, hipStream_t st) {
-    hipLaunchKernelGGL(zl3_check_kernel, dim3(1), dim3(512), 0, st, d_content, n, d_expect, d_result);
-    return hipGetLastError();
-}
 
 #define ZL3_SINK_LOG 26      // host entries: the output is downloaded in pieces of 64 MiB behind the copy stage (zl3_hint::sink_host)
 #define ZL3_SINK_EVENTS 64
 struct zl3_state_s {
     DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec;
-    PinBuf h_spec;
+    PinBuf h_spec, h_hash;
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
     hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
 };
@@ -734,10 +732,50 @@ extern "C" void zl3_free(zl3_state* s) {
     for (DevBuf* b : {&s->info, &s->hblk, &s->braw, &s->seg_first, &s->blk_slot, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word,
                       &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot, &s->spec}) b->release();
     s->h_spec.release();
+    s->h_hash.release();
     for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
     if (s->fill_fork) (void)hipEventDestroy(s->fill_fork);
     if (s->fill_join) (void)hipEventDestroy(s->fill_join);
     delete s;
+}
+
+// The content checksum of a large frame whose bytes lie in DEVICE memory (the device-resident entries; the host entries check
+// theirs where the download put them).  XXH64 is one chain through the whole content (zl_xxh64.h): four GPU lanes run it at
+// 0.5 GB/s -- 2 s for a frame of 1 GiB that was decoded in 14 ms, which is what this pipeline did until the end of round 3
+// (scripts/dev/checksum_cost.py) -- a CPU core at 15 GB/s and more.  So the bytes come down in pieces through two pinned buffers,
+// the copy of one piece behind the hashing of the one before, as zl_compress_device_finish does for the same reason.
+static bool zl3_hash_on_host(zl3_state* s, const u8* d_ptr, u64 n, hipStream_t st, u32* low32) {
+    const size_t piece = (size_t)16 << 20;
+    if (!s->h_hash.ensure(2 * piece)) return false;
+    zlx::Xxh64 h;
+    u64 sent = 0;
+    size_t k = 0;
+    auto fetch = [&](size_t slot) -> size_t {
+        const size_t len = (size_t)std::min<u64>(piece, n - sent);
+        if (hipMemcpyAsync((u8*)s->h_hash.p + slot * piece, d_ptr + sent, len, hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+        sent += len;
+        return len;
+    };
+    size_t len_cur = n ? fetch(0) : 0;
+    if (n && !len_cur) return false;
+    while (len_cur) {
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        size_t len_next = 0;
+        if (sent < n) { len_next = fetch((k + 1) & 1); if (!len_next) return false; }
+        h.update((const u8*)s->h_hash.p + (k & 1) * piece, len_cur);
+        len_cur = len_next;
+        k++;
+    }
+    if (h.total != n) return false;
+    *low32 = h.low32();
+    return true;
+}
+
+extern "C" hipError_t zl3_check_content(zl3_state* s, const u8* d_content, u64 n, const u8* d_expect, u64* d_result, hipStream_t st) {
+    u32 hash = 0;
+    if (d_expect && (!s || !zl3_hash_on_host(s, d_content, n, st, &hash))) return hipErrorUnknown;
+    hipLaunchKernelGGL(zl3_check_kernel, dim3(1), dim3(512), 0, st, d_content, n, d_expect, d_result, d_expect ? 1u : 0u, hash);
+    return hipGetLastError();
 }
 
 // Decodes one large frame.  Returns 0 (the result word of the frame has been written on the device),
@@ -931,7 +969,12 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (nsink && !info.err) *hint->sunk = (u64)nsink << ZL3_SINK_LOG;  // (a frame that failed or goes to the general kernel is downloaded as a whole, whatever was copied)
         if (hint && hint->run_out && !info.err) { hint->run_out[0] = info.produced; for (int k = 0; k < 3; k++) hint->run_out[1 + k] = info.rep_end[k]; }
     }
-    hipLaunchKernelGGL(zl3_finish_kernel, dim3(1), dim3(512), 0, st, d.info, fd, d_src, (const u8*)d_dst, d_result, (u32)ignore_checksum);
+    u32 have_hash = 0, hash = 0;
+    if (!ignore_checksum && !info.err && info.has_checksum) {  // (the host entries come with ignore_checksum set: they hash what they have downloaded)
+        if (!zl3_hash_on_host(s, d_dst + fd.dst_off, info.produced, st, &hash)) return ZL_ERR(ZL_E_GENERIC);
+        have_hash = 1;
+    }
+    hipLaunchKernelGGL(zl3_finish_kernel, dim3(1), dim3(512), 0, st, d.info, fd, d_src, (const u8*)d_dst, d_result, (u32)ignore_checksum, have_hash, hash);
     stamp("finish");
     return hipGetLastError() == hipSuccess ? 0 : ZL_ERR(ZL_E_GENERIC);
 }
