@@ -303,6 +303,17 @@ def test_one_frame_with_a_checksum_is_still_decoded_on_every_slot():
         assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)
         bad = buf[:r].copy(); bad[first // 2] ^= 0x01
         assert _lib.is_error(L.zl_decompressDCtx(dctx, back.ctypes.data, n, bad.ctypes.data, r))
+        # ... and without the table: the frame is walked, its bytes come down while the last stage runs and a second thread hashes
+        # them as they land (zl3_hint::sink_hash), the rest behind the call
+        L.zl_CCtx_setParameter(cctx, 9006, 0)
+        r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+        assert not _lib.is_error(r) and int(L.zl_findFrameCompressedSize(buf.ctypes.data, r)) == r
+        back.fill(0)
+        assert L.zl_decompressDCtx(dctx, back.ctypes.data, n, buf.ctypes.data, r) == n and np.array_equal(back, host)
+        bad = buf[:r].copy(); bad[r - 1] ^= 0x80
+        e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, bad.ctypes.data, r)
+        assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)
+        assert L.zl_decompressDCtx(dctx, back.ctypes.data, n, buf.ctypes.data, r) == n and np.array_equal(back, host)
     finally:
         L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -237,6 +238,7 @@ struct zl_dctx_s {
     size_t frame_runs = 0;             // runs of blocks decoded by decode_walked_frame_in_runs / decode_hinted_frame_in_runs so far
     u8* sink_host = nullptr;   // host entries decoding one large frame: where its bytes go (zl3_hint::sink_host)
     u64 sunk = 0;              // ... and how many of them are there already
+    void* sink_hash = nullptr; // ... and the running XXH64 of those (zl3_hint::sink_hash), when the frame carries a content checksum that is to be checked
     bool ev_valid = false;
     double kernel_ms = 0;
     double stage_ms[4] = {0, 0, 0, 0};
@@ -580,7 +582,7 @@ size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     if (d->chunk_off[std::min(nchunks, per)] < h.header_size) return ZL_ERR(ZL_E_FALLBACK);
     if (!d->d_run_off.ensure(rel.size() * 8) || !d->d_run_results.ensure(nruns * 8)) return kGpuUnavailable;
     if (hipMemcpyAsync(d->d_run_off.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    hint.sink_host = nullptr;
+    hint.sink_host = nullptr; hint.sink_hash = nullptr;
     for (size_t r = 0; r < nruns; r++) {
         const size_t c0 = r * per, c1 = std::min(nchunks, c0 + per);
         zl_frame_desc run;
@@ -700,7 +702,7 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     std::vector<zl3_hblk> hb;
     u64 out_pos = 0, left[4] = {0, 1, 4, 8};
     u32 cur[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the latest block in front of the run that describes the Huffman tree, the LL, OF, ML table
-    hint.host_blocks = nullptr; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.sink_host = nullptr;
+    hint.host_blocks = nullptr; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.sink_host = nullptr; hint.sink_hash = nullptr;
     hint.headerless = 1; hint.not_last = 0; hint.tail = 0; hint.size_unknown = 1; hint.run_out = left;
     hint.dict_id = 0;
     for (size_t r = 0; r < nruns; r++) {
@@ -840,6 +842,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         }
         hint.sink_host = (n == 1 && d->sink_host) ? d->sink_host : nullptr;  // (a host entry decoding ONE frame: the output is downloaded as it is finished)
         hint.sunk = &d->sunk;
+        hint.sink_hash = hint.sink_host ? d->sink_hash : nullptr;
         if (i < d->host_walk.size() && !d->host_walk[i].blocks.empty()) {
             hint.host_blocks = d->host_walk[i].blocks.data();
             hint.nblocks = (u32)d->host_walk[i].blocks.size();
@@ -1132,7 +1135,29 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
     std::vector<size_t> res(nruns, 0);
     u32 tail = 0;  // ONE frame with a content checksum: its 4 bytes are covered by the last chunk's listed size
     if (t.one_frame) { FrameHeader h; if (!ZL_IS_ERR(parse_frame_header(h, src, t.data_bytes)) && !h.skippable && h.has_checksum) tail = 4; }
+    // ONE frame's content checksum covers all of it, one chain (zl_xxh64.h): a thread of its own follows the runs in order and hashes
+    // every run's bytes as soon as they are in the caller's buffer -- beside the later runs' work instead of behind all of it
+    // (1 GiB: 38 ms of one core, which used to double the call)
+    const bool hashing = tail && !d->ignore_checksum;
+    std::vector<std::atomic<int>> landed(nruns);  // 0: not yet, 1: the run's bytes are there, 2: the run failed
+    for (auto& x : landed) x.store(0);
+    zlx::Xxh64 hasher;
+    auto range_of = [&](size_t s, size_t& c0, size_t& c1) { c0 = std::min<size_t>(t.nchunks, (nsec * s / nruns) * sec); c1 = std::min<size_t>(t.nchunks, (nsec * (s + 1) / nruns) * sec); };
+    std::thread hash_thread;
+    if (hashing) hash_thread = std::thread([&]() {
+        for (size_t s = 0; s < nruns; s++) {
+            int st_ = 0;
+            while ((st_ = landed[s].load(std::memory_order_acquire)) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (st_ != 1) return;
+            size_t c0, c1;
+            range_of(s, c0, c1);
+            if (c0 == c1) continue;
+            const u64 out0 = (u64)c0 * ZL_BLOCK_MAX, out1 = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, t.content);
+            hasher.update(dst + out0, (size_t)(out1 - out0));
+        }
+    });
     run_on_slots(d, plan, nruns, [&](int w, size_t s) {
+        struct Mark { std::atomic<int>& f; size_t& r; ~Mark() { f.store(ZL_IS_ERR(r) ? 2 : 1, std::memory_order_release); } } mark{landed[s], res[s]};
         const size_t c0 = std::min<size_t>(t.nchunks, (nsec * s / nruns) * sec), c1 = std::min<size_t>(t.nchunks, (nsec * (s + 1) / nruns) * sec);
         if (c0 == c1) return;
         const u64 out0 = (u64)c0 * ZL_BLOCK_MAX, out1 = std::min<u64>((u64)c1 * ZL_BLOCK_MAX, t.content);
@@ -1150,11 +1175,12 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
         p->run_tail = 0;
         if (!ZL_IS_ERR(res[s]) && res[s] != out1 - out0) res[s] = ZL_ERR(ZL_E_FALLBACK);
     });
+    if (hash_thread.joinable()) hash_thread.join();
     for (size_t s = 0; s < nruns; s++) if (ZL_IS_ERR(res[s])) return res[s];
     d->last_slots = slots;
-    if (tail && !d->ignore_checksum) {  // the runs regenerate pieces; the checksum covers the whole
-        const size_t v = verify_frame_checksum_on_host(src, t.data_bytes, dst, (size_t)t.content);
-        if (ZL_IS_ERR(v)) return v;
+    if (hashing) {  // the runs regenerate pieces; the checksum covers the whole
+        if (hasher.total != t.content || t.data_bytes < 4) return ZL_ERR(ZL_E_FALLBACK);
+        if (hasher.low32() != rd_le(src + t.data_bytes - 4, 4)) return ZL_ERR(ZL_E_CHECKSUM_WRONG);
     }
     return (size_t)t.content;
 }
@@ -1240,7 +1266,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     }
     // ---- index frames on the host (serial header walk, zstd.c:41335)
     std::vector<zl_frame_desc> table;
-    std::vector<u8> known;
+    std::vector<u8> known, has_ck;
     std::vector<zl_dctx_s::HostWalk> walks;  // per data frame: its blocks when it is large enough for the large-frame pipeline
     size_t pos = 0;
     bool any = false;
@@ -1261,6 +1287,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             fd.dst_cap = h.content_size;
             table.push_back(fd);
             known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
+            has_ck.push_back(h.has_checksum ? 1 : 0);
             if (hw.blocks.size() <= ZL2_MAXB || hw.blocks.size() != h.nblocks) hw.blocks.clear();  // (small frames take the lane pipeline, which indexes on the device)
             hw.host_src = src + pos;
             walks.push_back(std::move(hw));
@@ -1309,6 +1336,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     size_t total = 0, i = 0;
     std::vector<u8> big(table.size(), 0);  // frames the large-frame pipeline decoded: their content checksum is verified below, on the host
+    zlx::Xxh64 sink_hasher;                // ... for ONE frame whose bytes come down while its last stage runs: fed piece by piece as they land (zl3_hint::sink_hash)
     while (i < table.size()) {
         size_t j = i;
         u64 off = total;
@@ -1325,11 +1353,13 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         d->host_walk.assign(std::make_move_iterator(walks.begin() + i), std::make_move_iterator(walks.begin() + j));
         d->sink_host = (table.size() == 1 && known[0] && d->pipeline) ? (u8*)dst : nullptr;
         d->sunk = 0;
+        d->sink_hash = (d->sink_host && has_ck[0] && !d->ignore_checksum) ? &sink_hasher : nullptr;  // the checksum's chain runs beside the download
         d->host_verify = true;
         size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
         d->host_verify = false;
         d->host_walk.clear();
         d->sink_host = nullptr;
+        d->sink_hash = nullptr;
         if (ZL_IS_ERR(e)) return e;
         for (size_t k = 0; k < cnt && k < d->took_big.size(); k++) big[i + k] = d->took_big[k];
         if (hipMemcpyAsync(d->h_results.p, d->d_results.p, cnt * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -1351,6 +1381,12 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         for (size_t k = 0; k < table.size(); k++) {
             if (!big[k]) continue;
             const u64 end = k + 1 < table.size() ? table[k + 1].dst_off : (u64)total;
+            if (table.size() == 1 && have != 0 && sink_hasher.total == have && has_ck[0] && table[0].src_size >= 4) {
+                // the chain has followed the download so far: the rest of the frame, and the comparison (zstd.c:41646-41660)
+                sink_hasher.update((const u8*)dst + have, total - have);
+                if (sink_hasher.low32() != rd_le(src + table[0].src_off + table[0].src_size - 4, 4)) return ZL_ERR(ZL_E_CHECKSUM_WRONG);
+                continue;
+            }
             const size_t v = verify_frame_checksum_on_host(src + table[k].src_off, (size_t)table[k].src_size, (const u8*)dst + table[k].dst_off, (size_t)(end - table[k].dst_off));
             if (ZL_IS_ERR(v)) return v;
         }

@@ -30,6 +30,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 
 #include "zl_blocks.h"
 #include "zl_decode3.h"
@@ -723,6 +725,7 @@ struct zl3_state_s {
     DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec;
     PinBuf h_spec, h_hash;
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
+    hipEvent_t sink_done[ZL3_SINK_EVENTS] = {};  // behind the download of each piece (zl3_hint::sink_hash)
     hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
 };
 
@@ -734,6 +737,7 @@ extern "C" void zl3_free(zl3_state* s) {
     s->h_spec.release();
     s->h_hash.release();
     for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->sink_done) if (e) (void)hipEventDestroy(e);
     if (s->fill_fork) (void)hipEventDestroy(s->fill_fork);
     if (s->fill_join) (void)hipEventDestroy(s->fill_join);
     delete s;
@@ -955,13 +959,43 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
             }
         }
         // the download of what is finished, piece by piece behind the events, on a stream of its own (the host thread waits in
-        // these calls when the memory is pageable; the copy kernels are all queued by now)
-        for (u32 k = 0; k < nsink; k++) {
-            const u64 off = (u64)k << ZL3_SINK_LOG;
-            if (hipStreamWaitEvent(side->part_stream[1], s->sink_ev[k], 0) != hipSuccess ||
-                hipMemcpyAsync(hint->sink_host + fd.dst_off + off, d_dst + fd.dst_off + off, (size_t)1 << ZL3_SINK_LOG, hipMemcpyDeviceToHost, side->part_stream[1]) != hipSuccess)
-                return ZL_ERR(ZL_E_GENERIC);
+        // these calls when the memory is pageable; the copy kernels are all queued by now).  With a content checksum to check
+        // (sink_hash) a second thread runs the XXH64 chain over every piece as soon as the event behind its copy has fired: the
+        // calling thread is busy inside the copies, and hashing 1 GiB behind them instead of beside them costs 22 - 38 ms.
+        std::atomic<u32> recorded{0};
+        std::atomic<bool> hash_bad{false};
+        std::thread hash_thread;
+        if (nsink && hint->sink_hash) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            for (u32 k = 0; k < nsink; k++)
+                if (!s->sink_done[k] && hipEventCreateWithFlags(&s->sink_done[k], hipEventDisableTiming) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            hash_thread = std::thread([&, dev]() {
+                (void)hipSetDevice(dev);
+                zlx::Xxh64* hx = (zlx::Xxh64*)hint->sink_hash;
+                for (u32 k = 0; k < nsink; k++) {
+                    u32 seen;
+                    while ((seen = recorded.load(std::memory_order_acquire)) <= k && seen != 0xFFFFFFFFu) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    if (seen == 0xFFFFFFFFu || hipEventSynchronize(s->sink_done[k]) != hipSuccess) { hash_bad.store(true); return; }
+                    hx->update(hint->sink_host + fd.dst_off + ((u64)k << ZL3_SINK_LOG), (size_t)1 << ZL3_SINK_LOG);
+                }
+            });
         }
+        bool copies_ok = true;
+        for (u32 k = 0; k < nsink && copies_ok; k++) {
+            const u64 off = (u64)k << ZL3_SINK_LOG;
+            copies_ok = hipStreamWaitEvent(side->part_stream[1], s->sink_ev[k], 0) == hipSuccess &&
+                        hipMemcpyAsync(hint->sink_host + fd.dst_off + off, d_dst + fd.dst_off + off, (size_t)1 << ZL3_SINK_LOG, hipMemcpyDeviceToHost, side->part_stream[1]) == hipSuccess;
+            if (copies_ok && hash_thread.joinable()) {
+                copies_ok = hipEventRecord(s->sink_done[k], side->part_stream[1]) == hipSuccess;
+                if (copies_ok) recorded.store(k + 1, std::memory_order_release);
+            }
+        }
+        if (hash_thread.joinable()) {
+            if (!copies_ok) recorded.store(0xFFFFFFFFu, std::memory_order_release);
+            hash_thread.join();
+        }
+        if (!copies_ok || hash_bad.load()) return ZL_ERR(ZL_E_GENERIC);
         if (nsink && hipStreamSynchronize(side->part_stream[1]) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("resolve");
