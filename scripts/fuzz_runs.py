@@ -37,6 +37,25 @@ bad = 0
 t0 = time.time()
 
 
+import torch
+from zstdlite_amd.device import DeviceCodec
+codec = DeviceCodec()
+
+
+def ours_device(f, n, nrun, with_copy):
+    """the device-resident entry: with the caller's host copy of the frame, or with device pointers only (the library then
+    brings the compressed bytes down itself for the run plan); the content checksum is hashed on the host from device memory"""
+    assert L.zl_DCtx_setParameter(codec.dctx, 9009, nrun) == 0
+    h = np.frombuffer(f, dtype=np.uint8).copy()
+    d_src = torch.from_numpy(h).cuda()
+    d_dst = torch.zeros(max(n, 1), dtype=torch.uint8, device="cuda")
+    try:
+        total, _ = codec.decompress(d_src, codec.frame_table([len(f)], [n]), d_dst, host_copy=h if with_copy else None)
+    except z.ZstdError:
+        return (1 << 64) - 1, None
+    return total, d_dst.cpu().numpy()
+
+
 def ours(f, n, nrun):
     assert L.zl_DCtx_setParameter(dctx, 9009, nrun) == 0
     out = np.zeros(max(n, 1), dtype=np.uint8)
@@ -70,7 +89,11 @@ for rd in range(rounds):
         b = bytes(b)
         nrun = int(rng.integers(16, 80))
         code, want = o.decompress_code(b, len(data))
-        r, out = ours(b, len(data), nrun)
+        entry = int(rng.integers(0, 4))  # host entry twice as often as each flavour of the device entry
+        if entry < 2 or len(b) < 32 or is_error(o.L.zlo_find_frame_compressed_size(b, len(b))) or o.L.zlo_find_frame_compressed_size(b, len(b)) != len(b):
+            r, out = ours(b, len(data), nrun)  # (the device entry is handed exactly one frame: the host entry takes the cut and the glued ones)
+        else:
+            r, out = ours_device(b, len(data), nrun, entry == 2)
         if is_error(code) != is_error(r):
             bad += 1
             print(f"FAIL round {rd} frame {i} run length {nrun}: oracle {o.error_name(code) if is_error(code) else code}, ours {_lib.error_name(r) if is_error(r) else r}")

@@ -363,6 +363,12 @@ def test_frames_decoded_in_runs_of_blocks(ref, oracle):
             total, _ = codec.decompress(d_src, codec.frame_table([len(comp)], [len(data)]), d_dst, host_copy=h)
             assert total == len(data) and bytes(d_dst.cpu().numpy()) == data
             assert int(L.zl_dctx_frame_runs(codec.dctx)) > before
+            # ... and without it: the library brings the compressed bytes down itself for the run plan
+            before = int(L.zl_dctx_frame_runs(codec.dctx))
+            d_dst.zero_()
+            total, _ = codec.decompress(d_src, codec.frame_table([len(comp)], [len(data)]), d_dst)
+            assert total == len(data) and bytes(d_dst.cpu().numpy()) == data
+            assert int(L.zl_dctx_frame_runs(codec.dctx)) > before
         comp, data = frames[1]
         h = np.frombuffer(comp, dtype=np.uint8).copy()
         h[-2] ^= 0x20  # the footer

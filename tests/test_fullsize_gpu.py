@@ -404,6 +404,19 @@ def test_reference_frame_of_more_than_4_gib_is_decoded_in_runs():
         assert int(L.zl_dctx_frame_runs(dctx)) >= 5
         assert np.array_equal(back, host)
         assert dt < 60, f"{dt:.1f} s"
+        # the device-resident entry, with nothing but device pointers: the compressed bytes come down once for the run plan
+        from zstdlite_amd.device import DeviceCodec
+        codec = DeviceCodec()
+        d_src = torch.from_numpy(comp[:r]).to(dev)
+        d_out = torch.zeros(n, dtype=torch.uint8, device=dev)
+        t0 = time.time()
+        got, _ = codec.decompress(d_src, codec.frame_table([r], [n]), d_out)
+        assert got == n and time.time() - t0 < 60
+        assert int(L.zl_dctx_frame_runs(codec.dctx)) >= 5
+        back[:] = d_out.cpu().numpy()
+        assert np.array_equal(back, host)
+        codec.close()
+        del d_src, d_out
         comp[r - 2] ^= 0x04   # the footer
         e = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
         assert _lib.is_error(e) and "match checksum" in _lib.error_name(e), _lib.error_name(e)

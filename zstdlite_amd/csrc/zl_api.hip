@@ -233,6 +233,7 @@ struct zl_dctx_s {
     bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
     std::vector<zl_dctx_s*> peers;
+    ByteBuf h_run_src;                 // decode_walked_frame_in_runs: the compressed bytes of a frame the caller holds in device memory only
     DevBuf d_chunk_off, d_run_off, d_run_results;  // (d_run_off, d_run_results: decode_hinted_frame_in_runs)
     size_t large_frames = 0;
     size_t frame_runs = 0;             // runs of blocks decoded by decode_walked_frame_in_runs / decode_hinted_frame_in_runs so far
@@ -862,10 +863,22 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             e3 = decode_hinted_frame_in_runs(d, tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, st, base);
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }
-        if (e3 != 0 && i < d->host_walk.size() && d->host_walk[i].host_src && !has_dict && !d->run_headerless && !d->run_not_last &&
+        if (e3 != 0 && !has_dict && !d->run_headerless && !d->run_not_last &&
             (tbl[i].dst_cap >= 0xFFFFD000ull || tbl[i].src_size >= 0xFFFFFF00ull || d->run_blocks)) {
+            const u8* host_src = i < d->host_walk.size() ? d->host_walk[i].host_src : nullptr;
+            if (!host_src) {
+                // the device-resident entry without a host copy of the frame: the run plan needs a look into every block, which
+                // is the host's kind of work -- the compressed bytes come down once (3 GB of a 4.5 GiB frame: 0.1 - 0.3 s, against
+                // 400 s of the general kernel)
+                d->h_run_src.n = 0;
+                u8* at = d->h_run_src.grow((size_t)tbl[i].src_size);
+                if (!at) return kGpuUnavailable;
+                if (hipMemcpyAsync(at, d_src + tbl[i].src_off, (size_t)tbl[i].src_size, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+                host_src = at;
+            }
             if (!d->d_run_results.ensure(64)) return kGpuUnavailable;
-            e3 = decode_walked_frame_in_runs(d, tbl[i], d->host_walk[i].host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
+            e3 = decode_walked_frame_in_runs(d, tbl[i], host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
+            if (d->h_run_src.cap > ((size_t)64 << 20)) { free(d->h_run_src.p); d->h_run_src.p = nullptr; d->h_run_src.n = d->h_run_src.cap = 0; }  // (not kept: gigabytes)
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }
         if (e3 != 0) e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
@@ -1175,6 +1188,7 @@ size_t decompress_sharded_with_seek_table(zl_dctx* d, u8* dst, const u8* src, co
         p->run_tail = 0;
         if (!ZL_IS_ERR(res[s]) && res[s] != out1 - out0) res[s] = ZL_ERR(ZL_E_FALLBACK);
     });
+    for (auto& x : landed) { int zero = 0; (void)x.compare_exchange_strong(zero, 2); }  // (every run has marked itself; a guard against waiting for one that never ran)
     if (hash_thread.joinable()) hash_thread.join();
     for (size_t s = 0; s < nruns; s++) if (ZL_IS_ERR(res[s])) return res[s];
     d->last_slots = slots;
