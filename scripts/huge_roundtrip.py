@@ -26,18 +26,23 @@ for layout, seek, slots in ((0, 0, 1), (1, 0, 1), (2, 1, 3), (1, 1, 2)):
     cctx, dctx = L.zl_createCCtx(), L.zl_createDCtx()
     L.zl_CCtx_setParameter(cctx, 9003, layout); L.zl_CCtx_setParameter(cctx, 9006, seek); L.zl_CCtx_setParameter(cctx, 9007, slots)
     L.zl_DCtx_setParameter(dctx, 9008, slots)
-    t1 = time.time()
-    r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
-    assert not _lib.is_error(r), _lib.error_name(r)
-    t2 = time.time()
-    back.fill(0)
-    r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
-    t3 = time.time()
+    for rep in range(2):  # (the first call of a context allocates its device and pinned buffers -- gigabytes here; the second is the rate)
+        t1 = time.time()
+        r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
+        assert not _lib.is_error(r), _lib.error_name(r)
+        t2 = time.time()
+        back.fill(0)
+        t2b = time.time()
+        r2 = L.zl_decompressDCtx(dctx, back.ctypes.data, n, comp.ctypes.data, r)
+        t3 = time.time()
+        if rep == 0:
+            first = (n / (t2 - t1) / 1e9, n / (t3 - t2b) / 1e9)
+    t2 = t2 - 0.0
     assert r2 == n, _lib.error_name(r2) if _lib.is_error(r2) else r2
     assert np.array_equal(back, host), "our decoder: bytes differ"
     ok_ref = ref.decompress(comp[:r].tobytes(), n) == host.tobytes()
     assert ok_ref, "reference decoder: bytes differ"
-    print(f"layout {layout} seek {seek} slots {slots}: {r} bytes, compress {n / (t2 - t1) / 1e9:.1f} GB/s, decompress {n / (t3 - t2) / 1e9:.1f} GB/s, reference decode ok", flush=True)
+    print(f"layout {layout} seek {seek} slots {slots}: {r} bytes, compress {n / (t2 - t1) / 1e9:.1f} GB/s, decompress {n / (t3 - t2b) / 1e9:.1f} GB/s (first call of the contexts: {first[0]:.1f} / {first[1]:.1f}), reference decode ok", flush=True)
     L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
 # device-resident entries
 for layout in ("frames", "one_frame"):
