@@ -37,7 +37,6 @@ for layout, seek, slots in ((0, 0, 1), (1, 0, 1), (2, 1, 3), (1, 1, 2)):
         t3 = time.time()
         if rep == 0:
             first = (n / (t2 - t1) / 1e9, n / (t3 - t2b) / 1e9)
-    t2 = t2 - 0.0
     assert r2 == n, _lib.error_name(r2) if _lib.is_error(r2) else r2
     assert np.array_equal(back, host), "our decoder: bytes differ"
     ok_ref = ref.decompress(comp[:r].tobytes(), n) == host.tobytes()

@@ -554,11 +554,11 @@ size_t dctx_prepare_dict(zl_dctx* d, hipStream_t st) {
 // ONE frame of this library of 4 GiB or more, device-resident, with the caller's chunk hint (zl_decompress_device_hint): the
 // large-frame pipeline plans below 4 GiB (32-bit positions), the general kernel is one workgroup for the whole frame (400 s
 // for 4.5 GiB).  The hint says where every chunk's blocks start and sections of 512 chunks are self-contained (include/
-// zl_hip.h), so the frame goes through the pipeline in runs of 16 sections (1 GiB of content) -- the first with the header,
-// the others as headerless runs of blocks, only the last with the Last_Block and the footer: what the host entries do with a
-// seek table (decompress_sharded_with_seek_table).  The content checksum covers the whole: one more kernel behind the runs.
-// Returns 0 with the frame's result word written, or ZL_ERR(ZL_E_FALLBACK): hint and frame do not agree, or a run failed --
-// the general kernel then decides what the frame is.
+// zl_hip.h), so the frame goes through the pipeline in runs of 16 sections (1 GiB of content), each a headerless run of blocks
+// (the first starts behind the frame header), only the last with the Last_Block and the footer: what the host entries do with a
+// seek table (decompress_sharded_with_seek_table).  The content checksum covers the whole: hashed behind the runs
+// (zl3_check_content).  Returns 0 with the frame's result word written -- the size, or the error of the first run whose data
+// is damaged -- or ZL_ERR(ZL_E_FALLBACK) when hint and frame do not agree: the general kernel then decides what the frame is.
 size_t decode_hinted_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8* d_src, u8* d_dst, u64* d_result, hipStream_t st, zl3_hint hint) {
     const size_t nchunks = d->chunk_off.size() - 1;
     u8 head[18];  // (the longest frame header, zstd.h ZSTD_FRAMEHEADERSIZE_MAX)
@@ -720,7 +720,7 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
             if (!seen) dn[nd++] = cur[q];
         }
         std::sort(dn, dn + nd);
-        u64 s0 = blk[b0].at - 3;
+        const u64 s0 = blk[b0].at - 3;
         const u64 s1 = b1 < nb ? blk[b1].at - 3 : end_pos;
         const u64 base = nd ? std::min<u64>(s0, blk[dn[0]].at - 3) : s0;
         if (s1 - base >= 0xFFFFFF00ull || out_pos > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);

@@ -309,7 +309,7 @@ bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
 // Does this call append the seek table?  On request (ZL_c_seekTable) -- and, unasked, behind ONE frame of 4 GiB or more: the
 // large-frame decoder plans frames below 4 GiB (32-bit positions, zl_decode3.hip), a larger one it could only hand to the
 // general kernel, one workgroup for the whole frame: 4.5 GiB decoded in 400 s (scripts/huge_roundtrip.py).  With the table
-// the same frame is decoded section by section (16 GB/s from host memory).  The table is a skippable frame behind the data
+// the same frame is decoded section by section (27 - 33 GB/s from host memory).  The table is a skippable frame behind the data
 // frame: a reader that takes the first frame gets all of the content, as without it.
 inline bool wants_seek_table(const zl_cctx* c, size_t n, bool one_frame) {
     return c->seek_table || (one_frame && n >= (size_t)0xFFFFD000ull);
