@@ -179,7 +179,13 @@ typedef struct {
     uint64_t dst_cap;  /* bytes available there */
 } zl_frame_t;
 
-/* Decode nframes frames described by the host table `frames` from d_src into d_dst. */
+/* Decode nframes frames described by the host table `frames` from d_src into d_dst.
+ * Frames of more than eight blocks are decoded one after the other by the large-frame pipeline, and this call waits for
+ * each of them (it reads their block counts back); for such a frame with a content checksum -- unless
+ * ZL_d_forceIgnoreChecksum is set -- the regenerated bytes are also brought to the host in 16 MiB pieces and hashed there:
+ * XXH64 is one serial chain, 0.5 GB/s on GPU lanes against 25 GB/s and more on a CPU core.  Frames of
+ * 4 GiB and more are decoded in runs of blocks (ZL_d_runBlocks above); without zl_decompress_device_hint_host_copy their
+ * COMPRESSED bytes are brought down once for the run plan. */
 size_t zl_decompress_device_async(zl_dctx *dctx, void *d_dst, const void *d_src, const zl_frame_t *frames,
                                   size_t nframes, void *stream);
 /* results (host, may be NULL) receives the per-frame regenerated sizes / error codes. */
