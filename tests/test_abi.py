@@ -86,6 +86,15 @@ def test_context_options_mirror_reference_glue():
         z.zstd_compress(12345)
     info = z.zstd_info(open(os.path.join(GOLDEN, "data.json.zst"), "rb").read())
     assert info == {"compressed_size": 126, "uncompressed_size": 172, "dict_id": 0, "has_checksum": True}
+    # the knobs the reference does not have are bounded like its own (include/zl_hip.h): ZL_d_runBlocks 0 or 16..8192,
+    # ZL_d_devices 0..64; an unknown parameter is refused, not ignored
+    L = _lib.lib()
+    d = z.zstd_dctx()
+    for value, ok in ((0, True), (16, True), (8192, True), (15, False), (8193, False), (-1, False)):
+        assert (L.zl_DCtx_setParameter(d._ptr, 9009, value) == 0) == ok, value
+    assert L.zl_DCtx_setParameter(d._ptr, 9008, 65) != 0 and L.zl_DCtx_setParameter(d._ptr, 9008, 2) == 0
+    assert _lib.is_error(L.zl_DCtx_setParameter(d._ptr, 4242, 1))
+    assert L.zl_dctx_frame_runs(d._ptr) == 0 and L.zl_dctx_large_frames(d._ptr) == 0
 
 
 def _build_c_consumer(tmp_path):
