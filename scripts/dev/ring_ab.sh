@@ -5,6 +5,7 @@ for v in "$@"; do
   if [ "$v" = base ]; then unset ZL_HIP_LIB; else export ZL_HIP_LIB=$PWD/zstdlite_amd/build/variants/libzl_hip.$v.so; fi
   echo "=== $v"
   ZL_PROF=1 python scripts/kernel_bench.py 268435456 text,iid10,rand,int20 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/entropy .*//'
-  ZL_PROF=1 python scripts/kernel_bench.py 469762048 text 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/entropy .*//'
-  ZL_PROF=2 python scripts/kernel_bench.py 268435456 text 2>&1 | grep "match phases"
+  ZL_PROF=1 python scripts/kernel_bench.py 939524096 text 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/entropy .*//'
+  ZL_PROF=1 python scripts/kernel_bench.py 1073741824 mix 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/scan .*//'
+  [ -n "$ZL_AB_STAMPS" ] && ZL_PROF=2 python scripts/kernel_bench.py 268435456 text 2>&1 | grep "match phases"
 done

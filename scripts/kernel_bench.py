@@ -2,14 +2,14 @@
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
-from zstdlite_amd.device import DeviceCodec, gen_device
+from zstdlite_amd.device import DeviceCodec, gen_device, gen_mixed
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else (256 << 20)
 kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["rand", "iid10", "text", "int20"]
 import os
 codec = DeviceCodec(profile=int(os.environ.get("ZL_PROF", "2")), frame_layout=os.environ.get("ZL_LAYOUT", "frames"))  # ZL_LAYOUT=one_frame: the windowed layout's kernels
 for kind in kinds:
-    src = gen_device(kind, n, dev)
+    src = gen_mixed(n, dev)[0] if kind == "mix" else gen_device(kind, n, dev)
     comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=dev)
     back = torch.empty(n, dtype=torch.uint8, device=dev)
     best = {}

@@ -40,7 +40,7 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #include "zl_match_common.h"
 
-template <int LLOG, int SLOG, int RLOG = 0>
+template <int LLOG, int SLOG>
 struct MatchSharedT {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
     // mean the nearest such position in front of it, so candidates reach 64 KiB back (an older entry
@@ -51,12 +51,9 @@ struct MatchSharedT {
     u16 jump[2][WIN];
     u8 mark[WIN];
     u32 cand[WIN];  // [7:0] match length, [31:8] offset of each lane's best match
+    u32 cand_end;   // always 0: what the window's last lane reads as its neighbour's candidate (lean body)
     u32 scan_a[4], scan_b[4];
     u32 rep;      // offset of the most recent sequence (repeat-offset candidate)
-    // RLOG != 0: the chunk's most recent 2^RLOG bytes (position x at x mod 2^RLOG; the first 16 bytes once more behind the
-    // end, so that an 8-byte read never wraps).  A window's own bytes, its candidates' bytes and the extension words are
-    // read from here with ds_read_b64 (gfx950 takes unaligned LDS addresses); only candidates older than the ring go to memory.
-    alignas(16) u8 ring[RLOG ? (1 << RLOG) + 16 : 16];
 };
 
 __device__ __forceinline__ void block_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
@@ -143,8 +140,11 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 // function of the data (sequences found in the previous window), so the output stays deterministic.
 // ---------------------------------------------------------------------------------------
 #define WIN2 (2 * ENC_THREADS)
-#ifndef ZL_RING_LOG
-#define ZL_RING_LOG 0   // bulk instantiation: log2 of the bytes of the chunk kept in LDS (0: none, every candidate is gathered from memory).  Measured in round 4 (profiles/r04_ring_experiment.txt): 2^13 / 2^14 / 2^15 bytes = 5 / 4 / 2 workgroups per CU ran text at 4.31 / 4.41 / 6.61 ms per 256 MiB against 3.61 without -- an iteration is a chain of dependent steps that lasts 6800 cycles even with two workgroups per CU, and occupancy is what hides it
+#ifndef ZL_MATCH_SGPRS
+#define ZL_MATCH_SGPRS 88  // a CU admits seven 256-thread workgroups up to 96 scalar registers per wave (six from 97; MI355X_MICROARCH.md, Residency); the lean body took the bulk instantiation to 97
+#endif
+#ifndef ZL_LEAN
+#define ZL_LEAN 1  // the bulk path's interior windows take the lean stride-1 body (0: the general body everywhere)
 #endif
 #ifndef ZL_DENSE_SEQS
 #define ZL_DENSE_SEQS 24  // sequences per 512 bytes from which on the stride-1 body is used
@@ -205,14 +205,9 @@ __device__ __forceinline__ bool worth_it(u32 len, u32 off, u32 rep) {
 // HI: the operating point of levels >= 5 (no dictionary): tables of 2^14 + 2^13 entries (48 KiB of LDS: three workgroups per
 // CU instead of seven) and verification up to 72 bytes per lane.  The CPU model of the parse (scripts/dev/sim/sim.c) gives
 // text +3.2 %, python sources +5.3 % of ratio for it; what the device gives and costs is in DESIGN.md 3.3.
-// RLOG: the chunk's most recent 2^RLOG bytes are kept in LDS (MatchSharedT::ring) and serve the window's own bytes, every
-// candidate that young and the extension words; global memory is read once, in order, a KiB per trip (plus the candidates
-// older than the ring).  Same candidates, same bytes written: the output does not depend on RLOG.
-template <bool DICT, bool PROF, bool FAR, bool INTRA, bool HI = false, int RLOG = 0>
-__global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
+template <bool DICT, bool PROF, bool FAR, bool INTRA, bool HI = false>
+__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATCH_SGPRS))) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     static_assert(!(DICT && HI), "the dictionary's table image has the base sizes");
-    static_assert(RLOG == 0 || (!DICT && !FAR), "the ring holds chunk positions from 0 up");
-    constexpr u32 RB = RLOG ? (1u << RLOG) : 1u, RM = RB - 1;
     constexpr int LLOG = HI ? LONG_LOG_HI : LONG_LOG;
     constexpr u32 lshift = 64u - (u32)LLOG;
     constexpr u32 lane_cap = (FAR || HI) ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP;
@@ -225,7 +220,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     // 4.368 (1.014x the reference's size), text 4.604 -> 4.533 (reference 4.512).  2^14 + 2^11 ran as fast and cost the sources
     // twice as much.
     constexpr int SLOG = HI ? SHORT_LOG_HI : (FAR ? SHORT_LOG_FAR : ((DICT || INTRA) ? SHORT_LOG : SHORT_LOG_BULK));
-    __shared__ MatchSharedT<LLOG, SLOG, RLOG> S;
+    __shared__ MatchSharedT<LLOG, SLOG> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = zl_spread(blockIdx.x, nchunks);
@@ -242,6 +237,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     const u32 D = DICT ? a.dict_len : 0u;
     const u8* const dict = a.dict;
     static_assert(!(DICT && FAR), "a dictionary frame is a frame of its own");
+    constexpr bool LEAN = ZL_LEAN && !DICT && !PROF && !FAR && !INTRA && !HI;
     // bytes of the frame in front of this chunk INSIDE THE CHUNK'S SECTION: a source position is a chunk position that may be
     // "negative", down to -reach_sec.  (Until round 3 the repeat-offset, far-hint and one-byte backward-extension checks used the
     // bytes in front of the chunk in the whole FRAME: the stride-2 body's backward extension could read -- and make a sequence
@@ -253,26 +249,9 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
         if (FAR) return src + (ptrdiff_t)(i32)q;
         return q >= D ? src + (q - D) : dict + q;
     };
-    // ---- the ring (RLOG): positions [lo_pos, filled) are resident; `fillv` holds this thread's four bytes of the KiB at `filled`,
-    // asked for a fill earlier, so that in steady state no window waits for memory
-    auto rd64 = [&](u32 q) -> u64 { u64 x; __builtin_memcpy(&x, S.ring + (q & RM), 8); return x; };
-    auto fill_load = [&](u32 base) -> u32 {
-        const u32 x = base + 4 * t;
-        u32 w = 0;
-        if (x + 4 <= n) __builtin_memcpy(&w, src + x, 4);
-        else for (u32 k = 0; k < 4; k++) if (x + k < n) w |= (u32)src[x + k] << (8 * k);
-        return w;
-    };
-    auto fill_store = [&](u32 base, u32 w) {
-        const u32 o = (base + 4 * t) & RM;
-        *(u32*)(S.ring + o) = w;
-        if (o < 16) *(u32*)(S.ring + RB + o) = w;
-    };
-    u32 filled = 0, ring_lo = 0, lo_pos = 0, fillv = 0;
-    if (RLOG) fillv = fill_load(0);
     for (u32 i = t; i < (1u << LLOG) / 2; i += ENC_THREADS) S.tbl_long[i] = D ? a.dict_hash[i] : 0u;
     for (u32 i = t; i < (1u << SLOG) / 2; i += ENC_THREADS) S.tbl_short[i] = D ? a.dict_hash[(1u << LONG_LOG) / 2 + i] : 0u;
-    if (t == 0) S.rep = 0;
+    if (t == 0) { S.rep = 0; S.cand_end = 0; }
     const bool intra_on = INTRA && (FAR || (cd.flags & 1u));  // uniform
     // (a launch that mixes small inputs with chunks of large ones -- a batch -- must write for every chunk what a launch of
     // its own would: the chunks of large inputs hash as the bulk instantiation does)
@@ -303,22 +282,124 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     for (u32 ip = 0; ip < n;) {
         u32 win, win_seqs = 0, win_lits = 0;
-        if (RLOG) {
-            // everything a window reads of the chunk -- its own bytes, 16 per lane in the stride-2 body, and the verification
-            // words up to lane_cap + 8 behind its last position -- must be resident before it starts
-            const u32 need = ip + (dense ? WIN : WIN2) + lane_cap + 24;
-            bool wrote = false;
-            while (filled < need && filled < n) {
-                fill_store(filled, fillv);
-                filled += 1024;
-                fillv = filled < n ? fill_load(filled) : 0u;
-                wrote = true;
+        // ---- the stride-1 body for the windows of the bulk path that lie well inside the chunk (both this window's and the next
+        // one's reads are in bounds, the window's own bytes were prefetched): the same candidates, the same parse, the same
+        // bytes written as the general body below, but no bounds tests, no per-lane conditions held as wave masks (the
+        // compiler keeps a per-lane bool in a pair of scalar registers and combines them on the CU's ONE scalar unit, which
+        // the 28 resident waves share: 184 scalar instructions per wave and window in round 3, most of them mask logic and
+        // exec-mask saves around one-line conditionals), selects instead of branches, candidates fetched by every lane (a lane
+        // without one reads its own position: the same line its neighbours read).
+        if (LEAN && dense && ip + 2 * WIN + 8 <= n && pref_ip == ip) {
+            win = WIN;
+            const u32 p = ip + t;
+            const u64 v = v_pref;
+            const u32 rep = S.rep;
+            const u32 hl = hash_long(v, lshift), hs = hash_short_rt(v, sbsh, sshift);
+            u32 best_len = 0, best_off = 0;
+            if (carry < WIN) {  // (otherwise the whole window lies inside an earlier match: nothing to search)
+                const u32 el = ((const unsigned short*)S.tbl_long)[hl], es = ((const unsigned short*)S.tbl_short)[hs];
+                // distance to the nearest position an entry can mean; 0 = no candidate (empty entry, the position itself 64 KiB on, in front of the chunk)
+                u32 dl = el ? ((p + 1 - el) & 0xFFFF) : 0u, ds = es ? ((p + 1 - es) & 0xFFFF) : 0u;
+                dl = dl - 1 < p ? dl : 0u;
+                ds = ds - 1 < p ? ds : 0u;
+                const u32 dr = rep - 1 < p ? rep : 0u;
+                const u64 w_r = ld64(src + (p - dr)), w_l = ld64(src + (p - dl)), w_s = ld64(src + (p - ds));
+                v_pref = ld64(src + p + WIN);  // the next window's own bytes travel with this window's candidates
+                u32 l_r = common_bytes(v, w_r), l_l = common_bytes(v, w_l), l_s = common_bytes(v, w_s);
+                l_r = dr ? l_r : 0u; l_l = dl ? l_l : 0u; l_s = ds ? l_s : 0u;
+                // repeat offset from 4 bytes, table candidates from 5; the long table's wins a tie against the short one's
+                best_len = l_r >= MIN_MATCH ? l_r : 0u;
+                best_off = dr;
+                const bool take_l = l_l > (best_len > MIN_MATCH ? best_len : MIN_MATCH);
+                best_len = take_l ? l_l : best_len; best_off = take_l ? dl : best_off;
+                const bool take_s = l_s > (best_len > MIN_MATCH ? best_len : MIN_MATCH);
+                best_len = take_s ? l_s : best_len; best_off = take_s ? ds : best_off;
+                // extend while whole 8-byte words keep matching
+                while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
+                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + (p - best_off) + best_len));
+                    best_len += l;
+                    if (l < 8) break;
+                }
+            } else {
+                v_pref = ld64(src + p + WIN);
             }
-            if (wrote) lds_barrier();
-            lo_pos = filled > RB ? filled - RB : 0u;
-            lo_pos = lo_pos > ring_lo ? lo_pos : ring_lo;
-        }
-        if (dense) {
+            pref_ip = ip + WIN;
+            bool has_match = best_len >= MIN_MATCH;
+            S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
+            lds_barrier();
+            // one-step lazy evaluation against the neighbour's candidate (the window's last lane reads cand_end = 0: a gain of 0, below any match's)
+            {
+                const u32 nx = S.cand[t + 1];
+                const int g1 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1)) + 4;
+                const int g2 = 4 * (int)(nx & 0xFF) - (int)(31 - __clz((nx >> 8) + 1));
+                has_match = has_match && g2 <= g1;
+            }
+            const u32 wbase = t & ~63u, wave = t >> 6;
+            u32 jr[6];
+            u32 jp = t + (has_match ? best_len : 1u);
+    #pragma unroll
+            for (int r = 0; r < 6; r++) {
+                jr[r] = jp;
+                const u32 far = __shfl(jp, (int)((jp - wbase) & 63), 64);
+                jp = (jp < wbase + 64) ? far : jp;
+            }
+            S.jump[0][t] = (u16)jp;
+            lds_barrier();
+            u32 enter = carry, my_entry = 0xFFFFFFFFu;
+    #pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                if (enter < 64 * (k + 1)) {
+                    if (k == wave) my_entry = enter;
+                    enter = S.jump[0][enter];
+                }
+            }
+            carry = enter - WIN;
+            S.mark[t] = (t == my_entry) ? 1 : 0;
+    #pragma unroll
+            for (int r = 0; r < 6; r++) {
+                asm volatile("" ::: "memory");
+                if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
+            }
+            asm volatile("" ::: "memory");
+            const bool on_path = S.mark[t] != 0;
+            const bool is_seq = on_path && has_match, is_lit = on_path && !has_match;
+            const u64 ms = __ballot(is_seq), ml = __ballot(is_lit);
+            const u64 below = (1ull << (t & 63)) - 1;
+            if ((t & 63) == 0) S.scan_a[wave] = (u32)__popcll(ms) | ((u32)__popcll(ml) << 16);
+            lds_barrier();
+            u32 pre = 0, tot = 0;
+    #pragma unroll
+            for (u32 w = 0; w < 4; w++) {
+                const u32 x = S.scan_a[w];
+                if (w < wave) pre += x;
+                tot += x;
+            }
+            const u32 ex_s = (pre & 0xFFFF) + (u32)__popcll(ms & below), ex_l = (pre >> 16) + (u32)__popcll(ml & below);
+            const u32 tot_s = tot & 0xFFFF, tot_l = tot >> 16;
+            if (is_lit) lits[nlit + ex_l] = (u8)v;
+            if (is_seq) {
+                zl_seq sq;
+                sq.lit_cum = nlit + ex_l;
+                sq.match_len = best_len;
+                sq.offset = best_off;
+                sq.pos = p;
+                seqs[nseq + ex_s] = sq;
+                if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
+            }
+            for (u32 ph = 0; ph < 4; ph++) {
+                if (ph == wave) {
+                    const unsigned short val = (unsigned short)(p + 1);
+                    ((unsigned short*)S.tbl_long)[hl] = val;
+                    ((unsigned short*)S.tbl_short)[hs] = val;
+                }
+                if (ph < 3) lds_barrier();
+            }
+            nseq += tot_s;
+            nlit += tot_l;
+            win_seqs = tot_s;
+            win_lits = tot_l;
+            lds_barrier();
+        } else if (dense) {
             win = WIN;
             const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
             const u32 rep = S.rep;
@@ -333,8 +414,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 in_range[j] = p < n;
                 can_match[j] = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
                 v[j] = 0;
-                if (RLOG) { if (in_range[j]) { v[j] = rd64(p); if (!can_match[j]) v[j] &= 0xFF; } }
-                else if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
+                if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
                 else if (can_match[j]) v[j] = ld64(src + p);
                 else if (in_range[j]) v[j] = src[p];
                 if (FAR) far_off[j] = ((pref_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
@@ -417,22 +497,16 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     const bool same_lr = have_l[j] && have_r[j] && q_l[j] == q_r[j];
                     const bool same_sr = have_s[j] && have_r[j] && q_s[j] == q_r[j];
                     const bool same_sl = have_s[j] && have_l[j] && q_s[j] == q_l[j];
-                    if (RLOG) {
-                        if (have_r[j]) { if (q_r[j] >= lo_pos) w_r[j] = rd64(q_r[j]); else w_r[j] = ld64(at(q_r[j])); }
-                        if (have_l[j] && !same_lr) { if (q_l[j] >= lo_pos) w_l[j] = rd64(q_l[j]); else w_l[j] = ld64(at(q_l[j])); }
-                        if (have_s[j] && !same_sr && !same_sl) { if (q_s[j] >= lo_pos) w_s[j] = rd64(q_s[j]); else w_s[j] = ld64(at(q_s[j])); }
-                    } else {
                     if (have_r[j]) w_r[j] = ld64(at(q_r[j]));
                     if (have_l[j] && !same_lr) w_l[j] = ld64(at(q_l[j]));
                     if (have_s[j] && !same_sr && !same_sl) w_s[j] = ld64(at(q_s[j]));
-                    }
                     if (FAR && have_f[j]) w_f[j] = ld64(at(ip + t + ENC_THREADS * j - far_off[j]));
                     if (same_lr) w_l[j] = w_r[j];
                     if (same_sr) w_s[j] = w_r[j];
                     else if (same_sl) w_s[j] = w_l[j];
                 }
             }
-            if (!RLOG) {   // the next window's own bytes travel together with this window's candidates
+            {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN + t;
                 pref_ip = ip + WIN;
                 v_pref = 0;
@@ -451,14 +525,10 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
-                    const bool res_b = RLOG && q_best[j] >= lo_pos;  // the match's source lies in the ring
                     while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < lane_cap && p + best_len[j] + 8 <= n) {
                         const u32 qv = q_best[j] + best_len[j];
                         if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
-                        const u64 mine = RLOG ? rd64(p + best_len[j]) : ld64(src + p + best_len[j]);
-                        u64 theirs;
-                        if (res_b) theirs = rd64(qv); else theirs = ld64(at(qv));
-                        const u32 l = common_bytes(mine, theirs);
+                        const u32 l = common_bytes(ld64(src + p + best_len[j]), ld64(at(qv)));
                         best_len[j] += l;
                         if (l < 8) break;
                     }
@@ -660,8 +730,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             const bool can0 = p + 8 <= n, can1 = p + 9 <= n;  // the last 7 bytes of a chunk are always literals
             // 16 bytes from p - 1: the byte in front of p (for extending a match backwards), the 8 bytes at p, the 8 at p + 1
             u64 lo = 0, hi = 0;
-            if (RLOG && p >= 1 && p + 15 <= n) { lo = rd64(p - 1); hi = rd64(p + 7); }
-            else if (!RLOG && pref_ip2 == ip) { lo = pref0; hi = pref1; }  // fetched while the previous window was being searched
+            if (pref_ip2 == ip) { lo = pref0; hi = pref1; }  // fetched while the previous window was being searched
             else if (p >= 1 && p + 15 <= n) { lo = ld64(src + p - 1); hi = ld64(src + p + 7); }
             else { for (u32 i = 0; i < 8; i++) { if (p + i >= 1 && p + i - 1 < n) lo |= (u64)src[p + i - 1] << (8 * i); if (p + 7 + i < n) hi |= (u64)src[p + 7 + i] << (8 * i); } }
             const u32 byte_before = (u32)lo & 0xFF;
@@ -706,21 +775,15 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             u64 w_r = 0, w_l = 0, w_s = 0, w_f = 0;
             if (can0 && search) {  // (as in the stride-1 body: candidates are fetched by the lanes that have one, each position once)
                 const bool same_lr = have_l && have_r && q_l == q_r, same_sr = have_s && have_r && q_s == q_r, same_sl = have_s && have_l && q_s == q_l;
-                if (RLOG) {
-                    if (have_r) { if (q_r >= lo_pos) w_r = rd64(q_r); else w_r = ld64(at(q_r)); }
-                    if (have_l && !same_lr) { if (q_l >= lo_pos) w_l = rd64(q_l); else w_l = ld64(src + q_l); }
-                    if (have_s && !same_sr && !same_sl) { if (q_s >= lo_pos) w_s = rd64(q_s); else w_s = ld64(src + q_s); }
-                } else {
                 if (have_r) w_r = ld64(at(q_r));
                 if (have_l && !same_lr) w_l = ld64(src + q_l);
                 if (have_s && !same_sr && !same_sl) w_s = ld64(src + q_s);
-                }
                 if (FAR && have_f) w_f = ld64(at(p - far_off2));
                 if (same_lr) w_l = w_r;
                 if (same_sr) w_s = w_r;
                 else if (same_sl) w_s = w_l;
             }
-            if (!RLOG) {   // the next window's own bytes travel together with this window's candidates
+            {   // the next window's own bytes travel together with this window's candidates
                 const u32 pn = ip + WIN2 + 2 * t;
                 pref_ip2 = ip + WIN2;
                 pref0 = 0; pref1 = 0;
@@ -735,12 +798,8 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 if (have_s && best_len < 8 && l_s >= MIN_MATCH && l_s > best_len) { best_len = l_s; best_off = p - q_s; q_best = q_s; }
                 if (FAR && have_f && best_len < 8 && common_bytes(v0, w_f) == 8) { best_len = 8; best_off = far_off2; q_best = p - far_off2; }
                 // extend while whole 8-byte words keep matching
-                const bool res_b = RLOG && q_best >= lo_pos;  // the match's source lies in the ring
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap && p + best_len + 8 <= n) {
-                    const u64 mine = RLOG ? rd64(p + best_len) : ld64(src + p + best_len);
-                    u64 theirs;
-                    if (res_b) theirs = rd64(q_best + best_len); else theirs = ld64(at(q_best + best_len));
-                    const u32 l = common_bytes(mine, theirs);
+                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(at(q_best + best_len)));
                     best_len += l;
                     if (l < 8) break;
                 }
@@ -750,8 +809,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             // front of the candidate is fetched now (it is needed when the sequence is written): if it
             // equals the byte in front of p and that byte is still a free literal, the match starts there.
             u32 cand_before = 0x100;
-            if (RLOG) { if (has_match && p >= 1 && q_best >= 1) { if (q_best - 1 >= lo_pos) cand_before = S.ring[(q_best - 1) & RM]; else cand_before = src[q_best - 1]; } }
-            else if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach_sec >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);  // (inside the chunk's SECTION: the byte in front of a section is not this launch's to read -- a pledged stream's second job holds its own section only, and sections are self-contained)
+            if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach_sec >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);  // (inside the chunk's SECTION: the byte in front of a section is not this launch's to read -- a pledged stream's second job holds its own section only, and sections are self-contained)
             const bool back_ok = cand_before == byte_before;
     #ifndef ZL_SPARSE_MIN
 #define ZL_SPARSE_MIN 5
@@ -798,7 +856,7 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
                 const u32 mend = 2 * t + best_len;  // window-relative end of the match
                 const bool odd_end = has_match && (mend & 1) && p + best_len < n;
                 u32 tail_byte = 0;
-                if (odd_end) tail_byte = RLOG ? S.ring[(p + best_len) & RM] : src[p + best_len];
+                if (odd_end) tail_byte = src[p + best_len];
                 // ---- greedy parse over the 256 nodes (even positions): wave-local closure, chain, marks
                 const u32 nxt = has_match ? ((mend + 1) >> 1) : t + 1u;  // next node on the path
                 u32 jr[6];
@@ -924,10 +982,6 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_match_auto_kernel(zl_match_arg
             }
             nlit += to - ip;
             ip = to;
-            if (RLOG && ip >= filled) {  // nothing of the ring is of use behind the jump: it starts again just in front of ip
-                ring_lo = filled = (ip - 16) & ~1023u;
-                fillv = fill_load(filled);
-            }
         }
 #if ZL_DENSE_LIT_PCT_FAR
         // windowed layout: the dense body where MATCHES COVER the data (literals at most this share of the window), not where
@@ -1378,8 +1432,8 @@ extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipSt
     else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false, false, false, ZL_RING_LOG>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
-    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false, false, ZL_RING_LOG>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else if (a->stats) hipLaunchKernelGGL((zl_match_auto_kernel<false, true, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 
@@ -2880,7 +2934,7 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
 // debug: what the runtime says about resident workgroups per CU (not part of include/zl_hip.h)
 extern "C" int zl_debug_occupancy(int which) {
     int n = -1;
-    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false, false, false, ZL_RING_LOG>, ENC_THREADS, 0);
+    if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false, false>, ENC_THREADS, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
     return n;
 }
