@@ -196,10 +196,18 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.far_hints = joined ? (const u32*)es.far_hints.p : nullptr;
     m.intra = c->any_small ? 1u : 0u;
     m.pad0 = 0;
+#ifdef ZL_TRACE
+    // development build: the match kernel stamps a timeline of one workgroup's iterations behind the 128 bytes of phase sums
+    if (prof && c->profile >= 2 && c->d_stats.ensure(128 + ZL_TRACE_BYTES)) {
+        (void)hipMemsetAsync(c->d_stats.p, 0, 128 + ZL_TRACE_BYTES, st);
+        m.stats = (u64*)c->d_stats.p;
+    }
+#else
     if (prof && c->profile >= 2 && c->d_stats.ensure(128)) {
         (void)hipMemsetAsync(c->d_stats.p, 0, 128, st);
         m.stats = (u64*)c->d_stats.p;
     }
+#endif
     if (prof) (void)hipEventRecord(c->ev[0], st);
     if (joined && c->dict_use) {
         // ONE frame with a dictionary (zstd.c:27550: the dictionary's content is history in front of the frame's first byte):
@@ -559,6 +567,15 @@ size_t zl_cctx_far_ms(const zl_cctx* c, double* ms) {
     return 0;
 }
 
+#ifdef ZL_TRACE
+// development build: the timeline the match kernel stamped (ZL_TRACE_BYTES / 8 words)
+size_t zl_cctx_trace(const zl_cctx* c, unsigned long long* out, size_t words) {
+    if (!c || !out || !c->d_stats.p) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (words > ZL_TRACE_BYTES / 8) words = ZL_TRACE_BYTES / 8;
+    (void)hipMemcpy(out, (const u8*)c->d_stats.p + 128, words * 8, hipMemcpyDeviceToHost);
+    return words;
+}
+#endif
 // not part of the public header: match-kernel phase cycle sums {find, parse, emit, insert, iterations}
 size_t zl_cctx_phase_stats(const zl_cctx* c, unsigned long long* out8) {
     if (!c || !out8 || !c->profile) return ZL_ERR(ZL_E_STAGE_WRONG);

@@ -38,6 +38,10 @@
 #define ZL_FAR_LIST_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)ZL_FAR_LIST_CAP * 8 + 64))
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 
+#define ZL_TRACE_BYTES (1 << 20)                 // development builds (-DZL_TRACE=<chunk>): timeline of that chunk's match workgroup
+#define ZL_TRACE_POINTS 16                       // stamps per wave and iteration
+#define ZL_TRACE_ITERS ((ZL_TRACE_BYTES / 8) / (4 * ZL_TRACE_POINTS))
+
 struct zl_chunk_desc {
     u64 src_off;   // first byte of the chunk inside the source buffer
     u32 src_size;  // <= ZL_CHUNK

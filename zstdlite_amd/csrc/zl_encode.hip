@@ -49,7 +49,6 @@ struct MatchSharedT {
     u32 tbl_long[(1 << LLOG) / 2];
     u32 tbl_short[(1 << SLOG) / 2];
     u16 jump[2][WIN];
-    u8 mark[WIN];
     u32 cand[WIN];  // [7:0] match length, [31:8] offset of each lane's best match
     u32 cand_end;   // always 0: what the window's last lane reads as its neighbour's candidate (lean body)
     u32 scan_a[4], scan_b[4];
@@ -117,6 +116,24 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
     if (go_s) prev_s = atomicCAS(ws, old_s, (old_s & ~(0xFFFFu << shs)) | (val << shs));
     if (go_l && prev_l != old_l) insert16_retry(wl, prev_l, shl, val, mine, ip, win);
     if (go_s && prev_s != old_s) insert16_retry(ws, prev_s, shs, val, mine, ip, win);
+}
+
+// Which nodes of a wave's 64 lie on the path that enters at `entry` (a lane of this wave, or none)?  jr[r] = the node 2^r steps
+// on (window-relative; >= wbase + 64: outside).  Every node that is marked marks the node 2^r steps on, r = 0..5: the marks
+// travel from lane to lane through ds_permute (each lane SENDS a 1 to the lane it names; lanes that have nothing to say name
+// lane 0, which no step can land on, and whatever arrives there is ignored) -- six LDS-crossbar round trips and no memory.
+// Rounds 1-3 kept the marks in an LDS byte array: a read and a dependent write per round, fourteen round trips.
+__device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wbase, u32 my_entry) {
+    const u32 lane = t & 63;
+    u32 mk = (t == my_entry) ? 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const bool send = mk != 0 && jr[r] < wbase + 64;
+        const u32 dst = send ? ((jr[r] & 63) << 2) : 0u;
+        const u32 got = (u32)__builtin_amdgcn_ds_permute((int)dst, 1);
+        mk |= lane ? got : 0u;
+    }
+    return mk != 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -237,7 +254,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     const u32 D = DICT ? a.dict_len : 0u;
     const u8* const dict = a.dict;
     static_assert(!(DICT && FAR), "a dictionary frame is a frame of its own");
+#ifdef ZL_TRACE
+    constexpr bool LEAN = ZL_LEAN && !DICT && !FAR && !INTRA && !HI;  // (the stamped instantiation is the profiling one)
+    u32 tr_it = 0;
+    const bool tr_on = PROF && a.stats != nullptr && c == (u32)(ZL_TRACE) && (threadIdx.x & 63) == 0;
+#define TR(k_) do { if (tr_on && tr_it < ZL_TRACE_ITERS) { asm volatile("" ::: "memory"); a.stats[16 + (tr_it * 4 + (threadIdx.x >> 6)) * ZL_TRACE_POINTS + (k_)] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } while (0)
+#else
     constexpr bool LEAN = ZL_LEAN && !DICT && !PROF && !FAR && !INTRA && !HI;
+#define TR(k_) do { } while (0)
+#endif
     // bytes of the frame in front of this chunk INSIDE THE CHUNK'S SECTION: a source position is a chunk position that may be
     // "negative", down to -reach_sec.  (Until round 3 the repeat-offset, far-hint and one-byte backward-extension checks used the
     // bytes in front of the chunk in the whole FRAME: the stride-2 body's backward extension could read -- and make a sequence
@@ -293,6 +318,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             win = WIN;
             const u32 p = ip + t;
             const u64 v = v_pref;
+            TR(0);
             const u32 rep = S.rep;
             const u32 hl = hash_long(v, lshift), hs = hash_short_rt(v, sbsh, sshift);
             u32 best_len = 0, best_off = 0;
@@ -303,6 +329,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 dl = dl - 1 < p ? dl : 0u;
                 ds = ds - 1 < p ? ds : 0u;
                 const u32 dr = rep - 1 < p ? rep : 0u;
+#ifdef ZL_TRACE
+                if (tr_on && (dl + ds + dr) == 0xFFFFFFF0u) tr_it += 0;  // (makes the stamp wait for the look-ups)
+#endif
+                TR(1);
                 const u64 w_r = ld64(src + (p - dr)), w_l = ld64(src + (p - dl)), w_s = ld64(src + (p - ds));
                 v_pref = ld64(src + p + WIN);  // the next window's own bytes travel with this window's candidates
                 u32 l_r = common_bytes(v, w_r), l_l = common_bytes(v, w_l), l_s = common_bytes(v, w_s);
@@ -314,7 +344,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 best_len = take_l ? l_l : best_len; best_off = take_l ? dl : best_off;
                 const bool take_s = l_s > (best_len > MIN_MATCH ? best_len : MIN_MATCH);
                 best_len = take_s ? l_s : best_len; best_off = take_s ? ds : best_off;
-                // extend while whole 8-byte words keep matching
+                TR(2);
+                // extend while whole 8-byte words keep matching.  (Fetching the 32 bytes behind a full match on both sides AT ONCE --
+                // one round trip instead of up to four dependent ones, which are 3800 of an iteration's 11 000 cycles -- was measured
+                // SLOWER, 9.3 -> 11.9 ms per 896 MiB of text: every lane-load is a tag look-up in the CU's L1, the L1 makes one per
+                // clock, and it is the match kernel's bound; the loop's later rounds have few lanes left.  profiles/r04_match_timeline*.)
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
                     const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + (p - best_off) + best_len));
                     best_len += l;
@@ -324,9 +358,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 v_pref = ld64(src + p + WIN);
             }
             pref_ip = ip + WIN;
+            TR(3);
             bool has_match = best_len >= MIN_MATCH;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
             lds_barrier();
+            TR(4);
             // one-step lazy evaluation against the neighbour's candidate (the window's last lane reads cand_end = 0: a gain of 0, below any match's)
             {
                 const u32 nx = S.cand[t + 1];
@@ -344,7 +380,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 jp = (jp < wbase + 64) ? far : jp;
             }
             S.jump[0][t] = (u16)jp;
+            TR(5);
             lds_barrier();
+            TR(6);
             u32 enter = carry, my_entry = 0xFFFFFFFFu;
     #pragma unroll
             for (u32 k = 0; k < 4; k++) {
@@ -354,14 +392,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 }
             }
             carry = enter - WIN;
-            S.mark[t] = (t == my_entry) ? 1 : 0;
-    #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                asm volatile("" ::: "memory");
-                if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
-            }
-            asm volatile("" ::: "memory");
-            const bool on_path = S.mark[t] != 0;
+            TR(7);
+            const bool on_path = zl_path_marks(jr, t, wbase, my_entry);
+            TR(8);
             const bool is_seq = on_path && has_match, is_lit = on_path && !has_match;
             const u64 ms = __ballot(is_seq), ml = __ballot(is_lit);
             const u64 below = (1ull << (t & 63)) - 1;
@@ -376,6 +409,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             }
             const u32 ex_s = (pre & 0xFFFF) + (u32)__popcll(ms & below), ex_l = (pre >> 16) + (u32)__popcll(ml & below);
             const u32 tot_s = tot & 0xFFFF, tot_l = tot >> 16;
+            TR(9);
             if (is_lit) lits[nlit + ex_l] = (u8)v;
             if (is_seq) {
                 zl_seq sq;
@@ -386,6 +420,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 seqs[nseq + ex_s] = sq;
                 if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
             }
+            TR(10);
             for (u32 ph = 0; ph < 4; ph++) {
                 if (ph == wave) {
                     const unsigned short val = (unsigned short)(p + 1);
@@ -398,7 +433,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             nlit += tot_l;
             win_seqs = tot_s;
             win_lits = tot_l;
+            TR(11);
             lds_barrier();
+            TR(12);
+#ifdef ZL_TRACE
+            tr_it++;
+#endif
         } else if (dense) {
             win = WIN;
             const u64 s0 = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -601,20 +641,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 }
             }
             const u32 next_carry = enter - WIN;  // uniform: where the path enters the next window
-            // (marks stay inside the wave's 64 bytes: LDS executes a wave's accesses in program order, the
-            // asm statements only keep the compiler from caching or reordering them)
-            S.mark[t] = (t == my_entry) ? 1 : 0;
-    #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                asm volatile("" ::: "memory");
-                if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
-            }
-            asm volatile("" ::: "memory");
+            const bool on_path0 = zl_path_marks(jr, t, wbase, my_entry);
             const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
             bool is_seq[PPT], is_lit[PPT], on_path[PPT];
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
-                on_path[j] = S.mark[t + ENC_THREADS * j] != 0;
+                on_path[j] = on_path0;
                 is_seq[j] = on_path[j] && has_match[j];
                 is_lit[j] = on_path[j] && !has_match[j] && in_range[j];
             }
@@ -878,15 +910,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     }
                 }
                 const u32 next_carry = enter - ENC_THREADS;
-                S.mark[t] = (t == my_entry) ? 1 : 0;
-        #pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    asm volatile("" ::: "memory");
-                    if (S.mark[t] && jr[r] < wbase + 64) S.mark[jr[r]] = 1;
-                }
-                asm volatile("" ::: "memory");
+                const bool on_path = zl_path_marks(jr, t, wbase, my_entry);
                 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
-                const bool on_path = S.mark[t] != 0;
                 const bool is_seq = on_path && has_match;
                 // backward extension by one byte.  The byte in front of an on-path node is a literal owned by the
                 // node before it on the path: the odd byte of a lane without a match, or the byte behind a match
