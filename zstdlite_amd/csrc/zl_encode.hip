@@ -40,7 +40,8 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #include "zl_match_common.h"
 
-template <int LLOG, int SLOG>
+#define ZL_WBUF_BYTES 320
+template <int LLOG, int SLOG, bool WBUF = false>
 struct MatchSharedT {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
     // mean the nearest such position in front of it, so candidates reach 64 KiB back (an older entry
@@ -53,6 +54,10 @@ struct MatchSharedT {
     u32 cand_end;   // always 0: what the window's last lane reads as its neighbour's candidate (lean body)
     u32 scan_a[4], scan_b[4];
     u32 rep;      // offset of the most recent sequence (repeat-offset candidate)
+    // lean body: the window's own bytes [wbuf_ip, + 320): every lane's eight and the words the extension loop compares them
+    // with.  Twenty lanes fetch them (16 bytes each) where 256 lanes fetched eight overlapping bytes each and every extension
+    // round 64 more: a lane-load is a tag look-up in the CU's L1 whatever its neighbours read, and those look-ups bound the kernel.
+    alignas(16) u8 wbuf[WBUF ? ZL_WBUF_BYTES : 16];
 };
 
 __device__ __forceinline__ void block_scan2(u32* sa, u32* sb, u32 a, u32 b, u32& ex_a, u32& ex_b, u32& tot_a, u32& tot_b) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // 4.368 (1.014x the reference's size), text 4.604 -> 4.533 (reference 4.512).  2^14 + 2^11 ran as fast and cost the sources
     // twice as much.
     constexpr int SLOG = HI ? SHORT_LOG_HI : (FAR ? SHORT_LOG_FAR : ((DICT || INTRA) ? SHORT_LOG : SHORT_LOG_BULK));
-    __shared__ MatchSharedT<LLOG, SLOG> S;
+    __shared__ MatchSharedT<LLOG, SLOG, ZL_LEAN && !DICT && !FAR && !INTRA && !HI> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = zl_spread(blockIdx.x, nchunks);
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
     u32 carry = 0;           // where the parse enters the next window, in bytes (uniform)
     bool dense = !a.sparse_only || D != 0;  // which body the next window gets (uniform); dictionary frames use the stride-1 body throughout
+    u32 wbuf_ip = 0xFFFFFFFFu;  // lean body: the position S.wbuf starts at (uniform)
     u64 v_pref = 0;          // stride 1: prefetched bytes of position pref_ip + t
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
@@ -314,10 +320,25 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         // the 28 resident waves share: 184 scalar instructions per wave and window in round 3, most of them mask logic and
         // exec-mask saves around one-line conditionals), selects instead of branches, candidates fetched by every lane (a lane
         // without one reads its own position: the same line its neighbours read).
-        if (LEAN && dense && ip + 2 * WIN + 8 <= n && pref_ip == ip) {
+        if (LEAN && dense && ip + 2 * WIN + 8 <= n) {
             win = WIN;
             const u32 p = ip + t;
-            const u64 v = v_pref;
+            if (wbuf_ip != ip) {  // (the window in front took another body: chunk start, a stride-2 stretch)
+                if (t < ZL_WBUF_BYTES / 16) *(uint4*)(S.wbuf + 16 * t) = ld128(src + ip + 16 * t);
+                lds_barrier();
+            }
+            // the next window's bytes are asked for now and put in place behind the barrier that ends this window's reads
+            const bool wb_next = ip + 3 * WIN + 8 <= n;  // (uniform: the next window qualifies for this body as far as its bounds go)
+            uint4 wb_pref = make_uint4(0, 0, 0, 0);
+            if (wb_next && t < ZL_WBUF_BYTES / 16) wb_pref = ld128(src + ip + WIN + 16 * t);
+            // eight bytes at window offset o (o + 8 <= 320): three aligned words, funnel-shifted
+            auto wb64 = [&](u32 o) -> u64 {
+                const u32* const w = (const u32*)S.wbuf + (o >> 2);
+                const u32 d0 = w[0], d1 = w[1], d2 = w[2];
+                const u32 sh = o & 3;
+                return (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+            };
+            const u64 v = wb64(t);
             TR(0);
             const u32 rep = S.rep;
             const u32 hl = hash_long(v, lshift), hs = hash_short_rt(v, sbsh, sshift);
@@ -334,7 +355,6 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
 #endif
                 TR(1);
                 const u64 w_r = ld64(src + (p - dr)), w_l = ld64(src + (p - dl)), w_s = ld64(src + (p - ds));
-                v_pref = ld64(src + p + WIN);  // the next window's own bytes travel with this window's candidates
                 u32 l_r = common_bytes(v, w_r), l_l = common_bytes(v, w_l), l_s = common_bytes(v, w_s);
                 l_r = dr ? l_r : 0u; l_l = dl ? l_l : 0u; l_s = ds ? l_s : 0u;
                 // repeat offset from 4 bytes, table candidates from 5; the long table's wins a tie against the short one's
@@ -350,18 +370,17 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 // SLOWER, 9.3 -> 11.9 ms per 896 MiB of text: every lane-load is a tag look-up in the CU's L1, the L1 makes one per
                 // clock, and it is the match kernel's bound; the loop's later rounds have few lanes left.  profiles/r04_match_timeline*.)
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
-                    const u32 l = common_bytes(ld64(src + p + best_len), ld64(src + (p - best_off) + best_len));
+                    const u32 l = common_bytes(wb64(t + best_len), ld64(src + (p - best_off) + best_len));
                     best_len += l;
                     if (l < 8) break;
                 }
-            } else {
-                v_pref = ld64(src + p + WIN);
             }
-            pref_ip = ip + WIN;
             TR(3);
             bool has_match = best_len >= MIN_MATCH;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
             lds_barrier();
+            if (wb_next && t < ZL_WBUF_BYTES / 16) *(uint4*)(S.wbuf + 16 * t) = wb_pref;
+            wbuf_ip = wb_next ? ip + WIN : 0xFFFFFFFFu;
             TR(4);
             // one-step lazy evaluation against the neighbour's candidate (the window's last lane reads cand_end = 0: a gain of 0, below any match's)
             {
