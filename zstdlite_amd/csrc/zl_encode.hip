@@ -165,6 +165,12 @@ __device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wba
 #ifndef ZL_MATCH_SGPRS
 #define ZL_MATCH_SGPRS 88  // a CU admits seven 256-thread workgroups up to 96 scalar registers per wave (six from 97; MI355X_MICROARCH.md, Residency); the lean body took the bulk instantiation to 97
 #endif
+#ifndef ZL_LEAN_EXT16
+#define ZL_LEAN_EXT16 1
+#endif
+#ifndef ZL_LEAN_DEDUPE
+#define ZL_LEAN_DEDUPE 0  // (measured: 8.45 -> 8.67 ms per 896 MiB of text with it)
+#endif
 #ifndef ZL_LEAN
 #define ZL_LEAN 1  // the bulk path's interior windows take the lean stride-1 body (0: the general body everywhere)
 #endif
@@ -354,7 +360,17 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 if (tr_on && (dl + ds + dr) == 0xFFFFFFF0u) tr_it += 0;  // (makes the stamp wait for the look-ups)
 #endif
                 TR(1);
+#if ZL_LEAN_DEDUPE
+                // a lane-load is an L1 tag look-up: only lanes that have a candidate fetch it, and a position named twice is fetched once
+                u64 w_r = 0, w_l = 0, w_s = 0;
+                if (dr) w_r = ld64(src + (p - dr));
+                if (dl && dl != dr) w_l = ld64(src + (p - dl));
+                if (ds && ds != dr && ds != dl) w_s = ld64(src + (p - ds));
+                w_l = dl == dr ? w_r : w_l;
+                w_s = ds == dr ? w_r : (ds == dl ? w_l : w_s);
+#else
                 const u64 w_r = ld64(src + (p - dr)), w_l = ld64(src + (p - dl)), w_s = ld64(src + (p - ds));
+#endif
                 u32 l_r = common_bytes(v, w_r), l_l = common_bytes(v, w_l), l_s = common_bytes(v, w_s);
                 l_r = dr ? l_r : 0u; l_l = dl ? l_l : 0u; l_s = ds ? l_s : 0u;
                 // repeat offset from 4 bytes, table candidates from 5; the long table's wins a tie against the short one's
@@ -369,11 +385,29 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 // one round trip instead of up to four dependent ones, which are 3800 of an iteration's 11 000 cycles -- was measured
                 // SLOWER, 9.3 -> 11.9 ms per 896 MiB of text: every lane-load is a tag look-up in the CU's L1, the L1 makes one per
                 // clock, and it is the match kernel's bound; the loop's later rounds have few lanes left.  profiles/r04_match_timeline*.)
+#if ZL_LEAN_EXT16
+                // sixteen bytes per round: half the dependent round trips and half the look-ups of the lanes that go the whole way
+                static_assert(!LEAN || lane_cap == 40, "8 + 16 + 16");
+                while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
+                    const uint4 b = ld128(src + (p - best_off) + best_len);
+                    const u32 o = t + best_len;
+                    const u32* const w = (const u32*)S.wbuf + (o >> 2);
+                    const u32 d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+                    const u32 sh = o & 3;
+                    const u64 a_lo = (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+                    const u64 a_hi = (u64)__builtin_amdgcn_alignbyte(d3, d2, sh) | ((u64)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32);
+                    const u32 l0 = common_bytes(a_lo, (u64)b.x | ((u64)b.y << 32)), l1 = common_bytes(a_hi, (u64)b.z | ((u64)b.w << 32));
+                    const u32 l = l0 + (l0 == 8 ? l1 : 0u);
+                    best_len += l;
+                    if (l < 16) break;
+                }
+#else
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
                     const u32 l = common_bytes(wb64(t + best_len), ld64(src + (p - best_off) + best_len));
                     best_len += l;
                     if (l < 8) break;
                 }
+#endif
             }
             TR(3);
             bool has_match = best_len >= MIN_MATCH;
