@@ -7,5 +7,6 @@ for v in "$@"; do
   ZL_PROF=1 python scripts/kernel_bench.py 268435456 text,iid10,rand,int20 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/entropy .*//'
   ZL_PROF=1 python scripts/kernel_bench.py 939524096 text 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/entropy .*//'
   ZL_PROF=1 python scripts/kernel_bench.py 1073741824 mix 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/scan .*//'
+  ZL_LAYOUT=one_frame ZL_PROF=1 python scripts/kernel_bench.py 1073741824 mix 2>&1 | grep -v "amdgpu.ids\|phases\|roles" | sed 's/scan .*far/far/; s/decode .*//; s/^/one_frame /'
   [ -n "$ZL_AB_STAMPS" ] && ZL_PROF=2 python scripts/kernel_bench.py 268435456 text 2>&1 | grep "match phases"
 done

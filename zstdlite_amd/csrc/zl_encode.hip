@@ -40,7 +40,7 @@
 #define WIN_LOG (PPT == 1 ? 8 : 9)
 #include "zl_match_common.h"
 
-#define ZL_WBUF_BYTES 320
+#define ZL_WBUF_BYTES 352  // 256 positions of a window + the longest verification (72) + a last word and its alignment slack
 template <int LLOG, int SLOG, bool WBUF = false>
 struct MatchSharedT {
     // 16-bit entries, two per word: (position + 1) mod 2^16, 0 = empty.  A lookup takes the entry to
@@ -165,8 +165,8 @@ __device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wba
 #ifndef ZL_MATCH_SGPRS
 #define ZL_MATCH_SGPRS 88  // a CU admits seven 256-thread workgroups up to 96 scalar registers per wave (six from 97; MI355X_MICROARCH.md, Residency); the lean body took the bulk instantiation to 97
 #endif
-#ifndef ZL_LEAN_EXT16
-#define ZL_LEAN_EXT16 1
+#ifndef ZL_WBUF
+#define ZL_WBUF 1
 #endif
 #ifndef ZL_LEAN_DEDUPE
 #define ZL_LEAN_DEDUPE 0  // (measured: 8.45 -> 8.67 ms per 896 MiB of text with it)
@@ -248,7 +248,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // 4.368 (1.014x the reference's size), text 4.604 -> 4.533 (reference 4.512).  2^14 + 2^11 ran as fast and cost the sources
     // twice as much.
     constexpr int SLOG = HI ? SHORT_LOG_HI : (FAR ? SHORT_LOG_FAR : ((DICT || INTRA) ? SHORT_LOG : SHORT_LOG_BULK));
-    __shared__ MatchSharedT<LLOG, SLOG, ZL_LEAN && !DICT && !FAR && !INTRA && !HI> S;
+    constexpr bool WB = ZL_WBUF && !DICT;  // the stride-1 bodies read the own bytes of a window from S.wbuf (the positions of a dictionary frame are virtual: not built)
+    __shared__ MatchSharedT<LLOG, SLOG, WB> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = zl_spread(blockIdx.x, nchunks);
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
     u32 pref_ip2 = 0xFFFFFFFFu;
     u32 hint_pref = 0;       // FAR: the hint word of the prefetched position
+    u32 hint_ip = 0xFFFFFFFFu;  // stride 1: the window hint_pref was fetched for
     const bool prof = PROF && a.stats != nullptr && t == 0;
     u64 c_find = 0, c_parse = 0, c_emit = 0, c_ins = 0, c_it = 0;
     for (u32 ip = 0; ip < n;) {
@@ -326,24 +328,45 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         // the 28 resident waves share: 184 scalar instructions per wave and window in round 3, most of them mask logic and
         // exec-mask saves around one-line conditionals), selects instead of branches, candidates fetched by every lane (a lane
         // without one reads its own position: the same line its neighbours read).
-        if (LEAN && dense && ip + 2 * WIN + 8 <= n) {
-            win = WIN;
-            const u32 p = ip + t;
+        // ---- stride-1 windows well inside the chunk read their own bytes -- the eight of every lane, and the words the extension
+        // loop compares -- from S.wbuf: 22 lanes fetch 16 bytes each where 256 lanes fetched eight overlapping bytes each and every
+        // extension round 64 more.  The bytes of the next window are asked for at the top and put in place behind the barrier
+        // that ends the reads this window makes of the buffer.
+        const bool wb_ok = WB && dense && ip + 2 * WIN + 8 <= n;       // (uniform; the reads of this window and of the next are in bounds)
+        const bool wb_next = wb_ok && ip + 3 * WIN + 8 <= n;           // (the next window qualifies as far as its bounds go)
+        uint4 wb_pref = make_uint4(0, 0, 0, 0);
+        if (wb_ok) {
             if (wbuf_ip != ip) {  // (the window in front took another body: chunk start, a stride-2 stretch)
                 if (t < ZL_WBUF_BYTES / 16) *(uint4*)(S.wbuf + 16 * t) = ld128(src + ip + 16 * t);
                 lds_barrier();
             }
-            // the next window's bytes are asked for now and put in place behind the barrier that ends this window's reads
-            const bool wb_next = ip + 3 * WIN + 8 <= n;  // (uniform: the next window qualifies for this body as far as its bounds go)
-            uint4 wb_pref = make_uint4(0, 0, 0, 0);
             if (wb_next && t < ZL_WBUF_BYTES / 16) wb_pref = ld128(src + ip + WIN + 16 * t);
-            // eight bytes at window offset o (o + 8 <= 320): three aligned words, funnel-shifted
-            auto wb64 = [&](u32 o) -> u64 {
-                const u32* const w = (const u32*)S.wbuf + (o >> 2);
-                const u32 d0 = w[0], d1 = w[1], d2 = w[2];
-                const u32 sh = o & 3;
-                return (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
-            };
+        }
+        // eight bytes at window offset o: three aligned words, funnel-shifted
+        auto wb64 = [&](u32 o) -> u64 {
+            const u32* const w = (const u32*)S.wbuf + (o >> 2);
+            const u32 d0 = w[0], d1 = w[1], d2 = w[2];
+            const u32 sh = o & 3;
+            return (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+        };
+        // sixteen bytes at window offset o against sixteen bytes in memory: how many agree from the start
+        auto wb_common16 = [&](u32 o, const u8* theirs) -> u32 {
+            const uint4 b = ld128(theirs);
+            const u32* const w = (const u32*)S.wbuf + (o >> 2);
+            const u32 d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+            const u32 sh = o & 3;
+            const u64 a_lo = (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+            const u64 a_hi = (u64)__builtin_amdgcn_alignbyte(d3, d2, sh) | ((u64)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32);
+            const u32 l0 = common_bytes(a_lo, (u64)b.x | ((u64)b.y << 32)), l1 = common_bytes(a_hi, (u64)b.z | ((u64)b.w << 32));
+            return l0 + (l0 == 8 ? l1 : 0u);
+        };
+        auto wb_advance = [&]() {  // behind the barrier that ends the reads of the buffer
+            if (wb_next && t < ZL_WBUF_BYTES / 16) *(uint4*)(S.wbuf + 16 * t) = wb_pref;
+            wbuf_ip = wb_next ? ip + WIN : 0xFFFFFFFFu;
+        };
+        if (LEAN && wb_ok) {
+            win = WIN;
+            const u32 p = ip + t;
             const u64 v = wb64(t);
             TR(0);
             const u32 rep = S.rep;
@@ -385,36 +408,19 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 // one round trip instead of up to four dependent ones, which are 3800 of an iteration's 11 000 cycles -- was measured
                 // SLOWER, 9.3 -> 11.9 ms per 896 MiB of text: every lane-load is a tag look-up in the CU's L1, the L1 makes one per
                 // clock, and it is the match kernel's bound; the loop's later rounds have few lanes left.  profiles/r04_match_timeline*.)
-#if ZL_LEAN_EXT16
-                // sixteen bytes per round: half the dependent round trips and half the look-ups of the lanes that go the whole way
-                static_assert(!LEAN || lane_cap == 40, "8 + 16 + 16");
+                // (sixteen bytes per round: half the dependent round trips; 8.42 -> 7.98 ms per 896 MiB of text.  All 32 bytes at once: 8.67)
+                static_assert((lane_cap - 8) % 16 == 0, "8 + 16 k");
                 while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
-                    const uint4 b = ld128(src + (p - best_off) + best_len);
-                    const u32 o = t + best_len;
-                    const u32* const w = (const u32*)S.wbuf + (o >> 2);
-                    const u32 d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-                    const u32 sh = o & 3;
-                    const u64 a_lo = (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
-                    const u64 a_hi = (u64)__builtin_amdgcn_alignbyte(d3, d2, sh) | ((u64)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32);
-                    const u32 l0 = common_bytes(a_lo, (u64)b.x | ((u64)b.y << 32)), l1 = common_bytes(a_hi, (u64)b.z | ((u64)b.w << 32));
-                    const u32 l = l0 + (l0 == 8 ? l1 : 0u);
+                    const u32 l = wb_common16(t + best_len, src + (p - best_off) + best_len);
                     best_len += l;
                     if (l < 16) break;
                 }
-#else
-                while (best_len >= 8 && (best_len & 7) == 0 && best_len < lane_cap) {
-                    const u32 l = common_bytes(wb64(t + best_len), ld64(src + (p - best_off) + best_len));
-                    best_len += l;
-                    if (l < 8) break;
-                }
-#endif
             }
             TR(3);
             bool has_match = best_len >= MIN_MATCH;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
             lds_barrier();
-            if (wb_next && t < ZL_WBUF_BYTES / 16) *(uint4*)(S.wbuf + 16 * t) = wb_pref;
-            wbuf_ip = wb_next ? ip + WIN : 0xFFFFFFFFu;
+            wb_advance();
             TR(4);
             // one-step lazy evaluation against the neighbour's candidate (the window's last lane reads cand_end = 0: a gain of 0, below any match's)
             {
@@ -507,10 +513,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 in_range[j] = p < n;
                 can_match[j] = p + 8 <= n;  // the last 7 bytes of a chunk are always literals
                 v[j] = 0;
-                if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
+                if (wb_ok) v[j] = wb64(t);
+                else if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
                 else if (can_match[j]) v[j] = ld64(src + p);
                 else if (in_range[j]) v[j] = src[p];
-                if (FAR) far_off[j] = ((pref_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
+                if (FAR) far_off[j] = ((hint_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
                 hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
                 word_l[j] = word_s[j] = 0;
             }
@@ -599,13 +606,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     else if (same_sl) w_s[j] = w_l[j];
                 }
             }
-            {   // the next window's own bytes travel together with this window's candidates
+            {   // the next window's own bytes travel together with this window's candidates (unless S.wbuf will hold them)
                 const u32 pn = ip + WIN + t;
-                pref_ip = ip + WIN;
-                v_pref = 0;
-                if (pn + 8 <= n) v_pref = ld64(src + pn);
-                else if (pn < n) v_pref = src[pn];
-                if (FAR) hint_pref = pn < n ? hints[pn >> ZL_FAR_HINT_LOG] : 0u;
+                if (!wb_next) {
+                    pref_ip = ip + WIN;
+                    v_pref = 0;
+                    if (pn + 8 <= n) v_pref = ld64(src + pn);
+                    else if (pn < n) v_pref = src[pn];
+                }
+                if (FAR) { hint_ip = ip + WIN; hint_pref = pn < n ? hints[pn >> ZL_FAR_HINT_LOG] : 0u; }
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
@@ -618,6 +627,14 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
                     // extend while whole 8-byte words keep matching
+                    if (wb_ok) {  // sixteen bytes per round, the own words from S.wbuf (never a dictionary frame)
+                        static_assert((lane_cap - 8) % 16 == 0, "8 + 16 k");
+                        while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < lane_cap) {
+                            const u32 l = wb_common16(t + best_len[j], at(q_best[j] + best_len[j]));
+                            best_len[j] += l;
+                            if (l < 16) break;
+                        }
+                    } else
                     while (best_len[j] >= 8 && (best_len[j] & 7) == 0 && best_len[j] < lane_cap && p + best_len[j] + 8 <= n) {
                         const u32 qv = q_best[j] + best_len[j];
                         if (qv < D && qv + 8 > D) break;  // the source would run off the end of the dictionary
@@ -652,6 +669,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             }
             const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             lds_barrier();
+            if (wb_ok) wb_advance();
             // ---- one-step lazy evaluation (cf. the ip+1 long-match check of zstd.c:30025-30040): if the
             // next position holds a clearly better match, emit this byte as a literal instead
     #pragma unroll
