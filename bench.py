@@ -85,7 +85,7 @@ def cpu_baseline(host_bytes, log, frames=None, reps=5):
     ncores = os.cpu_count() or 1
     for label, workers in (("mt", ncores), ("1t", 0)):  # 1-thread output stays in the buffer for the decode leg
         best = 1e9
-        for _ in range(reps if label == "mt" else max(1, reps - 1)):
+        for _ in range(reps):
             cctx = L.ZSTD_createCCtx()
             L.ZSTD_CCtx_setParameter(cctx, 100, 3)
             if workers:
@@ -179,6 +179,36 @@ def one_frame_leg(device, src, log):
             "roofline": {"bound": "hbm", "kernel": {"match": "zl_match_auto_kernel<false, false, true, true, false>", "far": "zl_far_build_kernel + zl_far_probe_kernel",
                                                     "entropy": "zl_entropy_kernel", "gather": "zl_gather_kernel", "scan": "zl_scan_sizes_kernel"}[dom],
                          "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": ckm[dom]}}
+
+
+def per_input_full_leg(codec, device, n, log):
+    """Every SURVEY 8(d) input at the FULL size on its own -- BASELINE configs[2] read literally is the first row: a 1 GiB
+    vector of uniform random bytes (8192 raw-block frames) -- through the same device entries as the headline: round trip
+    checked bit for bit, best of three."""
+    import torch
+    from zstdlite_amd.device import gen_device
+    out = {}
+    comp = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
+    back = torch.empty(n, dtype=torch.uint8, device=device)
+    content = codec.chunk_content_sizes(n)
+    for kind in ("rand", "iid10", "text", "int20"):
+        src = gen_device(kind, n, device)
+        tc = td = 1e9
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _, total, fs = codec.compress(src, comp)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            got, _ = codec.decompress(comp, codec.frame_table(fs, content), back)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            tc, td = min(tc, t1 - t0), min(td, t2 - t1)
+        assert got == n and torch.equal(back, src), f"{kind}: round trip is not bit-exact"
+        assert total <= codec.bound(n)
+        km = codec.kernel_ms()
+        out[kind] = {"bytes": n, "compressed_bytes": int(total), "ratio": n / total, "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9,
+                     "roundtrip_GBps": n / (tc + td) / 1e9, "match_ms": km.get("match"), "bit_exact": True}
+        log(f"per input, full size {kind}: {out[kind]}")
+        del src
+    return out
 
 
 def long_range_leg(device, log):
@@ -695,7 +725,13 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     n = args.size
-    src, kinds, quarter = gen_mixed(n, device)
+    # ONE vector of world * n bytes, rank r holds bytes plan_shards(world * n, world)[r] of it (shard r has its own generator
+    # seeds; shard 0 is the one-GPU vector): the ranks do not compress copies of the same gigabyte
+    from zstdlite_amd.shard import plan_shards
+    shards = [(r * n, (r + 1) * n) for r in range(world)]
+    if n % (128 << 10) == 0:
+        assert shards == plan_shards(world * n, world), "the ranks' byte ranges are the shard plan of the whole vector"
+    src, kinds, quarter = gen_mixed(n, device, shard=rank)
     if args.dry:
         codec = _DryCodec()
     else:
@@ -776,6 +812,31 @@ def main():
         dist.barrier()
         gather_ms = (time.perf_counter() - tg) * 1e3
     assert torch.equal(back, src), "round trip is not bit-exact"
+    # ---- each direction on its own, same bracket (barrier + synchronize, max over ranks): north_star's target is the
+    # AGGREGATE zstd_decompress() rate; compression alone next to it
+    def timed(fn):
+        for _ in range(min(2, args.warmup)):
+            fn()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0d = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        sync()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0d
+        if world > 1:
+            tm = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        return el / args.steps
+    _, total_d, fsizes_d = codec.compress(src, comp)
+    tbl_d = codec.frame_table(fsizes_d, content)
+    t_dec = timed(lambda: codec.decompress(comp, tbl_d, back))
+    assert torch.equal(back, src), "decompression alone is not bit-exact"
+    t_cmp = timed(lambda: codec.compress(src, comp))
     ms_per_step = elapsed / args.steps * 1e3
     kms = {k: v / args.steps for k, v in kms_sum.items()}
 
@@ -791,10 +852,11 @@ def main():
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"zstd_compress() then zstd_decompress() of a {n >> 20} MiB raw vector per GPU, level 3 (BASELINE configs[2] + its decode); vector = 4 equal parts rand/iid10/text/int20 (SURVEY 8d); one independent frame per 128 KiB chunk",
-                       "bytes_per_gpu": n, "chunk_bytes": 128 << 10, "frames_per_gpu": int(len(content)),
+            "config": {"workload": f"zstd_compress() then zstd_decompress() of a {n >> 20} MiB raw vector per GPU, level 3 (BASELINE configs[2] + its decode); vector = 4 equal parts rand/iid10/text/int20 (SURVEY 8d); one independent frame per 128 KiB chunk (frame content 131072 bytes)" + (f"; the {world} ranks hold the {world} shards of ONE {world * n >> 20} MiB vector (own seeds per shard)" if world > 1 else ""),
+                       "bytes_per_gpu": n, "chunk_bytes": 128 << 10, "frame_content_bytes": 128 << 10, "frames_per_gpu": int(len(content)), "vector_bytes": world * n, "shard_of_rank": [list(x) for x in shards],
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective" + ("; compressed shards gathered to rank 0 over RCCL" if world > 1 else "")},
             "ratio": n / csize, "compressed_bytes": int(csize), "bit_exact_roundtrip": True,
+            "decompress_only_GBps_aggregate": world * n / t_dec / 1e9, "compress_only_GBps_aggregate": world * n / t_cmp / 1e9,
             "compress_GBps_kernels": (n / (t_comp / 1e3) / 1e9) if t_comp else None,
             "decompress_GBps_kernel": (n / (kms["decode"] / 1e3) / 1e9) if kms.get("decode") else None,
             "kernel_ms": kms,
@@ -844,7 +906,8 @@ def main():
             per[k] = {"bytes": int(part.numel()), "compressed": int(tot), "ratio": part.numel() / tot}
         out["per_input"] = per
         if world == 1 and not args.no_extra:
-            for name, leg in (("one_frame_layout", lambda: one_frame_leg(device, src, log)), ("long_range", lambda: long_range_leg(device, log)),
+            for name, leg in (("one_frame_layout", lambda: one_frame_leg(device, src, log)), ("per_input_full", lambda: per_input_full_leg(codec, device, n, log)),
+                              ("long_range", lambda: long_range_leg(device, log)),
                               ("c4_small_objects_dict", lambda: c4_leg(log))):
                 try:
                     out[name] = leg()
@@ -853,6 +916,9 @@ def main():
             # the DEFAULT layout of the host entries (what an R caller gets) has its own roofline entry next to the headline's
             if isinstance(out.get("one_frame_layout"), dict) and "roofline" in out["one_frame_layout"]:
                 out["roofline_one_frame"] = out["one_frame_layout"].pop("roofline")
+                # the same round trip in the DEFAULT layout of zl_compress2 (one frame): what an R caller's bytes look like
+                of = out["one_frame_layout"]
+                out["value_one_frame"] = 1.0 / (1.0 / of["compress_GBps"] + 1.0 / of["decompress_GBps"])
         if world == 1 and not args.no_cpu:
             # ---- cpu_baseline leg: the only place bench.py touches oracle/ (the reference libzstd
             # built into oracle/_ref): timed on the host cores, and -- for BASELINE config C2 -- used

@@ -959,7 +959,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 const u32 mend = 2 * t + best_len;  // window-relative end of the match
                 const bool odd_end = has_match && (mend & 1) && p + best_len < n;
                 u32 tail_byte = 0;
-                if (odd_end) tail_byte = src[p + best_len];
+                // (the byte behind a match of up to 14 bytes is one of the lane's own sixteen; a load here is a memory round trip in the parse)
+                if (odd_end) {
+                    if (best_len <= 14) { const u32 idx = best_len + 1; tail_byte = (u32)((idx < 8 ? lo : hi) >> (8 * (idx & 7))) & 0xFF; }
+                    else tail_byte = src[p + best_len];
+                }
                 // ---- greedy parse over the 256 nodes (even positions): wave-local closure, chain, marks
                 const u32 nxt = has_match ? ((mend + 1) >> 1) : t + 1u;  // next node on the path
                 u32 jr[6];

@@ -174,9 +174,11 @@ def gen_device(kind, n, device, seed=0x9E3779B9):
     raise ValueError(kind)
 
 
-def gen_mixed(n, device):
+def gen_mixed(n, device, shard=0):
     """The bench workload: n bytes, one quarter each of rand / iid10 / text / int20 (the four
-    inputs of BASELINE.md section 2, which quotes the reference's ratio on 256 MiB of each)."""
+    inputs of BASELINE.md section 2, which quotes the reference's ratio on 256 MiB of each).
+    shard: which n-byte shard of a larger vector this is (bench.py --gpus N: rank r holds shard r; every shard has
+    its own generator seeds, shard 0 is the one-GPU vector)."""
     q = n // 4
-    parts = [gen_device(k, q if i < 3 else n - 3 * q, device) for i, k in enumerate(("rand", "iid10", "text", "int20"))]
+    parts = [gen_device(k, q if i < 3 else n - 3 * q, device, seed=0x9E3779B9 + 0x01000193 * shard) for i, k in enumerate(("rand", "iid10", "text", "int20"))]
     return torch.cat(parts), ("rand", "iid10", "text", "int20"), q
