@@ -147,6 +147,13 @@ size_t zl_DCtx_setParameter(zl_dctx *dctx, int param, int value);
 size_t zl_DCtx_getParameter(const zl_dctx *dctx, int param, int *value);
 size_t zl_DCtx_loadDictionary(zl_dctx *dctx, const void *dict, size_t dictSize);
 
+/* FORMAT STRICTNESS (a stated divergence from libzstd on DAMAGED input): every decoder of this library requires each
+ * entropy stream -- the four Huffman streams of a literals section, the sequence bitstream -- to be consumed exactly, as the
+ * format document says.  libzstd's Huffman fast path (zstd.c:38890-38940) does not check that, so a few damaged frames that
+ * ZSTD_decompressDCtx accepts (returning bytes that are not what was compressed) are REJECTED here with
+ * "Data corruption detected" (ZL_E_CORRUPTION, libzstd's ZSTD_error_corruption_detected = 20).  Never the other way round: whatever this library accepts, libzstd accepts, with the same
+ * bytes (tests/test_oracle.py, tests/test_decode_gpu.py).  On valid frames the results are identical. */
+
 /* replaces ZSTD_decompressDCtx (zstd.h:290; call sites src/raw-file.c:189,
  * src/serialize.c:197): decodes every frame in [src, src+srcSize) -- concatenated small frames in
  * parallel on the lane pipeline, a frame of many blocks (what ZSTD_compress2 and zl_compress2 write for
@@ -171,7 +178,10 @@ size_t zl_decompress_batch(zl_dctx *dctx, size_t n, void *const *dsts, const siz
 /* ---- device-resident entries (new): data already in HBM, used by bench.py and by callers
  * that keep buffers on the GPU.  Pointers are device addresses; `stream` is a hipStream_t
  * (NULL = the context's own stream).  The *_async calls only enqueue work; *_finish waits
- * for it and returns the total bytes or the first error. ----------------------------------- */
+ * for it and returns the total bytes or the first error.
+ * NULL is NOT the legacy default stream: the context's own stream is non-blocking, i.e. not ordered behind work queued on
+ * the default stream.  A caller that produces d_src on the default stream either passes a stream of its own that is, or
+ * synchronises first (zstdlite_amd/device.py does the latter). ----------------------------- */
 typedef struct {
     uint64_t src_off;  /* frame start inside d_src */
     uint64_t src_size; /* compressed size of the frame */
@@ -205,7 +215,11 @@ size_t zl_decompress_device_hint_host_copy(zl_dctx *dctx, const void *hostSrc, s
  * entry), or ONE frame (ZL_c_frameLayout = ZL_layout_one_frame).  d_dst must hold zl_compressBound(srcSize)
  * bytes.  After _finish, frameSizes (host, may be NULL, capacity zl_compress_device_nframes(srcSize)) holds
  * the compressed size of every chunk -- its frame, or its run of blocks inside the one frame (the first
- * includes the frame header): what zl_decompress_device_hint takes.  Returns total compressed bytes. */
+ * includes the frame header): what zl_decompress_device_hint takes.  Returns total compressed bytes.
+ * One configuration is NOT asynchronous: ONE frame with ZL_c_checksumFlag.  The frame's content checksum is one XXH64 over
+ * all of the input (zstd.c:27733), a serial chain that runs on a host core; zl_compress_device_async brings the input down
+ * and hashes it before it returns, so that on return the frame in d_dst is complete and d_src may be reused -- exactly as
+ * for every other configuration a stream-ordered consumer may assume. */
 size_t zl_compress_device_nframes(size_t srcSize);
 size_t zl_compress_device_async(zl_cctx *cctx, void *d_dst, size_t dstCapacity, const void *d_src, size_t srcSize,
                                 void *stream);

@@ -56,6 +56,20 @@ def test_frame_size_helpers_on_golden(golden, oracle):
     assert table[1].src_off == cases[10]["csize"] and table[1].dst_off == cases[10]["n"]
 
 
+def test_info_batch_agrees_with_the_single_call(golden):
+    """zstd_info_batch (row N4: src/zstd-info.c:22-95 over a list) = zstd_info per item, on every golden frame, a frame cut
+    short, bytes that are no frame, and an empty item."""
+    import zstdlite_amd as z
+    cases, _ = golden
+    items = [c["comp"] for c in cases] + [cases[3]["comp"][:7], b"abcdefgh", b"", cases[5]["comp"][:4]]
+    got = z.zstd_info_batch(items)
+    for i, b in enumerate(items):
+        one = z.zstd_info(b) if len(b) else {"compressed_size": None, "uncompressed_size": None, "dict_id": 0, "has_checksum": False}
+        for k in ("compressed_size", "uncompressed_size", "dict_id", "has_checksum"):
+            assert got[k][i] == one[k], (i, k, got[k][i], one[k])
+    assert z.zstd_info_batch([]) == {"compressed_size": [], "uncompressed_size": [], "dict_id": [], "has_checksum": []}
+
+
 def test_bound_dominates_reference_bound(oracle):
     L = _lib.lib()
     for n in [0, 1, 100, 65536, 131072, 131073, 1 << 20, (1 << 30) + 5]:

@@ -471,3 +471,88 @@ def test_no_sequence_reaches_in_front_of_its_section():
         assert b"".join(out) == z.zstd_compress(raw)
     finally:
         L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+
+
+def _ref_batch_lib():
+    import os
+    from zl_testlib import REF_SO
+    R = C.CDLL(os.path.join(os.path.dirname(REF_SO), "libzl_ref_batch.so"))
+    assert R.zlr_init(REF_SO.encode()) == 0
+    R.zlr_batch.restype = C.c_double
+    R.zlr_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return R
+
+
+@pytest.mark.parametrize("kind", ["rand", "iid10", "text", "int20"])
+def test_every_input_at_one_gib(codec, kind):
+    """Every SURVEY 8(d) input on its own at 2^30 bytes; kind "rand" is BASELINE configs[2] read literally: zstd_compress() of
+    a 1 GiB vector of uniform random bytes, level 3 -- 8192 frames of one raw block each, inside the bound, back bit for bit."""
+    dev = torch.device("cuda", 0)
+    n = 1 << 30
+    src = gen_device(kind, n, dev)
+    comp, total, fs = codec.compress(src)
+    assert len(fs) == n // CHUNK and total == int(fs.sum()) and total <= codec.bound(n)
+    if kind == "rand":
+        # a raw block: frame header (magic 4, descriptor 1, content size 4) + block header 3 + the bytes
+        assert (fs == CHUNK + 12).all(), (int(fs.min()), int(fs.max()))
+        head = comp[:12].cpu().numpy()
+        assert bytes(head[:4]) == b"\x28\xb5\x2f\xfd" and (int(head[9]) & 6) == 0  # Raw_Block
+    else:
+        ref_ratio = {"iid10": 2.042, "text": 4.212, "int20": 1.272}[kind]  # BASELINE.md section 2, reference level 3
+        assert n / total >= ref_ratio / 1.05, (kind, n / total)
+    back = torch.empty_like(src)
+    got, res = codec.decompress(comp, codec.frame_table(fs, codec.chunk_content_sizes(n)), back)
+    assert got == n and (res == CHUNK).all() and torch.equal(back, src)
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref")
+def test_one_gib_of_frames_through_the_reference_decoder(codec):
+    """The encoder's whole 1 GiB output -- 8192 frames -- is decoded by the REFERENCE's ZSTD_decompressDCtx, one context per host
+    thread (oracle/zl_ref_batch.c), and must regenerate the vector bit for bit: until round 4 the largest input that went to the
+    reference decoder was 320 MiB."""
+    import os
+    dev = torch.device("cuda", 0)
+    n = 1 << 30
+    src, _, _ = gen_mixed(n, dev)
+    comp, total, fs = codec.compress(src)
+    blob = comp[:total].cpu().numpy()
+    host = src.cpu().numpy()
+    k = len(fs)
+    in_size = np.asarray(fs, dtype=np.uint64)
+    in_off = np.concatenate([[0], np.cumsum(in_size)[:-1]]).astype(np.uint64)
+    out_cap = np.full(k, CHUNK, dtype=np.uint64)
+    out_off = (np.arange(k, dtype=np.uint64) * np.uint64(CHUNK))
+    out = np.zeros(n, dtype=np.uint8)
+    out_size = np.zeros(k, dtype=np.uint64)
+    R = _ref_batch_lib()
+    R.zlr_batch(1, 3, min(os.cpu_count() or 1, 256), None, 0, k, blob.ctypes.data, in_off.ctypes.data, in_size.ctypes.data,
+                out.ctypes.data, out_off.ctypes.data, out_cap.ctypes.data, out_size.ctypes.data)
+    assert (out_size == CHUNK).all(), out_size[out_size != CHUNK][:4]
+    assert np.array_equal(out, host)
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref")
+def test_device_one_frame_with_checksum_is_complete_when_async_returns():
+    """ONE frame with a content checksum through the device-resident entry: when zl_compress_device_async returns
+    the frame in d_dst is complete and d_src may be overwritten -- the checksum is the one of the bytes that were compressed,
+    whatever happens to d_src before zl_compress_device_finish."""
+    from zl_testlib import Ref
+    dev = torch.device("cuda", 0)
+    n = 5 * CHUNK + 777
+    c = DeviceCodec(include_checksum=True, frame_layout="one_frame")
+    src = gen_device("text", n, dev)
+    keep = src.cpu().numpy().tobytes()
+    dst = torch.zeros(c.bound(n), dtype=torch.uint8, device=dev)
+    r = c.L.zl_compress_device_async(c.cctx, C.c_void_p(dst.data_ptr()), dst.numel(), C.c_void_p(src.data_ptr()), n, None)
+    assert r == 0
+    src.zero_()  # the caller reuses its input before _finish
+    torch.cuda.synchronize()
+    sizes = (C.c_size_t * c.L.zl_compress_device_nframes(n))()
+    total = c.L.zl_compress_device_finish(c.cctx, sizes)
+    assert total < (1 << 62) and total == sum(sizes)
+    frame = dst[:total].cpu().numpy().tobytes()
+    assert (frame[4] >> 2) & 1  # Content_Checksum_flag
+    ref = Ref()
+    assert ref.decompress(frame, n) == keep  # (the reference verifies the checksum)
+    c.close()

@@ -28,7 +28,7 @@ from ._lib import FrameT, ZstdError, is_error
 __all__ = [
     "zstd_compress", "zstd_decompress", "zstd_serialize", "zstd_unserialize", "zstd_cctx", "zstd_dctx",
     "zstd_cctx_settings", "zstd_dctx_settings", "zstd_info", "zstd_dict_id", "zstd_version",
-    "zstd_compress_batch", "zstd_decompress_batch", "zstd_compress_bound", "zstdfile", "zstd_clear_cache", "ZstdError",
+    "zstd_compress_batch", "zstd_decompress_batch", "zstd_info_batch", "zstd_compress_bound", "zstdfile", "zstd_clear_cache", "ZstdError",
 ]
 
 ZL_c_compressionLevel = 100
@@ -387,7 +387,7 @@ def zstd_info(src):
         "compressed_size": None if is_error(csize) else csize,
         "uncompressed_size": None if usize >= _ERROR else usize,
         "dict_id": L.zl_getDictID_fromFrame(ptr, n),
-        "has_checksum": bool(n >= 5 and (b[4] >> 2) & 1),
+        "has_checksum": bool(n >= 5 and b[:4] == b"\x28\xb5\x2f\xfd" and (b[4] >> 2) & 1),  # (only a zstd frame has the flag)
     }
 
 
@@ -471,6 +471,44 @@ def _content_sizes(blob, sizes, off):
     val = np.where(fflag == 1, val + np.uint64(256), val)
     ok = (magic == np.uint64(0xFD2FB528)) & (sizes >= (pos + fbytes).astype(np.uint64)) & ((fhd & np.uint64(8)) == 0) & (fbytes > 0)
     return np.where(ok, val, np.uint64(0))
+
+
+def zstd_info_batch(srcs):
+    """zstd_info() of n buffers at once (row N4 of SURVEY 8f: R/zstd-info.R:18 / src/zstd-info.c:22-95 called in an lapply loop):
+    the frame headers are parsed vectorised, as zstd_decompress_batch does; only the compressed size, which needs the
+    block headers walked (zstd.c:41335), is one C call per item.  Returns a dict of equal-length lists; None where the
+    reference's zstd_info() gives NA."""
+    L = _lib.lib()
+    n = len(srcs)
+    if n == 0:
+        return {"compressed_size": [], "uncompressed_size": [], "dict_id": [], "has_checksum": []}
+    blob, sizes, off = _pack_items(srcs, "zstd_info_batch()")
+    idx = off[:-1, None].astype(np.int64) + np.arange(18, dtype=np.int64)[None, :]
+    np.minimum(idx, blob.size - 1, out=idx)
+    h = blob[idx].astype(np.uint64)
+    magic = h[:, 0] | (h[:, 1] << np.uint64(8)) | (h[:, 2] << np.uint64(16)) | (h[:, 3] << np.uint64(24))
+    is_frame = (magic == np.uint64(0xFD2FB528)) & (sizes >= 5)
+    fhd = h[:, 4]
+    dflag, single = fhd & np.uint64(3), (fhd >> np.uint64(5)) & np.uint64(1)
+    dbytes = np.where(dflag == 3, 4, dflag).astype(np.int64)
+    dpos = 5 + (1 - single.astype(np.int64))
+    rows = np.arange(n)
+    did = np.zeros(n, dtype=np.uint64)
+    for k in range(4):
+        did |= np.where(k < dbytes, h[rows, np.minimum(dpos + k, 17)] << np.uint64(8 * k), np.uint64(0))
+    did = np.where(is_frame & (sizes >= (dpos + dbytes).astype(np.uint64)), did, np.uint64(0))
+    usize = _content_sizes(blob, sizes, off)
+    fflag = fhd >> np.uint64(6)
+    known = is_frame & ((fflag != 0) | (single == 1)) & ((usize != 0) | (sizes >= 6))
+    base = blob.ctypes.data
+    csize = []
+    for i in range(n):
+        r = L.zl_findFrameCompressedSize(C.c_void_p(base + int(off[i])), int(sizes[i]))
+        csize.append(None if is_error(r) else int(r))
+    return {"compressed_size": csize,
+            "uncompressed_size": [int(u) if k else None for u, k in zip(usize.tolist(), known.tolist())],
+            "dict_id": [int(d) for d in did.tolist()],
+            "has_checksum": [bool(f and (int(x) >> 2) & 1) for x, f in zip(fhd.tolist(), is_frame.tolist())]}
 
 
 def zstd_decompress_batch(srcs, *, dctx=None, **opts):

@@ -29,7 +29,7 @@ def build_variant(name, defines, verbose=False):
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, f"libzl_hip.{name}.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    cmd = [hipcc] + FLAGS + ["-I" + CSRC] + list(defines) + ["-shared", "-o", out] + srcs
+    cmd = [hipcc] + FLAGS + ["-I" + CSRC] + list(defines) + ["-shared", "-Wl,-z,nodelete", "-o", out] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -54,7 +54,8 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        # -z nodelete: the library keeps worker threads parked in its own code (zl_host.h ZlPool); unloading it would unmap them
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,nodelete", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

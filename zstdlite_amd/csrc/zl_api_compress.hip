@@ -56,6 +56,7 @@ struct zl_cctx_s {
     size_t pending_chunks = 0, pending_groups = 0;
     bool pending_hash = false;        // the pending call writes ONE frame with a content checksum: XXH64 of the whole input goes behind the last block
     const u8* pending_src = nullptr;  // ... the input (device) and its size, where the frame is being written
+    size_t pending_footer = 0;        // ... bytes zl_compress_device_async put behind the frame itself (the checksum)
     u8* pending_dst = nullptr;
     size_t pending_n = 0;
     // diagnostics
@@ -309,6 +310,9 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
 // first chunk (cctx_enqueue_group).
 bool use_one_frame(const zl_cctx* c, size_t n, bool host_entry) {
     if (n <= ZL_CHUNK) return false;
+    // (a dictionary frame of 4 GiB and more would meet neither the seek-table path nor the runs of blocks of the decoder, both of
+    // which refuse a dictionary, and end on the general kernel's one workgroup: such input keeps independent frames -- ADVICE r3)
+    if (!c->dict.empty() && n >= (size_t)0xFFFFD000ull && c->layout != 2) return false;
     if (c->layout == 1) return false;
     if (c->layout == 2) return true;
     return host_entry;
@@ -484,42 +488,14 @@ size_t zl_CCtx_loadDictionary(zl_cctx* c, const void* dict, size_t n) {
     return 0;
 }
 
-size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void* d_src, size_t n, void* stream) {
-    if (!c) return ZL_ERR(ZL_E_GENERIC);
-    if (!device_ok()) return kGpuUnavailable;
-    if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
-    if (cap < zl_compressBound(n)) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
-    hipStream_t st = cctx_stream(c, stream);
-    const size_t nchunks = fill_chunk_table(c, n);
-    if (ZL_IS_ERR(nchunks)) return nchunks;
-    const bool one = use_one_frame(c, n, false);
-    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, one ? (u64)n : 0);
-    if (ZL_IS_ERR(e)) return e;
-    c->pending = true;
-    c->pending_stream = st;
-    c->pending_hash = one && c->checksum;
-    c->pending_src = (const u8*)d_src;
-    c->pending_dst = (u8*)d_dst;
-    c->pending_n = n;
-    return 0;
-}
-
-size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
-    if (!c || !c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
-    c->pending = false;
+// ONE frame with a content checksum through the device-resident entry: the XXH64 of the input and the four footer bytes.
+// Runs inside zl_compress_device_async, on the calling thread, BEFORE it returns (round 3 did it in _finish: until then the frame
+// in d_dst said "checksum" and had none, and a caller that overwrote d_src in stream order behind _async got a wrong one written
+// -- ADVICE r3).  With this configuration the call is therefore not asynchronous: it returns once the frame is complete.
+static size_t seal_one_frame_checksum(zl_cctx* c) {
     if (hipStreamSynchronize(c->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (c->ev_valid) {
-        for (int k = 0; k < 4; k++) {
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
-            c->kernel_ms[k] = ms;
-        }
-        c->far_ms = 0;
-        if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->far_ms = ms; }
-        if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
-    }
     size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
-    if (c->pending_hash) {
+    {
         // ONE frame with a content checksum, content in device memory: the XXH64 chain runs on the host (zl_xxh64.h says why),
         // over pieces brought down through two pinned buffers so that the copy of one piece hides behind the hashing of the
         // one before.  Rare on this entry (its default layout is independent frames, each checked on the device).
@@ -542,10 +518,54 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
         const u32 x = h.low32();
         u8 le[4] = {(u8)x, (u8)(x >> 8), (u8)(x >> 16), (u8)(x >> 24)};
         if (hipMemcpyAsync(c->pending_dst + total, le, 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);  // (the bound leaves room)
-        total += 4;
         ((u32*)c->h_fsize.p)[c->pending_chunks - 1] += 4;  // (the last chunk's size covers the frame's footer: what the decoder's chunk hint expects)
         c->pending_hash = false;
     }
+    c->pending_footer = 4;
+    return 0;
+}
+
+size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void* d_src, size_t n, void* stream) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    if (!device_ok()) return kGpuUnavailable;
+    if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    if (cap < zl_compressBound(n)) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
+    hipStream_t st = cctx_stream(c, stream);
+    const size_t nchunks = fill_chunk_table(c, n);
+    if (ZL_IS_ERR(nchunks)) return nchunks;
+    const bool one = use_one_frame(c, n, false);
+    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, one ? (u64)n : 0);
+    if (ZL_IS_ERR(e)) return e;
+    c->pending = true;
+    c->pending_stream = st;
+    c->pending_hash = one && c->checksum;
+    c->pending_src = (const u8*)d_src;
+    c->pending_dst = (u8*)d_dst;
+    c->pending_n = n;
+    c->pending_footer = 0;
+    if (c->pending_hash) {
+        const size_t r = seal_one_frame_checksum(c);
+        if (ZL_IS_ERR(r)) { c->pending = false; return r; }
+    }
+    return 0;
+}
+
+size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
+    if (!c || !c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
+    c->pending = false;
+    if (hipStreamSynchronize(c->pending_stream) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    if (c->ev_valid) {
+        for (int k = 0; k < 4; k++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
+            c->kernel_ms[k] = ms;
+        }
+        c->far_ms = 0;
+        if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->far_ms = ms; }
+        if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
+    }
+    size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];
+    total += c->pending_footer;
     if (frame_sizes) {
         const u32* fs = (const u32*)c->h_fsize.p;
         for (size_t i = 0; i < c->pending_chunks; i++) frame_sizes[i] = fs[i];

@@ -152,8 +152,9 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
 // A few host threads that stay around between calls, for the per-object loops of the batch entries (pack, header parse,
 // unpack: 100k memcpys of a few hundred bytes).  Starting seven threads costs 0.2-0.5 ms, which is what such a loop takes
 // on one thread; waking sleeping ones costs a tenth of that.  One user at a time (a second caller runs its loop itself);
-// the workers are never joined (the object is leaked on purpose: they sleep on it until the process ends); a forked child
-// starts its own.
+// the workers are never joined (the object is leaked on purpose: they sleep on it until the process ends -- which is why the
+// library is linked with -z nodelete: unloading it would unmap the code they sleep in); a forked child has none of them and
+// runs its loops on the calling thread.
 struct ZlPool {
     static const size_t kWorkers = 7;
     std::mutex m, user;

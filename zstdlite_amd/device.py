@@ -48,7 +48,14 @@ class DeviceCodec:
 
     @staticmethod
     def _stream():
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        """The stream the library is to enqueue on: torch's current stream -- unless that is the default stream, whose handle is
+        NULL, which the C-ABI reads as "the context's own stream" (include/zl_hip.h): a non-blocking stream that is NOT ordered
+        behind what torch has queued on the default stream.  Torch's work is drained first in that case, so that a tensor that
+        is still being produced (torch.randint(...) a line above) is complete before the kernels read it."""
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream == 0:
+            cur.synchronize()
+        return C.c_void_p(cur.cuda_stream)
 
     def bound(self, n):
         return self.L.zl_compressBound(n)
