@@ -1,24 +1,33 @@
-"""Dev: where does a reference frame written at a high level go?  (level-19 frames on the general kernel)
-usage: python scripts/dev/l19_probe.py [MiB=32] [level=19]"""
+"""Dev: where does a reference frame written at a high level go, and how fast?  (level-19 frames on the general kernel)
+Device-resident decode of ONE reference-made frame, as bench.py's N1 leg.  usage: python scripts/dev/l19_probe.py [MiB=64] [levels=3,12,19]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import numpy as np
-import zstdlite_amd as z
+import numpy as np, torch
 from zstdlite_amd import _lib
+from zstdlite_amd.device import DeviceCodec
 from zl_testlib import GENERATORS, LONG_RANGE, Ref
-mib = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-level = int(sys.argv[2]) if len(sys.argv) > 2 else 19
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+levels = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "3,12,19").split(",")]
 ref = Ref()
 q = (mib << 20) // 4
-data = b"".join(GENERATORS[k](q) for k in ("iid10", "text", "int20")) + LONG_RANGE["corpus"](None)[:q]
-t0 = time.time(); frame = ref.compress(data, level=level); t1 = time.time()
-print(f"reference level {level}: {len(data)} -> {len(frame)} bytes in {t1 - t0:.1f}s")
-d = z.zstd_dctx()
-L = _lib.lib()
-for it in range(3):
-    t0 = time.time(); back = z.zstd_decompress(frame, dctx=d); dt = time.time() - t0
-assert back == data
-import ctypes as C
-ms = (C.c_double * 5)()
-L.zl_dctx_kernel_ms(d._ptr, ms)
-print(f"decompress {len(data) / dt / 1e9:.3f} GB/s (host entry); large frames {L.zl_dctx_large_frames(d._ptr)}; kernel ms decode {ms[0]:.2f} index {ms[1]:.2f} entropy {ms[2]:.2f} exec {ms[3]:.2f} general {ms[4]:.2f}")
+corpus = LONG_RANGE["corpus"](None)
+data = b"".join(GENERATORS[k](q) for k in ("iid10", "text", "int20")) + (corpus * (q // len(corpus) + 1))[:q]
+dev = torch.device("cuda", 0)
+n = len(data)
+plain = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev)
+for level in levels:
+    t0 = time.time(); frame = np.frombuffer(ref.compress(data, level=level), dtype=np.uint8).copy(); t1 = time.time()
+    codec = DeviceCodec(profile=True)
+    d_src = torch.from_numpy(frame).to(dev)
+    d_dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    tbl = codec.frame_table([int(frame.size)], [n])
+    best = 1e9
+    for it in range(4):
+        d_dst.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        total, res = codec.decompress(d_src, tbl, d_dst)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    ok = total == n and torch.equal(d_dst, plain)
+    km = codec.kernel_ms()
+    print(f"level {level:2d}: {n} -> {frame.size} bytes ({t1 - t0:.1f}s on the host); decode {n / best / 1e9:7.2f} GB/s ({best * 1e3:.2f} ms) exact {ok}; large frames {_lib.lib().zl_dctx_large_frames(codec.dctx)}; "
+          + " ".join(f"{k} {v:.2f}" for k, v in km.items() if k.startswith("d")), flush=True)
+    codec.close()

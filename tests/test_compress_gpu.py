@@ -396,6 +396,46 @@ def test_level_five_is_a_stronger_operating_point(ref):
     assert ref.decompress(t5[:first], 131072) == text[:131072]
 
 
+@pytest.mark.parametrize("level", [6, 9, 12])
+def test_level_six_and_up_follow_the_repeat_offset_history(ref, level):
+    """Levels >= 6 run operating point 6: the lazy rule also looks two positions on (zstd.c:31546, depth 2) and
+    the entropy stage follows the decoder's three-entry repeat-offset history sequence by sequence, emitting codes 2 and 3 and
+    the literal-less forms (zstd.c:19665, :44291) -- level 5 and below only ever wrote "new" or "repeat 1".  A wrong history
+    would make the REFERENCE decoder copy from wrong offsets: it must regenerate every input bit for bit, in both layouts,
+    from one block to many sections; the output must be smaller than level 5's, and the level-3 bytes are what they were
+    (scripts/dev/same_bytes.py).  The hash chains and optimal parser behind the reference's levels 7 and up are not built:
+    the ratio bar against the reference at the same level is met on text at 6 and 9 only."""
+    import warnings
+    from zl_testlib import LONG_RANGE
+    from ratio_inputs import INPUTS
+    corpus = LONG_RANGE["corpus"](None)
+    cases = [("corpus", corpus), ("corpus_3M", corpus[:3 << 20]), ("text", GENERATORS["text"](5 << 20, seed=level)), ("records", LONG_RANGE["records"](8 << 20)),
+             ("iid10", GENERATORS["iid10"](1 << 20, seed=level)), ("one_chunk", corpus[:100000]), ("tiny", corpus[:900])]
+    cases += [(name, gen(1 << 18)) for name, gen in list(INPUTS.items())[:8]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (levels above 6 run at 6: the mirror says so)
+        for name, data in cases:
+            for layout in ("auto", "frames"):
+                out = z.zstd_compress(data, level=level, frame_layout=layout)
+                if layout == "auto":
+                    assert ref.decompress(out, len(data)) == data, (name, layout)
+                else:  # independent frames: the reference decodes them one after the other
+                    pos, got = 0, []
+                    while pos < len(out):
+                        k = z.zstd_info(out[pos:])["compressed_size"]
+                        got.append(ref.decompress(out[pos:pos + k], 131072))
+                        pos += k
+                    assert b"".join(got) == data, (name, layout)
+                assert z.zstd_decompress(out) == data, (name, layout)
+        c5, c6 = z.zstd_compress(corpus, level=5), z.zstd_compress(corpus, level=level)
+        text = cases[2][1]
+        t5, t6 = z.zstd_compress(text, level=5), z.zstd_compress(text, level=level)
+    assert len(c6) < len(c5) * 0.995 and len(t6) < len(t5), (len(c5), len(c6), len(t5), len(t6))
+    if level <= 9:
+        assert len(t6) <= len(ref.compress(text, level=level)) * 1.05
+    assert z.zstd_compress(corpus, level=level) == c6  # deterministic
+
+
 def test_ratio_sweep_small_sizes(ref):
     """the 5 % ratio bar was pinned at 8 MiB and above only, while zstd_serialize() of ordinary R objects lives
     between 1 KB and 1 MB.  Eight kinds of input (tests/ratio_inputs.py: the SURVEY 8d generators, three kinds of float64

@@ -191,6 +191,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.stats = nullptr;
     m.sparse_only = c->level < 3 ? 1u : 0u;
     m.hi = c->level >= 5 ? 1u : 0u;
+    m.lazy2 = c->level >= 6 ? 1u : 0u;
     m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
     m.dict_len = c->dict_use;
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
@@ -243,6 +244,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.out_stride = sd.out;
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
+    e.exact_rep = c->level >= 6 ? 1u : 0u;
     e.joined = joined ? 1u : 0u;
     e.chunk_base = (u32)(frame_chunk0 + first);
     e.total_chunks = (u32)nchunks;
@@ -431,7 +433,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value >= 5 ? 5 : (value >= 3 ? 3 : value);
+        c->level = value >= 6 ? 6 : (value >= 5 ? 5 : (value >= 3 ? 3 : value));
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;

@@ -683,6 +683,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                         if (g2 > g1) has_match[j] = false;
                     }
                 }
+                // levels >= 6: ... and two positions on (zstd.c:31546 ZSTD_compressBlock_lazy_generic at depth 2 asks for a gain of 7 there)
+                if (a.lazy2 && has_match[j] && w + 2 < WIN) {
+                    const u32 nx = S.cand[w + 2];
+                    if (nx) {
+                        const int g1 = 4 * (int)best_len[j] - (int)(31 - __clz(best_off[j] + 1)) + 7;
+                        const int g2 = 4 * (int)(nx & 0xFF) - (int)(31 - __clz((nx >> 8) + 1));
+                        if (g2 > g1) has_match[j] = false;
+                    }
+                }
             }
             // ---- greedy parse over the window.  Every wave owns 64 consecutive positions: it closes its own
             // (position -> next position) links by pointer jumping through lane shuffles, which tells for
@@ -2328,12 +2337,48 @@ __device__ __noinline__ void block_boundary(const zl_seq* seqs, u32 nseq, u32 nl
 // literal length and offset code value of sequence i inside its block (zstd.c:25186 ZSTD_seqToCodes input):
 // the first sequence of a block counts its literals from the block start and always spells its
 // offset out, so that no block depends on the history its predecessor leaves behind.
-__device__ __forceinline__ void seq_fields(const zl_seq* seqs, u32 i, u32 blk_first_seq, u32 blk_first_lit, const zl_seq& s, u32& ll, u32& ob) {
+__device__ __forceinline__ void seq_fields(const zl_seq* seqs, u32 i, u32 blk_first_seq, u32 blk_first_lit, const zl_seq& s, u32& ll, u32& ob, bool exact) {
     const bool first = i == blk_first_seq;
     const u32 prev_cum = first ? blk_first_lit : seqs[i - 1].lit_cum;
     const u32 prev_off = first ? 0u : seqs[i - 1].offset;
     ll = s.lit_cum - prev_cum;
-    ob = (ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3;
+    ob = exact ? s.pos : ((ll > 0 && s.offset == prev_off) ? 1u : s.offset + 3);  // (exact: exact_rep_codes has left the code value in `pos`)
+}
+
+// Levels >= 6: the offset code value of every sequence of ONE block under the decoder's three-entry repeat-offset history
+// (zstd.c:19665 ZSTD_storeSeq / zstd.c:44291 ZSTD_updateRep: with literals in front, the most recent three offsets are codes
+// 1, 2, 3; without, the second and third and "the first minus one"), followed sequence by sequence on one lane and written
+// into the records' `pos` field (nothing reads positions once the block boundaries are known).  What the history holds when
+// the block starts is what the block in front left behind, which this lane does not know: an unknown entry is 0, which no
+// offset equals, and every code it emits says what the decoder's history looks like afterwards whatever lay underneath -- a new
+// offset pushes, a repeat code moves its entry to the front.  Eight records are fetched per trip: the chain depends on the
+// history, not on memory.
+__device__ __noinline__ void exact_rep_codes(zl_seq* seqs, u32 first, u32 end, u32 first_lit) {
+    u32 r0 = 0, r1 = 0, r2 = 0, prev_cum = first_lit;
+    for (u32 base = first; base < end; base += 8) {
+        uint4 rec[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (base + k < end) __builtin_memcpy(&rec[k], &seqs[base + k], 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (base + k >= end) break;
+            const u32 o = rec[k].z, ll = rec[k].x - prev_cum;  // {lit_cum, match_len, offset, pos}
+            prev_cum = rec[k].x;
+            u32 ob;
+            if (ll) {
+                if (o == r0) ob = 1;
+                else if (o == r1) { ob = 2; r1 = r0; r0 = o; }
+                else if (o == r2) { ob = 3; r2 = r1; r1 = r0; r0 = o; }
+                else { ob = o + 3; r2 = r1; r1 = r0; r0 = o; }
+            } else {
+                if (o == r1) { ob = 1; r1 = r0; r0 = o; }
+                else if (o == r2) { ob = 2; r2 = r1; r1 = r0; r0 = o; }
+                else if (r0 > 1 && o == r0 - 1) { ob = 3; r2 = r1; r1 = r0; r0 = o; }
+                else { ob = o + 3; r2 = r1; r1 = r0; r0 = o; }
+            }
+            seqs[base + k].pos = ob;
+        }
+    }
 }
 
 // (The serial helpers above are __noinline__: inlined, their registers weigh on a kernel that is held to 64
@@ -2435,6 +2480,10 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
         for (u32 i = t; i < 256 + ZL_ENC_BLOCKS + 1; i += ENC_THREADS) S.stage[i] = 0;
     } else if (t <= ZL_ENC_BLOCKS) block_boundary(seqs, nseq, nlit, n, t, nbk, &S.blk_seq[t], &S.blk_lit[t]);
     __syncthreads();
+    // levels >= 6: a lane per block follows the decoder's repeat-offset history through its block (the other waves go on to the literal
+    // histogram, which does not look at sequences; everybody meets again in front of the sequence statistics)
+    const bool exact = a.exact_rep != 0;
+    if (exact && nseq && t < nbk) exact_rep_codes(const_cast<zl_seq*>(seqs), S.blk_seq[t], S.blk_seq[t + 1], S.blk_lit[t]);
 
     // =========================== statistics of the whole chunk: literal histogram, sequence codes and their histograms
     // (zstd.c:20692 ZSTD_compressLiterals, zstd.c:25265 ZSTD_buildSequencesStatistics).  The serial
@@ -2470,6 +2519,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
     // (the three code histograms likewise in four copies per bin, in the staging words -- 3 KiB that nothing else uses during this
     // pass --, summed into seq_hist behind the barrier: a text chunk's 18 000 sequences share a handful of codes)
     u32* const SH = S.stage + (lane & 3);
+    if (exact) zl_sync_global();  // (the code values were written by other lanes)
     if (nseq) {
         for (u32 j = 0; j < nbk; j++) {
             const u32 f_seq = S.blk_seq[j], e_seq = S.blk_seq[j + 1], f_lit = S.blk_lit[j];
@@ -2482,14 +2532,14 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 if (two) s1 = seqs[i + 1];
                 if (!first) sp = seqs[i - 1];
                 const u32 prev_cum = first ? f_lit : sp.lit_cum, prev_off = first ? 0u : sp.offset;  // (seq_fields: a block's first sequence spells its offset out)
-                const u32 ll0 = s0.lit_cum - prev_cum, ob0 = (ll0 > 0 && s0.offset == prev_off) ? 1u : s0.offset + 3;
+                const u32 ll0 = s0.lit_cum - prev_cum, ob0 = exact ? s0.pos : ((ll0 > 0 && s0.offset == prev_off) ? 1u : s0.offset + 3);
                 const u32 cl0 = ll_code(ll0), co0 = hb32(ob0), cm0 = ml_code(s0.match_len);
                 atomicAdd(&SH[4 * (64 * T_LL + cl0)], 1u);
                 atomicAdd(&SH[4 * (64 * T_OF + co0)], 1u);
                 atomicAdd(&SH[4 * (64 * T_ML + cm0)], 1u);
                 code_k[T_LL][i] = (u8)cl0; code_k[T_OF][i] = (u8)co0; code_k[T_ML][i] = (u8)cm0;
                 if (two) {
-                    const u32 ll1 = s1.lit_cum - s0.lit_cum, ob1 = (ll1 > 0 && s1.offset == s0.offset) ? 1u : s1.offset + 3;
+                    const u32 ll1 = s1.lit_cum - s0.lit_cum, ob1 = exact ? s1.pos : ((ll1 > 0 && s1.offset == s0.offset) ? 1u : s1.offset + 3);
                     const u32 cl1 = ll_code(ll1), co1 = hb32(ob1), cm1 = ml_code(s1.match_len);
                     atomicAdd(&SH[4 * (64 * T_LL + cl1)], 1u);
                     atomicAdd(&SH[4 * (64 * T_OF + co1)], 1u);
@@ -2867,7 +2917,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 if (e < ns) {
                     const u32 i = e_seq - 1 - e;
                     const zl_seq sq_ = seqs[i];
-                    r.lit_cum = sq_.lit_cum; r.match_len = sq_.match_len; r.offset = sq_.offset;
+                    r.lit_cum = sq_.lit_cum; r.match_len = sq_.match_len; r.offset = exact ? sq_.pos : sq_.offset;  // (exact: the code value itself, exact_rep_codes)
                     if (i == f_seq) { r.prev_cum = f_lit; r.prev_off = 0; }  // (seq_fields: a block's first sequence counts its literals from the block start and spells its offset out)
                     else { const zl_seq pq = seqs[i - 1]; r.prev_cum = pq.lit_cum; r.prev_off = pq.offset; }
                     if (e > 0) { r.bo = state_k[T_OF][i]; r.bl = state_k[T_LL][i]; r.bm = state_k[T_ML][i]; }  // states before this sequence
@@ -2884,7 +2934,7 @@ __global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_a
                 u32 cl = 0, cm = 0, co = 0;
                 if (e < ns) {
                     const u32 ll = rec.lit_cum - rec.prev_cum;
-                    const u32 ob = (ll > 0 && rec.offset == rec.prev_off) ? 1u : rec.offset + 3;
+                    const u32 ob = exact ? rec.offset : ((ll > 0 && rec.offset == rec.prev_off) ? 1u : rec.offset + 3);
                     cl = ll_code(ll); cm = ml_code(rec.match_len); co = hb32(ob);
                     const u32 nl_ = e_LL_bits[cl], nm = e_ML_bits[cm];
                     extra = (u64)(ll - e_LL_base[cl]);
