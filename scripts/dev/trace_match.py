@@ -8,7 +8,8 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "text"
 n = (int(sys.argv[2]) if len(sys.argv) > 2 else 256) << 20
 dev = torch.device("cuda", 0)
 src = gen_mixed(n, dev)[0] if kind == "mix" else gen_device(kind, n, dev)
-codec = DeviceCodec(profile=2, frame_layout="frames")
+import os
+codec = DeviceCodec(profile=2, frame_layout=os.environ.get("ZL_LAYOUT", "frames"))
 for _ in range(2):
     codec.compress(src)
 POINTS = 16

@@ -180,6 +180,10 @@ __device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wba
 #ifndef ZL_DENSE_SEQS_FAR
 #define ZL_DENSE_SEQS_FAR 8  // the same for the windowed layout, whose callers sit behind PCIe and asked for the reference's ratio
 #endif
+#ifndef ZL_SUB8_DIV
+#define ZL_SUB8_DIV 8  // one frame: the eight-lane look-up-and-insert phases while at least 1 in 8 of a window's sequences has an offset below 64
+                       // (1 in 4: match 7.52 ms, python sources 4.373; 1 in 8: 7.55 / 4.390; 1 in 16: 7.82 / 4.403; always, round 3: 8.00 / 4.420)
+#endif
 #ifndef ZL_SUB_LANES
 #define ZL_SUB_LANES 8   // dense body, look-up-and-insert phases: lanes of a wave that read and insert together (64: the whole wave at once)
 #endif
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     u32 carry = 0;           // where the parse enters the next window, in bytes (uniform)
     bool dense = !a.sparse_only || D != 0;  // which body the next window gets (uniform); dictionary frames use the stride-1 body throughout
     u32 wbuf_ip = 0xFFFFFFFFu;  // lean body: the position S.wbuf starts at (uniform)
+    bool sub8 = true;           // stride-1 body with INTRA: look up and insert eight lanes after eight lanes (uniform; see there)
     u64 v_pref = 0;          // stride 1: prefetched bytes of position pref_ip + t
     u32 pref_ip = 0xFFFFFFFFu;
     u64 pref0 = 0, pref1 = 0;  // stride 2: prefetched bytes [p-1, p+15) of position pref_ip2 + 2t
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 word_l[j] = word_s[j] = 0;
             }
             const bool search = carry < WIN;  // otherwise the whole window lies inside an earlier match
+            TR(0);
             // candidates of both positions are fetched together: one memory round trip.  A lane without
             // a candidate reads its own position and is masked out afterwards.
             u64 w_r[PPT], w_l[PPT], w_s[PPT], w_f[PPT];
@@ -554,6 +560,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                             // NEAREST repeat of records of 8 or 16 bytes -- a column of doubles, R's numeric vector -- whose
                             // neighbours differ in one or two bytes: seq(0, by = 0.25) matched its ninth-last value and paid a full byte
                             // per literal where the last value leaves 2 to 4 bits (1.57x the reference's size; tests/ratio_inputs.py).
+                            // The eight sub-phases are 32 dependent LDS operations per wave, the waves one behind the other: 3900 of an
+                            // iteration's 13 900 cycles on text in one frame (scripts/dev/trace_match.py), where they buy nothing.  Chunks of one
+                            // frame take them only while short offsets are what the data yields (sub8, decided window by window below).
+                            if (sub8) {
 #pragma unroll
                             for (u32 sub = 0; sub < 64 / ZL_SUB_LANES; sub++) {
                                 if (((t & 63) / ZL_SUB_LANES) == sub && can_match[j]) {
@@ -562,6 +572,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                                     tl[hl[j]] = val; ts[hs[j]] = val;
                                 }
                                 asm volatile("" ::: "memory");
+                            }
+                            } else if (can_match[j]) {  // the whole wave at once: a lookup sees the window up to the start of its wave
+                                el = tl[hl[j]]; es = ts[hs[j]];
+                                const unsigned short val = (unsigned short)(V + 1);
+                                tl[hl[j]] = val; ts[hs[j]] = val;
                             }
                         }
                         if (ph < 3) lds_barrier();
@@ -588,6 +603,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     }
                 }
             }
+            TR(1);
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
                 w_r[j] = w_l[j] = w_s[j] = 0;
@@ -626,6 +642,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     if (have_s[j] && best_len[j] < 8 && l_s >= tmin && l_s > best_len[j]) { best_len[j] = l_s; best_off[j] = D + p - q_s[j]; q_best[j] = q_s[j]; }
                     // the far offset: worth its longer code only when all eight bytes agree and nothing nearer does as well
                     if (FAR && have_f[j] && best_len[j] < 8 && common_bytes(v[j], w_f[j]) == 8) { best_len[j] = 8; best_off[j] = far_off[j]; q_best[j] = p - far_off[j]; }
+                    TR(2);
                     // extend while whole 8-byte words keep matching
                     if (wb_ok) {  // sixteen bytes per round, the own words from S.wbuf (never a dictionary frame)
                         static_assert((lane_cap - 8) % 16 == 0, "8 + 16 k");
@@ -667,9 +684,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 const u32 lo = __shfl_up((u32)v[0], 8, 64), hi = __shfl_up((u32)(v[0] >> 32), 8, 64);
                 back_mine = (u64)lo | ((u64)hi << 32);
             }
+            TR(3);
             const u64 s1 = prof ? __builtin_amdgcn_s_memtime() : 0;
             lds_barrier();
             if (wb_ok) wb_advance();
+            TR(4);
             // ---- one-step lazy evaluation (cf. the ip+1 long-match check of zstd.c:30025-30040): if the
             // next position holds a clearly better match, emit this byte as a literal instead
     #pragma unroll
@@ -711,7 +730,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 jp = (jp < wbase + 64) ? far : jp;
             }
             S.jump[0][t] = (u16)jp;  // where a path entering at t leaves this wave's segment
+            TR(5);
             lds_barrier();
+            TR(6);
             u32 enter = carry, my_entry = 0xFFFFFFFFu;
     #pragma unroll
             for (u32 k = 0; k < 4; k++) {
@@ -721,7 +742,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 }
             }
             const u32 next_carry = enter - WIN;  // uniform: where the path enters the next window
+            TR(7);
             const bool on_path0 = zl_path_marks(jr, t, wbase, my_entry);
+            TR(8);
             const u64 s2 = prof ? __builtin_amdgcn_s_memtime() : 0;
             bool is_seq[PPT], is_lit[PPT], on_path[PPT];
     #pragma unroll
@@ -764,19 +787,25 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 const u64 ms = __ballot(is_seq[0]), ml = __ballot(is_lit[0]);
                 const u64 below = (1ull << (t & 63)) - 1;
                 const u32 ws = (u32)__popcll(ms), wl = (u32)__popcll(ml);
-                if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16);
+                // (one frame: how many of the wave's sequences have an offset below 64 rides along in the top bits)
+                const u32 wn = (FAR && INTRA) ? (u32)__popcll(__ballot(is_seq[0] && best_off[0] < 64)) : 0u;
+                if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16) | (wn << 25);
                 lds_barrier();
-                u32 pre = 0, tot = 0;
+                u32 pre = 0, tot = 0, nshort = 0;
     #pragma unroll
                 for (u32 w = 0; w < 4; w++) {
-                    const u32 x = S.scan_a[w];
+                    const u32 xx = S.scan_a[w], x = xx & 0x1FFFFFFu;
                     if (w < wave) pre += x;
                     tot += x;
+                    nshort += xx >> 25;
                 }
                 ex_s[0] = (pre & 0xFFFF) + (u32)__popcll(ms & below);
                 ex_l[0] = (pre >> 16) + (u32)__popcll(ml & below);
                 tot_s = tot & 0xFFFF;
                 tot_l = tot >> 16;
+                // the next window looks up and inserts eight lanes at a time while a quarter of this one's sequences repeat at a
+                // distance below 64 (records of 8 or 16 bytes, the next line of a listing); a pure function of the data
+                if (FAR && INTRA && tot_s >= 4) sub8 = nshort * ZL_SUB8_DIV >= tot_s;
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
@@ -793,6 +822,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 }
             }
             carry = next_carry;
+            TR(10);
             const u64 s3 = prof ? __builtin_amdgcn_s_memtime() : 0;
             // ---- insert every position of the window (most recent position wins)
     #pragma unroll
@@ -816,7 +846,13 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             nlit += tot_l;
             win_seqs = tot_s;
             win_lits = tot_l;
+            TR(11);
             lds_barrier();
+            TR(12);
+#ifdef ZL_TRACE
+            if (tr_on && tr_it < ZL_TRACE_ITERS) a.stats[16 + (tr_it * 4 + (threadIdx.x >> 6)) * ZL_TRACE_POINTS + 9] = a.stats[16 + (tr_it * 4 + (threadIdx.x >> 6)) * ZL_TRACE_POINTS + 10];
+            tr_it++;
+#endif
             if (prof) {
                 const u64 s4 = __builtin_amdgcn_s_memtime();
                 c_find += s1 - s0; c_parse += s2 - s1; c_emit += s3 - s2; c_ins += s4 - s3; c_it++;
@@ -1537,6 +1573,9 @@ extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipSt
         else hipLaunchKernelGGL((zl_match_auto_kernel<false, false, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         return hipGetLastError();
     }
+#ifdef ZL_TRACE
+    if (a->far_hints && a->stats) { hipLaunchKernelGGL((zl_match_auto_kernel<false, true, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks); return hipGetLastError(); }
+#endif
     if (a->far_hints) hipLaunchKernelGGL((zl_match_auto_kernel<false, false, true, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len && a->intra) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, true>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     else if (a->dict_len) hipLaunchKernelGGL((zl_match_auto_kernel<true, false, false, false>), dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
