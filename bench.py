@@ -929,6 +929,12 @@ def main():
                     out["end_to_end"] = end_to_end_leg(host, device, log)
                 except Exception as e:
                     out["end_to_end"] = {"error": repr(e)}
+                try:  # the streaming entries on the same vector (scripts/stream_bench.py)
+                    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                    import stream_bench
+                    out["streaming"] = stream_bench.main(log=log, host=host)
+                except Exception as e:
+                    out["streaming"] = {"error": repr(e)}
             _, tot_f, fs_f = codec.compress(src, comp)  # the per-chunk frames of the vector: input of the threaded CPU decode
             cb = cpu_baseline(host, log, frames=(comp[:tot_f].cpu().numpy(), np.asarray(fs_f, dtype=np.int64), np.asarray(content, dtype=np.int64)))
             if cb is not None:

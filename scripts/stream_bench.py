@@ -44,10 +44,11 @@ def stream_decompress(L, dptr, comp, csize, dst, piece):
     return outb.pos
 
 
-def main(mib=1024, log=print):
-    n = mib << 20
+def main(mib=1024, log=print, host=None):
     L = _lib.lib()
-    host = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy()
+    if host is None:
+        host = gen_mixed(mib << 20, torch.device("cuda", 0))[0].cpu().numpy()
+    n = host.size
     comp = np.empty(L.zl_compressBound(n) + (1 << 20), dtype=np.uint8); comp.fill(1)
     back = np.empty(n, dtype=np.uint8); back.fill(1)
     cctx, dctx = z.zstd_cctx(), z.zstd_dctx()
