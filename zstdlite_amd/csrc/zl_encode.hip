@@ -165,6 +165,12 @@ __device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wba
 #ifndef ZL_MATCH_SGPRS
 #define ZL_MATCH_SGPRS 88  // a CU admits seven 256-thread workgroups up to 96 scalar registers per wave (six from 97; MI355X_MICROARCH.md, Residency); the lean body took the bulk instantiation to 97
 #endif
+#ifndef ZL_SPARSE_MIN
+#define ZL_SPARSE_MIN 5
+#endif
+#ifndef ZL_CHEAP_BITS
+#define ZL_CHEAP_BITS 36  // tenths of a bit: chunks whose bytes cost less keep only long matches (0: off)
+#endif
 #ifndef ZL_WBUF
 #define ZL_WBUF 1
 #endif
@@ -309,6 +315,36 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // of the mix's ratio (text +4.0 %, python sources +1.2 %).  Uniform.
     const bool back_on = ZL_BACK_MAX != 0 && (ZL_BACK_BULK || FAR || HI || DICT || intra_on);
     lds_barrier();
+    // ---- What is a match worth?  A sequence with a new offset costs some 24 bits (an offset of 2^k takes k extra bits on top of
+    // the three codes); the literals it replaces cost what the chunk's bytes cost.  Where bytes are CHEAP -- the order-0 entropy
+    // of 16 KiB sampled from the chunk's four quarters is below ZL_CHEAP_BITS/10 bits, e.g. i.i.d. data over a dozen symbols -- a new-offset match of
+    // fewer than eight bytes loses bits, and looking for such matches is all that the search does there: i.i.d. bytes over ten
+    // letters took 1.47 ms per 256 MiB for 0.5 sequences per 512 bytes that made the output LARGER than their literals would
+    // have (2.344 with them, 2.35 without).  Such chunks keep only matches of eight bytes and more (or a repeat offset), their
+    // windows are then mostly match-free, and the search acceleration below skips seven windows in eight, as on random bytes.
+    // The bulk path only (large inputs, independent frames, level 3); a pure function of the chunk's bytes.
+    u32 smin = ZL_SPARSE_MIN;  // stride-2 body: shortest new-offset match kept (uniform)
+    if (LEAN && ZL_CHEAP_BITS && n >= 16384) {
+        u32* const bins = S.cand;  // [256]
+        bins[t] = 0;
+        lds_barrier();
+        for (u32 part = 0; part < 4; part++) {  // 4 KiB at the start of every quarter of the chunk
+            const uint4 x = ld128(src + (size_t)part * (n >> 2) + 16 * t);
+            const u32 w4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) { atomicAdd(&bins[w4[k] & 0xFF], 1u); atomicAdd(&bins[(w4[k] >> 8) & 0xFF], 1u); atomicAdd(&bins[(w4[k] >> 16) & 0xFF], 1u); atomicAdd(&bins[w4[k] >> 24], 1u); }
+        }
+        lds_barrier();
+        const u32 c = bins[t];
+        float bits = c ? (float)c * (14.0f - __log2f((float)c)) : 0.0f;  // c * log2(16384 / c)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d, 64);
+        if ((t & 63) == 0) S.scan_b[t >> 6] = __float_as_uint(bits);
+        lds_barrier();
+        const float total = __uint_as_float(S.scan_b[0]) + __uint_as_float(S.scan_b[1]) + __uint_as_float(S.scan_b[2]) + __uint_as_float(S.scan_b[3]);
+        if (total * 10.0f < (float)ZL_CHEAP_BITS * 16384.0f) smin = 8;
+        lds_barrier();
+    }
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
@@ -404,9 +440,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 // repeat offset from 4 bytes, table candidates from 5; the long table's wins a tie against the short one's
                 best_len = l_r >= MIN_MATCH ? l_r : 0u;
                 best_off = dr;
-                const bool take_l = l_l > (best_len > MIN_MATCH ? best_len : MIN_MATCH);
+                const u32 floor_t = smin > MIN_MATCH + 1 ? smin - 1 : MIN_MATCH;  // (a table candidate must be longer than this)
+                const bool take_l = l_l > (best_len > floor_t ? best_len : floor_t);
                 best_len = take_l ? l_l : best_len; best_off = take_l ? dl : best_off;
-                const bool take_s = l_s > (best_len > MIN_MATCH ? best_len : MIN_MATCH);
+                const bool take_s = l_s > (best_len > floor_t ? best_len : floor_t);
                 best_len = take_s ? l_s : best_len; best_off = take_s ? ds : best_off;
                 TR(2);
                 // extend while whole 8-byte words keep matching.  (Fetching the 32 bytes behind a full match on both sides AT ONCE --
@@ -959,10 +996,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             u32 cand_before = 0x100;
             if (has_match && p >= 1 && (FAR ? (i32)q_best + (i32)reach_sec >= 1 : q_best >= 1)) cand_before = *at(q_best - 1);  // (inside the chunk's SECTION: the byte in front of a section is not this launch's to read -- a pledged stream's second job holds its own section only, and sections are self-contained)
             const bool back_ok = cand_before == byte_before;
-    #ifndef ZL_SPARSE_MIN
-#define ZL_SPARSE_MIN 5
-#endif
-        if (has_match && best_off != rep && best_len + (back_ok ? 1u : 0u) < ZL_SPARSE_MIN) has_match = false;
+        if (has_match && best_off != rep && best_len + (back_ok ? 1u : 0u) < smin) has_match = false;
             S.cand[t] = has_match ? (best_len | (best_off << 8)) : 0u;
             // does any lane of the workgroup hold a match?  (one word per wave next to the candidates, read behind the same barrier)
             {
