@@ -168,6 +168,9 @@ __device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wba
 #ifndef ZL_SPARSE_MIN
 #define ZL_SPARSE_MIN 5
 #endif
+#ifndef ZL_CHEAP_FAR_MIN
+#define ZL_CHEAP_FAR_MIN 12  // chunks of cheap bytes take a far hint only when the far probe measured at least this many bytes
+#endif
 #ifndef ZL_CHEAP_BITS
 #define ZL_CHEAP_BITS 36  // tenths of a bit: chunks whose bytes cost less keep only long matches (0: off)
 #endif
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // 4 and 5 bytes long, 12 bytes apart.  Uniform; folds to the constants of the layout where the instantiation knows them.
     const bool tiny = INTRA && !DICT && !FAR && !HI && intra_on && n <= 16384u;
     const u32 sbsh = FAR ? 64u - 8u * ZL_SHORT_BYTES_FAR : (tiny ? 32u : ((INTRA && !DICT && !HI && intra_on) ? 24u : 64u - 8u * ZL_SHORT_BYTES));
-    const u32 tmin = tiny ? MIN_MATCH : MIN_MATCH + 1;  // shortest match a table candidate may be (a repeat offset: MIN_MATCH)
+    const u32 tmin0 = tiny ? MIN_MATCH : MIN_MATCH + 1;  // shortest match a table candidate may be (a repeat offset: MIN_MATCH)
     // backward extension of matches (stride-1 body): everywhere but on the bulk path -- the chunks of large inputs at level 3
     // in the independent-frames layout, whose measure is GB/s: there it cost 6.7 % of match time (5.09 -> 5.43 ms) for 0.4 %
     // of the mix's ratio (text +4.0 %, python sources +1.2 %).  Uniform.
@@ -322,9 +325,11 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // letters took 1.47 ms per 256 MiB for 0.5 sequences per 512 bytes that made the output LARGER than their literals would
     // have (2.344 with them, 2.35 without).  Such chunks keep only matches of eight bytes and more (or a repeat offset), their
     // windows are then mostly match-free, and the search acceleration below skips seven windows in eight, as on random bytes.
-    // The bulk path only (large inputs, independent frames, level 3); a pure function of the chunk's bytes.
+    // Level 3 and below, chunks of large inputs in either layout (the level >= 5 instantiations, dictionaries and small inputs keep
+    // the fixed minimum: their ratios are pinned); a pure function of the chunk's bytes.
     u32 smin = ZL_SPARSE_MIN;  // stride-2 body: shortest new-offset match kept (uniform)
-    if (LEAN && ZL_CHEAP_BITS && n >= 16384) {
+    bool cheap = false;
+    if ((LEAN || (FAR && !HI)) && ZL_CHEAP_BITS && n >= 16384) {
         u32* const bins = S.cand;  // [256]
         bins[t] = 0;
         lds_barrier();
@@ -342,9 +347,14 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         if ((t & 63) == 0) S.scan_b[t >> 6] = __float_as_uint(bits);
         lds_barrier();
         const float total = __uint_as_float(S.scan_b[0]) + __uint_as_float(S.scan_b[1]) + __uint_as_float(S.scan_b[2]) + __uint_as_float(S.scan_b[3]);
-        if (total * 10.0f < (float)ZL_CHEAP_BITS * 16384.0f) smin = 8;
+        cheap = total * 10.0f < (float)ZL_CHEAP_BITS * 16384.0f;
         lds_barrier();
     }
+    // (cheap bytes alone do not say it: records that repeat, a column of doubles are cheap byte for byte AND all matches, short
+    // ones between the long ones included.  The chunk's first 4 KiB are searched as ever; the rule starts behind them where
+    // matches covered less than a tenth of those bytes.)
+    u32 probed = 0, probed_lits = 0;
+#define tmin (smin > tmin0 ? smin : tmin0)  /* stride-1 bodies: shortest match a table candidate may be */
 
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
@@ -559,7 +569,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 else if (pref_ip == ip) v[j] = v_pref;  // fetched while the previous window was being searched
                 else if (can_match[j]) v[j] = ld64(src + p);
                 else if (in_range[j]) v[j] = src[p];
-                if (FAR) far_off[j] = ((hint_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
+                if (FAR) {
+                    const u32 hw = (hint_ip == ip) ? hint_pref : (in_range[j] ? hints[p >> ZL_FAR_HINT_LOG] : 0u);
+                    far_off[j] = (smin > ZL_SPARSE_MIN && (hw >> 26) < ZL_CHEAP_FAR_MIN) ? 0u : (hw & 0x3FFFFFFu);  // (cheap bytes: a far offset costs 30 bits)
+                }
                 hl[j] = hs[j] = best_len[j] = best_off[j] = q_best[j] = 0;
                 word_l[j] = word_s[j] = 0;
             }
@@ -926,7 +939,10 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             bool have_r = false, have_l = false, have_s = false, have_f = false;
             u32 q_r = p, q_l = p, q_s = p;
             u32 far_off2 = 0;
-            if (FAR) far_off2 = ((pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u)) & 0x3FFFFFFu;
+            if (FAR) {
+                const u32 hw = (pref_ip2 == ip) ? hint_pref : (in0 ? hints[p >> ZL_FAR_HINT_LOG] : 0u);
+                far_off2 = (smin > ZL_SPARSE_MIN && (hw >> 26) < ZL_CHEAP_FAR_MIN) ? 0u : (hw & 0x3FFFFFFu);  // (cheap bytes: a far offset costs 30 bits)
+            }
             u32 el = 0, es = 0;
             if (can0) { hl0 = hash_long(v0, lshift); hs0 = hash_short_rt(v0, sbsh, sshift); }
             if (can1) { hl1 = hash_long(v1, lshift); hs1 = hash_short_rt(v1, sbsh, sshift); }
@@ -1170,8 +1186,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         else
 #endif
         dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= (FAR ? ZL_DENSE_SEQS_FAR : ZL_DENSE_SEQS));
-        (void)win_lits;
+        if (cheap && probed < 4096) {
+            probed += win; probed_lits += win_lits;
+            if (probed >= 4096 && (probed - probed_lits) * 10 < probed) smin = 8;
+        }
     }
+#undef tmin
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
         atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)c_parse);
