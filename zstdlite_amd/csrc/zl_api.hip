@@ -1276,6 +1276,9 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             // scripts/fuzz_seek.py)
             const size_t r = decompress_with_seek_table(d, (u8*)dst, cap, src, t);
             if (!ZL_IS_ERR(r)) return r;
+            // (two failures are not the table's: no device / no memory -- the walk needs the same --, and a wrong content checksum
+            // behind runs that all decoded and added up, which the walk would decode to the same bytes a second time: ADVICE r3)
+            if (r == kGpuUnavailable || r == ZL_ERR(ZL_E_CHECKSUM_WRONG)) return r;
         }
     }
     // ---- index frames on the host (serial header walk, zstd.c:41335)
