@@ -838,7 +838,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 const u64 below = (1ull << (t & 63)) - 1;
                 const u32 ws = (u32)__popcll(ms), wl = (u32)__popcll(ml);
                 // (one frame: how many of the wave's sequences have an offset below 64 rides along in the top bits)
-                const u32 wn = (FAR && INTRA) ? (u32)__popcll(__ballot(is_seq[0] && best_off[0] < 64)) : 0u;
+                const u32 wn = (FAR && INTRA && !HI) ? (u32)__popcll(__ballot(is_seq[0] && best_off[0] < 64)) : 0u;
                 if ((t & 63) == 0) S.scan_a[wave] = ws | (wl << 16) | (wn << 25);
                 lds_barrier();
                 u32 pre = 0, tot = 0, nshort = 0;
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 tot_l = tot >> 16;
                 // the next window looks up and inserts eight lanes at a time while a quarter of this one's sequences repeat at a
                 // distance below 64 (records of 8 or 16 bytes, the next line of a listing); a pure function of the data
-                if (FAR && INTRA && tot_s >= 4) sub8 = nshort * ZL_SUB8_DIV >= tot_s;
+                if (FAR && INTRA && !HI && tot_s >= 4) sub8 = nshort * ZL_SUB8_DIV >= tot_s;  // (levels >= 5 keep the sub-phases throughout: they asked for ratio)
             }
     #pragma unroll
             for (int j = 0; j < PPT; j++) {
