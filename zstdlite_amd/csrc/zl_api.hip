@@ -1520,7 +1520,7 @@ size_t zl_decompressStream(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input)
     const size_t in0 = input->pos, out0 = output->pos;
     auto hand_out = [&]() {
         const size_t k = std::min(output->size - output->pos, S.out.size() - S.out_pos);
-        if (k) memcpy((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
+        zl_memcpy_mt((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
         output->pos += k;
         S.out_pos += k;
         if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }

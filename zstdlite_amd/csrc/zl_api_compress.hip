@@ -1005,7 +1005,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
     auto& S = c->cs;
     auto hand_out = [&]() {
         const size_t k = std::min(output->size - output->pos, S.out.size() - S.out_pos);
-        if (k) memcpy((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
+        zl_memcpy_mt((u8*)output->dst + output->pos, S.out.p + S.out_pos, k);
         output->pos += k;
         S.out_pos += k;
         if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }
