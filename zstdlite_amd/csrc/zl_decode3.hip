@@ -910,8 +910,13 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     if (!info.err) {
         if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
             return kGpuUnavailable;
+        // An exec workgroup works through a RUN of consecutive segments; what a run's bytes copy from in front of the run waits for
+        // the ordered copies.  Eight segments per run keep those few on a frame of thousands of blocks -- and leave a frame of a few
+        // hundred with a few dozen workgroups, each as long as its eight blocks (0.75 ms a block): a 64 MiB reference frame spent
+        // 6 of its 16 ms there.  The run shrinks with the frame so that the launch still fills the device (three workgroups per CU).
+        const u32 exec_run = std::max<u32>(1u, std::min<u32>((u32)ZL3_EXEC_RUN, info.nsegs / (3u * (u32)g_num_cu)));
         zl3_big big;
-        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = ZL3_EXEC_RUN;
+        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = exec_run;
         big.dict_len = have_dict ? hint->dict_len : 0u; big.dict_end = have_dict ? hint->dict_end : nullptr;
         if (hipMemcpyAsync(s->big.p, &big, sizeof(big), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemsetAsync(s->tile_flag.p, 0, ntiles * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -942,7 +947,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         }
         stamp("offsets");
         if (fill_st != st && hipStreamWaitEvent(st, s->fill_join, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (zl2_launch_segments_exec(&a, ZL3_EXEC_RUN, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (zl2_launch_segments_exec(&a, exec_run, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("exec");
         // the deferred bytes: one launch per group of output, in order (the first group has nothing in front of it to wait for,
         // but bytes of its later runs may wait for its earlier ones)
