@@ -245,8 +245,14 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  * Inside such a session ZL_e_flush cuts no run: the frame's runs end at 64 MiB boundaries and at the
  * pledged end only, so a flush hands out the jobs that are complete and keeps collecting the rest
  * (the reference's glue never flushes; a frame of its own in mid-frame would be an invalid stream).
+ * So in a pledged session a return of 0 from ZL_e_flush does NOT mean that everything consumed so far
+ * can be decoded from the output: up to one job of input stays collected until its boundary or the end.
  * Without a pledge every job is a frame of its own with its own recorded size: valid zstd that
  * ZSTD_decompressStream / ZSTD_decompress read frame after frame.
+ * A full job runs on a host thread of the context's own while the caller's next pieces are collected
+ * (one job at a time): its output is handed out by the call that fills the next job, or by ZL_e_flush /
+ * ZL_e_end, whichever comes first.  Every other entry that takes the context waits for that job first;
+ * the context is still one-caller-at-a-time.
  * Returns the bytes still waiting to be handed out (0 at ZL_e_end: the session is complete), or an
  * error code.  Decompression: input is collected until it holds complete frames; those are decoded
  * at once (all routes of zl_decompressDCtx, frames without a recorded size included) and handed out

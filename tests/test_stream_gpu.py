@@ -266,7 +266,9 @@ def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
     cut = 74 << 20
     parts = [comp.feed(data[:cut]), comp.flush(), comp.feed(data[cut:cut + 1000]), comp.flush(), comp.flush(), comp.finish(data[cut + 1000:])]
     blob = b"".join(parts)
-    assert len(parts[0]) > 0 and parts[1] == b""  # the first job came out with the feed; the flush cut nothing
+    # the first job runs beside the feed (round 4) and comes out with the feed or, at the latest, with the flush behind it;
+    # the flushes after it cut nothing
+    assert len(parts[0]) + len(parts[1]) > 0 and parts[3] == b"" and parts[4] == b""
     assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob) and ref.L.ZSTD_getFrameContentSize(blob, len(blob)) == n
     assert blob == z.zstd_compress(data)
     assert ref.decompress(blob, n) == data

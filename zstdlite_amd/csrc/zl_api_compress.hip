@@ -80,10 +80,21 @@ struct zl_cctx_s {
         bool finishing = false; // ZL_e_end has compressed the rest; only handing out remains
         bool joined = false;    // the session's jobs are consecutive runs of blocks of ONE frame (decided when the first input arrives)
         zlx::Xxh64 hash;        // joined session with ZL_c_checksumFlag: the content checksum runs through all jobs
+        // round 4: a full job runs on a thread of its own while the caller's next pieces are collected (one job at a time; every
+        // other entry that touches the context waits for it first: cs_wait)
+        std::thread job;
+        bool job_on = false;
+        ByteBuf job_in, job_out;  // the running job's input and what it wrote
+        size_t job_ret = 0;       // ... its byte count or error code
     } cs;
 };
 
 namespace {
+
+// a streaming job that runs beside the caller (zl_compressStream2) is finished before anything else uses the context
+inline void cs_wait(zl_cctx* c) {
+    if (c->cs.job_on) { c->cs.job.join(); c->cs.job_on = false; }
+}
 
 hipStream_t cctx_stream(zl_cctx* c, void* user) {
     if (user) return (hipStream_t)user;
@@ -396,6 +407,7 @@ zl_cctx* zl_createCCtx(void) { return new (std::nothrow) zl_cctx_s(); }
 
 size_t zl_freeCCtx(zl_cctx* c) {
     if (!c) return 0;
+    cs_wait(c);
     if (c->pending) (void)hipStreamSynchronize(c->pending_stream);
     if (c->ev_far) (void)hipEventDestroy(c->ev_far);
     for (zl_cctx* p : c->peers) (void)zl_freeCCtx(p);
@@ -430,6 +442,7 @@ size_t zl_freeCCtx(zl_cctx* c) {
 // not built: above 5 nothing deepens further, and the ratio falls behind the reference's at those levels.
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
@@ -475,6 +488,7 @@ size_t zl_CCtx_getParameter(const zl_cctx* c, int param, int* value) {
 // ones), so the ratio gain is the content's.
 size_t zl_CCtx_loadDictionary(zl_cctx* c, const void* dict, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     c->dict.clear();
     c->dict_uploaded = false;
     c->dict_formatted = false;
@@ -529,6 +543,7 @@ static size_t seal_one_frame_checksum(zl_cctx* c) {
 
 size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void* d_src, size_t n, void* stream) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (cap < zl_compressBound(n)) return ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
@@ -834,7 +849,13 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
 extern "C" {
 
 // replaces ZSTD_compress2 (zstd.h:599): host buffers in and out.
+static size_t compress2_impl(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n);
 size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
+    if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
+    return compress2_impl(c, dst, cap, src, n);
+}
+static size_t compress2_impl(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
@@ -877,6 +898,7 @@ size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n
 size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* caps, const void* const* srcs,
                          const size_t* sizes, size_t* results) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (n == 0) return 0;
@@ -970,6 +992,7 @@ size_t zl_CStreamOutSize(void) { return zl_compressBound(ZL_CHUNK); }
 
 size_t zl_CCtx_setPledgedSrcSize(zl_cctx* c, unsigned long long pledged) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:23795: only between sessions
     c->cs.pledged = pledged;
     return 0;
@@ -977,7 +1000,11 @@ size_t zl_CCtx_setPledgedSrcSize(zl_cctx* c, unsigned long long pledged) {
 
 size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    cs_wait(c);
     if (reset == ZL_reset_session_only || reset == ZL_reset_session_and_parameters) {
+        c->cs.job_in.clear();
+        c->cs.job_out.clear();
+        c->cs.job_ret = 0;
         c->cs.stage.clear();
         c->cs.out.clear();
         c->cs.out_pos = 0;
@@ -1010,6 +1037,43 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.out_pos += k;
         if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }
     };
+    // what a job that ran beside the caller wrote becomes what waits to be handed out (S.out is empty whenever this is called)
+    auto collect = [&]() -> size_t {
+        if (!S.job_on) return 0;
+        cs_wait(c);
+        const size_t r = S.job_ret;
+        S.job_in.clear();
+        if (ZL_IS_ERR(r)) { S.job_out.clear(); return r; }
+        S.job_out.n = r;
+        std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
+        S.job_out.clear();
+        S.out_pos = 0;
+        S.emitted = true;
+        return 0;
+    };
+    // a FULL job: on a thread of its own, so that the caller's next pieces are copied while it is uploaded, compressed and brought
+    // down (the job before it is collected first: one at a time)
+    auto start_job = [&]() -> size_t {
+        { const size_t e = collect(); if (ZL_IS_ERR(e)) return e; }
+        std::swap(S.stage.p, S.job_in.p); std::swap(S.stage.n, S.job_in.n); std::swap(S.stage.cap, S.job_in.cap);
+        S.stage.clear();
+        const size_t n = S.job_in.size(), bound = zl_compressBound(n);
+        S.job_out.clear();
+        if (!S.job_out.reserve(bound)) return ZL_ERR(ZL_E_MEMORY);
+        const u64 pledged = S.pledged, consumed_end = S.consumed;
+        const bool joined = S.joined;
+        if (joined && ((consumed_end - n) % ZL_STREAM_JOB != 0 || !(n == ZL_STREAM_JOB || consumed_end == pledged))) return ZL_ERR(ZL_E_STAGE_WRONG);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        auto body = [c, n, bound, pledged, consumed_end, joined, dev]() {
+            (void)hipSetDevice(dev);
+            auto& T = c->cs;
+            T.job_ret = joined ? compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash)
+                               : compress2_impl(c, T.job_out.p, bound, T.job_in.p, n);
+        };
+        try { S.job = std::thread(body); S.job_on = true; } catch (...) { body(); S.job_on = true; S.job = std::thread([]() {}); }  // (no thread to be had: the job runs here)
+        return 0;
+    };
     auto run_job = [&]() -> size_t {  // the collected input -> frames, appended to what waits to be handed out
         const size_t n = S.stage.size(), bound = zl_compressBound(n), old = S.out.size();
         u8* at = S.out.grow(bound);
@@ -1027,7 +1091,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
             if ((S.consumed - n) % ZL_STREAM_JOB != 0 || !(n == ZL_STREAM_JOB || S.consumed == pledged)) { S.out.n = old; return ZL_ERR(ZL_E_STAGE_WRONG); }
             r = compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &S.hash);
         } else
-            r = zl_compress2(c, at, bound, S.stage.p, n);
+            r = compress2_impl(c, at, bound, S.stage.p, n);
         S.out.n = old + (ZL_IS_ERR(r) ? 0 : r);
         if (ZL_IS_ERR(r)) return r;
         S.stage.clear();
@@ -1046,10 +1110,15 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.started = true;
         if (S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.consumed > S.pledged) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140: more than was pledged
         if (S.stage.size() == ZL_STREAM_JOB) {
-            const size_t e = run_job();
+            const size_t e = start_job();
             if (ZL_IS_ERR(e)) return e;
             hand_out();
         }
+    }
+    if (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && S.job_on) {  // the job that is still running comes out first
+        const size_t e = collect();
+        if (ZL_IS_ERR(e)) return e;
+        hand_out();
     }
     if (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && !S.finishing) {
         if (end_op == ZL_e_end && S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.pledged != S.consumed) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140
