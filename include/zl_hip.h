@@ -92,6 +92,12 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * decode_walked_frame_in_runs).  ZL_d_runBlocks = N (16 .. 8192; 0 = default) makes every frame of more than N blocks that a
  * host entry decodes take that path, in runs of at most N blocks: how tests and fuzzers reach it with frames of a few MiB. */
 #define ZL_d_runBlocks 9009
+/* ONE frame of 256 MiB of content or more that zl_decompressDCtx is handed in host memory moves slab by slab (round 4): a thread
+ * uploads it piece by piece from the start of the call, it is decoded in runs of blocks as those arrive (the same runs, with the
+ * output so far as history) and every run's bytes come down -- and are hashed, when the frame carries a checksum -- while the
+ * next run is decoded.  ZL_d_slabMiB = N (0 = default 256) sets that threshold in MiB: how tests reach the path with small
+ * frames (together with ZL_d_runBlocks for the size of the runs).  ZL_d_pipeline = 0 switches it off. */
+#define ZL_d_slabMiB 9010
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
 #define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
 

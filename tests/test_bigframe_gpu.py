@@ -376,3 +376,61 @@ def test_frames_decoded_in_runs_of_blocks(ref, oracle):
             codec.decompress(torch.from_numpy(h).cuda(), codec.frame_table([len(comp)], [len(data)]), torch.zeros(len(data), dtype=torch.uint8, device="cuda"), host_copy=h)
     finally:
         codec.close()
+
+
+@needs_ref
+def test_one_frame_from_host_memory_moves_slab_by_slab(ref, oracle):
+    """zl_decompressDCtx of ONE large frame in host memory (round 4, zl_api.hip SlabIO): the upload starts with the call, the frame
+    is decoded in runs of blocks as their bytes arrive and every run's output comes down -- and is hashed -- beside the next run.
+    ZL_d_slabMiB = 1 sends frames of a few MiB down that path, in pieces and runs of a few hundred KiB (ZL_d_runBlocks bounds the
+    runs' blocks as well).  Frames the reference wrote and this library's own, with and without a content checksum; the runs must
+    have been taken, the bytes must be the input; damaged frames get the oracle's verdict."""
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    text = GENERATORS["text"](5 << 20, seed=13)
+    ints = GENERATORS["int20"](2 << 20, seed=14)
+    mixed = b"".join((text, noise, ints, bytes(1 << 18))[k % 4][(k * 55555) % (1 << 19):][: 192 << 10] for k in range(30))
+    own = z.zstd_cctx(level=3, include_checksum=True)
+    frames = [(ref.compress(text, level=3), text), (ref.compress(mixed, level=3, checksum=True), mixed),
+              (ref.compress(mixed, level=9), mixed), (ref.compress(text, level=19, checksum=True), text),
+              (ref.compress(noise * 3, level=3), noise * 3),
+              (z.zstd_compress(mixed, cctx=own), mixed), (z.zstd_compress(text), text), (z.zstd_compress(noise * 2 + text), noise * 2 + text)]
+    dctx = z.zstd_dctx()
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0  # ZL_d_slabMiB
+    for comp, data in frames:
+        for nrun in (0, 16, 33):
+            assert L.zl_DCtx_setParameter(dctx._ptr, 9009, nrun) == 0  # ZL_d_runBlocks
+            before = int(L.zl_dctx_frame_runs(dctx._ptr))
+            assert z.zstd_decompress(comp, dctx=dctx) == data, nrun
+            assert int(L.zl_dctx_frame_runs(dctx._ptr)) - before >= 2, (len(data), len(comp), nrun)
+    # the same calls without the pipeline take the whole-frame route: no runs
+    plain = z.zstd_dctx()
+    assert L.zl_DCtx_setParameter(plain._ptr, 9010, 1) == 0 and L.zl_DCtx_setParameter(plain._ptr, 9005, 0) == 0
+    assert z.zstd_decompress(frames[1][0], dctx=plain) == frames[1][1] and int(L.zl_dctx_frame_runs(plain._ptr)) == 0
+    # damage: in the blocks, in the header, in the footer
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9009, 20) == 0
+    for comp, data in (frames[1], frames[5]):
+        errs = 0
+        for k in range(30):
+            bad = bytearray(comp)
+            if k == 0:
+                bad[-2] ^= 0x20  # the content checksum
+            else:
+                for _ in range(int(rng.integers(1, 3))):
+                    bad[int(rng.integers(4, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            bad = bytes(bad)
+            try:
+                want = oracle.decompress(bad, cap=len(data))
+            except Exception:
+                want = None
+            try:
+                got = z.zstd_decompress(bad, dctx=dctx)
+            except z.ZstdError:
+                got = None
+            assert (got is None) == (want is None), ("verdicts differ", k)
+            assert got == want
+            errs += got is None
+        assert errs >= 10
+    assert z.zstd_decompress(frames[0][0], dctx=dctx) == frames[0][1]  # the context is fine after the failures
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9010, -1) != 0 and L.zl_DCtx_setParameter(dctx._ptr, 9010, 0) == 0

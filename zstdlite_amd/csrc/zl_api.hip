@@ -21,6 +21,8 @@
 #include "zl_kernels.h"
 #include "zl_decode3.h"
 #include "zl_xxh64.h"
+#include "zl_copy_pair.h"
+#include <mutex>
 
 static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
 
@@ -184,8 +186,71 @@ bool read_seek_table(const u8* src, size_t n, SeekTable& t) {
 }  // namespace
 
 // =========================================================================================
+// the process's copy streams (zl_copy_pair.h)
+// =========================================================================================
+const ZlCopyPair* zl_copy_pair(void) {
+    static std::mutex m;
+    static ZlCopyPair pairs[64];
+    static bool made[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> l(m);
+    ZlCopyPair& p = pairs[dev];
+    if (made[dev]) return p.up && p.down ? &p : nullptr;
+    made[dev] = true;
+    p.up = p.down = nullptr;
+    p.duplex = 0;
+    if (hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p.down, hipStreamNonBlocking) != hipSuccess) { p.up = p.down = nullptr; return nullptr; }
+    const size_t probe = (size_t)16 << 20;
+    void *pin = nullptr, *mem = nullptr;
+    if (hipHostMalloc(&pin, 2 * probe, hipHostMallocDefault) == hipSuccess && hipMalloc(&mem, 2 * probe) == hipSuccess) {
+        for (int attempt = 0; attempt < 8 && !p.duplex; attempt++) {
+            if (attempt) {  // a fresh stream in place of one of the two, in turn
+                hipStream_t& again = (attempt & 1) ? p.down : p.up;
+                (void)hipStreamDestroy(again);
+                again = nullptr;
+                if (hipStreamCreateWithFlags(&again, hipStreamNonBlocking) != hipSuccess) { p.up = p.down = nullptr; break; }
+            }
+            p.duplex = zl_bind_copy_pair(p.up, p.down, pin, mem, probe) ? 1 : 0;
+#ifdef ZL_DEV_SWITCHES
+            if (getenv("ZL_DEBUG_SLAB")) fprintf(stderr, "[zl copy pair] device %d, attempt %d: %s\n", dev, attempt, p.duplex ? "two fast engines" : "not yet");
+#endif
+        }
+    }
+    if (pin) (void)hipHostFree(pin);
+    if (mem) (void)hipFree(mem);
+    return p.up && p.down ? &p : nullptr;
+}
+
+// =========================================================================================
 // contexts
 // =========================================================================================
+// One large frame from host memory to host memory, slab by slab (round 4): until now such a call uploaded the
+// whole frame, ran the large-frame pipeline's stages over all of it and only then (beside its last stage) brought the bytes
+// down -- three legs one after the other, 22 GB/s on a link that moves 56 either way.  Now a thread uploads the frame piece by
+// piece from the moment the call starts (beside the host's header walk), the frame is decoded in RUNS of blocks with the output
+// so far as history (decode_walked_frame_in_runs, what frames of 4 GiB and more always took), each run as soon as its bytes
+// have arrived, and a second thread brings every run's output down -- and a third hashes it -- while the next run is decoded.
+struct SlabIO {
+    std::atomic<u64> uploaded{0};  // bytes [0, uploaded) of the call's input are in device memory
+    std::atomic<u64> decoded{0};   // bytes [0, decoded) of the frame's content are final in device memory
+    std::atomic<u64> landed{0};    // ... and in the caller's buffer
+    std::atomic<int> up_state{0};  // 0 uploading, 1 all there, 2 failed
+    std::atomic<int> stop{0};      // 1: `decoded` is final, 2: give up
+    std::atomic<int> down_done{0};
+    bool voided = false;           // the runs handed the frame back to the whole-frame routes: what has landed does not count
+    u64 total = 0;                 // bytes of input
+    u64 run_bytes = (u64)64 << 20; // a run ends behind this many compressed bytes (or 8192 blocks / ZL_d_runBlocks)
+    bool wait_uploaded(u64 upto) {
+        upto = std::min(upto, total);
+        while (uploaded.load(std::memory_order_acquire) < upto) {
+            if (up_state.load() == 2 || stop.load() == 2) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
+        return true;
+    }
+};
+
 struct zl_dctx_s {
     int ignore_checksum = 0;
     int pipeline = 1;  // ZL_d_pipeline
@@ -230,6 +295,8 @@ struct zl_dctx_s {
     std::vector<u8> took_big;          // per frame of the last dctx_enqueue: 1 when the large-frame pipeline decoded it
     int devices = 1;                   // ZL_d_devices
     int run_blocks = 0;                // ZL_d_runBlocks
+    int slab_mib = 0;                  // ZL_d_slabMiB
+    SlabIO* slab = nullptr;            // the host entry's call in progress decodes ONE frame slab by slab
     bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
     std::vector<zl_dctx_s*> peers;
@@ -431,6 +498,10 @@ size_t zl_DCtx_setParameter(zl_dctx* d, int param, int value) {
     case ZL_d_runBlocks:
         if (value != 0 && (value < 16 || value > 8192)) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
         d->run_blocks = value;
+        return 0;
+    case ZL_d_slabMiB:
+        if (value < 0 || value > 65536) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        d->slab_mib = value;
         return 0;
     case ZL_d_devices:
         if (value < 0 || value > 64) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
@@ -696,10 +767,19 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     const size_t nb = blk.size();
     const u64 bound = std::min<u64>(fd.dst_cap, (u64)nb * ZL_BLOCK_MAX);
     const size_t per = d->run_blocks ? (size_t)d->run_blocks : 8192;
-    if (d->run_blocks ? nb <= per : (bound < 0xFFFFD000ull && fd.src_size < 0xFFFFFF00ull)) return ZL_ERR(ZL_E_FALLBACK);  // (the pipeline takes it as a whole)
+    SlabIO* const io = d->slab;  // (a host entry that moves the frame slab by slab: every frame it sends here is decoded in runs)
+    if (!io && (d->run_blocks ? nb <= per : (bound < 0xFFFFD000ull && fd.src_size < 0xFFFFFF00ull))) return ZL_ERR(ZL_E_FALLBACK);  // (the pipeline takes it as a whole)
     if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && h.content_size > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
-    // ---- run by run
-    const size_t nruns = (nb + per - 1) / per;
+    // ---- run by run: `per` blocks each -- slab by slab, also no more compressed bytes than a slab holds
+    std::vector<size_t> cuts{0};
+    for (size_t b = 0; b < nb;) {
+        size_t e = b;
+        u64 bytes = 0;
+        while (e < nb && e - b < per && (!io || bytes < io->run_bytes)) { bytes += (e + 1 < nb ? blk[e + 1].at : end_pos + 3) - blk[e].at; e++; }
+        cuts.push_back(e);
+        b = e;
+    }
+    const size_t nruns = cuts.size() - 1;
     std::vector<zl3_hblk> hb;
     u64 out_pos = 0, left[4] = {0, 1, 4, 8};
     u32 cur[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the latest block in front of the run that describes the Huffman tree, the LL, OF, ML table
@@ -707,7 +787,7 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     hint.headerless = 1; hint.not_last = 0; hint.tail = 0; hint.size_unknown = 1; hint.run_out = left;
     hint.dict_id = 0;
     for (size_t r = 0; r < nruns; r++) {
-        const size_t b0 = r * per, b1 = std::min(nb, b0 + per);
+        const size_t b0 = cuts[r], b1 = cuts[r + 1];
         // which tables does the run take over from the blocks in front of it?
         u32 need = 0, have = 0;
         for (size_t b = b0; b < b1 && have != 15u; b++) { need |= blk[b].use.uses & ~have; have |= blk[b].use.defs; }
@@ -745,7 +825,19 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         hint.dict_formatted = r ? 1u : 0u;
         for (int k = 0; k < 3; k++) hint.dict_rep[k] = (u32)left[1 + k];
         left[0] = ~0ull;
+#ifdef ZL_DEV_SWITCHES
+        static const bool dbg_slab = getenv("ZL_DEBUG_SLAB") != nullptr;
+        auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+        const double t_a = now_ms();
+#endif
+        if (io && !io->wait_uploaded(fd.src_off + s1)) return ZL_ERR(ZL_E_GENERIC);  // (donors lie in front of the run: uploaded before it)
+#ifdef ZL_DEV_SWITCHES
+        const double t_b = now_ms();
+#endif
         const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p, 1, st, &d->side, &hint);
+#ifdef ZL_DEV_SWITCHES
+        if (dbg_slab) fprintf(stderr, "[zl slab] run %zu: blocks %zu, %.1f MiB in, waited %.2f ms for them, decoded in %.2f ms (landed so far %.0f MiB)\n", r, b1 - b0, (double)(s1 - s0) / 1048576.0, t_b - t_a, now_ms() - t_b, io ? (double)io->landed.load() / 1048576.0 : 0.0);
+#endif
         if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
         if (left[0] == ~0ull) {
             // the run reported an error.  The host has walked every block and handed the run its tables: what is left is damage
@@ -757,11 +849,13 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
             return 0;
         }
         out_pos += left[0];
+        if (io && h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos <= h.content_size) io->decoded.store(out_pos, std::memory_order_release);  // (the download thread follows)
         d->frame_runs++;
         for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
     }
     if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos != h.content_size) return ZL_ERR(ZL_E_FALLBACK);
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
+    if (io && !io->wait_uploaded(fd.src_off + n)) return ZL_ERR(ZL_E_GENERIC);
     if (zl3_check_content(d->big, d_dst + fd.dst_off, out_pos, check ? d_src + fd.src_off + end_pos : nullptr, d_result, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     return 0;
 }
@@ -864,7 +958,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }
         if (e3 != 0 && !has_dict && !d->run_headerless && !d->run_not_last &&
-            (tbl[i].dst_cap >= 0xFFFFD000ull || tbl[i].src_size >= 0xFFFFFF00ull || d->run_blocks)) {
+            (tbl[i].dst_cap >= 0xFFFFD000ull || tbl[i].src_size >= 0xFFFFFF00ull || d->run_blocks || d->slab)) {
             const u8* host_src = i < d->host_walk.size() ? d->host_walk[i].host_src : nullptr;
             if (!host_src) {
                 // the device-resident entry without a host copy of the frame: the run plan needs a look into every block, which
@@ -880,6 +974,10 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             e3 = decode_walked_frame_in_runs(d, tbl[i], host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
             if (d->h_run_src.cap > ((size_t)64 << 20)) { free(d->h_run_src.p); d->h_run_src.p = nullptr; d->h_run_src.n = d->h_run_src.cap = 0; }  // (not kept: gigabytes)
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
+        }
+        if (e3 != 0 && d->slab) {  // the whole-frame routes need the whole frame, and decode it from its start again
+            d->slab->voided = true;
+            if (!d->slab->wait_uploaded(d->slab->total)) return ZL_ERR(ZL_E_GENERIC);
         }
         if (e3 != 0) e3 = zl3_decode_frame(d->big, &tbl[i], d_src, d_dst, (u64*)d->d_results.p + i, (d->ignore_checksum || d->host_verify) ? 1 : 0, st, &d->side, &hint);
         if (e3 == 0) { plan[i].route = 3; d->large_frames++; d->took_big[i] = 1; }
@@ -1128,7 +1226,7 @@ bool ensure_peers(zl_dctx* d, int slots) {
         p->is_peer = true;
         d->peers.push_back(p);
     }
-    for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; d->peers[s]->run_blocks = d->run_blocks; }
+    for (int s = 0; s < slots; s++) { d->peers[s]->ignore_checksum = d->ignore_checksum; d->peers[s]->devices = 1; d->peers[s]->pipeline = d->pipeline; d->peers[s]->run_blocks = d->run_blocks; d->peers[s]->slab_mib = d->slab_mib; }
     return true;
 }
 
@@ -1281,6 +1379,44 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             if (r == kGpuUnavailable || r == ZL_ERR(ZL_E_CHECKSUM_WRONG)) return r;
         }
     }
+    // ---- a large call: the upload starts now, beside the header walk, on a thread and a stream of its own (SlabIO above)
+    hipStream_t st = dctx_stream(d, nullptr);
+    SlabIO io;
+    io.total = n;
+    const u64 slab_min = d->slab_mib ? (u64)d->slab_mib << 20 : (u64)256 << 20;
+    std::thread up_th, down_th, hash_th;
+    struct Joiner {  // whatever way the call ends: nobody is left behind
+        SlabIO& io; zl_dctx* d; std::thread &a, &b, &c;
+        ~Joiner() { io.stop.store(2); for (std::thread* t : {&a, &b, &c}) if (t->joinable()) t->join(); d->slab = nullptr; }
+    } joiner{io, d, up_th, down_th, hash_th};
+    const bool tiny = d->slab_mib != 0 && d->slab_mib < 64;  // (tests: frames of a few MiB in pieces and runs of a few hundred KiB)
+    if (tiny) io.run_bytes = (u64)256 << 10;
+    bool early = d->pipeline && d->dict.empty() && !d->is_peer && cap >= slab_min && n >= (tiny ? (size_t)4096 : (size_t)1 << 20) && d->d_src.ensure(n + 16);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const ZlCopyPair* const pair = early ? zl_copy_pair() : nullptr;  // the upload and the download on two copy engines (zl_copy_pair.h)
+    if (!pair) early = false;
+    if (early) up_th = std::thread([&io, d, src, n, dev, pair, tiny]() {
+        (void)hipSetDevice(dev);
+        size_t piece = tiny ? (size_t)256 << 10 : (size_t)16 << 20;
+#ifdef ZL_DEV_SWITCHES
+        if (getenv("ZL_SLAB_UP_MIB")) piece = (size_t)atoi(getenv("ZL_SLAB_UP_MIB")) << 20;
+#endif
+        for (size_t pos = 0; pos < n; pos += piece) {
+            const size_t len = std::min(piece, n - pos);
+            if (io.stop.load() == 2) { io.up_state.store(2); return; }
+#ifdef ZL_DEV_SWITCHES
+            timespec q0; clock_gettime(CLOCK_MONOTONIC, &q0);
+#endif
+            if (hipMemcpyAsync((u8*)d->d_src.p + pos, src + pos, len, hipMemcpyHostToDevice, pair->up) != hipSuccess || hipStreamSynchronize(pair->up) != hipSuccess) { io.up_state.store(2); return; }
+#ifdef ZL_DEV_SWITCHES
+            if (getenv("ZL_DEBUG_SLAB")) { timespec q1; clock_gettime(CLOCK_MONOTONIC, &q1); fprintf(stderr, "[zl slab] up %4zu MiB + %zu MiB: %.2f ms\n", pos >> 20, len >> 20, (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6); }
+#endif
+            io.uploaded.store(pos + len, std::memory_order_release);
+        }
+        io.up_state.store(1);
+    });
+    auto end_upload = [&]() { if (up_th.joinable()) { io.stop.store(2); up_th.join(); io.stop.store(0); } };  // (routes that upload for themselves)
     // ---- index frames on the host (serial header walk, zstd.c:41335)
     std::vector<zl_frame_desc> table;
     std::vector<u8> known, has_ck;
@@ -1324,6 +1460,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         if (all_known && d->dict.empty() && table.size() >= 2) plan = dctx_slots(d, (size_t)content, table.size() / 512);
         const int slots = plan.slots;
         if (slots > 1 && content <= cap && ensure_peers(d, peers_needed(d, plan))) {
+            end_upload();
             const size_t nruns = runs_for(plan, table.size() / 512);
             std::vector<size_t> cut(nruns + 1, 0), res(nruns, 0);
             std::vector<u64> out_at(nruns + 1, 0);
@@ -1348,9 +1485,61 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
             return (size_t)content;
         }
     }
-    hipStream_t st = dctx_stream(d, nullptr);
     if (!d->d_src.ensure(n + 16) || !d->d_dst.ensure(cap + 16)) return kGpuUnavailable;
-    if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    // ONE frame the host has walked, large enough: slab by slab.  Everything else: the whole input first (it is on its way already)
+    const bool slabs = early && table.size() == 1 && known[0] && !walks[0].blocks.empty() && table[0].dst_cap >= slab_min && table[0].dst_cap <= cap && dst;
+    if (early && !slabs) {
+        if (!io.wait_uploaded(n)) return ZL_ERR(ZL_E_GENERIC);
+    } else if (!early) {
+        if (hipMemcpyAsync(d->d_src.p, src, n, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    zlx::Xxh64 slab_hasher;
+    const bool slab_hashing = slabs && has_ck[0] && !d->ignore_checksum;
+    if (slabs) {
+        if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
+        u8* const out = (u8*)dst;
+        down_th = std::thread([&io, d, out, dev, pair, tiny]() {
+            (void)hipSetDevice(dev);
+            u64 piece = tiny ? (u64)512 << 10 : (u64)32 << 20;
+#ifdef ZL_DEV_SWITCHES
+            if (getenv("ZL_SLAB_DOWN_MIB")) piece = (u64)atoi(getenv("ZL_SLAB_DOWN_MIB")) << 20;
+#endif
+            u64 have = 0;
+            for (;;) {
+                const int s = io.stop.load(std::memory_order_acquire);
+                const u64 upto = io.decoded.load(std::memory_order_acquire);
+                if (s == 2) break;
+                // (pieces on a fixed grid: the runtime pins the caller's pages for every copy and remembers the ranges it has pinned --
+                // the same ranges in every call over the same buffer cost that once, ranges cut by the runs' timing every time:
+                // 25 GB/s instead of 56)
+                if (upto >= have + piece || (s == 1 && upto > have)) {
+                    const u64 len = std::min(piece, upto - have);
+#ifdef ZL_DEV_SWITCHES
+                    timespec q0; clock_gettime(CLOCK_MONOTONIC, &q0);
+#endif
+                    if (hipMemcpyAsync(out + have, (const u8*)d->d_dst.p + have, (size_t)len, hipMemcpyDeviceToHost, pair->down) != hipSuccess || hipStreamSynchronize(pair->down) != hipSuccess) break;
+#ifdef ZL_DEV_SWITCHES
+                    if (getenv("ZL_DEBUG_SLAB")) { timespec q1; clock_gettime(CLOCK_MONOTONIC, &q1); fprintf(stderr, "[zl slab] down %4llu MiB + %llu MiB: %.2f ms\n", (unsigned long long)(have >> 20), (unsigned long long)(len >> 20), (q1.tv_sec - q0.tv_sec) * 1e3 + (q1.tv_nsec - q0.tv_nsec) * 1e-6); }
+#endif
+                    have += len;
+                    io.landed.store(have, std::memory_order_release);
+                } else if (s == 1) break;
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            io.down_done.store(1, std::memory_order_release);
+        });
+        if (slab_hashing) hash_th = std::thread([&io, &slab_hasher, out]() {  // the content checksum's chain, behind the download piece by piece
+            u64 hashed = 0;
+            for (;;) {
+                const int done = io.down_done.load(std::memory_order_acquire);
+                const u64 upto = io.landed.load(std::memory_order_acquire);
+                if (upto > hashed) { slab_hasher.update(out + hashed, (size_t)(upto - hashed)); hashed = upto; }
+                else if (done) break;
+                else std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        });
+        d->slab = &io;
+    }
     size_t total = 0, i = 0;
     std::vector<u8> big(table.size(), 0);  // frames the large-frame pipeline decoded: their content checksum is verified below, on the host
     zlx::Xxh64 sink_hasher;                // ... for ONE frame whose bytes come down while its last stage runs: fed piece by piece as they land (zl3_hint::sink_hash)
@@ -1368,12 +1557,28 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         if (!d->h_frames.ensure(cnt * sizeof(zl_frame_desc)) || !d->h_results.ensure(cnt * sizeof(u64))) return kGpuUnavailable;
         memcpy(d->h_frames.p, &table[i], cnt * sizeof(zl_frame_desc));
         d->host_walk.assign(std::make_move_iterator(walks.begin() + i), std::make_move_iterator(walks.begin() + j));
-        d->sink_host = (table.size() == 1 && known[0] && d->pipeline) ? (u8*)dst : nullptr;
+        d->sink_host = (table.size() == 1 && known[0] && d->pipeline && !slabs) ? (u8*)dst : nullptr;
         d->sunk = 0;
         d->sink_hash = (d->sink_host && has_ck[0] && !d->ignore_checksum) ? &sink_hasher : nullptr;  // the checksum's chain runs beside the download
         d->host_verify = true;
         size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, cnt, st);
         d->host_verify = false;
+        if (slabs) {  // the threads behind the runs finish what has been announced (or give up with the call)
+            d->slab = nullptr;
+            io.stop.store(ZL_IS_ERR(e) ? 2 : 1, std::memory_order_release);
+#ifdef ZL_DEV_SWITCHES
+            timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+#endif
+            down_th.join();
+#ifdef ZL_DEV_SWITCHES
+            if (getenv("ZL_DEBUG_SLAB")) { timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1); fprintf(stderr, "[zl slab] download %.2f ms behind the last run\n", (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6); }
+#endif
+            if (hash_th.joinable()) hash_th.join();
+            if (!io.voided && !ZL_IS_ERR(e)) {
+                d->sunk = io.landed.load();
+                if (slab_hashing) sink_hasher = slab_hasher;
+            }
+        }
         d->host_walk.clear();
         d->sink_host = nullptr;
         d->sink_hash = nullptr;

@@ -14,6 +14,7 @@
 #include "zl_encode.h"
 #include "zl_format.h"
 #include "zl_host.h"
+#include "zl_copy_pair.h"
 #include "zl_kernels.h"
 #include "zl_xxh64.h"
 
@@ -45,7 +46,7 @@ struct zl_cctx_s {
         void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
-    hipStream_t copy_stream = nullptr, down_stream = nullptr;
+    hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
     double batch_ms[5] = {0, 0, 0, 0, 0};  // ZL_c_profile: the last zl_compress_batch call: {pack on the host, upload, kernels, download, unpack on the host}
     int copy_pair_duplex = -1;  // -1: not bound yet; 1 / 0: the pair's copies overlap / take turns (zl_bind_copy_pair)
     std::vector<hipEvent_t> pipe_events;  // grow-only pool for the pipeline
@@ -414,8 +415,6 @@ size_t zl_freeCCtx(zl_cctx* c) {
     c->peers.clear();
     for (auto& es : c->sets) es.release();
     for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
     for (DevBuf* b : bufs) b->release();
     PinBuf* pins[] = {&c->h_chunks, &c->h_fsize, &c->h_totals, &c->h_stage_in, &c->h_stage_out};
@@ -662,24 +661,12 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
     if (!c->d_src.ensure(n + 16) || !c->d_dst.ensure(bound + 16) || !c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64)))
         return kGpuUnavailable;
-    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
-    if (!c->down_stream && hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
-    if (c->copy_pair_duplex < 0 && dst) {
-        // the upload and the download stream on two copy engines (zl_host.h): bound once per context, a new download stream tried
-        // a few times when the first falls onto the upload stream's engine
-        const size_t probe = (size_t)16 << 20;
-        c->copy_pair_duplex = 0;
-        if (c->h_stage_in.ensure(2 * probe) && c->d_src.cap >= 2 * probe) {
-            for (int attempt = 0; attempt < 8 && !c->copy_pair_duplex; attempt++) {
-                if (attempt) {  // a fresh stream in place of one of the two, in turn
-                    hipStream_t& again = (attempt & 1) ? c->down_stream : c->copy_stream;
-                    (void)hipStreamDestroy(again);
-                    again = nullptr;
-                    if (hipStreamCreateWithFlags(&again, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;
-                }
-                c->copy_pair_duplex = zl_bind_copy_pair(c->copy_stream, c->down_stream, c->h_stage_in.p, c->d_src.p, probe) ? 1 : 0;
-            }
-        }
+    {   // the upload and the download stream on two copy engines: the process's pair for this device (zl_copy_pair.h)
+        const ZlCopyPair* pair = zl_copy_pair();
+        if (!pair) return kGpuUnavailable;
+        c->copy_stream = pair->up;
+        c->down_stream = pair->down;
+        c->copy_pair_duplex = pair->duplex;
     }
     for (int k = 0; k < ZL_PIPE_SETS; k++)
         if (!c->sets[k].st && hipStreamCreateWithFlags(&c->sets[k].st, hipStreamNonBlocking) != hipSuccess) return kGpuUnavailable;

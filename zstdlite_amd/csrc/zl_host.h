@@ -128,7 +128,17 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
         (void)hipStreamSynchronize(up);
         (void)hipStreamSynchronize(down);
     };
-    both();  // the binding copies
+    {   // the binding copies: a stream keeps the engine its first copy took, and that copy takes the first engine that is idle when
+        // it is issued -- so the second stream's first copy is issued while the first stream's is certainly under way (issued
+        // right behind it, it often found the engine still idle: the pair then took turns for good; round 4)
+        (void)hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, up);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        do { clock_gettime(CLOCK_MONOTONIC, &t1); } while ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) < 100000);
+        (void)hipMemcpyAsync(hp + bytes, dp + bytes, bytes, hipMemcpyDeviceToHost, down);
+        (void)hipStreamSynchronize(up);
+        (void)hipStreamSynchronize(down);
+    }
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     double t_up = 1e9, t_dn = 1e9, t_both = 1e9;
     for (int k = 0; k < 2; k++) {
@@ -141,7 +151,11 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
         double t3 = now();
         t_up = t1 - t0 < t_up ? t1 - t0 : t_up; t_dn = t2 - t1 < t_dn ? t2 - t1 : t_dn; t_both = t3 - t2 < t_both ? t3 - t2 : t_both;
     }
-    return t_both < 0.75 * (t_up + t_dn);
+#ifdef ZL_DEV_SWITCHES
+    if (getenv("ZL_DEBUG_SLAB")) fprintf(stderr, "[zl bind] %zu MiB: up %.3f ms, down %.3f ms, both %.3f ms\n", bytes >> 20, t_up, t_dn, t_both);
+#endif
+    // (together in less than three quarters of one after the other -- and neither direction on one of the slow engines)
+    return t_both < 0.75 * (t_up + t_dn) && t_dn < 1.3 * t_up && t_up < 1.3 * t_dn;
 }
 
 // A few host threads that stay around between calls, for the per-object loops of the batch entries (pack, header parse,
