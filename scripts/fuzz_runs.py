@@ -3,6 +3,7 @@ else wrote are decoded) with frames of a few MiB: ZL_d_runBlocks = N sends every
 Reference-made frames (levels 1 .. 19, with and without checksum, compressible, incompressible and mixed so that raw blocks,
 treeless literals and Repeat_Mode all occur at run boundaries) and this library's own one frame.  Intact: bit-exact, and the runs
 must actually have been taken; damaged or cut short: the verdict and the bytes of the oracle.
+Round 4: the host entry also with ZL_d_slabMiB = 1 -- the same runs with the upload, the download and the hash beside them.
 usage: fuzz_runs.py [rounds=20] [seed=1]"""
 import ctypes as C
 import sys
@@ -56,8 +57,9 @@ def ours_device(f, n, nrun, with_copy):
     return total, d_dst.cpu().numpy()
 
 
-def ours(f, n, nrun):
-    assert L.zl_DCtx_setParameter(dctx, 9009, nrun) == 0
+def ours(f, n, nrun, slab=0):
+    """the host entry; slab: ZL_d_slabMiB = 1 -- the frame moves slab by slab (upload, runs, download and hash side by side)"""
+    assert L.zl_DCtx_setParameter(dctx, 9009, nrun) == 0 and L.zl_DCtx_setParameter(dctx, 9010, slab) == 0
     out = np.zeros(max(n, 1), dtype=np.uint8)
     src = np.frombuffer(f, dtype=np.uint8)
     r = L.zl_decompressDCtx(dctx, out.ctypes.data, n, src.ctypes.data, len(f))
@@ -67,9 +69,9 @@ def ours(f, n, nrun):
 # intact frames, every run length: bit-exact, and in runs
 for i, (f, data) in enumerate(base):
     took = []
-    for nrun in (16, 17, 24, 33, 64):
+    for nrun, slab in ((16, 0), (17, 0), (24, 0), (33, 0), (64, 0), (0, 1), (16, 1), (33, 1)):
         before = L.zl_dctx_frame_runs(dctx)
-        r, out = ours(f, len(data), nrun)
+        r, out = ours(f, len(data), nrun, slab)
         if is_error(r) or r != len(data) or out[:r].tobytes() != data:
             bad += 1
             print(f"FAIL intact frame {i} run length {nrun}: {_lib.error_name(r) if is_error(r) else r}")
@@ -91,7 +93,7 @@ for rd in range(rounds):
         code, want = o.decompress_code(b, len(data))
         entry = int(rng.integers(0, 4))  # host entry twice as often as each flavour of the device entry
         if entry < 2 or len(b) < 32 or is_error(o.L.zlo_find_frame_compressed_size(b, len(b))) or o.L.zlo_find_frame_compressed_size(b, len(b)) != len(b):
-            r, out = ours(b, len(data), nrun)  # (the device entry is handed exactly one frame: the host entry takes the cut and the glued ones)
+            r, out = ours(b, len(data), nrun, int(rng.integers(0, 2)))  # (the device entry is handed exactly one frame: the host entry takes the cut and the glued ones)
         else:
             r, out = ours_device(b, len(data), nrun, entry == 2)
         if is_error(code) != is_error(r):
