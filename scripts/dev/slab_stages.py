@@ -16,6 +16,13 @@ back = np.empty(n, dtype=np.uint8); back.fill(1)
 cctx = L.zl_createCCtx()
 r = L.zl_compress2(cctx, comp.ctypes.data, cap, host.ctypes.data, n)
 import os
+if os.environ.get("REF"):  # a frame the reference wrote (level REF) instead of this library's
+    from zl_testlib import Ref
+    ref = Ref()
+    rc = ref.L.ZSTD_createCCtx()
+    ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_compressionLevel, int(os.environ["REF"]))
+    r = ref.L.ZSTD_compress2(rc, comp.ctypes.data, cap, host.ctypes.data, n)
+    ref.L.ZSTD_freeCCtx(rc)
 if os.environ.get("FREE_CCTX"):
     L.zl_freeCCtx(cctx)
 dctx = L.zl_createDCtx()

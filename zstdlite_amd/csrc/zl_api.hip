@@ -1391,7 +1391,12 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     } joiner{io, d, up_th, down_th, hash_th};
     const bool tiny = d->slab_mib != 0 && d->slab_mib < 64;  // (tests: frames of a few MiB in pieces and runs of a few hundred KiB)
     if (tiny) io.run_bytes = (u64)256 << 10;
-    bool early = d->pipeline && d->dict.empty() && !d->is_peer && cap >= slab_min && n >= (tiny ? (size_t)4096 : (size_t)1 << 20) && d->d_src.ensure(n + 16);
+    bool early = d->pipeline && d->dict.empty() && !d->is_peer && cap >= slab_min && n >= (tiny ? (size_t)4096 : (size_t)1 << 20);
+    if (early) {  // (only when the input opens with a frame that is large by its own word: a buffer of many frames is dealt out below as before)
+        FrameHeader h0;
+        early = !ZL_IS_ERR(parse_frame_header(h0, src, n)) && !h0.skippable && h0.content_size != ZL_CONTENTSIZE_UNKNOWN && h0.content_size >= slab_min && h0.content_size <= cap;
+    }
+    early = early && d->d_src.ensure(n + 16);
     int dev = 0;
     (void)hipGetDevice(&dev);
     const ZlCopyPair* const pair = early ? zl_copy_pair() : nullptr;  // the upload and the download on two copy engines (zl_copy_pair.h)
