@@ -52,9 +52,9 @@ try:
 except Exception as e:  # (oracle/_ref not built)
     print("no reference build:", e)
     sys.exit(0)
-for level in (3,):
+for level, ck in ((3, 0), (3, 1)):
     rc = ref.L.ZSTD_createCCtx()
-    ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_compressionLevel, level); ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_checksumFlag, 1)
+    ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_compressionLevel, level); ref.L.ZSTD_CCtx_setParameter(rc, ref.ZSTD_c_checksumFlag, ck)
     r = ref.L.ZSTD_compress2(rc, comp.ctypes.data, cap, host.ctypes.data, n)
     ref.L.ZSTD_freeCCtx(rc)
-    sweep(r, f"reference frame level {level}, checksum 1")
+    sweep(r, f"reference frame level {level}, checksum {ck}")

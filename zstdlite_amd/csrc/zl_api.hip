@@ -240,7 +240,7 @@ struct SlabIO {
     std::atomic<int> down_done{0};
     bool voided = false;           // the runs handed the frame back to the whole-frame routes: what has landed does not count
     u64 total = 0;                 // bytes of input
-    u64 run_bytes = (u64)64 << 20; // a run ends behind this many compressed bytes (or 8192 blocks / ZL_d_runBlocks)
+    u64 run_bytes = (u64)128 << 20; // a run ends behind this many compressed bytes (or 8192 blocks / ZL_d_runBlocks); 32 / 64 / 128 / 256 MiB on the 1 GiB frame of the reference: 49.5 / 47 / 42 / 49 ms
     bool wait_uploaded(u64 upto) {
         upto = std::min(upto, total);
         while (uploaded.load(std::memory_order_acquire) < upto) {
@@ -296,6 +296,10 @@ struct zl_dctx_s {
     int devices = 1;                   // ZL_d_devices
     int run_blocks = 0;                // ZL_d_runBlocks
     int slab_mib = 0;                  // ZL_d_slabMiB
+    // decode_walked_frame_in_runs keeps several runs in flight: each on a pipeline state, a stream and side streams of its own
+    struct RunSlot { zl3_state* big = nullptr; zl2_side side = {}; hipStream_t st = nullptr; };
+    static const int kRunSlots = 4;
+    RunSlot run_slot[kRunSlots];
     SlabIO* slab = nullptr;            // the host entry's call in progress decodes ONE frame slab by slab
     bool is_peer = false;              // a slot's context of another context's call: it never deals its work out again
     int last_slots = 1;                // device slots the last zl_decompressDCtx call used
@@ -473,6 +477,17 @@ size_t zl_freeDCtx(zl_dctx* d) {
     for (zl_dctx* p : d->peers) (void)zl_freeDCtx(p);
     d->peers.clear();
     zl3_free(d->big);
+    for (auto& rs : d->run_slot) {
+        zl3_free(rs.big);
+        if (rs.st) (void)hipStreamDestroy(rs.st);
+        if (rs.side.fork) (void)hipEventDestroy(rs.side.fork);
+        if (rs.side.join) (void)hipEventDestroy(rs.side.join);
+        if (rs.side.stream) (void)hipStreamDestroy(rs.side.stream);
+        for (int k = 0; k < 3; k++) {
+            if (rs.side.part_join[k]) (void)hipEventDestroy(rs.side.part_join[k]);
+            if (rs.side.part_stream[k]) (void)hipStreamDestroy(rs.side.part_stream[k]);
+        }
+    }
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -780,78 +795,156 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         b = e;
     }
     const size_t nruns = cuts.size() - 1;
+    // ---- several runs in flight (round 4).  A run's entropy stage needs its bytes and the tables in force where it starts -- not
+    // the output in front of it -- and lasts as long as its longest block's chains whatever the number of blocks (6 - 10 ms for the
+    // 128 KiB blocks of a frame the reference wrote): one run after the other paid that once per run, 73 ms for the 1 GiB frame that
+    // takes 52 as a whole.  So a run goes through the pipeline in two calls (zl3_hint::phase): the FIRST, up to the entropy stage,
+    // as soon as its bytes are there and a slot is free -- up to four runs in flight, each on a state and streams of its own --, the
+    // SECOND (output positions, execution, ordered copies) when the run in front of it is complete.
+    // (four slots where blocks are large -- the reference's 128 KiB, whose entropy stage lasts 6 - 10 ms --, two where they are this
+    // library's 16 KiB, whose stage is over in a millisecond or two: every slot costs its buffers, 5 GiB and 30 ms of allocation
+    // in a context's first call)
+    const int K = (end_pos / nb >= ((u64)24 << 10)) ? zl_dctx_s::kRunSlots : 2;
+    for (int k_ = 0; k_ < K; k_++) {
+        auto& rs = d->run_slot[k_];
+        if (!rs.big && !(rs.big = zl3_create())) return kGpuUnavailable;
+        if (!rs.st) {
+            if (hipStreamCreateWithFlags(&rs.st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&rs.side.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&rs.side.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&rs.side.join, hipEventDisableTiming) != hipSuccess)
+                return kGpuUnavailable;
+            for (int k = 0; k < 3; k++)
+                if (hipStreamCreateWithFlags(&rs.side.part_stream[k], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&rs.side.part_join[k], hipEventDisableTiming) != hipSuccess)
+                    return kGpuUnavailable;
+        }
+    }
+    (void)hipStreamSynchronize(st);  // (the caller's stream may still be uploading the frame or a table: the runs use streams of their own)
+    struct Drain {  // whatever way this ends: no kernel of a run is still at the scratch of its slot
+        zl_dctx* d;
+        ~Drain() { for (auto& rs : d->run_slot) { if (rs.st) (void)hipStreamSynchronize(rs.st); if (rs.side.stream) (void)hipStreamSynchronize(rs.side.stream); if (rs.side.part_stream[2]) (void)hipStreamSynchronize(rs.side.part_stream[2]); } }
+    } drain{d};
+    struct RunPlan { u64 s0, s1, base; u32 need, nd, dn[4]; zl_frame_desc run; };
     std::vector<zl3_hblk> hb;
     u64 out_pos = 0, left[4] = {0, 1, 4, 8};
-    u32 cur[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the latest block in front of the run that describes the Huffman tree, the LL, OF, ML table
-    hint.host_blocks = nullptr; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.sink_host = nullptr; hint.sink_hash = nullptr;
-    hint.headerless = 1; hint.not_last = 0; hint.tail = 0; hint.size_unknown = 1; hint.run_out = left;
-    hint.dict_id = 0;
-    for (size_t r = 0; r < nruns; r++) {
+    u32 cur[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // the latest block in front of the next run to be STARTED that describes the Huffman tree, the LL, OF, ML table
+    zl3_hint base_hint = hint;
+    base_hint.host_blocks = nullptr; base_hint.d_chunk_off = nullptr; base_hint.nchunks = 0; base_hint.sink_host = nullptr; base_hint.sink_hash = nullptr;
+    base_hint.headerless = 1; base_hint.not_last = 0; base_hint.tail = 0; base_hint.size_unknown = 1; base_hint.run_out = nullptr;
+    base_hint.dict_id = 0;
+    std::vector<RunPlan> plan(nruns);
+    for (size_t r = 0; r < nruns; r++) {  // what the largest run needs: every slot's buffers are sized for it at once
+        const u64 blocks = cuts[r + 1] - cuts[r];
+        base_hint.reserve_blocks = std::max<u32>(base_hint.reserve_blocks, (u32)blocks + 4);
+        base_hint.reserve_span = std::max<u64>(base_hint.reserve_span, std::min<u64>(fd.dst_cap, blocks * ZL_BLOCK_MAX));
+    }
+    size_t started = 0;  // runs whose first call has been made
+    // the first call of run r; wait: block until its bytes have arrived (else: only if they have).  1: started, 0: not yet, else an error code
+    auto start_run = [&](size_t r, bool wait) -> size_t {
         const size_t b0 = cuts[r], b1 = cuts[r + 1];
+        RunPlan& P = plan[r];
         // which tables does the run take over from the blocks in front of it?
         u32 need = 0, have = 0;
         for (size_t b = b0; b < b1 && have != 15u; b++) { need |= blk[b].use.uses & ~have; have |= blk[b].use.defs; }
-        u32 dn[4], nd = 0;  // the donors: distinct, in frame order
+        u32 nd = 0;  // the donors: distinct, in frame order
         for (int q = 0; q < 4; q++) {
             if (!((need >> q) & 1)) continue;
             if (cur[q] == 0xFFFFFFFFu) return ZL_ERR(ZL_E_FALLBACK);  // (repeats what nobody described: the general kernel names the error)
             bool seen = false;
-            for (u32 k = 0; k < nd; k++) seen = seen || dn[k] == cur[q];
-            if (!seen) dn[nd++] = cur[q];
+            for (u32 k = 0; k < nd; k++) seen = seen || P.dn[k] == cur[q];
+            if (!seen) P.dn[nd++] = cur[q];
         }
-        std::sort(dn, dn + nd);
-        const u64 s0 = blk[b0].at - 3;
-        const u64 s1 = b1 < nb ? blk[b1].at - 3 : end_pos;
-        const u64 base = nd ? std::min<u64>(s0, blk[dn[0]].at - 3) : s0;
-        if (s1 - base >= 0xFFFFFF00ull || out_pos > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
+        std::sort(P.dn, P.dn + nd);
+        P.need = need; P.nd = nd;
+        P.s0 = blk[b0].at - 3;
+        P.s1 = b1 < nb ? blk[b1].at - 3 : end_pos;
+        P.base = nd ? std::min<u64>(P.s0, blk[P.dn[0]].at - 3) : P.s0;
+        if (P.s1 - P.base >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);
+        if (io) {  // (donors lie in front of the run: uploaded before it)
+            if (!wait && io->uploaded.load(std::memory_order_acquire) < std::min<u64>(fd.src_off + P.s1, io->total)) return 0;
+            if (!io->wait_uploaded(fd.src_off + P.s1)) return ZL_ERR(ZL_E_GENERIC);
+        }
         hb.resize(b1 - b0 + nd);
-        for (size_t b = b0; b < b1; b++) { hb[b - b0].src_off = (u32)(blk[b].at - base); hb[b - b0].hdr = blk[b].hdr; }
-        for (u32 k = 0; k < nd; k++) { hb[b1 - b0 + k].src_off = (u32)(blk[dn[k]].at - base); hb[b1 - b0 + k].hdr = blk[dn[k]].hdr; }
-        hint.ndonors = nd;
+        for (size_t b = b0; b < b1; b++) { hb[b - b0].src_off = (u32)(blk[b].at - P.base); hb[b - b0].hdr = blk[b].hdr; }
+        for (u32 k = 0; k < nd; k++) { hb[b1 - b0 + k].src_off = (u32)(blk[P.dn[k]].at - P.base); hb[b1 - b0 + k].hdr = blk[P.dn[k]].hdr; }
+        zl3_hint hx = base_hint;
+        hx.ndonors = nd;
         for (int q = 0; q < 4; q++) {
-            hint.donor[q] = 0xFFFFFFFFu;
-            if ((need >> q) & 1) for (u32 k = 0; k < nd; k++) if (dn[k] == cur[q]) hint.donor[q] = k;
+            hx.donor[q] = 0xFFFFFFFFu;
+            if ((need >> q) & 1) for (u32 k = 0; k < nd; k++) if (P.dn[k] == cur[q]) hx.donor[q] = k;
         }
-        zl_frame_desc run;
-        run.src_off = fd.src_off + base;
-        run.src_size = s1 - base;
-        run.dst_off = fd.dst_off + out_pos;
-        run.dst_cap = std::min<u64>(fd.dst_cap - out_pos, (u64)(b1 - b0) * ZL_BLOCK_MAX);
-        hint.host_blocks = hb.data();
-        hint.nblocks = (u32)(b1 - b0);
-        hint.end_pos = (u32)(s1 - base);
-        hint.dict_end = d_dst + fd.dst_off + out_pos;
-        hint.dict_len = (u32)std::min<u64>(out_pos, 0x80000000ull);
-        hint.dict_formatted = r ? 1u : 0u;
-        for (int k = 0; k < 3; k++) hint.dict_rep[k] = (u32)left[1 + k];
-        left[0] = ~0ull;
+        P.run.src_off = fd.src_off + P.base;
+        P.run.src_size = P.s1 - P.base;
+        P.run.dst_off = 0;
+        P.run.dst_cap = std::min<u64>(fd.dst_cap, (u64)(b1 - b0) * ZL_BLOCK_MAX);  // (what the run may produce at most; the room that is left is the second call's to say)
+        hx.host_blocks = hb.data();
+        hx.nblocks = (u32)(b1 - b0);
+        hx.end_pos = (u32)(P.s1 - P.base);
+        hx.dict_end = nullptr;
+        hx.dict_len = r ? 1u : 0u;  // (is there history in front of the run, and does it bring tables: all the first call looks at)
+        hx.dict_formatted = r ? 1u : 0u;
+        hx.phase = 1;
+        zl_dctx_s::RunSlot& rs = d->run_slot[r % K];
+        const size_t e = zl3_decode_frame(rs.big, &P.run, d_src, d_dst, (u64*)d->d_run_results.p, 1, rs.st, &rs.side, &hx);
+        if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
+        for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
+        return 1;
+    };
+    for (size_t r = 0; r < nruns; r++) {
 #ifdef ZL_DEV_SWITCHES
         static const bool dbg_slab = getenv("ZL_DEBUG_SLAB") != nullptr;
         auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
         const double t_a = now_ms();
 #endif
-        if (io && !io->wait_uploaded(fd.src_off + s1)) return ZL_ERR(ZL_E_GENERIC);  // (donors lie in front of the run: uploaded before it)
+        // first calls: this run's (waiting for its bytes) and those of the next K - 1 whose bytes are there already
+        while (started < nruns && started < r + (size_t)K) {
+            const size_t e = start_run(started, started == r);
+            if (e == 0) break;
+            if (e != 1) return e;
+            started++;
+        }
+        // ... and while this run's entropy stage is under way, the first calls of the runs behind it as their bytes arrive
+        while (io && started < nruns && started < r + (size_t)K && hipStreamQuery(d->run_slot[r % K].st) == hipErrorNotReady) {
+            const size_t e = start_run(started, false);
+            if (e == 1) { started++; continue; }
+            if (e != 0) return e;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
 #ifdef ZL_DEV_SWITCHES
         const double t_b = now_ms();
 #endif
-        const size_t e = zl3_decode_frame(d->big, &run, d_src, d_dst, (u64*)d->d_run_results.p, 1, st, &d->side, &hint);
+        // the second call
+        const size_t b0 = cuts[r], b1 = cuts[r + 1];
+        RunPlan& P = plan[r];
+        if (out_pos > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
+        zl3_hint hx = base_hint;
+        hx.phase = 2;
+        hx.run_out = left;
+        hx.dict_end = d_dst + fd.dst_off + out_pos;
+        hx.dict_len = (u32)std::min<u64>(out_pos, 0x80000000ull);
+        hx.dict_formatted = r ? 1u : 0u;
+        for (int k = 0; k < 3; k++) hx.dict_rep[k] = (u32)left[1 + k];
+        zl_frame_desc run = P.run;
+        run.dst_off = fd.dst_off + out_pos;
+        run.dst_cap = std::min<u64>(fd.dst_cap - out_pos, (u64)(b1 - b0) * ZL_BLOCK_MAX);
+        left[0] = ~0ull;
+        zl_dctx_s::RunSlot& rs = d->run_slot[r % K];
+        const size_t e = zl3_decode_frame(rs.big, &run, d_src, d_dst, (u64*)d->d_run_results.p, 1, rs.st, &rs.side, &hx);
 #ifdef ZL_DEV_SWITCHES
-        if (dbg_slab) fprintf(stderr, "[zl slab] run %zu: blocks %zu, %.1f MiB in, waited %.2f ms for them, decoded in %.2f ms (landed so far %.0f MiB)\n", r, b1 - b0, (double)(s1 - s0) / 1048576.0, t_b - t_a, now_ms() - t_b, io ? (double)io->landed.load() / 1048576.0 : 0.0);
+        if (dbg_slab) fprintf(stderr, "[zl slab] run %zu: blocks %zu, %.1f MiB in, first calls (and the wait for bytes) %.2f ms, %zu runs started, second call %.2f ms (landed so far %.0f MiB)\n", r, b1 - b0, (double)(P.s1 - P.s0) / 1048576.0, t_b - t_a, started, now_ms() - t_b, io ? (double)io->landed.load() / 1048576.0 : 0.0);
 #endif
         if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
         if (left[0] == ~0ull) {
             // the run reported an error.  The host has walked every block and handed the run its tables: what is left is damage
             // inside a block, and that is the frame's result -- not 400 s of the general kernel finding the same
             u64 word = 0;
-            if (hipMemcpyAsync(&word, d->d_run_results.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            if (hipStreamSynchronize(rs.st) != hipSuccess || hipMemcpyAsync(&word, d->d_run_results.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             if (!ZL_IS_ERR(word) || word == ZL_ERR(ZL_E_FALLBACK)) return ZL_ERR(ZL_E_FALLBACK);
             if (hipMemcpyAsync(d_result, d->d_run_results.p, 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             return 0;
         }
+        if (hipStreamSynchronize(rs.st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);  // (the run's result word: written behind the readback that filled `left`)
         out_pos += left[0];
         if (io && h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos <= h.content_size) io->decoded.store(out_pos, std::memory_order_release);  // (the download thread follows)
         d->frame_runs++;
-        for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
     }
     if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos != h.content_size) return ZL_ERR(ZL_E_FALLBACK);
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
@@ -928,6 +1021,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0;
         hint.dict_rep[0] = 1; hint.dict_rep[1] = 4; hint.dict_rep[2] = 8;
         hint.size_unknown = 0; hint.run_out = nullptr; hint.ndonors = 0; hint.donor[0] = hint.donor[1] = hint.donor[2] = hint.donor[3] = 0xFFFFFFFFu;
+        hint.phase = 0; hint.reserve_blocks = 0; hint.reserve_span = 0;
         if (has_dict) {  // the dictionary's content is history in front of the frame; its tables stay with the general kernel (zl_decode3.h)
             hint.dict_len = (u32)(d->dict.size() - d->dict_content_off);
             hint.dict_end = (const u8*)d->d_dict.p + d->dict.size();
@@ -1391,6 +1485,9 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     } joiner{io, d, up_th, down_th, hash_th};
     const bool tiny = d->slab_mib != 0 && d->slab_mib < 64;  // (tests: frames of a few MiB in pieces and runs of a few hundred KiB)
     if (tiny) io.run_bytes = (u64)256 << 10;
+#ifdef ZL_DEV_SWITCHES
+    if (getenv("ZL_SLAB_RUN_MIB")) io.run_bytes = (u64)atoi(getenv("ZL_SLAB_RUN_MIB")) << 20;
+#endif
     bool early = d->pipeline && d->dict.empty() && !d->is_peer && cap >= slab_min && n >= (tiny ? (size_t)4096 : (size_t)1 << 20);
     if (early) {  // (only when the input opens with a frame that is large by its own word: a buffer of many frames is dealt out below as before)
         FrameHeader h0;

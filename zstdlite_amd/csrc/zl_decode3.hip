@@ -727,6 +727,8 @@ struct zl3_state_s {
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
     hipEvent_t sink_done[ZL3_SINK_EVENTS] = {};  // behind the download of each piece (zl3_hint::sink_hash)
     hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
+    // what phase 1 of a run in two calls leaves for phase 2 (zl3_hint::phase)
+    struct Saved { zl3_dev d; zl2_args a; zl3_info info; u64 span = 0; hipStream_t fill_st = nullptr; bool valid = false; } sv;
 };
 
 extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s(); }
@@ -785,7 +787,9 @@ extern "C" hipError_t zl3_check_content(zl3_state* s, const u8* d_content, u64 n
 // Decodes one large frame.  Returns 0 (the result word of the frame has been written on the device),
 // ZL_ERR(ZL_E_FALLBACK) when the frame has to take the general kernel, or another error of the launch itself.
 extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const u8* d_src, u8* d_dst, u64* d_result, int ignore_checksum, hipStream_t st, const zl2_side* side, const zl3_hint* hint) {
-    const zl_frame_desc fd = *fdp;
+    zl_frame_desc fd = *fdp;
+    const u32 phase = hint ? hint->phase : 0u;
+    if (phase == 1) fd.dst_off = 0;  // (the segments' descriptors carry it: phase 2 moves the output pointer instead)
 #ifdef ZL_DEV_SWITCHES  // development builds: ZL_DEBUG_BIG=1 prints the time of every stage to stderr (each stamp synchronises the stream)
     static const bool dbg = getenv("ZL_DEBUG_BIG") != nullptr;
     auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -794,6 +798,20 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
 #else
     auto stamp = [](const char*) {};
 #endif
+    zl3_dev d;
+    zl3_info info;
+    zl2_args a;
+    u64 span = 0;
+    hipStream_t fill_st = st;
+    const bool have_dict = hint && hint->dict_len != 0;
+    if (phase == 2) {  // the second call of a run: everything up to the entropy stage has been queued by the first
+        if (!s->sv.valid) return ZL_ERR(ZL_E_GENERIC);
+        s->sv.valid = false;
+        d = s->sv.d; a = s->sv.a; info = s->sv.info; span = s->sv.span; fill_st = s->sv.fill_st;
+        fd.dst_off = 0;
+        d_dst += fdp->dst_off;
+    }
+    if (phase != 2) {
     if (fd.src_size >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);  // block records are 32-bit
     if (!s->fill_fork && (hipEventCreateWithFlags(&s->fill_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->fill_join, hipEventDisableTiming) != hipSuccess)) { s->fill_fork = s->fill_join = nullptr; }
     // (dst_cap may be the room left in the caller's buffer rather than the frame's size: what the frame can produce is bounded by its input too)
@@ -801,15 +819,14 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     // blocks planned for: full blocks plus a generous allowance for encoders that split blocks (this library's own cut 16 KiB blocks)
     u32 cap_blocks = (u32)std::min<u64>((out_bound >> 13) + (fd.src_size >> 11) + 64, 1u << 22) & ~(u32)(ZL2_MAXB - 1);
     if (hint && hint->host_blocks && hint->nblocks + 4 > cap_blocks) cap_blocks = (hint->nblocks + 4 + ZL2_MAXB) & ~(u32)(ZL2_MAXB - 1);
+    if (hint && hint->reserve_blocks + 4 > cap_blocks) cap_blocks = (hint->reserve_blocks + 4 + ZL2_MAXB) & ~(u32)(ZL2_MAXB - 1);
     const u32 cap_segs = cap_blocks;  // (a segment holds at least one block)
     if (!s->info.ensure(sizeof(zl3_info)) || !s->hblk.ensure((size_t)cap_blocks * sizeof(zl3_hblk)) || !s->braw.ensure((size_t)cap_blocks * sizeof(zl2_blk_rec)) ||
         !s->seg_first.ensure(((size_t)cap_segs + 1) * 4) || !s->blk_slot.ensure((size_t)cap_blocks * 4) || !s->blk_dst.ensure(((size_t)cap_blocks + 1) * 4) ||
         !s->rep_start.ensure((size_t)cap_blocks * 12) || !s->word.ensure(64) || !s->big.ensure(sizeof(zl3_big)))
         return kGpuUnavailable;
-    zl3_dev d;
     d.info = (zl3_info*)s->info.p; d.hblk = (zl3_hblk*)s->hblk.p; d.braw = (zl2_blk_rec*)s->braw.p; d.seg_first = (u32*)s->seg_first.p; d.blk_slot = (u32*)s->blk_slot.p;
     d.blk_dst = (u32*)s->blk_dst.p; d.rep_start = (u32*)s->rep_start.p; d.max_blocks = (u32*)s->word.p; d.cap_blocks = cap_blocks;
-    const bool have_dict = hint && hint->dict_len != 0;
     d.have_dict = have_dict ? 1u : 0u;
     d.dict_id = have_dict ? hint->dict_id : 0u;
     d.dict_tables = (have_dict && hint->dict_formatted) ? 1u : 0u;
@@ -884,12 +901,11 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     if (!walked) hipLaunchKernelGGL(zl3_walk_kernel, dim3(1), dim3(64), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_parse_kernel, dim3((cap_blocks + 255) / 256), dim3(256), 0, st, d, fd, d_src);
     hipLaunchKernelGGL(zl3_segment_kernel, dim3(1), dim3(1024), 0, st, d);
-    zl3_info info;
     if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     stamp("walk+parse");
     if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
     if (!info.err) {
-        const size_t ns = info.nsegs;
+        const size_t ns = (hint && hint->reserve_blocks) ? std::max<size_t>(info.nsegs, (hint->reserve_blocks + ZL2_MAXB - 1) / ZL2_MAXB + 64) : (size_t)info.nsegs;  // (a segment of a run holds ZL2_MAXB blocks, or one that is large)
         if (!s->brec.ensure(ns * ZL2_MAXB * sizeof(zl2_blk_rec)) || !s->frec.ensure(ns * sizeof(zl2_frame_rec)) || !s->plan.ensure(ns * sizeof(zl2_frame_plan)) ||
             !s->frames.ensure(ns * sizeof(zl_frame_desc)) || !s->ext.ensure(ns * 4 * sizeof(zl2_blk_rec)) || !s->seg_tmp.ensure(ns * 64) || !s->order.ensure(ns * 8 + 64))
             return kGpuUnavailable;
@@ -904,31 +920,39 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     if (dbg) fprintf(stderr, "[zl3] blocks %u segments %u literals %llu sequences %llu err %u\n", info.nblocks, info.nsegs, (unsigned long long)info.lit_total, (unsigned long long)info.seq_total, info.err);
 #endif
     // output positions the links must cover: the recorded size, else what the blocks can produce at most (and the caller has room for)
-    const u64 span = info.fcs != ZL_CONTENTSIZE_UNKNOWN ? info.fcs : std::min<u64>(fd.dst_cap, (u64)info.nblocks * ZL_BLOCK_MAX);
+    span = info.fcs != ZL_CONTENTSIZE_UNKNOWN ? info.fcs : std::min<u64>(fd.dst_cap, (u64)info.nblocks * ZL_BLOCK_MAX);
     if (span >= 0xFFFFD000ull) return ZL_ERR(ZL_E_FALLBACK);  // links are 32-bit (and the exec kernel's in-batch form of one adds its batch size to a position)
+    }  // (phase != 2)
     const u64 ntiles = (span >> ZL3_TILE_LOG) + 1;
     if (!info.err) {
-        if (!s->lit.ensure(info.lit_total + 64) || !s->seq.ensure(info.seq_total * 16 + 64) || !s->link.ensure(span * 4 + 64) || !s->tile_flag.ensure(ntiles * 4))
+        if (phase != 2) {
+        const u64 rspan = std::max<u64>(span, hint ? std::min<u64>(hint->reserve_span, 0xFFFFD000ull) : 0);
+        // (the sequence records of later runs are not known yet: room for half as many again)
+        if (!s->lit.ensure(std::max<u64>(info.lit_total, hint && hint->reserve_span ? rspan : 0) + 64) || !s->seq.ensure((hint && hint->reserve_span && s->seq.cap < info.seq_total * 16 + 64 ? info.seq_total * 24 : info.seq_total * 16) + 64) ||
+            !s->link.ensure(rspan * 4 + 64) || !s->tile_flag.ensure(((rspan >> ZL3_TILE_LOG) + 1) * 4) || !s->tot.ensure((size_t)d.cap_blocks * 16))
             return kGpuUnavailable;
+        }
         // An exec workgroup works through a RUN of consecutive segments; what a run's bytes copy from in front of the run waits for
         // the ordered copies.  Eight segments per run keep those few on a frame of thousands of blocks -- and leave a frame of a few
         // hundred with a few dozen workgroups, each as long as its eight blocks (0.75 ms a block): a 64 MiB reference frame spent
         // 6 of its 16 ms there.  The run shrinks with the frame so that the launch still fills the device (three workgroups per CU).
         const u32 exec_run = std::max<u32>(1u, std::min<u32>((u32)ZL3_EXEC_RUN, info.nsegs / (3u * (u32)g_num_cu)));
-        zl3_big big;
-        big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = exec_run;
-        big.dict_len = have_dict ? hint->dict_len : 0u; big.dict_end = have_dict ? hint->dict_end : nullptr;
-        if (hipMemcpyAsync(s->big.p, &big, sizeof(big), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (phase != 1) {  // (the history is phase 2's to say)
+            zl3_big big;
+            big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = exec_run;
+            big.dict_len = have_dict ? hint->dict_len : 0u; big.dict_end = have_dict ? hint->dict_end : nullptr;
+            if (hipMemcpyAsync(s->big.p, &big, sizeof(big), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        }
+        if (phase != 2) {
         if (hipMemsetAsync(s->tile_flag.p, 0, ntiles * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         // every byte starts out final; the exec kernel writes the links of the waiting ones only (a plain fill at memory speed
         // instead of one more 4-byte store per output byte from the exec kernel's flush loops)
         // (on a stream of its own beside the entropy stage, whose serial chains leave the memory system idle: 4 GiB for a 1 GiB
         // frame, 1.2 ms that used to stand in front of it; joined again in front of the exec kernel)
-        hipStream_t fill_st = (side && side->part_stream[2] && s->fill_fork && s->fill_join) ? side->part_stream[2] : st;
+        fill_st = (side && side->part_stream[2] && s->fill_fork && s->fill_join) ? side->part_stream[2] : st;
         if (fill_st != st && (hipEventRecord(s->fill_fork, st) != hipSuccess || hipStreamWaitEvent(fill_st, s->fill_fork, 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
         if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (fill_st != st && hipEventRecord(s->fill_join, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        zl2_args a;
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
         a.ext = d.ext; a.big = (const zl3_big*)s->big.p;
@@ -939,7 +963,12 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         stamp("alloc");
         if (zl2_launch_segments_entropy(&a, st, side) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("entropy");
-        if (!s->tot.ensure((size_t)cap_blocks * 16)) return kGpuUnavailable;
+        }  // (phase != 2)
+        if (phase == 1) {
+            s->sv.d = d; s->sv.a = a; s->sv.info = info; s->sv.span = span; s->sv.fill_st = fill_st; s->sv.valid = true;
+            return 0;
+        }
+        a.dst = d_dst;
         hipLaunchKernelGGL(zl3_totals_kernel, dim3((info.nblocks + 255) / 256), dim3(256), 0, st, d, (const u32*)s->seq.p, (uint4*)s->tot.p);
         {   // the history the frame starts with: a formatted dictionary's three offsets, else 1, 4, 8
             const bool dr = have_dict && hint->dict_formatted;
@@ -1007,6 +1036,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
         if (nsink && !info.err) *hint->sunk = (u64)nsink << ZL3_SINK_LOG;  // (a frame that failed or goes to the general kernel is downloaded as a whole, whatever was copied)
         if (hint && hint->run_out && !info.err) { hint->run_out[0] = info.produced; for (int k = 0; k < 3; k++) hint->run_out[1 + k] = info.rep_end[k]; }
+    }
+    if (phase == 1) {  // (the walk found the run damaged: phase 2 writes that verdict)
+        s->sv.d = d; s->sv.a = a; s->sv.info = info; s->sv.span = span; s->sv.fill_st = fill_st; s->sv.valid = true;
+        return 0;
     }
     u32 have_hash = 0, hash = 0;
     if (!ignore_checksum && !info.err && info.has_checksum) {  // (the host entries come with ignore_checksum set: they hash what they have downloaded)
