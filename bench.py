@@ -384,6 +384,9 @@ def end_to_end_leg(host, device, log):
             tc, td = min(tc, t1 - t0), min(td, t2 - t1)
         assert np.array_equal(back, host)
         L.zl_freeCCtx(cctx); L.zl_freeDCtx(dctx)
+        # (the contexts give back ten GiB of device memory, which the driver wipes with the copy engines: downloads that start
+        # right behind it ran at half their rate for a few hundred ms -- scripts/dev/copy_thread_exit.py)
+        time.sleep(0.5)
         out[layout] = {"compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "compressed_bytes": int(r)}
     d = torch.empty(n, dtype=torch.uint8, device=device)
     hb = torch.from_numpy(back)
