@@ -936,7 +936,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // the ordered copies.  Eight segments per run keep those few on a frame of thousands of blocks -- and leave a frame of a few
         // hundred with a few dozen workgroups, each as long as its eight blocks (0.75 ms a block): a 64 MiB reference frame spent
         // 6 of its 16 ms there.  The run shrinks with the frame so that the launch still fills the device (three workgroups per CU).
-        const u32 exec_run = std::max<u32>(1u, std::min<u32>((u32)ZL3_EXEC_RUN, info.nsegs / (3u * (u32)g_num_cu)));
+        u32 exec_run = std::max<u32>(1u, std::min<u32>((u32)ZL3_EXEC_RUN, info.nsegs / (3u * (u32)g_num_cu)));
+#ifdef ZL_DEV_SWITCHES
+        if (getenv("ZL_EXEC_RUN")) exec_run = (u32)atoi(getenv("ZL_EXEC_RUN"));
+#endif
         if (phase != 1) {  // (the history is phase 2's to say)
             zl3_big big;
             big.info = d.info; big.link = (u32*)s->link.p; big.tile_flag = (u32*)s->tile_flag.p; big.blk_dst = d.blk_dst; big.rep_start = d.rep_start; big.seg_first = d.seg_first; big.exec_run = exec_run;
