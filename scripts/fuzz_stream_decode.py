@@ -1,5 +1,6 @@
 """Fuzz the streaming DEcoder with damaged input: reference-made and our own frames (100 bytes to 3 MB, with and without
-checksum), a few flipped bits, fed to zl_decompressStream in pieces of random sizes.  The session must end the way the oracle
+checksum), a few flipped bits, fed to zl_decompressStream in pieces of random sizes; every other round with the route that
+decodes a large frame while it arrives (round 4) opened for frames of 1 MiB.  The session must end the way the oracle
 ends on the whole buffer: an error (at whatever piece) when the oracle rejects, the oracle's bytes when it accepts -- and never
 hang.  usage: fuzz_stream_decode.py [rounds=100] [seed=1]"""
 import sys
@@ -10,6 +11,8 @@ import numpy as np
 import zstdlite_amd as z
 from zstdlite_amd import stream
 from zl_testlib import GENERATORS, Oracle, Ref, is_error
+from zstdlite_amd import _lib
+L = _lib.lib()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ref, o = Ref(), Oracle()
@@ -35,6 +38,8 @@ for rd in range(rounds):
         got, err = [], None
         try:
             dctx = z.zstd_dctx()  # (held: the session uses its pointer)
+            if rd & 1:  # every other round: frames of 1 MiB and more are decoded WHILE THEY ARRIVE (ZL_d_slabMiB = 1: pieces and runs of a few hundred KiB)
+                L.zl_DCtx_setParameter(dctx._ptr, 9010, 1); L.zl_DCtx_setParameter(dctx._ptr, 9009, int(rng.choice([0, 16, 40])))
             dec = stream.Decompressor(dctx._ptr)
             pos = 0
             while pos < len(b):

@@ -276,3 +276,83 @@ def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
     over = stream.Compressor(cctx._ptr, pledged=1000)
     with pytest.raises(stream.ZstdStreamError, match="Src size is incorrect"):
         over.feed(data[:2000])
+
+
+@needs_ref
+def test_a_large_frame_is_decoded_while_it_arrives(ref, oracle):
+    """Round 4 ("streaming decode of a large frame is not streaming"): zl_decompressStream used to collect a frame
+    to its last byte before the first one came out.  A frame whose header records ZL_d_slabMiB (32 MiB in a stream) of content or
+    more is now uploaded piece by piece, decoded in runs of blocks as they complete and handed out as the runs finish (zl_api.hip
+    StreamFrame).  Here with ZL_d_slabMiB = 1 and frames of a few MiB: output must start before the frame's last piece has been
+    fed, the bytes must be the input's, frames in front of and behind the large one (small ones, a skippable one) must come out
+    in order, a damaged frame must end in the error the oracle names for the whole buffer, and the frame's content checksum is checked."""
+    L = _lib.lib()
+    rng = np.random.default_rng(17)
+    text = GENERATORS["text"](4 << 20, seed=21)
+    mixed = b"".join((text, GENERATORS["rand"](1 << 20, seed=22), GENERATORS["int20"](2 << 20, seed=23))[k % 3][(k * 33333) % (1 << 19):][: 160 << 10] for k in range(30))
+    small = text[:70000]
+    skippable = (0x184D2A53).to_bytes(4, "little") + (9).to_bytes(4, "little") + b"skip me!!"
+    frames = {"ref3": ref.compress(mixed, level=3, checksum=True), "ref19": ref.compress(text, level=19), "own": z.zstd_compress(mixed, include_checksum=True),
+              "own_text": z.zstd_compress(text)}
+    data = {"ref3": mixed, "ref19": text, "own": mixed, "own_text": text}
+    for name, f in frames.items():
+        for piece in (1 << 20, 131702, 5000):
+            dctx = z.zstd_dctx()
+            assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0  # ZL_d_slabMiB
+            dec = stream.Decompressor(dctx._ptr)
+            before = int(L.zl_dctx_frame_runs(dctx._ptr))
+            got, early, asked = [], 0, False
+            for pos in range(0, len(f), piece):
+                got.append(dec.feed(f[pos:pos + piece]))
+                if not asked and pos + piece >= (len(f) * 3) // 5 and pos + piece < len(f):
+                    # three fifths of the frame are in (at least one run of 256 KiB is complete): calls without input wait for what is
+                    # in flight, so output must come now -- before the rest of the frame has been seen
+                    asked = True
+                    for _ in range(3):
+                        got.append(dec.feed(b""))
+                    early = sum(map(len, got))
+            assert b"".join(got) == data[name] and dec.at_frame_boundary, (name, piece)
+            assert int(L.zl_dctx_frame_runs(dctx._ptr)) - before >= 2, (name, piece)
+            assert not asked or early > 0, (name, piece, "nothing came out before the frame was complete")
+    # small frame, skippable frame, large frame, small frame: one stream, in order
+    cat = ref.compress(small, level=3) + skippable + frames["ref3"] + z.zstd_compress(small) + frames["own_text"]
+    want = small + mixed + small + text
+    for piece in (300000, 4096):
+        dctx = z.zstd_dctx()
+        assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0
+        dec = stream.Decompressor(dctx._ptr)
+        assert b"".join(dec.feed(cat[pos:pos + piece]) for pos in range(0, len(cat), piece)) == want and dec.at_frame_boundary
+    # a stream that stops inside the large frame is not at a frame boundary
+    dctx = z.zstd_dctx()
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0
+    dec = stream.Decompressor(dctx._ptr)
+    part = dec.feed(frames["ref3"][: len(frames["ref3"]) // 2])
+    assert not dec.at_frame_boundary and mixed.startswith(part)
+    # damage: the verdict is the oracle's for the whole buffer (an error at whatever piece, or the same bytes)
+    f = frames["ref3"]
+    errs = 0
+    for k in range(24):
+        bad = bytearray(f)
+        if k == 0:
+            bad[-1] ^= 0x40  # the content checksum
+        else:
+            for _ in range(int(rng.integers(1, 3))):
+                bad[int(rng.integers(8, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        try:
+            want_bytes = oracle.decompress(bad, cap=len(mixed) + 16)
+        except Exception:
+            want_bytes = None
+        dctx = z.zstd_dctx()
+        assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0
+        dec = stream.Decompressor(dctx._ptr)
+        try:
+            got_bytes = b"".join(dec.feed(bad[pos:pos + 200000]) for pos in range(0, len(bad), 200000))
+            if not dec.at_frame_boundary:
+                got_bytes = None
+        except stream.ZstdStreamError:
+            got_bytes = None
+        assert (got_bytes is None) == (want_bytes is None), ("verdicts differ", k)
+        assert got_bytes == want_bytes
+        errs += got_bytes is None
+    assert errs >= 8

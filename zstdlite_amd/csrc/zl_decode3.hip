@@ -41,6 +41,11 @@
 #include "zl_kernels.h"
 #include "zl_xxh64.h"
 
+#ifdef ZL_DEV_SWITCHES
+#define ZL_OOM_HERE (fprintf(stderr, "[zl oom] %s:%d\n", __FILE__, __LINE__), kGpuUnavailable)
+#else
+#define ZL_OOM_HERE kGpuUnavailable
+#endif
 namespace {
 
 struct zl3_dev {  // device pointers of one large-frame decode
@@ -824,7 +829,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     if (!s->info.ensure(sizeof(zl3_info)) || !s->hblk.ensure((size_t)cap_blocks * sizeof(zl3_hblk)) || !s->braw.ensure((size_t)cap_blocks * sizeof(zl2_blk_rec)) ||
         !s->seg_first.ensure(((size_t)cap_segs + 1) * 4) || !s->blk_slot.ensure((size_t)cap_blocks * 4) || !s->blk_dst.ensure(((size_t)cap_blocks + 1) * 4) ||
         !s->rep_start.ensure((size_t)cap_blocks * 12) || !s->word.ensure(64) || !s->big.ensure(sizeof(zl3_big)))
-        return kGpuUnavailable;
+        return ZL_OOM_HERE;
     d.info = (zl3_info*)s->info.p; d.hblk = (zl3_hblk*)s->hblk.p; d.braw = (zl2_blk_rec*)s->braw.p; d.seg_first = (u32*)s->seg_first.p; d.blk_slot = (u32*)s->blk_slot.p;
     d.blk_dst = (u32*)s->blk_dst.p; d.rep_start = (u32*)s->rep_start.p; d.max_blocks = (u32*)s->word.p; d.cap_blocks = cap_blocks;
     d.have_dict = have_dict ? 1u : 0u;
@@ -842,7 +847,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         walked = true;
     } else if (hint && hint->d_chunk_off && hint->nchunks) {
         const u32 nc = hint->nchunks;
-        if (!s->cnt.ensure((size_t)nc * 4) || !s->first.ensure((size_t)nc * 4)) return kGpuUnavailable;
+        if (!s->cnt.ensure((size_t)nc * 4) || !s->first.ensure((size_t)nc * 4)) return ZL_OOM_HERE;
         if (hipMemsetAsync(s->cnt.p, 0, (size_t)nc * 4, st) != hipSuccess || hipMemsetAsync(s->first.p, 0, (size_t)nc * 4, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         hipLaunchKernelGGL(zl3_chunk_walk_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, d, fd, d_src, hint->d_chunk_off, nc, (u32*)s->cnt.p, (const u32*)s->first.p, 0u, hint->headerless, hint->not_last, hint->tail);
         hipLaunchKernelGGL(zl3_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d, fd, (const u32*)s->cnt.p, (u32*)s->first.p, nc, hint->d_chunk_off, d_src, hint->headerless, hint->tail);
@@ -858,7 +863,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         const u32 nparts = (u32)((fd.src_size + ZL3_SPEC_PART - 1) / ZL3_SPEC_PART);
         const size_t list_bytes = (size_t)nparts * ZL3_SPEC_LIST * sizeof(zl3_spec_rec), cnt_bytes = (size_t)nparts * 4;
         const size_t total = cnt_bytes + list_bytes + 2 * cnt_bytes;  // counts | lists | start | first
-        if (!s->spec.ensure(total + 64) || !s->h_spec.ensure(total + sizeof(zl3_info) + 64)) return kGpuUnavailable;
+        if (!s->spec.ensure(total + 64) || !s->h_spec.ensure(total + sizeof(zl3_info) + 64)) return ZL_OOM_HERE;
         u32* d_counts = (u32*)s->spec.p;
         zl3_spec_rec* d_lists = (zl3_spec_rec*)((u8*)s->spec.p + cnt_bytes);
         u32* d_start = (u32*)((u8*)s->spec.p + cnt_bytes + list_bytes);
@@ -908,7 +913,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         const size_t ns = (hint && hint->reserve_blocks) ? std::max<size_t>(info.nsegs, (hint->reserve_blocks + ZL2_MAXB - 1) / ZL2_MAXB + 64) : (size_t)info.nsegs;  // (a segment of a run holds ZL2_MAXB blocks, or one that is large)
         if (!s->brec.ensure(ns * ZL2_MAXB * sizeof(zl2_blk_rec)) || !s->frec.ensure(ns * sizeof(zl2_frame_rec)) || !s->plan.ensure(ns * sizeof(zl2_frame_plan)) ||
             !s->frames.ensure(ns * sizeof(zl_frame_desc)) || !s->ext.ensure(ns * 4 * sizeof(zl2_blk_rec)) || !s->seg_tmp.ensure(ns * 64) || !s->order.ensure(ns * 8 + 64))
-            return kGpuUnavailable;
+            return ZL_OOM_HERE;
         d.brec = (zl2_blk_rec*)s->brec.p; d.frec = (zl2_frame_rec*)s->frec.p; d.plan = (zl2_frame_plan*)s->plan.p; d.frames = (zl_frame_desc*)s->frames.p;
         d.ext = (zl2_blk_rec*)s->ext.p; d.seg_tmp = (u32*)s->seg_tmp.p;
         hipLaunchKernelGGL(zl3_plan_kernel, dim3(1), dim3(1024), 0, st, d, fd);
@@ -930,7 +935,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // (the sequence records of later runs are not known yet: room for half as many again)
         if (!s->lit.ensure(std::max<u64>(info.lit_total, hint && hint->reserve_span ? rspan : 0) + 64) || !s->seq.ensure((hint && hint->reserve_span && s->seq.cap < info.seq_total * 16 + 64 ? info.seq_total * 24 : info.seq_total * 16) + 64) ||
             !s->link.ensure(rspan * 4 + 64) || !s->tile_flag.ensure(((rspan >> ZL3_TILE_LOG) + 1) * 4) || !s->tot.ensure((size_t)d.cap_blocks * 16))
-            return kGpuUnavailable;
+            return ZL_OOM_HERE;
         }
         // An exec workgroup works through a RUN of consecutive segments; what a run's bytes copy from in front of the run waits for
         // the ordered copies.  Eight segments per run keep those few on a frame of thousands of blocks -- and leave a frame of a few
@@ -972,6 +977,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
             return 0;
         }
         a.dst = d_dst;
+        a.src = d_src;  // (a caller that receives the frame piece by piece may have moved it to a larger buffer since the first call)
         hipLaunchKernelGGL(zl3_totals_kernel, dim3((info.nblocks + 255) / 256), dim3(256), 0, st, d, (const u32*)s->seq.p, (uint4*)s->tot.p);
         {   // the history the frame starts with: a formatted dictionary's three offsets, else 1, 4, 8
             const bool dr = have_dict && hint->dict_formatted;

@@ -238,6 +238,7 @@ static inline void zl_memcpy_mt(void* dst, const void* src, size_t n) {
 }
 
 inline bool ByteBuf::append(const void* src, size_t k) {
+    if (k == 0) return true;  // (nothing to add to a buffer that may not have been allocated yet)
     u8* at = grow(k);
     if (!at) return false;
     zl_memcpy_mt(at, src, k);
