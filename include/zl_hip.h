@@ -95,8 +95,9 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 /* ONE frame of 256 MiB of content or more that zl_decompressDCtx is handed in host memory moves slab by slab (round 4): a thread
  * uploads it piece by piece from the start of the call, it is decoded in runs of blocks as those arrive (the same runs, with the
  * output so far as history) and every run's bytes come down -- and are hashed, when the frame carries a checksum -- while the
- * next run is decoded.  ZL_d_slabMiB = N (0 = default 256) sets that threshold in MiB: how tests reach the path with small
- * frames (together with ZL_d_runBlocks for the size of the runs).  ZL_d_pipeline = 0 switches it off. */
+ * next run is decoded.  zl_decompressStream does the same with a frame of 32 MiB or more while it ARRIVES.
+ * ZL_d_slabMiB = N (0 = defaults: 256, and 32 in a stream) sets both thresholds in MiB: how tests reach the paths with small
+ * frames (together with ZL_d_runBlocks for the size of the runs).  ZL_d_pipeline = 0 switches them off. */
 #define ZL_d_slabMiB 9010
 #define ZL_d_stableOutBuffer 1001     /* zstd.h:2422 ZSTD_d_stableOutBuffer (accepted, no-op) */
 #define ZL_d_forceIgnoreChecksum 1002 /* zstd.h:2433 ZSTD_d_forceIgnoreChecksum */
@@ -261,8 +262,13 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  * the context is still one-caller-at-a-time.
  * Returns the bytes still waiting to be handed out (0 at ZL_e_end: the session is complete), or an
  * error code.  Decompression: input is collected until it holds complete frames; those are decoded
- * at once (all routes of zl_decompressDCtx, frames without a recorded size included) and handed out
- * as the output buffer allows.  Returns 0 when everything received so far has been decoded and
+ * at once (all routes of zl_decompressDCtx, frames without a recorded size included) -- straight into
+ * the caller's buffer when it has room for all of them -- and handed out as the output buffer allows.
+ * A frame whose header records 32 MiB of content or more (ZL_d_slabMiB; no dictionary) is not
+ * collected: every call uploads the bytes it is handed, the frame is decoded in runs of blocks as they
+ * complete and the output comes down into the caller's buffer as the runs finish, so the first bytes are
+ * out long before the last ones are in (round 4; until then a 1 GiB frame was buffered whole).  A call
+ * that brings no input waits for what is in flight.  Returns 0 when everything received so far has been decoded and
  * handed out, an error code, or a non-zero hint.  Sixteen calls in a row without progress return
  * the no-forward-progress errors of zstd.c:42957-42960. */
 typedef struct { const void *src; size_t size; size_t pos; } zl_inBuffer;  /* ZSTD_inBuffer  (zstd.h:805) */
