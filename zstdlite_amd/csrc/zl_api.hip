@@ -1003,7 +1003,18 @@ struct StreamFrame {
     zlx::Xxh64 hasher;
     u64 frame_end() const { return end_pos + (h.has_checksum ? 4u : 0u); }
     size_t nruns() const { return cuts.size() - 1; }
+#ifdef ZL_DEV_SWITCHES
+    double t_feed = 0, t_start = 0, t_finish = 0, t_down = 0; size_t calls = 0;  // ZL_DEBUG_SLAB: where a frame's calls spent their time
+#endif
 };
+#ifdef ZL_DEV_SWITCHES
+static double sf_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+#define SF_T0 const double sf_t0 = sf_now()
+#define SF_ADD(field) F.field += sf_now() - sf_t0
+#else
+#define SF_T0
+#define SF_ADD(field)
+#endif
 void stream_frame_free_impl(void* f_) {
     StreamFrame* f = (StreamFrame*)f_;
     if (!f) return;
@@ -1217,8 +1228,8 @@ size_t stream_frame_fallback(zl_dctx* d) {
 }
 
 // takes bytes that follow the frame's bytes so far: walked, uploaded.  Returns how many of [p, p + n) it took, or an error code;
-// *fell: the route was left (stream_frame_fallback has run: the collecting route's buffer holds the frame up to and including
-// the bytes taken here)
+// *fell: these are not a frame's blocks -- the caller leaves the route (stream_frame_fallback: the collecting route's buffer then
+// holds the frame up to and including the bytes taken here)
 size_t stream_frame_feed(zl_dctx* d, const u8* p, size_t n, bool* fell) {
     StreamFrame& F = *(StreamFrame*)d->ds.big;
     *fell = false;
@@ -1232,7 +1243,7 @@ size_t stream_frame_feed(zl_dctx* d, const u8* p, size_t n, bool* fell) {
     if (n == pre || F.got < F.h.header_size || (F.last_seen && F.got >= F.frame_end())) return pre;
     bool bad = false;
     const size_t took = stream_frame_walk(F, p + pre, n - pre, &bad);
-    if (bad) { *fell = true; const size_t e = stream_frame_fallback(d); return ZL_IS_ERR(e) ? e : pre; }
+    if (bad) { *fell = true; return pre; }  // (the caller leaves the route: stream_frame_fallback)
     if (took) {
         if (!devbuf_grow_keep(F.d_src, (size_t)(F.got + took + 64), (size_t)F.got)) return ZL_OOM_HERE;
         if (hipMemcpy((u8*)F.d_src.p + F.got, p + pre, took, hipMemcpyHostToDevice) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -1246,13 +1257,46 @@ size_t stream_frame_feed(zl_dctx* d, const u8* p, size_t n, bool* fell) {
 size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
     StreamFrame& F = *(StreamFrame*)d->ds.big;
     const bool idle_call = input->pos == input->size;  // nothing new is offered: whatever is in flight is waited for
+    const size_t out_at_entry = output->pos;
+    // what the call before this one has decoded starts coming down now, beside this call's upload and its waits for the runs --
+    // on a thread of its own for the length of the call: a copy into pageable memory does not return before it is done (upload,
+    // second calls and download were 17, 16 and 19 ms of the 1 GiB frame's 56, one behind the other)
+    size_t early_k = 0;
+    u8* early_at = nullptr;
+    std::thread early_th;
+    bool early_ok = true;
+    if (F.handed < F.out_pos && output->pos < output->size && output->dst && F.out_pos - F.handed >= ((u64)1 << 20)) {
+        early_k = (size_t)std::min<u64>(output->size - output->pos, F.out_pos - F.handed);
+        early_at = (u8*)output->dst + output->pos;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const u8* from = (const u8*)F.d_dst.p + F.handed;
+        try { early_th = std::thread([=, &early_ok]() { (void)hipSetDevice(dev); early_ok = hipMemcpy(early_at, from, early_k, hipMemcpyDeviceToHost) == hipSuccess; }); }
+        catch (...) { early_k = 0; }
+    }
+    auto land_early = [&]() -> bool {  // (before anything reads the bytes or the call returns)
+        if (!early_k) return true;
+        early_th.join();
+        if (!early_ok) return false;
+        if (F.hashing) F.hasher.update(early_at, early_k);
+        F.handed += early_k;
+        output->pos += early_k;
+        early_k = 0;
+        return true;
+    };
     if (input->pos < input->size) {
+        SF_T0;
         bool fell = false;
         const size_t took = stream_frame_feed(d, (const u8*)input->src + input->pos, input->size - input->pos, &fell);
+        if (ZL_IS_ERR(took) || fell) (void)land_early();
         if (ZL_IS_ERR(took)) return took;
-        if (fell) return 2;
         input->pos += took;
+        if (fell) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
+        SF_ADD(t_feed);
     }
+#ifdef ZL_DEV_SWITCHES
+    F.calls++;
+#endif
     auto start_more = [&]() -> size_t {
         while (F.started < F.nruns() && F.started - F.finished < (size_t)F.K) {
             if (F.started == 0) {  // (four slots where blocks are large, two where they are this library's 16 KiB: decode_walked_frame_in_runs)
@@ -1261,36 +1305,55 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
                 F.K = (nb0 && bytes0 / nb0 >= ((u64)24 << 10)) ? zl_dctx_s::kRunSlots : 2;
                 if (!stream_frame_slots(d, F.K)) return ZL_OOM_HERE;
             }
+            SF_T0;
             const size_t e = stream_frame_start(d, F, F.started);
+            SF_ADD(t_start);
             if (e != 0) return e;
             F.started++;
         }
         return 0;
     };
     size_t e = start_more();
+    if (e != 0) (void)land_early();
     if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
     if (e != 0) return e;
-    bool waited = false;
+    bool waited = early_k != 0;
     while (F.finished < F.started) {
         const bool full = F.started - F.finished == (size_t)F.K && F.started < F.nruns();
         const bool drain = F.last_seen && F.started == F.nruns();
         const bool must = full || drain || (idle_call && !waited && F.handed == F.out_pos);
         if (!must && hipStreamQuery(d->run_slot[F.finished % F.K].st) == hipErrorNotReady) break;
-        e = stream_frame_finish(d, F, F.finished);
+        {
+            SF_T0;
+            e = stream_frame_finish(d, F, F.finished);
+            SF_ADD(t_finish);
+        }
+        if (e != 0) (void)land_early();
         if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
         if (e != 0) return e;
         F.finished++;
         waited = true;
         e = start_more();
+        if (e != 0) (void)land_early();
         if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
         if (e != 0) return e;
         if (output->pos < output->size && !drain && !full) break;  // (what is there goes out first)
     }
-    if (F.handed < F.out_pos && output->pos < output->size) {
+    {
+        SF_T0;
+        if (!land_early()) return ZL_ERR(ZL_E_GENERIC);
+        SF_ADD(t_down);
+    }
+    // (what this call's second calls have just decoded waits for the next call, which brings it down beside its own work -- unless
+    // nothing is in flight to work on, the caller brought no input, or this call has handed out nothing yet)
+    const bool later = !idle_call && !F.last_seen && F.out_pos - F.handed >= ((u64)1 << 20) && output->pos != out_at_entry;
+    if (F.handed < F.out_pos && output->pos < output->size && !later) {
         if (!output->dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
         const size_t k = (size_t)std::min<u64>(output->size - output->pos, F.out_pos - F.handed);
         u8* at = (u8*)output->dst + output->pos;
+        SF_T0;
         if (hipMemcpy(at, (const u8*)F.d_dst.p + F.handed, k, hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        SF_ADD(t_down);
         if (F.hashing) F.hasher.update(at, k);
         F.handed += k;
         output->pos += k;
@@ -1299,6 +1362,9 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
         size_t verdict = 0;
         if (F.out_pos != F.h.content_size) verdict = ZL_ERR(ZL_E_CORRUPTION);  // zstd.c:41646
         else if (F.hashing && F.hasher.low32() != rd_le(F.footer, 4)) verdict = ZL_ERR(ZL_E_CHECKSUM_WRONG);
+#ifdef ZL_DEV_SWITCHES
+        if (getenv("ZL_DEBUG_SLAB")) fprintf(stderr, "[zl stream frame] %zu calls, %zu runs on %d slots: feed (walk + upload) %.1f ms, first calls %.1f ms, second calls %.1f ms, downloads %.1f ms\n", F.calls, F.nruns(), F.K, F.t_feed, F.t_start, F.t_finish, F.t_down);
+#endif
         stream_frame_free_impl(d->ds.big);
         d->ds.big = nullptr;
         return verdict;
@@ -2221,6 +2287,7 @@ size_t zl_decompressStream(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input)
                 bool fell = false;
                 const size_t took = stream_frame_feed(d, held.p, held.size(), &fell);
                 if (ZL_IS_ERR(took)) { stream_frame_free(S.big); S.big = nullptr; return took; }
+                if (fell) { const size_t f = stream_frame_fallback(d); if (ZL_IS_ERR(f)) return f; }
                 // (taken: on the device -- or, when the route was left at once, back in the session's buffer; what was not taken
                 // -- the start of a frame behind this one -- stays collected behind it)
                 if (took < held.size() && !S.acc.append(held.p + took, held.size() - took)) return ZL_ERR(ZL_E_MEMORY);
