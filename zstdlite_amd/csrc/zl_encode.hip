@@ -2477,7 +2477,10 @@ __device__ __noinline__ void exact_rep_codes(zl_seq* seqs, u32 first, u32 end, u
 // (The serial helpers above are __noinline__: inlined, their registers weigh on a kernel that is held to 64
 // of them -- measured 2.51 -> 2.39 ms.  Taking the phase stamps out at compile time as well removed most of
 // the remaining spills and was SLOWER, 2.56 ms: the allocator's choices matter more than the spill count.)
-__global__ __launch_bounds__(ENC_THREADS, 8) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
+#ifndef ZL_ENT_WGS
+#define ZL_ENT_WGS 8   // workgroups per CU the register budget is cut for (8: 64 VGPRs, the LDS footprint's own limit)
+#endif
+__global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ EntShared S;
     ZL_POISON(S, 8);
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
