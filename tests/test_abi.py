@@ -107,6 +107,8 @@ def test_context_options_mirror_reference_glue():
     for value, ok in ((0, True), (16, True), (8192, True), (15, False), (8193, False), (-1, False)):
         assert (L.zl_DCtx_setParameter(d._ptr, 9009, value) == 0) == ok, value
     assert L.zl_DCtx_setParameter(d._ptr, 9008, 65) != 0 and L.zl_DCtx_setParameter(d._ptr, 9008, 2) == 0
+    for value, ok in ((0, True), (1, True), (65536, True), (65537, False), (-1, False)):  # ZL_d_slabMiB
+        assert (L.zl_DCtx_setParameter(d._ptr, 9010, value) == 0) == ok, value
     assert _lib.is_error(L.zl_DCtx_setParameter(d._ptr, 4242, 1))
     assert L.zl_dctx_frame_runs(d._ptr) == 0 and L.zl_dctx_large_frames(d._ptr) == 0
 
