@@ -772,6 +772,9 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     if (ZL_IS_ERR(parse_frame_header(h, host_src, n)) || h.skippable || h.dict_id) return ZL_ERR(ZL_E_FALLBACK);
     std::vector<Block> blk;
     u64 pos = h.header_size;
+#ifdef ZL_DEV_SWITCHES
+    timespec w0; clock_gettime(CLOCK_MONOTONIC, &w0);
+#endif
     for (;;) {  // (the walk of find_frame_size, with 64-bit positions and a look into every compressed block)
         if (n - pos < 3) return ZL_ERR(ZL_E_FALLBACK);
         Block b;
@@ -789,6 +792,9 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         if (blk.size() > 0x7FFFFFFFu) return ZL_ERR(ZL_E_FALLBACK);
     }
     const u64 end_pos = pos;
+#ifdef ZL_DEV_SWITCHES
+    if (getenv("ZL_DEBUG_SLAB")) { timespec w1; clock_gettime(CLOCK_MONOTONIC, &w1); fprintf(stderr, "[zl slab] the runs' walk over %zu blocks: %.2f ms\n", blk.size(), (w1.tv_sec - w0.tv_sec) * 1e3 + (w1.tv_nsec - w0.tv_nsec) * 1e-6); }
+#endif
     if (h.has_checksum && n - pos < 4) return ZL_ERR(ZL_E_FALLBACK);
     const size_t nb = blk.size();
     const u64 bound = std::min<u64>(fd.dst_cap, (u64)nb * ZL_BLOCK_MAX);
@@ -1954,6 +1960,9 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         io.up_state.store(1);
     });
     auto end_upload = [&]() { if (up_th.joinable()) { io.stop.store(2); up_th.join(); io.stop.store(0); } };  // (routes that upload for themselves)
+#ifdef ZL_DEV_SWITCHES
+    timespec tw0; clock_gettime(CLOCK_MONOTONIC, &tw0);
+#endif
     // ---- index frames on the host (serial header walk, zstd.c:41335)
     std::vector<zl_frame_desc> table;
     std::vector<u8> known, has_ck;
@@ -1986,6 +1995,9 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
         pos += fs;
     }
     if (pos != n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
+#ifdef ZL_DEV_SWITCHES
+    if (getenv("ZL_DEBUG_SLAB")) { timespec tw1; clock_gettime(CLOCK_MONOTONIC, &tw1); fprintf(stderr, "[zl slab] the frame table's walk: %.2f ms\n", (tw1.tv_sec - tw0.tv_sec) * 1e3 + (tw1.tv_nsec - tw0.tv_nsec) * 1e-6); }
+#endif
     if (table.empty()) return 0;
     if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
     {   // several devices: independent frames with recorded sizes are dealt out in contiguous runs, a buffer of whole frames each
