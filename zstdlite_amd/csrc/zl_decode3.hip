@@ -17,7 +17,7 @@
 //   zl2_lit_kernel, zl2_seq_kernel (zl_decode2.hip)  the segments go through the lane pipeline's entropy
 //                       kernels as if they were frames; inherited tables are rebuilt in extra rounds;
 //                       repcodes stay symbolic for every block but the first
-//   zl3_offsets_kernel  one wave: output position and starting repcode history of every block
+//   zl3_offsets_kernel  sixteen waves: output position and starting repcode history of every block
 //   zl2_exec_kernel<true, false>  workgroup per run of 8 segments, all runs at once: bytes whose source lies in
 //                       another segment are left as links (frame positions)
 //   zl3_resolve_kernel  the deferred bytes: rounds in which every waiting byte walks up to 8 links towards the front
@@ -406,7 +406,6 @@ __global__ __launch_bounds__(1024) void zl3_segment_kernel(zl3_dev d) {
 __device__ __forceinline__ u32 max_def(u32 a, u32 b) { return (b == ZL3_NONE) ? a : b; }
 
 __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc fd) {
-    __shared__ u32 tile[6][1024];
     __shared__ u64 carry_sum[2];
     __shared__ u32 carry_def[4];
     __shared__ u32 most_blocks;
@@ -443,29 +442,53 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
     if (t == 0) { carry_sum[0] = 0; carry_sum[1] = 0; for (int q = 0; q < 4; q++) carry_def[q] = info->ndonors ? info->donor[q] : ZL3_NONE; }
     zl_sync_global();  // (the segments' numbers travel through memory)
     // ---- B: across segments: exclusive sums of the scratch needs, exclusive running maximum of the defining blocks
+    // (round 4: a scan by all 1024 threads -- wave scans, the sixteen wave totals folded through LDS.  One lane per column walked
+    // a tile's 1024 entries one after the other: 0.6 of the kernel's 0.87 ms on the 8192 segments of this library's 1 GiB frame)
+    __shared__ u64 wsum[2][16];
+    __shared__ u32 wdef[4][16];
+    const u32 lane = t & 63, wave = t >> 6;
     for (u32 s0 = 0; s0 < ns; s0 += 1024) {
         const u32 cnt = ns - s0 < 1024 ? ns - s0 : 1024;
-        if (t < cnt) for (int q = 0; q < 6; q++) tile[q][t] = d.seg_tmp[(size_t)(s0 + t) * 16 + q];
-        __syncthreads();
-        if (t < 6) {  // one lane per column
-            if (t < 2) {
-                u64 run = carry_sum[t];
-                for (u32 i = 0; i < cnt; i++) {
-                    const u32 v = tile[t][i];
-                    d.seg_tmp[(size_t)(s0 + i) * 16 + 6 + t] = (u32)run;  // (64-bit offsets: low word, high word)
-                    d.seg_tmp[(size_t)(s0 + i) * 16 + 12 + t] = (u32)(run >> 32);
-                    run += v;
-                }
-                carry_sum[t] = run;
-            } else {
-                u32 run = carry_def[t - 2];
-                for (u32 i = 0; i < cnt; i++) {
-                    const u32 v = tile[t][i];
-                    d.seg_tmp[(size_t)(s0 + i) * 16 + 6 + t] = run;  // words 8..11
-                    run = max_def(run, v);
-                }
-                carry_def[t - 2] = run;
+        const bool on = t < cnt;
+        const u32* in = d.seg_tmp + (size_t)(s0 + t) * 16;
+        u64 a[2] = {on ? (u64)in[0] : 0ull, on ? (u64)in[1] : 0ull};
+        u32 m[4] = {on ? in[2] : ZL3_NONE, on ? in[3] : ZL3_NONE, on ? in[4] : ZL3_NONE, on ? in[5] : ZL3_NONE};
+        const u64 own[2] = {a[0], a[1]};
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {  // inclusive scans inside the wave
+            u64 x[2];
+            u32 y[4];
+            for (int q = 0; q < 2; q++) x[q] = ((u64)__shfl_up((u32)(a[q] >> 32), dd, 64) << 32) | __shfl_up((u32)a[q], dd, 64);
+            for (int q = 0; q < 4; q++) y[q] = __shfl_up(m[q], dd, 64);
+            if ((int)lane >= dd) {
+                a[0] += x[0]; a[1] += x[1];
+                for (int q = 0; q < 4; q++) m[q] = max_def(y[q], m[q]);
             }
+        }
+        if (lane == 63) { wsum[0][wave] = a[0]; wsum[1][wave] = a[1]; for (int q = 0; q < 4; q++) wdef[q][wave] = m[q]; }
+        // what the lanes in front of this one (in its wave) add up to
+        u32 prev[4];
+        for (int q = 0; q < 4; q++) { prev[q] = __shfl_up(m[q], 1, 64); if (lane == 0) prev[q] = ZL3_NONE; }
+        __syncthreads();
+        u64 base[2] = {carry_sum[0], carry_sum[1]};
+        u32 bdef[4] = {carry_def[0], carry_def[1], carry_def[2], carry_def[3]};
+        for (u32 w = 0; w < wave; w++) {  // the waves in front of this one
+            base[0] += wsum[0][w]; base[1] += wsum[1][w];
+            for (int q = 0; q < 4; q++) bdef[q] = max_def(bdef[q], wdef[q][w]);
+        }
+        if (on) {
+            u32* o = d.seg_tmp + (size_t)(s0 + t) * 16;
+            for (int q = 0; q < 2; q++) {
+                const u64 run = base[q] + a[q] - own[q];
+                o[6 + q] = (u32)run;  // (64-bit offsets: low word, high word)
+                o[12 + q] = (u32)(run >> 32);
+            }
+            for (int q = 0; q < 4; q++) o[8 + q] = max_def(bdef[q], prev[q]);  // words 8..11
+        }
+        __syncthreads();
+        if (t == 1023) {  // (the last wave's base plus its own total: the tile's)
+            carry_sum[0] = base[0] + a[0]; carry_sum[1] = base[1] + a[1];
+            for (int q = 0; q < 4; q++) carry_def[q] = max_def(bdef[q], m[q]);
         }
         __syncthreads();
     }
@@ -567,29 +590,41 @@ __global__ __launch_bounds__(256) void zl3_totals_kernel(zl3_dev d, const u32* s
     blk_tot[b] = o;
 }
 
-__global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const uint4* blk_tot, u32 rep_a, u32 rep_b, u32 rep_c) {
+// (round 4: sixteen waves instead of one.  One wave took 1.17 ms for the 65 536 blocks of this library's 1 GiB frame -- a
+// twelfth of its decode, and 0.2 ms of every run of a frame decoded in runs.  Every wave now scans a contiguous share of the
+// blocks twice: once for its share's size and history FUNCTION (the same composition, kept symbolic), then -- the shares' sums
+// and functions folded into starting points by one lane -- again for the values it writes.)
+#define ZL3_OFF_WAVES 16
+__global__ __launch_bounds__(64 * ZL3_OFF_WAVES) void zl3_offsets_kernel(zl3_dev d, zl_frame_desc fd, const uint4* blk_tot, u32 rep_a, u32 rep_b, u32 rep_c) {
+    __shared__ u32 s_first[ZL3_OFF_WAVES];
+    __shared__ u64 s_sz[ZL3_OFF_WAVES];
+    __shared__ u32 s_f[ZL3_OFF_WAVES][3], s_r[ZL3_OFF_WAVES + 1][3], s_bad[ZL3_OFF_WAVES];
+    __shared__ u64 s_op[ZL3_OFF_WAVES + 1];
     zl3_info* info = d.info;
-    const u32 lane = threadIdx.x, nb = info->nblocks, ns = info->nsegs;
-    if (info->err) return;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6, nb = info->nblocks, ns = info->nsegs;
+    if (info->err) return;  // (uniform: nobody has written it since the launch)
     // the segments' errors first (lowest segment wins, as the reference would meet it first)
     {
         u32 first = ZL3_NONE;
-        for (u32 s = lane; s < ns; s += 64) if (d.frec[s].err && s < first) first = s;
+        for (u32 s = t; s < ns; s += 64 * ZL3_OFF_WAVES) if (d.frec[s].err && s < first) first = s;
 #pragma unroll
         for (int k = 32; k >= 1; k >>= 1) { const u32 o = __shfl_xor(first, k, 64); first = o < first ? o : first; }
-        if (first != ZL3_NONE) { if (lane == 0) info->err = d.frec[first].err; return; }
+        if (lane == 0) s_first[wave] = first;
+        __syncthreads();
+        first = s_first[0];
+        for (u32 w = 1; w < ZL3_OFF_WAVES; w++) first = s_first[w] < first ? s_first[w] : first;
+        if (first != ZL3_NONE) { if (t == 0) info->err = d.frec[first].err; return; }
     }
-    u64 op = 0;                    // uniform: output bytes in front of this batch
-    u32 r0 = rep_a, r1 = rep_b, r2 = rep_c;    // uniform: history in front of this batch (1, 4, 8 at the start of a frame, zstd.c:41433; a dictionary brings its own, zstd.c:42053)
-    u32 bad = 0;
-    for (u32 b0 = 0; b0 < nb; b0 += 64) {
+    const u32 tiles = (nb + 63) / 64, per = (tiles + ZL3_OFF_WAVES - 1) / ZL3_OFF_WAVES;
+    const u32 b_lo = wave * per * 64, b_hi = (wave + 1) * per * 64 < nb ? (wave + 1) * per * 64 : nb;
+    // one tile of 64 blocks: inclusive scans over the lanes -- sizes by addition, histories by composition (the earlier block's function first)
+    auto scan_tile = [&](u32 b0, u32& sz, u32& acc, u32& f0, u32& f1, u32& f2, bool& over) {
         const u32 b = b0 + lane;
-        u32 sz = 0;
-        u32 f0 = 0x80000000u, f1 = 0x80000001u, f2 = 0x80000002u;
-        if (b < nb) { const uint4 o = blk_tot[b]; sz = o.x; f0 = o.y; f1 = o.z; f2 = o.w; }
-        if (__ballot(sz > ZL_BLOCK_MAX)) bad = ZL_E_CORRUPTION;
-        // inclusive scans over the lanes: sizes by addition, histories by composition (the earlier block's function first)
-        u32 acc = sz;
+        sz = 0;
+        f0 = 0x80000000u; f1 = 0x80000001u; f2 = 0x80000002u;
+        if (b < b_hi) { const uint4 o = blk_tot[b]; sz = o.x; f0 = o.y; f1 = o.z; f2 = o.w; }
+        over = __ballot(sz > ZL_BLOCK_MAX) != 0;
+        acc = sz;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
             const u32 a = __shfl_up(acc, dd, 64);
@@ -600,24 +635,67 @@ __global__ __launch_bounds__(64) void zl3_offsets_kernel(zl3_dev d, zl_frame_des
                 f0 = n0; f1 = n1; f2 = n2;
             }
         }
-        // what the block starts with: the blocks in front of it in this batch, applied to the history in front of the batch
-        u32 e0 = __shfl_up(f0, 1, 64), e1 = __shfl_up(f1, 1, 64), e2 = __shfl_up(f2, 1, 64);
-        if (lane == 0) { e0 = 0x80000000u; e1 = 0x80000001u; e2 = 0x80000002u; }
-        if (b < nb) {
-            d.blk_dst[b] = (u32)(op + acc - sz);
-            d.rep_start[(size_t)b * 3 + 0] = ZL3_RESOLVE(e0, r0, r1, r2);
-            d.rep_start[(size_t)b * 3 + 1] = ZL3_RESOLVE(e1, r0, r1, r2);
-            d.rep_start[(size_t)b * 3 + 2] = ZL3_RESOLVE(e2, r0, r1, r2);
+    };
+    // ---- pass 1: this wave's share as ONE function of the history in front of it, and its size
+    {
+        u64 op = 0;
+        u32 F0 = 0x80000000u, F1 = 0x80000001u, F2 = 0x80000002u, bad = 0;
+        for (u32 b0 = b_lo; b0 < b_hi; b0 += 64) {
+            u32 sz, acc, f0, f1, f2;
+            bool over;
+            scan_tile(b0, sz, acc, f0, f1, f2, over);
+            if (over) bad = ZL_E_CORRUPTION;
+            const u32 t0 = __shfl(f0, 63, 64), t1 = __shfl(f1, 63, 64), t2 = __shfl(f2, 63, 64);
+            const u32 n0 = rep_compose(t0, F0, F1, F2), n1 = rep_compose(t1, F0, F1, F2), n2 = rep_compose(t2, F0, F1, F2);
+            F0 = n0; F1 = n1; F2 = n2;
+            op += __shfl(acc, 63, 64);
         }
-        const u32 t0 = __shfl(f0, 63, 64), t1 = __shfl(f1, 63, 64), t2 = __shfl(f2, 63, 64);
-        const u32 n0 = ZL3_RESOLVE(t0, r0, r1, r2), n1 = ZL3_RESOLVE(t1, r0, r1, r2), n2 = ZL3_RESOLVE(t2, r0, r1, r2);
-        r0 = n0; r1 = n1; r2 = n2;
-        op += __shfl(acc, 63, 64);
+        if (lane == 0) { s_sz[wave] = op; s_f[wave][0] = F0; s_f[wave][1] = F1; s_f[wave][2] = F2; s_bad[wave] = bad; }
     }
-    if (lane == 0) {
+    __syncthreads();
+    if (t == 0) {  // where every share starts: output position and history (1, 4, 8 at the start of a frame, zstd.c:41433; a dictionary brings its own, zstd.c:42053)
+        u64 op = 0;
+        u32 r0 = rep_a, r1 = rep_b, r2 = rep_c;
+        for (u32 w = 0; w < ZL3_OFF_WAVES; w++) {
+            s_op[w] = op; s_r[w][0] = r0; s_r[w][1] = r1; s_r[w][2] = r2;
+            const u32 n0 = ZL3_RESOLVE(s_f[w][0], r0, r1, r2), n1 = ZL3_RESOLVE(s_f[w][1], r0, r1, r2), n2 = ZL3_RESOLVE(s_f[w][2], r0, r1, r2);
+            r0 = n0; r1 = n1; r2 = n2;
+            op += s_sz[w];
+        }
+        s_op[ZL3_OFF_WAVES] = op; s_r[ZL3_OFF_WAVES][0] = r0; s_r[ZL3_OFF_WAVES][1] = r1; s_r[ZL3_OFF_WAVES][2] = r2;
+    }
+    __syncthreads();
+    // ---- pass 2: the values
+    {
+        u64 op = s_op[wave];
+        u32 r0 = s_r[wave][0], r1 = s_r[wave][1], r2 = s_r[wave][2];
+        for (u32 b0 = b_lo; b0 < b_hi; b0 += 64) {
+            const u32 b = b0 + lane;
+            u32 sz, acc, f0, f1, f2;
+            bool over;
+            scan_tile(b0, sz, acc, f0, f1, f2, over);
+            // what the block starts with: the blocks in front of it in this tile, applied to the history in front of the tile
+            u32 e0 = __shfl_up(f0, 1, 64), e1 = __shfl_up(f1, 1, 64), e2 = __shfl_up(f2, 1, 64);
+            if (lane == 0) { e0 = 0x80000000u; e1 = 0x80000001u; e2 = 0x80000002u; }
+            if (b < b_hi) {
+                d.blk_dst[b] = (u32)(op + acc - sz);
+                d.rep_start[(size_t)b * 3 + 0] = ZL3_RESOLVE(e0, r0, r1, r2);
+                d.rep_start[(size_t)b * 3 + 1] = ZL3_RESOLVE(e1, r0, r1, r2);
+                d.rep_start[(size_t)b * 3 + 2] = ZL3_RESOLVE(e2, r0, r1, r2);
+            }
+            const u32 t0 = __shfl(f0, 63, 64), t1 = __shfl(f1, 63, 64), t2 = __shfl(f2, 63, 64);
+            const u32 n0 = ZL3_RESOLVE(t0, r0, r1, r2), n1 = ZL3_RESOLVE(t1, r0, r1, r2), n2 = ZL3_RESOLVE(t2, r0, r1, r2);
+            r0 = n0; r1 = n1; r2 = n2;
+            op += __shfl(acc, 63, 64);
+        }
+    }
+    if (t == 0) {
+        const u64 op = s_op[ZL3_OFF_WAVES];
+        u32 bad = 0;
+        for (u32 w = 0; w < ZL3_OFF_WAVES; w++) bad |= s_bad[w];
         d.blk_dst[nb] = (u32)op;
         info->produced = op;
-        info->rep_end[0] = r0; info->rep_end[1] = r1; info->rep_end[2] = r2;
+        info->rep_end[0] = s_r[ZL3_OFF_WAVES][0]; info->rep_end[1] = s_r[ZL3_OFF_WAVES][1]; info->rep_end[2] = s_r[ZL3_OFF_WAVES][2];
         if (bad) info->err = bad;
         else if (op > fd.dst_cap) info->err = ZL_E_DSTSIZE_TOO_SMALL;
         else if (info->fcs != ZL_CONTENTSIZE_UNKNOWN && op != info->fcs) info->err = ZL_E_CORRUPTION;  // zstd.c:41646
@@ -981,7 +1059,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         hipLaunchKernelGGL(zl3_totals_kernel, dim3((info.nblocks + 255) / 256), dim3(256), 0, st, d, (const u32*)s->seq.p, (uint4*)s->tot.p);
         {   // the history the frame starts with: a formatted dictionary's three offsets, else 1, 4, 8
             const bool dr = have_dict && hint->dict_formatted;
-            hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64), 0, st, d, fd, (const uint4*)s->tot.p, dr ? hint->dict_rep[0] : 1u, dr ? hint->dict_rep[1] : 4u, dr ? hint->dict_rep[2] : 8u);
+            hipLaunchKernelGGL(zl3_offsets_kernel, dim3(1), dim3(64 * ZL3_OFF_WAVES), 0, st, d, fd, (const uint4*)s->tot.p, dr ? hint->dict_rep[0] : 1u, dr ? hint->dict_rep[1] : 4u, dr ? hint->dict_rep[2] : 8u);
         }
         stamp("offsets");
         if (fill_st != st && hipStreamWaitEvent(st, s->fill_join, 0) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -991,10 +1069,16 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // but bytes of its later runs may wait for its earlier ones)
         const bool sink = hint && hint->sink_host && hint->sunk && info.fcs != ZL_CONTENTSIZE_UNKNOWN && span >= ((u64)2 << ZL3_SINK_LOG) && side && side->part_stream[1];
         u32 nsink = 0;
-        for (u64 g = 0; g < span; g += (u64)1 << ZL3_GROUP_LOG) {
-            hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << ZL3_GROUP_LOG) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
+        // (this library's own 1 GiB frame, groups of 4 / 8 / 16 / 32 / 64 MiB: 12.6 / 12.8 / 13.6 / 14.7 / 16.6 ms -- its text quarter's
+        // walks grow with the group as the reference's do)
+        u32 glog = ZL3_GROUP_LOG;
+#ifdef ZL_DEV_SWITCHES
+        if (getenv("ZL_GROUP_LOG")) glog = (u32)atoi(getenv("ZL_GROUP_LOG"));
+#endif
+        for (u64 g = 0; g < span; g += (u64)1 << glog) {
+            hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << glog) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
                                d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, g, d.info);
-            const u64 done = g + ((u64)1 << ZL3_GROUP_LOG);
+            const u64 done = g + ((u64)1 << glog);
             if (sink && (done & (((u64)1 << ZL3_SINK_LOG) - 1)) == 0 && done < span && nsink < ZL3_SINK_EVENTS) {
                 if (!s->sink_ev[nsink] && hipEventCreateWithFlags(&s->sink_ev[nsink], hipEventDisableTiming) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
                 if (hipEventRecord(s->sink_ev[nsink], st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
