@@ -11,7 +11,7 @@
 //                       -- or the host's own walk is uploaded (host entries), or a lane per chunk walks the chunk's few
 //                       headers (frames of this library's one-frame layout, with the caller's chunk offsets)
 //   zl3_parse_kernel    lane per block: literal / sequence section headers               zstd.c:43146, :43707
-//   zl3_segment_kernel, zl3_plan_kernel   the frame becomes SEGMENTS: a block that describes tables plus the (up to 7) blocks behind it
+//   zl3_segment_kernel, zl3_plan_{a,b,c}_kernel   the frame becomes SEGMENTS: a block that describes tables plus the (up to 7) blocks behind it
 //                       that only repeat them; for each segment, the earlier blocks whose
 //                       Huffman tree / FSE tables it inherits are found with a running maximum
 //   zl2_lit_kernel, zl2_seq_kernel (zl_decode2.hip)  the segments go through the lane pipeline's entropy
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(1024) void zl3_segment_kernel(zl3_dev d) {
         if (t == 1023) { carry[0] = last; carry[1] = c1 + seg_incl; }
         __syncthreads();
     }
-    if (t == 0) { info->nsegs = carry[1]; d.seg_first[carry[1]] = nb; }
+    if (t == 0) { info->nsegs = carry[1]; d.seg_first[carry[1]] = nb; *d.max_blocks = 1; }  // (max_blocks: raised by zl3_plan_a_kernel)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -405,17 +405,16 @@ __global__ __launch_bounds__(1024) void zl3_segment_kernel(zl3_dev d) {
 // frame than anything in front of it, the donors of a run of blocks (whose indices lie BEHIND the run's own) included
 __device__ __forceinline__ u32 max_def(u32 a, u32 b) { return (b == ZL3_NONE) ? a : b; }
 
-__global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc fd) {
-    __shared__ u64 carry_sum[2];
-    __shared__ u32 carry_def[4];
-    __shared__ u32 most_blocks;
+// (round 4: three launches -- A and C over all segments on the whole device, B one workgroup's scan -- where one workgroup did all
+// three: 0.6 ms for the 8192 segments of this library's 1 GiB frame, a CU copying 65 536 block records)
+__global__ __launch_bounds__(256) void zl3_plan_a_kernel(zl3_dev d) {
     zl3_info* info = d.info;
     if (info->err) return;
-    const u32 t = threadIdx.x, ns = info->nsegs;
-    if (t == 0) most_blocks = 1;
-    __syncthreads();
+    const u32 ns = info->nsegs;
     // ---- A: inside each segment: where its blocks' literals and sequences go, totals, last defining blocks
-    for (u32 s = t; s < ns; s += 1024) {
+    {
+        const u32 s = blockIdx.x * 256 + threadIdx.x;
+        if (s >= ns) return;
         u32 lit = 0, seq = 0, def[4] = {ZL3_NONE, ZL3_NONE, ZL3_NONE, ZL3_NONE};
         const u32 b0 = d.seg_first[s], b1 = d.seg_first[s + 1];
         for (u32 b = b0; b < b1; b++) {
@@ -435,12 +434,20 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
             }
             d.brec[(size_t)s * ZL2_MAXB + (b - b0)] = r;
         }
-        if (b1 - b0 > 1) atomicMax(&most_blocks, b1 - b0);
+        if (b1 - b0 > 1) atomicMax(d.max_blocks, b1 - b0);  // (which instantiation of the literal / sequence kernels the segments take: 1 = the single-block ones; set to 1 by zl3_segment_kernel)
         u32* o = d.seg_tmp + (size_t)s * 16;
         o[0] = (lit + 15) & ~15u; o[1] = seq; o[2] = def[0]; o[3] = def[1]; o[4] = def[2]; o[5] = def[3];
     }
+}
+
+__global__ __launch_bounds__(1024) void zl3_plan_b_kernel(zl3_dev d) {
+    __shared__ u64 carry_sum[2];
+    __shared__ u32 carry_def[4];
+    zl3_info* info = d.info;
+    if (info->err) return;
+    const u32 t = threadIdx.x, ns = info->nsegs;
     if (t == 0) { carry_sum[0] = 0; carry_sum[1] = 0; for (int q = 0; q < 4; q++) carry_def[q] = info->ndonors ? info->donor[q] : ZL3_NONE; }
-    zl_sync_global();  // (the segments' numbers travel through memory)
+    __syncthreads();
     // ---- B: across segments: exclusive sums of the scratch needs, exclusive running maximum of the defining blocks
     // (round 4: a scan by all 1024 threads -- wave scans, the sixteen wave totals folded through LDS.  One lane per column walked
     // a tile's 1024 entries one after the other: 0.6 of the kernel's 0.87 ms on the 8192 segments of this library's 1 GiB frame)
@@ -492,9 +499,20 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
         }
         __syncthreads();
     }
-    zl_sync_global();
+    if (t == 0) {
+        info->lit_total = carry_sum[0];
+        info->seq_total = carry_sum[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void zl3_plan_c_kernel(zl3_dev d, zl_frame_desc fd) {
+    zl3_info* info = d.info;
+    if (info->err) return;
+    const u32 ns = info->nsegs;
     // ---- C: segment records
-    for (u32 s = t; s < ns; s += 1024) {
+    {
+        const u32 s = blockIdx.x * 256 + threadIdx.x;
+        if (s >= ns) return;
         const u32* o = d.seg_tmp + (size_t)s * 16;
         const u32 b0 = d.seg_first[s], b1 = d.seg_first[s + 1];
         zl2_frame_plan p;
@@ -544,12 +562,6 @@ __global__ __launch_bounds__(1024) void zl3_plan_kernel(zl3_dev d, zl_frame_desc
                 }
             }
         }
-    }
-    __syncthreads();
-    if (t == 0) {
-        info->lit_total = carry_sum[0];
-        info->seq_total = carry_sum[1];
-        *d.max_blocks = most_blocks;  // (which instantiation of the literal / sequence kernels the segments take: 1 = the single-block ones)
     }
 }
 
@@ -994,7 +1006,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
             return ZL_OOM_HERE;
         d.brec = (zl2_blk_rec*)s->brec.p; d.frec = (zl2_frame_rec*)s->frec.p; d.plan = (zl2_frame_plan*)s->plan.p; d.frames = (zl_frame_desc*)s->frames.p;
         d.ext = (zl2_blk_rec*)s->ext.p; d.seg_tmp = (u32*)s->seg_tmp.p;
-        hipLaunchKernelGGL(zl3_plan_kernel, dim3(1), dim3(1024), 0, st, d, fd);
+        const u32 plan_wgs = info.nsegs ? (info.nsegs + 255) / 256 : 1u;
+        hipLaunchKernelGGL(zl3_plan_a_kernel, dim3(plan_wgs), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(zl3_plan_b_kernel, dim3(1), dim3(1024), 0, st, d);
+        hipLaunchKernelGGL(zl3_plan_c_kernel, dim3(plan_wgs), dim3(256), 0, st, d, fd);
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("plan");
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);  // (blocks that ride on a dictionary's entropy tables)
