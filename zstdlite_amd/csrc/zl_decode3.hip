@@ -1034,7 +1034,11 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // the ordered copies.  Eight segments per run keep those few on a frame of thousands of blocks -- and leave a frame of a few
         // hundred with a few dozen workgroups, each as long as its eight blocks (0.75 ms a block): a 64 MiB reference frame spent
         // 6 of its 16 ms there.  The run shrinks with the frame so that the launch still fills the device (three workgroups per CU).
-        u32 exec_run = std::max<u32>(1u, std::min<u32>((u32)ZL3_EXEC_RUN, info.nsegs / (3u * (u32)g_num_cu)));
+        // (segments of several small blocks -- this library's own frames, whose matches rarely leave their chunk -- want shorter runs
+        // still: 1 GiB of them, runs of 1 / 2 / 3 / 4 / 5 / 8 segments: 12.5 / 11.3 / 10.4 / 10.8 / 11.5 / 12.1 ms; the reference's
+        // single-block segments: 27.7 / 23.5 / 22.3 / 22.4 / 23.5 / 20.9 ms, best at 6 - 8)
+        const u32 run_cap = info.nblocks >= 4u * info.nsegs ? 3u : (u32)ZL3_EXEC_RUN;
+        u32 exec_run = std::max<u32>(1u, std::min<u32>(run_cap, info.nsegs / (3u * (u32)g_num_cu)));
 #ifdef ZL_DEV_SWITCHES
         if (getenv("ZL_EXEC_RUN")) exec_run = (u32)atoi(getenv("ZL_EXEC_RUN"));
 #endif
