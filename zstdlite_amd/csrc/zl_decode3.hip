@@ -785,6 +785,19 @@ __global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* ds
 // the frame's result: checksum and size (zstd.c:41646-41660)
 // ---------------------------------------------------------------------------------------
 // (have_hash: the host has run the XXH64 chain over the regenerated bytes -- zl3_hash_on_host says why -- and hands its low 32 bits in)
+// which groups of output hold a byte that waits at all (zl3_decode_frame launches the ordered copies of those only)
+__global__ __launch_bounds__(256) void zl3_group_flags_kernel(const u32* tile_flag, u32* group_flag, u32 tiles_per_group, u64 ntiles) {
+    __shared__ u32 any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    const u64 t0 = (u64)blockIdx.x * tiles_per_group;
+    u32 mine = 0;
+    for (u32 i = threadIdx.x; i < tiles_per_group; i += 256) if (t0 + i < ntiles && tile_flag[t0 + i]) mine = 1;
+    if (mine) any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) group_flag[blockIdx.x] = any;
+}
+
 __global__ __launch_bounds__(512) void zl3_finish_kernel(zl3_info* info, zl_frame_desc fd, const u8* src_base, const u8* dst_base, u64* result, u32 ignore_checksum, u32 have_hash, u32 hash) {
     __shared__ __align__(16) u8 tile[8192];
     __shared__ u64 acc[4];
@@ -817,8 +830,8 @@ __global__ __launch_bounds__(512) void zl3_check_kernel(const u8* content, u64 n
 #define ZL3_SINK_LOG 26      // host entries: the output is downloaded in pieces of 64 MiB behind the copy stage (zl3_hint::sink_host)
 #define ZL3_SINK_EVENTS 64
 struct zl3_state_s {
-    DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec;
-    PinBuf h_spec, h_hash;
+    DevBuf info, hblk, braw, seg_first, blk_slot, brec, frec, plan, frames, ext, blk_dst, rep_start, seg_tmp, order, word, lit, seq, link, tile_flag, big, cnt, first, tot, spec, gflag;
+    PinBuf h_spec, h_hash, h_gflag;
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
     hipEvent_t sink_done[ZL3_SINK_EVENTS] = {};  // behind the download of each piece (zl3_hint::sink_hash)
     hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
@@ -830,8 +843,9 @@ extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s()
 extern "C" void zl3_free(zl3_state* s) {
     if (!s) return;
     for (DevBuf* b : {&s->info, &s->hblk, &s->braw, &s->seg_first, &s->blk_slot, &s->brec, &s->frec, &s->plan, &s->frames, &s->ext, &s->blk_dst, &s->rep_start, &s->seg_tmp, &s->order, &s->word,
-                      &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot, &s->spec}) b->release();
+                      &s->lit, &s->seq, &s->link, &s->tile_flag, &s->big, &s->cnt, &s->first, &s->tot, &s->spec, &s->gflag}) b->release();
     s->h_spec.release();
+    s->h_gflag.release();
     s->h_hash.release();
     for (hipEvent_t e : s->sink_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->sink_done) if (e) (void)hipEventDestroy(e);
@@ -1094,7 +1108,18 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
 #ifdef ZL_DEV_SWITCHES
         if (getenv("ZL_GROUP_LOG")) glog = (u32)atoi(getenv("ZL_GROUP_LOG"));
 #endif
+        // Groups without a single waiting byte -- raw blocks, blocks of literals only, matches that stay inside their exec run -- need
+        // no launch: which ones those are comes down behind the exec kernel (one more wait for the stream; half of the 256 launches
+        // of the 1 GiB mix, 9 - 16 us each, were for nothing).  Not with the host download beside this stage, whose events count launches.
+        const u32 ngroups = (u32)((span + (((u64)1 << glog) - 1)) >> glog);
+        const u32* gflags = nullptr;
+        if (!sink && ngroups > 8 && s->gflag.ensure((size_t)ngroups * 4) && s->h_gflag.ensure((size_t)ngroups * 4)) {
+            hipLaunchKernelGGL(zl3_group_flags_kernel, dim3(ngroups), dim3(256), 0, st, (const u32*)s->tile_flag.p, (u32*)s->gflag.p, (1u << glog) >> ZL3_TILE_LOG, ntiles);
+            if (hipMemcpyAsync(s->h_gflag.p, s->gflag.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            gflags = (const u32*)s->h_gflag.p;
+        }
         for (u64 g = 0; g < span; g += (u64)1 << glog) {
+            if (gflags && !gflags[g >> glog]) continue;
             hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << glog) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
                                d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, g, d.info);
             const u64 done = g + ((u64)1 << glog);
