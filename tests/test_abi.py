@@ -82,19 +82,21 @@ def test_context_options_mirror_reference_glue():
     with pytest.warns(UserWarning, match="init_dctx\\(\\): Unknown option 'bogus'"):
         z._init_dctx_with_opts({"bogus": 1})
     # the glue clamps to -5..22 (src/cctx.c:261-263); the context then reports the operating point it actually runs
-    # at -- 3, 5 or 6 above level 2 (include/zl_hip.h) -- and the mirror warns when that is not what was asked for
+    # at -- 3, 5 or 6 ... 15 above level 2 (include/zl_hip.h) -- and the mirror warns when that is not what was asked for
     # (round 1 echoed the number back and silently wrote level-3 output for level 19)
-    with pytest.warns(UserWarning, match="level 22 runs at this encoder's operating point 6"):
-        assert z.zstd_cctx_settings(z.zstd_cctx(level=99))["level"] == 6
+    with pytest.warns(UserWarning, match="level 22 runs at this encoder's operating point 15"):
+        assert z.zstd_cctx_settings(z.zstd_cctx(level=99))["level"] == 15
     assert z.zstd_cctx_settings(z.zstd_cctx(level=-99))["level"] == -5
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")  # levels the encoder implements as asked: no warning
-        for lv in (-5, 1, 2, 3, 5, 6):
+        for lv in (-5, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
             assert z.zstd_cctx_settings(z.zstd_cctx(level=lv))["level"] == lv
-    with pytest.warns(UserWarning, match="level 7 runs at this encoder's operating point 6"):
-        s = z.zstd_cctx_settings(z.zstd_cctx(level=7, include_checksum=True, num_threads=4))
-    assert s == {"level": 6, "num_threads": 4, "include_checksum": 1}
+    with pytest.warns(UserWarning, match="level 4 runs at this encoder's operating point 3"):
+        assert z.zstd_cctx_settings(z.zstd_cctx(level=4))["level"] == 3
+    with pytest.warns(UserWarning, match="level 16 runs at this encoder's operating point 15"):
+        s = z.zstd_cctx_settings(z.zstd_cctx(level=16, include_checksum=True, num_threads=4))
+    assert s == {"level": 15, "num_threads": 4, "include_checksum": 1}
     assert z.zstd_dctx_settings(z.zstd_dctx(validate_checksum=False))["validate_checksum"] == 1  # inverted, src/dctx.c:233
     with pytest.raises(z.ZstdError, match="only accepts raw vectors or strings"):
         z.zstd_compress(12345)

@@ -98,11 +98,12 @@ def _init_cctx_with_opts(opts, quiet=False):
             got = C.c_int(0)
             L.zl_CCtx_getParameter(cctx._ptr, ZL_c_compressionLevel, C.byref(got))
             if got.value != level and level > 3 and not quiet:
-                # the HIP encoder's deepest operating point is 6 (two-step lazy rule, the decoder's three repeat offsets followed
-                # exactly); it has no hash chains and no optimal parser (the reference's levels 7 and up): say so instead of
-                # silently writing something else than was asked for
+                # levels 6 - 15 run the deep match finder with the reference's own search depth, lazy depth and window at that
+                # level; the optimal parsers of the reference's levels 16 - 22 are not built: say so instead of silently writing
+                # something else than was asked for
                 warnings.warn(f"init_cctx(): level {level} runs at this encoder's operating point {got.value} "
-                              "(operating points: < 3, 3, 5 -- larger match tables and a deeper far search -- and 6 -- a two-step lazy rule and all three repeat offsets; see include/zl_hip.h)")
+                              "(operating points: < 3, 3, 5 and 6 ... 15 -- the reference's search depth, lazy depth and window at that level; "
+                              "the optimal parsers of levels 16 - 22 are not built; see include/zl_hip.h)")
         elif name == "num_threads":
             if int(val) > 1:
                 L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))

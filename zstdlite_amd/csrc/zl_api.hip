@@ -477,6 +477,28 @@ size_t zl_index_frames(const void* src_, size_t n, zl_frame_t* frames, size_t ca
 // =========================================================================================
 zl_dctx* zl_createDCtx(void) { return new (std::nothrow) zl_dctx_s(); }
 
+// The slots that keep several runs of one large frame in flight (decode_walked_frame_in_runs, the streaming route) each hold a
+// pipeline state sized for the frame's largest run -- several GiB.  Slots [from, kRunSlots) are given back: by zl_freeDCtx, and
+// when device memory runs out under them (a frame that decoded before must not fail on a device with less free HBM).
+static void release_run_slots(zl_dctx* d, int from) {
+    for (int k_ = from; k_ < zl_dctx_s::kRunSlots; k_++) {
+        auto& rs = d->run_slot[k_];
+        if (rs.st) (void)hipStreamSynchronize(rs.st);
+        zl3_free(rs.big);
+        rs.big = nullptr;
+        if (rs.st) (void)hipStreamDestroy(rs.st);
+        if (rs.side.fork) (void)hipEventDestroy(rs.side.fork);
+        if (rs.side.join) (void)hipEventDestroy(rs.side.join);
+        if (rs.side.stream) (void)hipStreamDestroy(rs.side.stream);
+        for (int k = 0; k < 3; k++) {
+            if (rs.side.part_join[k]) (void)hipEventDestroy(rs.side.part_join[k]);
+            if (rs.side.part_stream[k]) (void)hipStreamDestroy(rs.side.part_stream[k]);
+            rs.side.part_join[k] = nullptr; rs.side.part_stream[k] = nullptr;
+        }
+        rs.st = nullptr; rs.side.fork = nullptr; rs.side.join = nullptr; rs.side.stream = nullptr;
+    }
+}
+
 size_t zl_freeDCtx(zl_dctx* d) {
     if (!d) return 0;
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
@@ -488,17 +510,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     for (zl_dctx* p : d->peers) (void)zl_freeDCtx(p);
     d->peers.clear();
     zl3_free(d->big);
-    for (auto& rs : d->run_slot) {
-        zl3_free(rs.big);
-        if (rs.st) (void)hipStreamDestroy(rs.st);
-        if (rs.side.fork) (void)hipEventDestroy(rs.side.fork);
-        if (rs.side.join) (void)hipEventDestroy(rs.side.join);
-        if (rs.side.stream) (void)hipStreamDestroy(rs.side.stream);
-        for (int k = 0; k < 3; k++) {
-            if (rs.side.part_join[k]) (void)hipEventDestroy(rs.side.part_join[k]);
-            if (rs.side.part_stream[k]) (void)hipStreamDestroy(rs.side.part_stream[k]);
-        }
-    }
+    release_run_slots(d, 0);
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -765,7 +777,7 @@ bool block_use(const u8* b, u32 n, BlockUse& u) {
 struct Block { u64 at; u32 hdr; BlockUse use; };  // at: where the block's content starts in the frame (behind its 3-byte header)
 }  // namespace runs
 
-size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8* host_src, const u8* d_src, u8* d_dst, u64* d_result, hipStream_t st, zl3_hint hint) {
+size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8* host_src, const u8* d_src, u8* d_dst, u64* d_result, hipStream_t st, zl3_hint hint, int max_slots = zl_dctx_s::kRunSlots) {
     using namespace runs;
     const size_t n = (size_t)fd.src_size;
     FrameHeader h;
@@ -821,7 +833,7 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     // (four slots where blocks are large -- the reference's 128 KiB, whose entropy stage lasts 6 - 10 ms --, two where they are this
     // library's 16 KiB, whose stage is over in a millisecond or two: every slot costs its buffers, 5 GiB and 30 ms of allocation
     // in a context's first call)
-    const int K = (end_pos / nb >= ((u64)24 << 10)) ? zl_dctx_s::kRunSlots : 2;
+    const int K = std::min(max_slots, (end_pos / nb >= ((u64)24 << 10)) ? (int)zl_dctx_s::kRunSlots : 2);
     for (int k_ = 0; k_ < K; k_++) {
         auto& rs = d->run_slot[k_];
         if (!rs.big && !(rs.big = zl3_create())) return kGpuUnavailable;
@@ -1309,7 +1321,7 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
                 const size_t nb0 = F.cuts[1];
                 const u64 bytes0 = (nb0 < F.blk.size() ? F.blk[nb0].at - 3 : F.walked) - F.h.header_size;
                 F.K = (nb0 && bytes0 / nb0 >= ((u64)24 << 10)) ? zl_dctx_s::kRunSlots : 2;
-                if (!stream_frame_slots(d, F.K)) return ZL_OOM_HERE;
+                if (!stream_frame_slots(d, F.K)) return kGpuUnavailable;
             }
             SF_T0;
             const size_t e = stream_frame_start(d, F, F.started);
@@ -1321,6 +1333,7 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
     };
     size_t e = start_more();
     if (e != 0) (void)land_early();
+    if (e == kGpuUnavailable) { release_run_slots(d, 0); e = ZL_ERR(ZL_E_FALLBACK); }  // (device memory ran out under the runs in flight: the collecting route decodes the frame on one state)
     if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
     if (e != 0) return e;
     bool waited = early_k != 0;
@@ -1335,12 +1348,14 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
             SF_ADD(t_finish);
         }
         if (e != 0) (void)land_early();
+        if (e == kGpuUnavailable) { release_run_slots(d, 0); e = ZL_ERR(ZL_E_FALLBACK); }
         if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
         if (e != 0) return e;
         F.finished++;
         waited = true;
         e = start_more();
         if (e != 0) (void)land_early();
+        if (e == kGpuUnavailable) { release_run_slots(d, 0); e = ZL_ERR(ZL_E_FALLBACK); }
         if (e == ZL_ERR(ZL_E_FALLBACK)) { const size_t f = stream_frame_fallback(d); return ZL_IS_ERR(f) ? f : 2; }
         if (e != 0) return e;
         if (output->pos < output->size && !drain && !full) break;  // (what is there goes out first)
@@ -1507,6 +1522,13 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             }
             if (!d->d_run_results.ensure(64)) return kGpuUnavailable;
             e3 = decode_walked_frame_in_runs(d, tbl[i], host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
+            if (e3 == kGpuUnavailable) {
+                // device memory ran out with several runs in flight: the extra slots go back, and the frame is decoded with what ONE
+                // state can do -- run after run, or (a frame the pipeline plans whole) by the whole-frame route below
+                release_run_slots(d, 1);
+                if (!d->slab) e3 = decode_walked_frame_in_runs(d, tbl[i], host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint, 1);
+                if (e3 == kGpuUnavailable) { release_run_slots(d, 0); e3 = ZL_ERR(ZL_E_FALLBACK); }
+            }
             if (d->h_run_src.cap > ((size_t)64 << 20)) { free(d->h_run_src.p); d->h_run_src.p = nullptr; d->h_run_src.n = d->h_run_src.cap = 0; }  // (not kept: gigabytes)
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }

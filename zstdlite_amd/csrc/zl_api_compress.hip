@@ -28,6 +28,8 @@ struct zl_cctx_s {
     int pipeline = 1;  // ZL_c_pipeline: host entries overlap upload, kernels and download for large inputs
     u32 chunk_cap = ZL_CHUNK;  // the largest src_size in the chunk table being enqueued, if the caller knows it (zl_compress_batch): sizes the per-chunk scratch
     bool any_small = false;  // the chunk table being enqueued holds inputs of at most one chunk (zl_chunk_desc::flags bit 0)
+    bool one_input = false;  // the chunk table being enqueued cuts ONE contiguous input, in order (what the deep match finder of levels >= 6 sorts)
+    u64 input_total = 0;     // ... bytes of that input
     int last_slots = 1;  // device slots the last zl_compress2 call used
     int devices = 1;     // ZL_c_devices: device slots zl_compress2 spreads a large input over (0: every visible device)
     std::vector<zl_cctx_s*> peers;  // one context per slot, created on first use
@@ -41,9 +43,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
@@ -104,6 +106,19 @@ hipStream_t cctx_stream(zl_cctx* c, void* user) {
 }
 
 inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_CHUNK; }
+
+// Levels 6 - 15: the deep match finder (zl_deep.hip) with the reference's own search depth, lazy depth and window at that level
+// (zstd.c:29523-29550: searchLog 3 / 4 / 4 / 4 / 5 / 6 / 6 at levels 6 - 12 -> 2^searchLog candidates; lazy at 6 - 7, lazy2 from 8;
+// windowLog 21 up to level 8, 22 from 9).  Levels 13 - 15 (btlazy2: a binary tree finds the longest match among more candidates
+// than a chain visits) search deeper still; the optimal parsers of levels 16 - 22 are not built: they run as 15.
+struct DeepLevel { u32 k, lazy2, wlog; };
+inline DeepLevel deep_level(int level) {
+    static const DeepLevel tab[10] = {{8, 0, 21}, {16, 0, 21}, {16, 1, 21}, {16, 1, 22}, {32, 1, 22}, {64, 1, 22}, {96, 1, 22}, {128, 1, 22}, {192, 1, 22}, {256, 1, 22}};
+    return tab[std::min(std::max(level, 6), 15) - 6];
+}
+// ... which needs ONE contiguous input and no dictionary (a dictionary's content is not part of what is sorted): batches of
+// objects and dictionary contexts at these levels run the table-based parse at its deepest setting instead
+inline bool deep_on(const zl_cctx* c) { return c->level >= 6 && c->one_input && c->dict_use == 0; }
 
 inline u32 zl_rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
@@ -173,9 +188,31 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     if (!es.meta.ensure((size_t)cnt * sizeof(zl_chunk_meta)) || !es.lits.ensure((size_t)cnt * sd.lit) || !es.seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) ||
         !es.sst.ensure((size_t)cnt * sd.seq * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * sd.out))
         return kGpuUnavailable;
-    if (joined && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
+    const bool deep = deep_on(c);
+    const DeepLevel dl = deep_level(c->level);
+    if (joined && !deep && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
     c->far_valid = false;
-    if (joined) {
+    u64 deep_lo = 0;
+    if (deep) {
+        // every position's best earlier occurrence, section by section (zl_deep.hip), in front of the parse
+        const zl_chunk_desc* ht = (const zl_chunk_desc*)c->h_chunks.p + first;
+        zl_deep_args d;
+        d.src = d_src;
+        d.lo = deep_lo = ht[0].src_off;
+        d.hi = ht[cnt - 1].src_off + ht[cnt - 1].src_size;
+        d.total = c->input_total;
+        d.k = dl.k;
+        d.window = (1u << dl.wlog) - 1u;
+        d.mml = c->input_total > ((u64)256 << 10) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at these levels)
+        d.frames = joined ? 0u : 1u;
+        if (!es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(zl_deep_scratch_bytes())) return kGpuUnavailable;
+        d.scratch = es.deep_scratch.p;
+        d.scratch_bytes = zl_deep_scratch_bytes();
+        d.best = (u64*)es.deep_best.p;
+        if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
+        if (zl_launch_deep_search(&d, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        stage_ok("deep search");
+    } else if (joined) {
         if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
         // the far table over this launch group's input, then the hint words the match kernel reads
         zl_far_args f;
@@ -207,9 +244,15 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
     m.dict_len = c->dict_use;
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
-    m.far_hints = joined ? (const u32*)es.far_hints.p : nullptr;
+    m.far_hints = (joined && !deep) ? (const u32*)es.far_hints.p : nullptr;
     m.intra = c->any_small ? 1u : 0u;
     m.pad0 = 0;
+    m.deep_best = deep ? (const u64*)es.deep_best.p : nullptr;
+    m.deep_lo = deep_lo;
+    m.total = c->input_total;
+    m.joined = joined ? 1u : 0u;
+    m.pad1 = 0;
+    if (deep) m.lazy2 = dl.lazy2;
 #ifdef ZL_TRACE
     // development build: the match kernel stamps a timeline of one workgroup's iterations behind the 128 bytes of phase sums
     if (prof && c->profile >= 2 && c->d_stats.ensure(128 + ZL_TRACE_BYTES)) {
@@ -223,7 +266,9 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     }
 #endif
     if (prof) (void)hipEventRecord(c->ev[0], st);
-    if (joined && c->dict_use) {
+    if (deep) {
+        if (zl_launch_match_deep(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    } else if (joined && c->dict_use) {
         // ONE frame with a dictionary (zstd.c:27550: the dictionary's content is history in front of the frame's first byte):
         // the frame's first chunk is searched with the dictionary in front of it, exactly as a dictionary frame of its own
         // would be; the chunks behind it see the frame (far matches reach into chunk 0, not into the dictionary).
@@ -260,7 +305,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.joined = joined ? 1u : 0u;
     e.chunk_base = (u32)(frame_chunk0 + first);
     e.total_chunks = (u32)nchunks;
-    e.wlog = ZL_FAR_WLOG;
+    e.wlog = deep ? dl.wlog : (u32)ZL_FAR_WLOG;
     e.total_size = joined_total;
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.stats = m.stats ? m.stats + 8 : nullptr;
@@ -300,7 +345,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     const bool prof = c->profile && ngroups == 1;
     if (prof && !c->ev[0]) for (auto& e : c->ev) (void)hipEventCreate(&e);
-    if (prof && joined && !c->ev_far) (void)hipEventCreate(&c->ev_far);
+    if (prof && (joined || deep_on(c)) && !c->ev_far) (void)hipEventCreate(&c->ev_far);  // (the start of the far passes, or of the deep search)
     c->ev_valid = false;
     for (size_t g = 0; g < ngroups; g++) {
         const size_t first = g * group;
@@ -387,6 +432,8 @@ size_t fill_chunk_table(zl_cctx* c, size_t n) {
         t[i].flags = nchunks == 1 ? 1u : 0u;
     }
     c->any_small = nchunks == 1;
+    c->one_input = true;
+    c->input_total = n;
     return nchunks;
 }
 
@@ -431,21 +478,23 @@ size_t zl_freeCCtx(zl_cctx* c) {
 //   levels < 3   every other position probed throughout (cf. the step of ZSTD_fast, zstd.c:29340); reported as given
 //   level 3, 4   the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
 //                in the one-frame layout one position in 8 takes part in the far search.  Reported as 3.
-//   levels >= 5  the same parse with match tables four times the size (2^14 + 2^13 entries, three workgroups per CU instead
-//                of seven), verification up to 72 bytes per lane and one position in 4 in the far search.  64 MiB of text:
-//                4.36 -> 4.46 (the reference's level 5: 4.46); python sources, one frame: 4.24 -> 4.41 (reference level 3
-//                4.43, level 5 4.77); independent frames 3.48 -> 3.68.  1 GiB mix: match 5.0 -> 8.1 ms.  Reported as 5.
-//                Contexts with a dictionary keep the level-3 tables (the dictionary's table image has their size).
-// Measured against the reference at the same level: within 5 % of its ratio at levels 1, 2 and 3
-// (tests/test_compress_gpu.py).  The lazy and optimal parsers behind the reference's levels >= 5 (zstd.c:31546-33746) are
-// not built: above 5 nothing deepens further, and the ratio falls behind the reference's at those levels.
+//   level 5      the same parse with match tables four times the size (2^14 + 2^13 entries, three workgroups per CU instead
+//                of seven), verification up to 72 bytes per lane and one position in 4 in the far search.
+//   levels 6-15  the deep match finder (zl_deep.hip): every position's K most recent earlier occurrences inside the window,
+//                K, the lazy depth and the window as the reference has them at that level (deep_level above); python sources in
+//                one frame 0.996 / 0.996 / 0.989 of the reference's size at 6 / 9 / 12 (round 4's table-based point 6: 1.085 /
+//                1.128 / 1.149).  Contexts with a dictionary and the batch entries run the table-based parse at its deepest
+//                setting (two-step lazy rule, all three repeat offsets) at these levels.
+//   levels 16-22 run as 15: the optimal parsers (zstd.c:34586-36163) are not built.
+// Measured against the reference at the same level: within 5 % of its size at levels 1, 2, 3 and 6 ... 15
+// (tests/test_compress_gpu.py).
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     cs_wait(c);
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value >= 6 ? 6 : (value >= 5 ? 5 : (value >= 3 ? 3 : value));
+        c->level = value >= 16 ? 15 : (value >= 5 ? value : (value >= 3 ? 3 : value));
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
@@ -653,6 +702,8 @@ size_t compress2_pipelined(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_
             t[i].flags = 0;
         }
         c->any_small = false;
+        c->one_input = true;
+        c->input_total = n_total;
     }
     const size_t ngroups = (nchunks + ZL_PIPE_CHUNKS - 1) / ZL_PIPE_CHUNKS;
     const size_t bound = zl_compressBound(n);
@@ -909,6 +960,7 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         return kGpuUnavailable;
     zl_chunk_desc* t = (zl_chunk_desc*)c->h_chunks.p;
     c->any_small = false;
+    c->one_input = false;
     size_t largest = 0;
     for (size_t i = 0; i < n; i++) {
         largest = std::max(largest, sizes[i]);
@@ -1058,7 +1110,18 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
             T.job_ret = joined ? compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash)
                                : compress2_impl(c, T.job_out.p, bound, T.job_in.p, n);
         };
-        try { S.job = std::thread(body); S.job_on = true; } catch (...) { body(); S.job_on = true; S.job = std::thread([]() {}); }  // (no thread to be had: the job runs here)
+        try { S.job = std::thread(body); S.job_on = true; }
+        catch (...) {  // no thread to be had: the job runs here, and what it wrote becomes what waits to be handed out (as collect() would make it)
+            body();
+            const size_t r = S.job_ret;
+            S.job_in.clear();
+            if (ZL_IS_ERR(r)) { S.job_out.clear(); return r; }
+            S.job_out.n = r;
+            std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
+            S.job_out.clear();
+            S.out_pos = 0;
+            S.emitted = true;
+        }
         return 0;
     };
     auto run_job = [&]() -> size_t {  // the collected input -> frames, appended to what waits to be handed out
@@ -1128,6 +1191,9 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.started = S.emitted = S.finishing = S.joined = false;
         return 0;
     }
+    // ZL_e_flush inside a one-frame (pledged) session cuts no run: the input still collected is part of the answer, so that a caller
+    // who reads 0 as "everything consumed so far can be decoded from the output" (zstd.h:841-880) is never told so wrongly
+    if (end_op == ZL_e_flush && S.joined && !S.finishing) return S.out.size() - S.out_pos + S.stage.size();
     return S.out.size() - S.out_pos;
 }
 

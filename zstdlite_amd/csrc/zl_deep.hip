@@ -1,0 +1,430 @@
+// zl_deep.hip -- the deep match finder behind levels >= 6 for gfx950 (MI355X).
+//
+// The reference's levels 6-15 are its lazy strategies: at every position they look at the 2^searchLog most recent earlier
+// positions with the same hash of minMatch bytes inside a window of 2 - 4 MiB (hash chains and the row hash,
+// zstd.c:31546-33746 ZSTD_HcFindBestMatch / ZSTD_RowFindBestMatch), keep the longest, and weigh it against the matches one and
+// two positions on (ZSTD_compressBlock_lazy_generic, depth 1 / 2).  A chain is built by walking the input in order; this
+// machine cannot do that, but it can SORT:
+//
+//   zl_deep_key_kernel      every position p of a section (64 MiB) becomes the key  hash(minMatch bytes at p) << 32 | p
+//   radix sort              of the keys by their hash bits only (rocPRIM's device radix sort through hipcub: a plain library
+//                           primitive, as a GEMM would be).  The sort is stable, so inside one hash value the positions ascend:
+//                           the K entries in front of a position in the sorted order ARE its K most recent earlier occurrences
+//                           -- exactly the candidates a hash chain of depth K visits, whatever order the hardware worked in.
+//   zl_deep_search_kernel   a workgroup takes 256 consecutive sorted entries plus the K in front of them, fetches the 64 bytes
+//                           [p - 8, p + 56) around every one of these positions ONCE (the only gathers of the whole search:
+//                           one record per position instead of one per candidate) and keeps them in LDS; every lane then
+//                           measures its K predecessors against its own record -- LDS reads only --, keeps the best by the
+//                           lazy parsers' gain (4 * length - log2(offset), zstd.c:31653), counts the bytes that agree in
+//                           FRONT of both (the "catch up" of zstd.c:31707) and writes one word for its position.
+//   zl_match_deep_kernel    the window-parallel parse of zl_match_auto_kernel (zl_encode.hip) with its tables taken away: a
+//                           window's 256 lanes read their words (one coalesced load), try the repeat offset of the window in
+//                           front out of an LDS copy of the bytes it points at, apply the one- and two-step lazy rule, close
+//                           the greedy path with lane shuffles, extend backwards over free literals and emit.  No gathers,
+//                           no table, no inserts: what is left is the parse.
+//
+// Matches are measured over ZL_DEEP_CAP bytes; a longer one arrives as several pieces with one offset, which the pass behind
+// the parse joins (zl_merge_pieces).  CPU model with the reference's entropy stage behind it: scripts/dev/sim/deep_sim.c
+// (python sources, one frame: 1.001 / 0.998 / 0.996 of the reference's size at levels 6 / 9 / 12).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "zl_device.h"
+#include "zl_encode.h"
+#include "zl_format.h"
+#include "zl_kernels.h"
+#include "zl_match_common.h"
+
+#define DEEP_THREADS 256
+#define DEEP_SEC_BYTES ((u64)ZL_CHUNK << ZL_FAR_SECTION_LOG)  // 64 MiB: what is sorted at once, and what no offset crosses
+#define DEEP_SEC_MAX ((u32)DEEP_SEC_BYTES)
+
+// ---------------------------------------------------------------------------------------
+// keys: hash of the position's minMatch bytes above the position itself
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_key_kernel(const u8* sec, u32 n, u32 mml_shift, u64* keys) {
+    const u32 i = blockIdx.x * DEEP_THREADS + threadIdx.x;
+    if (i >= n) return;
+    u64 v = 0;
+    if (i + 8 <= n) v = ld64(sec + i);
+    else for (u32 b = 0; i + b < n; b++) v |= (u64)sec[i + b] << (8 * b);  // (the section's last bytes: zero-padded, like their records below)
+    const u32 h = (u32)(((v << mml_shift) * 0x9E3779B185EBCA87ULL) >> (64 - ZL_DEEP_HLOG));
+    keys[i] = ((u64)h << 32) | i;
+}
+
+// 16 bytes at section offset a (may be negative or run past the end): bytes outside [0, n) read as zero
+__device__ __forceinline__ uint4 deep_ld16(const u8* sec, i32 a, u32 n) {
+    if (a >= 0 && (u32)a + 16 <= n) return ld128(sec + a);
+    u32 w[4] = {0, 0, 0, 0};
+    for (u32 b = 0; b < 16; b++) {
+        const i32 q = a + (i32)b;
+        if (q >= 0 && (u32)q < n) w[b >> 2] |= (u32)sec[q] << (8 * (b & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ u32 cb64(u32 a0, u32 a1, u32 b0, u32 b1) {  // equal bytes from the start of two 8-byte words
+    return common_bytes((u64)a0 | ((u64)a1 << 32), (u64)b0 | ((u64)b1 << 32));
+}
+__device__ __forceinline__ u32 cb128(const uint4& a, const uint4& b) {
+    const u32 l0 = cb64(a.x, a.y, b.x, b.y);
+    return l0 == 8 ? 8 + cb64(a.z, a.w, b.z, b.w) : l0;
+}
+
+// ---------------------------------------------------------------------------------------
+// search: entry i of the sorted order against entries i - 1 ... i - K
+// ---------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64* sorted, u32 n, const u8* sec, u32 K, u32 window, u32 min_len, u32 frames, u64* best) {
+    constexpr u32 E = DEEP_THREADS + KMAX;
+    __shared__ uint4 rec[4][E];  // rec[j][e]: bytes [p - 8 + 16 j, p + 8 + 16 j) of entry e's position (one array per slice: consecutive lanes read consecutive slots)
+    __shared__ u32 spos[E];
+    __shared__ u32 shash[E];
+    const u32 t = threadIdx.x;
+    const u32 i0 = blockIdx.x * DEEP_THREADS;
+    for (u32 e = t; e < E; e += DEEP_THREADS) {
+        const i64 idx = (i64)i0 + (i64)e - KMAX;
+        u32 pos = 0, h = 0xFFFFFFFFu;  // (no entry: a hash no position has)
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (idx >= 0 && idx < (i64)n && (e >= (u32)KMAX || e + K >= (u32)KMAX)) {  // (of the entries in front only the K nearest are looked at)
+            const u64 key = sorted[idx];
+            pos = (u32)key;
+            h = (u32)(key >> 32);
+            const i32 a = (i32)pos - 8;
+            r0 = deep_ld16(sec, a, n); r1 = deep_ld16(sec, a + 16, n); r2 = deep_ld16(sec, a + 32, n); r3 = deep_ld16(sec, a + 48, n);
+        }
+        spos[e] = pos; shash[e] = h;
+        rec[0][e] = r0; rec[1][e] = r1; rec[2][e] = r2; rec[3][e] = r3;
+    }
+    __syncthreads();
+    const u32 e = t + KMAX;
+    if (i0 + t >= n) return;
+    const u32 p = spos[e], hme = shash[e];
+    const uint4 m0 = rec[0][e], m1 = rec[1][e], m2 = rec[2][e], m3 = rec[3][e];
+    const u32 chunk0 = p & ~(u32)(ZL_CHUNK - 1);  // (sections start on a chunk boundary)
+    u32 lo = p > window ? p - window : 0u;
+    if (frames && lo < chunk0) lo = chunk0;
+    u32 bl = 0, bo = 0, be = 0;
+    int bg = -1000000;
+    bool alive = true;
+    for (u32 k = 1; k <= K; k++) {
+        const u32 ce = e - k;
+        const u32 q = spos[ce];
+        alive = alive && shash[ce] == hme && q >= lo && q < p;  // (positions ascend inside a hash value: the first one below the window ends the walk)
+        if (!__any(alive)) break;
+        if (alive) {
+            u32 len = cb64(m0.z, m0.w, rec[0][ce].z, rec[0][ce].w);
+            if (len == 8) {
+                u32 l = cb128(m1, rec[1][ce]);
+                len += l;
+                if (l == 16) {
+                    l = cb128(m2, rec[2][ce]);
+                    len += l;
+                    if (l == 16) len += cb128(m3, rec[3][ce]);
+                }
+            }
+            if (len >= min_len) {
+                const int g = 4 * (int)len - (int)(31 - __clz(p - q + 1));
+                if (g > bg) { bg = g; bl = len; bo = p - q; be = ce; }  // (ties: the nearer one, met first)
+            }
+        }
+    }
+    u64 word = 0;
+    if (bl) {
+        // bytes that agree in front of both: the sequence may start there if the parse leaves those literals free
+        const u64 mine = (u64)m0.x | ((u64)m0.y << 32), theirs = (u64)rec[0][be].x | ((u64)rec[0][be].y << 32);
+        const u64 x = mine ^ theirs;
+        u32 back = x ? (u32)(__builtin_clzll(x) >> 3) : 8u;
+        const u32 q = p - bo;
+        const u32 lo_src = frames ? chunk0 : 0u;  // the source may not start in front of this (the section, or the frame)
+        if (back > q - lo_src) back = q - lo_src;
+        if (back > p - chunk0) back = p - chunk0;  // nor the sequence in front of its chunk
+        word = (u64)(bl | (back << 16)) | ((u64)bo << 32);
+    }
+    best[p] = word;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// extension: a match that filled its record (ZL_DEEP_CAP bytes) is measured on, so that the parse steps over it whole and the
+// lazy rule sees what it is worth.  Position order, a wave per 64 positions: position p with the offset of p - 1, both full, is
+// the INTERIOR of one longer match (its length is its neighbour's less one); every other full one is a HEAD, and the whole wave
+// measures a head's next ZL_DEEP_EXT bytes at once, sixteen per lane.  (python sources, 1 MB of one file, level 9: 1.069 -> 1.03 of
+// the reference's size -- scripts/dev/sim/deep_sim.c cap=56 / 255.)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_extend_kernel(u64* best, u32 n, const u8* sec) {
+    const u32 p = blockIdx.x * DEEP_THREADS + threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
+    const u64 w = p < n ? best[p] : 0ull;
+    const u32 len = (u32)w & 0xFFFFu, off = (u32)(w >> 32);
+    const bool full = len == ZL_DEEP_CAP;
+    const u64 fm = __ballot(full);
+    if (fm == 0) return;  // (uniform)
+    const u32 plen = __shfl_up(len, 1, 64), poff = __shfl_up(off, 1, 64);
+    const bool head = full && (lane == 0 || plen != ZL_DEEP_CAP || poff != off);
+    const u64 heads = __ballot(head);
+    u32 mine_ext = 0;
+    for (u64 hm = heads; hm; hm &= hm - 1) {
+        const u32 h = (u32)__builtin_ctzll(hm);
+        const u32 hp = p - lane + h, hoff = __shfl(off, (int)h, 64);
+        const u32 a = hp + ZL_DEEP_CAP + 16 * lane;
+        u32 part = 0;
+        if (a + 16 <= n) part = cb128(ld128(sec + a), ld128(sec + a - hoff));
+        else for (; part < 16 && a + part < n && sec[a + part] == sec[a + part - hoff]; part++) {}
+        const u64 whole = __ballot(part == 16);
+        const u32 first = ~whole ? (u32)__builtin_ctzll(~whole) : 64u;  // the first lane whose sixteen bytes do not all agree
+        const u32 tail = __shfl(part, (int)(first & 63), 64);
+        if (lane == h) mine_ext = first * 16 + (first < 64 ? tail : 0u);
+    }
+    // every full position: its head is the nearest one at or below it
+    const u64 at_or_below = heads & ((2ull << lane) - 1);
+    const u32 h = at_or_below ? 63u - (u32)__builtin_clzll(at_or_below) : 0u;
+    const u32 h_ext = __shfl(mine_ext, (int)h, 64);
+    if (full) {
+        const u32 d = lane - h;
+        const u32 total = ZL_DEEP_CAP + (h_ext > d ? h_ext - d : 0u);
+        best[p] = (w & ~0xFFFFull) | total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// the parse
+// ---------------------------------------------------------------------------------------
+#define DEEP_WBUF 352  // a window's own bytes: 256 positions + ZL_DEEP_CAP + a last word and its alignment slack
+#define DEEP_RBUF 368  // the bytes the repeat offset points at, from 8 in front of the window's first source on
+struct DeepShared {
+    u64 cand[DEEP_THREADS + 2];  // [31:0] length, [63:32] offset of each lane's match (0: none); two zero words behind the window: what the lazy rule reads there
+    u16 jump[DEEP_THREADS];
+    u32 scan_a[4];
+    u32 rep;                     // offset of the most recent sequence
+    u32 t_end[DEEP_THREADS], t_off[DEEP_THREADS];  // the merge pass
+    alignas(16) u8 wbuf[DEEP_WBUF];
+    alignas(16) u8 rbuf[DEEP_RBUF];
+};
+static_assert(255 + ZL_DEEP_CAP + 16 + 4 <= DEEP_WBUF && 8 + 255 + ZL_DEEP_CAP + 16 + 4 <= DEEP_RBUF, "the last lane's last round stays inside the buffers");
+
+// eight bytes at byte offset o of an LDS buffer: three aligned words, funnel-shifted
+__device__ __forceinline__ u64 lds64(const u8* buf, u32 o) {
+    const u32* const w = (const u32*)buf + (o >> 2);
+    const u32 d0 = w[0], d1 = w[1], d2 = w[2], sh = o & 3;
+    return (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+}
+__device__ __forceinline__ u32 lds_common16(const u8* a, u32 oa, const u8* b, u32 ob) {
+    const u32 l0 = common_bytes(lds64(a, oa), lds64(b, ob));
+    return l0 == 8 ? 8 + common_bytes(lds64(a, oa + 8), lds64(b, ob + 8)) : l0;
+}
+
+__global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_args a, u32 nchunks) {
+    __shared__ DeepShared S;
+    const u32 t = threadIdx.x;
+    const u32 c = zl_spread(blockIdx.x, nchunks);
+    const zl_chunk_desc cd = a.chunks[c];
+    const u8* src = a.src + cd.src_off;
+    const u32 n = cd.src_size;
+    u8* lits = a.lits + (size_t)c * a.lit_stride;
+    zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
+    const u64* const best = a.deep_best + (size_t)(cd.src_off - a.deep_lo);
+    // what may be read around the chunk: its section (no offset crosses one, zl_encode.h) and the input's end
+    const u64 sec_off = cd.src_off & (DEEP_SEC_BYTES - 1);
+    const u32 reach = a.joined ? (u32)sec_off : 0u;                                            // bytes in front of the chunk a source may lie in
+    const u64 sec_end = cd.src_off - sec_off + DEEP_SEC_BYTES;
+    const u32 avail = (u32)((a.total < sec_end ? a.total : sec_end) - cd.src_off);               // bytes readable from the chunk's first byte on
+    auto ld16 = [&](i32 o) -> uint4 {  // 16 bytes at chunk offset o; outside [-reach, avail): zero
+        if (o >= -(i32)reach && (i64)o + 16 <= (i64)avail) return ld128(src + o);
+        u32 w[4] = {0, 0, 0, 0};
+        for (u32 b = 0; b < 16; b++) {
+            const i32 q = o + (i32)b;
+            if (q >= -(i32)reach && (i64)q < (i64)avail) w[b >> 2] |= (u32)src[q] << (8 * (b & 3));
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    if (t < 2) S.cand[DEEP_THREADS + t] = 0;
+    if (t == 0) S.rep = 0;
+    u32 nseq = 0, nlit = 0, carry = 0;
+    uint4 wb_cur = make_uint4(0, 0, 0, 0);
+    if (t < DEEP_WBUF / 16) wb_cur = ld16((i32)(16 * t));
+    u64 bw_cur = t < n ? best[t] : 0ull;
+    lds_barrier();
+    for (u32 ip = 0; ip < n; ip += DEEP_THREADS) {
+        const u32 p = ip + t;
+        const bool in_range = p < n;
+        const u32 rep = S.rep;
+        if (t < DEEP_WBUF / 16) *(uint4*)(S.wbuf + 16 * t) = wb_cur;
+        // the bytes the repeat offset points at, for the whole window: [ip - rep - 8, + DEEP_RBUF)
+        if (rep && t < DEEP_RBUF / 16) *(uint4*)(S.rbuf + 16 * t) = ld16((i32)ip - (i32)rep - 8 + (i32)(16 * t));
+        // the next window's bytes and words travel while this one is parsed
+        uint4 wb_next = make_uint4(0, 0, 0, 0);
+        u64 bw_next = 0;
+        if (ip + DEEP_THREADS < n) {
+            if (t < DEEP_WBUF / 16) wb_next = ld16((i32)(ip + DEEP_THREADS + 16 * t));
+            if (p + DEEP_THREADS < n) bw_next = best[p + DEEP_THREADS];
+        }
+        lds_barrier();
+        const u64 v = lds64(S.wbuf, t);
+        // (the eight bytes in front of a position are what the lane eight positions down holds)
+        const u64 v_front = (u64)__shfl_up((u32)v, 8, 64) | ((u64)__shfl_up((u32)(v >> 32), 8, 64) << 32);
+        u32 best_len = 0, best_off = 0, back = 0;
+        if (in_range && carry < DEEP_THREADS) {  // (otherwise the whole window lies inside an earlier match)
+            const u32 room = n - p;
+            u32 len_d = (u32)bw_cur & 0xFFFFu;
+            const u32 off_d = (u32)(bw_cur >> 32), back_d = ((u32)bw_cur >> 16) & 0xFFu;
+            if (len_d > room) len_d = room;
+            // the repeat offset: measured out of the two LDS buffers
+            u32 l_r = 0;
+            if (rep && p + reach >= rep) {
+                l_r = common_bytes(v, lds64(S.rbuf, t + 8));
+                for (u32 o = 8; l_r == o && o < ZL_DEEP_CAP; o += 16) l_r += lds_common16(S.wbuf, t + o, S.rbuf, t + 8 + o);
+                if (l_r > room) l_r = room;
+            }
+            // a repeat offset costs no offset bits and leaves the history as it is: it wins unless the other is clearly better
+            const int g_d = len_d >= MIN_MATCH ? 4 * (int)len_d - (int)(31 - __clz(off_d + 1)) : -1000;
+            const int g_r = l_r >= MIN_MATCH ? 4 * (int)l_r + 4 : -2000;
+            if (g_r >= g_d || (off_d == rep && l_r >= MIN_MATCH)) {
+                if (l_r >= MIN_MATCH) {
+                    best_len = (off_d == rep && len_d > l_r) ? len_d : l_r;  // (the same match, measured further by the search)
+                    best_off = rep;
+                    if ((t & 63) >= 8) {
+                        const u64 x = v_front ^ lds64(S.rbuf, t);
+                        back = x ? (u32)(__builtin_clzll(x) >> 3) : 8u;
+                        const u32 src_room = p + reach - rep;  // bytes between the section's (frame's) start and the source
+                        if (back > src_room) back = src_room;
+                    }
+                }
+            } else { best_len = len_d; best_off = off_d; back = back_d; }
+        }
+        bool has_match = best_len >= MIN_MATCH;
+        S.cand[t] = has_match ? ((u64)best_len | ((u64)best_off << 32)) : 0ull;
+        lds_barrier();
+        // ---- lazy evaluation against the matches one and two positions on (zstd.c:31546 ZSTD_compressBlock_lazy_generic: a gain of 4 / 7 is asked for)
+        if (has_match) {
+            const int g0 = 4 * (int)best_len - (int)(31 - __clz(best_off + 1));
+            const u64 n1 = S.cand[t + 1];
+            if (n1 && 4 * (int)(u32)n1 - (int)(31 - __clz((u32)(n1 >> 32) + 1)) > g0 + 4) has_match = false;
+            const u64 n2 = S.cand[t + 2];
+            if (a.lazy2 && n2 && 4 * (int)(u32)n2 - (int)(31 - __clz((u32)(n2 >> 32) + 1)) > g0 + 7) has_match = false;
+        }
+        // ---- greedy parse over the window: wave-local closure with lane shuffles, the four segments chained through LDS
+        const u32 wbase = t & ~63u, wave = t >> 6;
+        u32 jr[6];
+        u32 jp = t + (has_match ? best_len : 1u);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            jr[r] = jp;
+            const u32 far = __shfl(jp, (int)((jp - wbase) & 63), 64);
+            jp = (jp < wbase + 64) ? far : jp;
+        }
+        S.jump[t] = (u16)jp;
+        lds_barrier();
+        u32 enter = carry, my_entry = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            if (enter < 64 * (k + 1)) {
+                if (k == wave) my_entry = enter;
+                enter = S.jump[enter];
+            }
+        }
+        carry = enter - DEEP_THREADS;
+        const bool on_path = zl_path_marks(jr, t, wbase, my_entry);
+        bool is_seq = on_path && has_match, is_lit = on_path && !has_match && in_range;
+        // ---- backward extension over the free literals in front of a sequence, inside its wave (zstd.c:31707 "catch up")
+        u32 bk = 0;
+        {
+            const u64 ms0 = __ballot(is_seq), ml0 = __ballot(is_lit);
+            const u32 lane = t & 63;
+            if (is_seq && back) {
+                const u64 below_inv = ~ml0 & ((1ull << lane) - 1);                                  // lanes below that are NOT literals
+                const u32 run = below_inv ? lane - (64u - (u32)__builtin_clzll(below_inv)) : lane;  // free literals right in front of this lane
+                bk = back < run ? back : run;
+            }
+            // a literal lane asks the next sequence lane above it how far back that one reaches
+            const u64 above = lane == 63 ? 0ull : (ms0 >> (lane + 1));
+            const u32 nxt_seq = above ? lane + 1 + (u32)__builtin_ctzll(above) : lane;
+            const u32 k_nxt = __shfl(bk, (int)nxt_seq, 64);
+            if (is_lit && above && k_nxt >= nxt_seq - lane) is_lit = false;
+        }
+        // ---- compaction ranks from ballots; the four waves exchange their totals through LDS
+        const u64 ms = __ballot(is_seq), ml = __ballot(is_lit);
+        const u64 below = (1ull << (t & 63)) - 1;
+        if ((t & 63) == 0) S.scan_a[wave] = (u32)__popcll(ms) | ((u32)__popcll(ml) << 16);
+        lds_barrier();
+        u32 pre = 0, tot = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) {
+            const u32 x = S.scan_a[w];
+            if (w < wave) pre += x;
+            tot += x;
+        }
+        const u32 ex_s = (pre & 0xFFFF) + (u32)__popcll(ms & below), ex_l = (pre >> 16) + (u32)__popcll(ml & below);
+        const u32 tot_s = tot & 0xFFFF, tot_l = tot >> 16;
+        if (is_lit) lits[nlit + ex_l] = (u8)v;
+        if (is_seq) {
+            zl_seq sq;
+            sq.lit_cum = nlit + ex_l;
+            sq.match_len = best_len + bk;
+            sq.offset = best_off;
+            sq.pos = p - bk;
+            seqs[nseq + ex_s] = sq;
+            if (ex_s + 1 == tot_s) S.rep = best_off;  // last sequence of the window
+        }
+        nseq += tot_s;
+        nlit += tot_l;
+        wb_cur = wb_next;
+        bw_cur = bw_next;
+        lds_barrier();
+    }
+    const u32 out_n = zl_merge_pieces(seqs, nseq, S.t_end, S.t_off, S.scan_a);
+    if (t == 0) {
+        a.meta[c].nseq = out_n;
+        a.meta[c].nlit = nlit;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+namespace {
+size_t g_sort_temp = 0;  // hipcub's temporary storage for a full section (a function of the item count only)
+size_t sort_temp_bytes() {
+    if (!g_sort_temp) {
+        size_t b = 0;
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, DEEP_SEC_MAX, 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
+        g_sort_temp = (b + 255) & ~(size_t)255;
+    }
+    return g_sort_temp;
+}
+}  // namespace
+
+extern "C" size_t zl_deep_scratch_bytes(void) { return 2 * (size_t)DEEP_SEC_MAX * sizeof(u64) + sort_temp_bytes() + 256; }
+
+extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream) {
+    if (a->hi <= a->lo) return hipSuccess;
+    if (a->scratch_bytes < zl_deep_scratch_bytes()) return hipErrorInvalidValue;
+    u64* const keys_a = (u64*)a->scratch;
+    u64* const keys_b = keys_a + DEEP_SEC_MAX;
+    void* const temp = keys_b + DEEP_SEC_MAX;
+    const u32 mml_shift = 64u - 8u * a->mml;
+    for (u64 s0 = a->lo; s0 < a->hi;) {
+        const u64 s1 = std::min<u64>(a->hi, (s0 & ~(DEEP_SEC_BYTES - 1)) + DEEP_SEC_BYTES);
+        const u32 n = (u32)(s1 - s0);
+        const u8* sec = a->src + s0;
+        const u32 blocks = (n + DEEP_THREADS - 1) / DEEP_THREADS;
+        hipLaunchKernelGGL(zl_deep_key_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, sec, n, mml_shift, keys_a);
+        size_t tb = sort_temp_bytes();
+        const hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, tb, (const u64*)keys_a, keys_b, n, 32, 32 + ZL_DEEP_HLOG, stream);
+        if (e != hipSuccess) return e;
+        u64* const best = a->best + (s0 - a->lo);
+        if (a->k <= 16) hipLaunchKernelGGL((zl_deep_search_kernel<16>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
+        else if (a->k <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
+        else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best);
+        hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec);
+        s0 = s1;
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_match_deep_kernel, dim3(nchunks), dim3(DEEP_THREADS), 0, stream, *a, nchunks);
+    return hipGetLastError();
+}

@@ -78,6 +78,36 @@ struct zl_match_args {
     u32 intra;             // some chunk of the launch has flags bit 0 set (selects the kernel instantiation that can honour it)
     u32 pad0;
     const u32* far_hints;  // windowed layout only: per chunk ZL_FAR_HINT_WORDS words, [25:0] an offset worth trying around these 32 bytes (0: none)
+    // levels >= 6 (zl_deep.hip): the best earlier occurrence of every position, found before this kernel runs
+    const u64* deep_best;  // one word per input byte from position deep_lo on (ZL_DEEP_* below), or null
+    u64 deep_lo;           // input position of deep_best[0]
+    u64 total;             // bytes of the whole input (the last readable byte of a chunk's section lies below it)
+    u32 joined;            // the chunks are runs of blocks of ONE frame: a source may lie in front of its chunk (inside the chunk's section)
+    u32 pad1;
+};
+
+// ---- the deep match finder (levels >= 6; zl_deep.hip).  Restates what the reference's lazy strategies search -- the most recent
+// positions with the same hash of minMatch bytes, up to 2^searchLog of them, inside the window (zstd.c:31546-33746: hash chains
+// and the row hash) -- for a machine that cannot walk the input in order: the positions of a section are SORTED by that hash
+// (stable: ascending positions inside a hash value), so a position's K predecessors in the sorted order ARE its K most recent
+// earlier occurrences; a workgroup takes 256 consecutive sorted entries, fetches 64 bytes around every position once, and all
+// comparisons run out of LDS.  Result: one word per position -- the best candidate by the lazy parsers' gain 4 * length - log2(offset).
+#define ZL_DEEP_HLOG 22        // bits of the hash the sort looks at
+#define ZL_DEEP_CAP 56         // bytes a candidate is measured over: a position's record holds [p - 8, p + 56)
+#define ZL_DEEP_BACK 8         // ... and up to this many bytes in front of both
+#define ZL_DEEP_EXT 1024       // a match that fills the record is measured on, this many bytes at most (zl_deep_extend_kernel)
+// best word (64 bits): [15:0] length (0: no candidate), [23:16] bytes that agree in front of both, [63:32] offset
+struct zl_deep_args {
+    const u8* src;     // the input (positions below are offsets into it)
+    u64 lo, hi;        // the positions this call covers: whole chunks of ONE input, in order; sections of 2^(17 + ZL_FAR_SECTION_LOG) bytes are searched one after the other
+    u64 total;         // bytes of the whole input
+    u32 k;             // candidates per position
+    u32 window;        // farthest offset
+    u32 mml;           // bytes the hash covers (4, 5 or 6) = shortest match
+    u32 frames;        // 1: independent frames -- a candidate must lie inside the position's own chunk
+    void* scratch;     // zl_deep_scratch_bytes()
+    size_t scratch_bytes;
+    u64* best;         // out: one word per position, best[p - lo]
 };
 
 struct zl_far_args {
@@ -125,6 +155,9 @@ struct zl_gather_args {
 };
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+extern "C" size_t zl_deep_scratch_bytes(void);
+extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream);
+extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream);

@@ -158,13 +158,15 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
     return t_both < 0.75 * (t_up + t_dn) && t_dn < 1.3 * t_up && t_up < 1.3 * t_dn;
 }
 
+}  // namespace
+
 // A few host threads that stay around between calls, for the per-object loops of the batch entries (pack, header parse,
 // unpack: 100k memcpys of a few hundred bytes).  Starting seven threads costs 0.2-0.5 ms, which is what such a loop takes
 // on one thread; waking sleeping ones costs a tenth of that.  One user at a time (a second caller runs its loop itself);
 // the workers are never joined (the object is leaked on purpose: they sleep on it until the process ends -- which is why the
 // library is linked with -z nodelete: unloading it would unmap the code they sleep in); a forked child has none of them and
 // runs its loops on the calling thread.
-struct ZlPool {
+struct __attribute__((visibility("hidden"))) ZlPool {
     static const size_t kWorkers = 7;
     std::mutex m, user;
     std::condition_variable cv_work, cv_done;
@@ -198,9 +200,11 @@ struct ZlPool {
         cv_done.wait(l, [&] { return done == want; });
     }
 };
-inline ZlPool* g_pool = nullptr;  // (this header sits inside each API file's anonymous namespace: one pool for the compression entries, one for the decompression entries)
-inline std::once_flag g_pool_once;
-inline ZlPool* zl_pool() {
+// ONE pool per process: the struct and the two variables have external linkage (inline, C++17), so the translation units that
+// include this header share them (until round 4 they sat inside the anonymous namespace below: a pool per API file, 14 parked threads).
+__attribute__((visibility("hidden"))) inline ZlPool* g_pool = nullptr;
+__attribute__((visibility("hidden"))) inline std::once_flag g_pool_once;
+__attribute__((visibility("hidden"))) inline ZlPool* zl_pool() {
     std::call_once(g_pool_once, []() {
         pthread_atfork(nullptr, nullptr, []() { g_pool = nullptr; });  // (the child has none of the workers: it runs its loops itself)
         ZlPool* p = new (std::nothrow) ZlPool();
@@ -212,6 +216,8 @@ inline ZlPool* zl_pool() {
     });
     return g_pool;
 }
+
+namespace {
 
 // f(begin, end) over [0, n) on up to 8 host threads (the calling one among them); ranges of at least `grain` items, so
 // small batches stay on the caller.

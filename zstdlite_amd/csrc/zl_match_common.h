@@ -2,6 +2,7 @@
 // LDS-only barrier.
 #pragma once
 #include "zl_device.h"
+#include "zl_encode.h"
 
 #ifndef LONG_LOG
 #define LONG_LOG 13        // 8-byte-hash table: 2^13 16-bit entries (16 KiB LDS)
@@ -74,3 +75,68 @@ __device__ __forceinline__ u32 common_bytes(u64 a, u64 b) {
 // behind the loop, which re-reads the sequences) must use zl_sync_global() -- vmcnt(0) + barrier -- not
 // this; tests/test_fullsize_gpu.py::test_one_gib_ten_times_on_fresh_contexts is the net under it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Which nodes of a wave's 64 lie on the path that enters at `entry` (a lane of this wave, or none)?  jr[r] = the node 2^r steps
+// on (window-relative; >= wbase + 64: outside).  Every node that is marked marks the node 2^r steps on, r = 0..5: the marks
+// travel from lane to lane through ds_permute (each lane SENDS a 1 to the lane it names; lanes that have nothing to say name
+// lane 0, which no step can land on, and whatever arrives there is ignored) -- six LDS-crossbar round trips and no memory.
+// Rounds 1-3 kept the marks in an LDS byte array: a read and a dependent write per round, fourteen round trips.
+__device__ __forceinline__ bool zl_path_marks(const u32 (&jr)[6], u32 t, u32 wbase, u32 my_entry) {
+    const u32 lane = t & 63;
+    u32 mk = (t == my_entry) ? 1u : 0u;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const bool send = mk != 0 && jr[r] < wbase + 64;
+        const u32 dst = send ? ((jr[r] & 63) << 2) : 0u;
+        const u32 got = (u32)__builtin_amdgcn_ds_permute((int)dst, 1);
+        mk |= lane ? got : 0u;
+    }
+    return mk != 0;
+}
+
+// ---- merge continuation pieces.  A lane verifies a bounded number of bytes, so a longer match arrives as several sequences:
+// one starts where the last one ends, with the same offset and no literal between them.  Coded as they are, every piece after
+// the first would spell its offset out (a repeat offset needs a literal in front of it, zstd.c:19680); joined, they are the one
+// sequence the reference would have found.  One pass over the chunk's sequences, 256 at a time, compacting in place: heads move
+// down, pieces add their length to their head.  t_end, t_off: 256 words of LDS each; scan_a: 4 words.  Returns the new count.
+__device__ __forceinline__ u32 zl_merge_pieces(zl_seq* seqs, u32 nseq, u32* t_end, u32* t_off, u32* scan_a) {
+    const u32 t = threadIdx.x;
+    u32 out_n = nseq;
+    if (nseq > 1) {
+        zl_sync_global();  // the sequences were written by other lanes
+        u32 carried_end = 0xFFFFFFFFu, carried_off = 0;  // of the last sequence of the tile before (uniform)
+        out_n = 0;
+        for (u32 base = 0; base < nseq; base += 256) {
+            const u32 i = base + t;
+            const bool on = i < nseq;
+            zl_seq sq;
+            sq.lit_cum = sq.match_len = sq.offset = sq.pos = 0;
+            if (on) sq = seqs[i];
+            t_end[t] = on ? sq.pos + sq.match_len : 0xFFFFFFFFu;
+            t_off[t] = sq.offset;
+            zl_sync_global();  // every lane holds its sequence before any slot of the array is rewritten
+            const u32 pe = t ? t_end[t - 1] : carried_end, po = t ? t_off[t - 1] : carried_off;
+            const bool cont = on && sq.pos == pe && sq.offset == po;
+            const bool head = on && !cont;
+            const u64 mh = __ballot(head);
+            const u32 wave = t >> 6, wh = (u32)__popcll(mh);
+            if ((t & 63) == 0) scan_a[wave] = wh;
+            const u32 last = (nseq - base < 256 ? nseq - base : 256) - 1;
+            const u32 next_end = t_end[last], next_off = t_off[last];
+            lds_barrier();
+            u32 pre = 0, tot = 0;
+#pragma unroll
+            for (u32 w = 0; w < 4; w++) { const u32 x = scan_a[w]; if (w < wave) pre += x; tot += x; }
+            // heads up to and including this lane: the head's new slot is that count minus one
+            const u32 dest = out_n + pre + (u32)__popcll(mh & ((2ull << (t & 63)) - 1)) - 1;
+            if (head) seqs[dest] = sq;
+            zl_sync_global();  // heads are in place before their pieces add to them
+            if (cont) atomicAdd(&seqs[dest].match_len, sq.match_len);
+            carried_end = next_end;
+            carried_off = next_off;
+            out_n += tot;
+            lds_barrier();
+        }
+    }
+    return out_n;
+}
