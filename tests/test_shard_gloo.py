@@ -96,6 +96,30 @@ def test_bench_spawns_its_own_ranks_dry():
         assert line["n_gpus"] == n and line["world_size"] == n and line["per_rank_ok"]
 
 
+def test_bench_dry_at_the_shape_of_config_c5():
+    """BASELINE config C5 (8 GiB over 8 GPUs) has never run on hardware here (the pool hands out one GPU); what CAN be pinned without
+    it: eight ranks over gloo go through the bench's whole control flow -- shard plan, size all-gather, payload gather to rank 0,
+    barrier-bracketed max-over-ranks timing -- and every rank's byte range is the shard plan of ONE vector of 8 x the per-rank
+    size (the same plan at C5's literal size).  A control-flow test, not a measurement."""
+    import json
+    import subprocess
+    from zstdlite_amd.shard import plan_shards
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    per_rank = 5 * CHUNK
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry", "--gpus", "8", "--size", str(per_rank), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["dry"] is True and line["n_gpus"] == 8 and line["world_size"] == 8 and line["per_rank_ok"]
+    assert line["vector_bytes"] == 8 * per_rank
+    assert [tuple(x) for x in line["shard_of_rank"]] == plan_shards(8 * per_rank, 8)
+    # the plan at C5's own size: contiguous, chunk-aligned, 1 GiB each, covering the vector
+    plan = plan_shards(8 << 30, 8)
+    assert plan == [(r << 30, (r + 1) << 30) for r in range(8)]
+    assert all(a % CHUNK == 0 for a, _ in plan)
+
+
 def _sub_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

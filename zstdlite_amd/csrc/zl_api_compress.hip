@@ -246,7 +246,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
     m.far_hints = (joined && !deep) ? (const u32*)es.far_hints.p : nullptr;
     m.intra = c->any_small ? 1u : 0u;
-    m.pad0 = 0;
+    m.accel = c->level < 0 ? (u32)std::min(-c->level, 7) : 0u;
     m.deep_best = deep ? (const u64*)es.deep_best.p : nullptr;
     m.deep_lo = deep_lo;
     m.total = c->input_total;
@@ -301,6 +301,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.out_stride = sd.out;
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
+    e.raw_lits = c->level < 0 ? 1u : 0u;
     e.exact_rep = c->level >= 6 ? 1u : 0u;
     e.joined = joined ? 1u : 0u;
     e.chunk_base = (u32)(frame_chunk0 + first);

@@ -79,22 +79,37 @@ template <int KMAX>
 __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64* sorted, u32 n, const u8* sec, u32 K, u32 window, u32 min_len, u32 frames, u64* best) {
     constexpr u32 E = DEEP_THREADS + KMAX;
     __shared__ uint4 rec[4][E];  // rec[j][e]: bytes [p - 8 + 16 j, p + 8 + 16 j) of entry e's position (one array per slice: consecutive lanes read consecutive slots)
-    __shared__ u32 spos[E];
-    __shared__ u32 shash[E];
+    __shared__ u32 spos[E + 1];
+    __shared__ u32 shash[E + 1];  // (one entry behind the block: does the last one have a twin?)
+    __shared__ u8 shave[E + 1];
     const u32 t = threadIdx.x;
     const u32 i0 = blockIdx.x * DEEP_THREADS;
-    for (u32 e = t; e < E; e += DEEP_THREADS) {
+    // positions and hashes first: an entry whose hash neither neighbour shares has no candidate and is nobody's candidate
+    for (u32 e = t; e < E + 1; e += DEEP_THREADS) {
         const i64 idx = (i64)i0 + (i64)e - KMAX;
-        u32 pos = 0, h = 0xFFFFFFFFu;  // (no entry: a hash no position has)
-        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        u32 pos = 0, h = 0xFFFFFFFFu;
+        bool have = false;
         if (idx >= 0 && idx < (i64)n && (e >= (u32)KMAX || e + K >= (u32)KMAX)) {  // (of the entries in front only the K nearest are looked at)
             const u64 key = sorted[idx];
             pos = (u32)key;
             h = (u32)(key >> 32);
-            const i32 a = (i32)pos - 8;
+            have = true;
+        }
+        spos[e] = pos; shash[e] = h; shave[e] = have ? 1 : 0;
+    }
+    __syncthreads();
+    for (u32 e = t; e < E; e += DEEP_THREADS) {
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        const u32 h = shash[e];
+        const bool twin = (e > 0 && shave[e - 1] && shash[e - 1] == h) || (shave[e + 1] && shash[e + 1] == h);
+#if defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 2)
+        if (shave[e] && twin && spos[e] == 0x7FFFFFF1u) {  // (experiment: no record loads)
+#else
+        if (shave[e] && twin) {
+#endif
+            const i32 a = (i32)spos[e] - 8;
             r0 = deep_ld16(sec, a, n); r1 = deep_ld16(sec, a + 16, n); r2 = deep_ld16(sec, a + 32, n); r3 = deep_ld16(sec, a + 48, n);
         }
-        spos[e] = pos; shash[e] = h;
         rec[0][e] = r0; rec[1][e] = r1; rec[2][e] = r2; rec[3][e] = r3;
     }
     __syncthreads();
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
     for (u32 k = 1; k <= K; k++) {
         const u32 ce = e - k;
         const u32 q = spos[ce];
-        alive = alive && shash[ce] == hme && q >= lo && q < p;  // (positions ascend inside a hash value: the first one below the window ends the walk)
+        alive = alive && shave[ce] && shash[ce] == hme && q >= lo && q < p;  // (positions ascend inside a hash value: the first one below the window ends the walk)
         if (!__any(alive)) break;
         if (alive) {
             u32 len = cb64(m0.z, m0.w, rec[0][ce].z, rec[0][ce].w);
@@ -142,7 +157,13 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
         if (back > p - chunk0) back = p - chunk0;  // nor the sequence in front of its chunk
         word = (u64)(bl | (back << 16)) | ((u64)bo << 32);
     }
+#if defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 1)
+    if (word == 0x123456789ABCDEFull) best[p] = word;  // (experiment: no scattered store)
+#elif defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 4)
+    best[i0 + t] = word;  // (experiment: the store in sorted order, coalesced)
+#else
     best[p] = word;
+#endif
 }
 
 
@@ -241,6 +262,34 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
     };
     if (t < 2) S.cand[DEEP_THREADS + t] = 0;
     if (t == 0) S.rep = 0;
+    // ---- what is a match worth?  (zl_match_auto_kernel, zl_encode.hip, says it at length: a sequence with a new offset costs some 24
+    // bits, the literals it replaces cost what the chunk's bytes cost; where bytes are cheap -- i.i.d. data over a dozen symbols --
+    // new-offset matches of fewer than eight bytes lose bits, and the deep search finds MANY of them: every position of such data
+    // has sixteen earlier occurrences of its five bytes.)  Order-0 entropy of 16 KiB sampled from the chunk's four quarters; the
+    // rule starts behind the chunk's first 4 KiB, where matches covered less than a tenth of those bytes.
+    bool cheap = false;
+    if (n >= 16384) {
+        u32* const bins = S.t_end;  // [256]
+        bins[t] = 0;
+        lds_barrier();
+        for (u32 part = 0; part < 4; part++) {
+            const uint4 x = ld128(src + (size_t)part * (n >> 2) + 16 * t);
+            const u32 w4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) { atomicAdd(&bins[w4[k] & 0xFF], 1u); atomicAdd(&bins[(w4[k] >> 8) & 0xFF], 1u); atomicAdd(&bins[(w4[k] >> 16) & 0xFF], 1u); atomicAdd(&bins[w4[k] >> 24], 1u); }
+        }
+        lds_barrier();
+        const u32 cnt = bins[t];
+        float bits = cnt ? (float)cnt * (14.0f - __log2f((float)cnt)) : 0.0f;  // cnt * log2(16384 / cnt)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d, 64);
+        if ((t & 63) == 0) S.scan_a[t >> 6] = __float_as_uint(bits);
+        lds_barrier();
+        const float total = __uint_as_float(S.scan_a[0]) + __uint_as_float(S.scan_a[1]) + __uint_as_float(S.scan_a[2]) + __uint_as_float(S.scan_a[3]);
+        cheap = total * 10.0f < 36.0f * 16384.0f;  // below 3.6 bits per byte
+        lds_barrier();
+    }
+    u32 smin = MIN_MATCH, probed = 0, probed_lits = 0;  // shortest new-offset match kept (uniform)
     u32 nseq = 0, nlit = 0, carry = 0;
     uint4 wb_cur = make_uint4(0, 0, 0, 0);
     if (t < DEEP_WBUF / 16) wb_cur = ld16((i32)(16 * t));
@@ -270,6 +319,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
             u32 len_d = (u32)bw_cur & 0xFFFFu;
             const u32 off_d = (u32)(bw_cur >> 32), back_d = ((u32)bw_cur >> 16) & 0xFFu;
             if (len_d > room) len_d = room;
+            if (len_d < smin) len_d = 0;
             // the repeat offset: measured out of the two LDS buffers
             u32 l_r = 0;
             if (rep && p + reach >= rep) {
@@ -369,6 +419,10 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         }
         nseq += tot_s;
         nlit += tot_l;
+        if (cheap && probed < 4096) {
+            probed += DEEP_THREADS; probed_lits += tot_l;
+            if (probed >= 4096 && (probed - probed_lits) * 10 < probed) smin = 8;
+        }
         wb_cur = wb_next;
         bw_cur = bw_next;
         lds_barrier();

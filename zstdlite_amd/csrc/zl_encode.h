@@ -76,7 +76,7 @@ struct zl_match_args {
     const u8* dict;   // those bytes
     const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)
     u32 intra;             // some chunk of the launch has flags bit 0 set (selects the kernel instantiation that can honour it)
-    u32 pad0;
+    u32 accel;             // negative levels (-accel): windows without a match are skipped (1 + accel) times as eagerly (cf. the step of ZSTD_fast, zstd.c:29340: targetLength = -level)
     const u32* far_hints;  // windowed layout only: per chunk ZL_FAR_HINT_WORDS words, [25:0] an offset worth trying around these 32 bytes (0: none)
     // levels >= 6 (zl_deep.hip): the best earlier occurrence of every position, found before this kernel runs
     const u64* deep_best;  // one word per input byte from position deep_lo on (ZL_DEEP_* below), or null
@@ -92,7 +92,7 @@ struct zl_match_args {
 // (stable: ascending positions inside a hash value), so a position's K predecessors in the sorted order ARE its K most recent
 // earlier occurrences; a workgroup takes 256 consecutive sorted entries, fetches 64 bytes around every position once, and all
 // comparisons run out of LDS.  Result: one word per position -- the best candidate by the lazy parsers' gain 4 * length - log2(offset).
-#define ZL_DEEP_HLOG 22        // bits of the hash the sort looks at
+#define ZL_DEEP_HLOG 24        // bits of the hash the sort looks at: three passes of the radix sort (all 32 bits -- equal hashes are then equal minMatch bytes, and a position without a twin in the sorted order is never fetched -- cost a fourth pass, 0.35 ms per section, and spared the fetches of random bytes only: 1 GiB mix 73.3 -> 74.0 ms, text 17.6 -> 19.4 ms per 256 MiB)
 #define ZL_DEEP_CAP 56         // bytes a candidate is measured over: a position's record holds [p - 8, p + 56)
 #define ZL_DEEP_BACK 8         // ... and up to this many bytes in front of both
 #define ZL_DEEP_EXT 1024       // a match that fills the record is measured on, this many bytes at most (zl_deep_extend_kernel)
@@ -135,6 +135,7 @@ struct zl_entropy_args {
     u32 out_stride;
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
+    u32 raw_lits;      // negative levels: literals are stored, not Huffman-coded (zstd.c:20675 ZSTD_literalsCompressionIsDisabled: strategy fast with a target length, i.e. every negative level)
     u32 exact_rep;     // levels >= 6: the three-entry repeat-offset history of the decoder is followed sequence by sequence, codes 2 and 3 are emitted
     // single-frame layout: the chunks of this launch are consecutive runs of blocks of ONE frame
     u32 joined;        // 1: chunk 0 of the frame carries the frame header, only the frame's last chunk sets Last_Block, no per-chunk checksum

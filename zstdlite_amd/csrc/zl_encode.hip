@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         // emitted as literals without searching or inserting.  A pure function of the data, so the
         // output stays deterministic.  Any sequence resets it.
         miss = (win_seqs == 0 && carry == 0) ? miss + 1 : 0;
-        u32 skip = miss >> 2;
+        u32 skip = (miss * (1u + a.accel)) >> 2;  // (negative levels: -accel)
 #ifndef ZL_SKIP_MAX
 #define ZL_SKIP_MAX 7
 #endif
@@ -2538,7 +2538,7 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
         // but not the lanes of one instruction -- and those are what the LDS serialises: literals over a ten-letter alphabet put
         // six lanes on every bin): the lanes that hit one byte value spread over four neighbouring banks.
         u32* const H = &S.hist[0][0] + (lane & 3);
-        const u32 body = nlit & ~15u;
+        const u32 body = a.raw_lits ? 0u : (nlit & ~15u);  // (negative levels store their literals: nothing to count)
         u32 zeros = 0;
         for (u32 i = t * 16; i < body; i += ENC_THREADS * 16) {
             const uint4 v = ld128(lit + i);
@@ -2554,7 +2554,7 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
             }
         }
         if (zeros) atomicAdd(&H[0], zeros);
-        if (t < nlit - body) atomicAdd(&H[4 * (u32)lit[body + t]], 1u);
+        if (!a.raw_lits && t < nlit - body) atomicAdd(&H[4 * (u32)lit[body + t]], 1u);
     }
     // (the three code histograms likewise in four copies per bin, in the staging words -- 3 KiB that nothing else uses during this
     // pass --, summed into seq_hist behind the barrier: a text chunk's 18 000 sequences share a handful of codes)
@@ -2611,6 +2611,7 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
             u32 mode = 0;
             if (nlit > 63 && present == 1) mode = 1;   // zstd.c:20725 minLitSize, :20750 RLE
             else if (nlit > 63 && present >= 2) mode = 2;
+            if (a.raw_lits) mode = 0;
             S.lit_mode = mode;
             S.tree_size = 0;
         }
