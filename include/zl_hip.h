@@ -257,8 +257,11 @@ size_t zl_index_frames(const void *src, size_t srcSize, zl_frame_t *frames, size
  * Inside such a session ZL_e_flush cuts no run: the frame's runs end at 64 MiB boundaries and at the
  * pledged end only, so a flush hands out the jobs that are complete and keeps collecting the rest
  * (the reference's glue never flushes; a frame of its own in mid-frame would be an invalid stream).
- * So in a pledged session a return of 0 from ZL_e_flush does NOT mean that everything consumed so far
- * can be decoded from the output: up to one job of input stays collected until its boundary or the end.
+ * So in a pledged session NOT everything consumed so far can be decoded from what a flush hands out: up to one
+ * job of input stays collected until its boundary or the end, and ZL_e_flush says so -- the first flush after
+ * input has arrived returns the bytes that wait to be handed out PLUS the input bytes that stay collected
+ * (non-zero: zstd.h:841-880 reads that as "not fully flushed").  The same flush repeated without new input
+ * returns only the former, so that the loop zstd.h documents ("call again until it returns 0") ends.
  * Without a pledge every job is a frame of its own with its own recorded size: valid zstd that
  * ZSTD_decompressStream / ZSTD_decompress read frame after frame.
  * A full job runs on a host thread of the context's own while the caller's next pieces are collected

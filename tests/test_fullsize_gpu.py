@@ -207,8 +207,21 @@ def test_device_slots_behind_the_host_entries():
                 got, used = _host_roundtrip(L, host, layout, slots, seek)
                 assert np.array_equal(got, one), (layout, seek, slots)
                 assert used[0] == slots and (used[1] == 1 if (layout == 2 and not seek) else used[1] >= slots), (layout, seek, slots, used)
+    # BASELINE config C5's shape: eight slots (on one device here) write the bytes one slot writes, for an input of 8 x 128 MiB + a tail
+    got8, used8 = _host_roundtrip(L, host, 2, 8, 1)
+    assert np.array_equal(got8, _host_roundtrip(L, host, 2, 1, 1)[0]) and used8[0] == 8
+
+
+def test_device_slots_on_every_visible_device():
+    """The multi-device leg of the test above (ZL_c_devices = 0: every visible device): needs more than one GPU; the pool's boxes
+    have one, so it skips there -- on its own, so that the one-device body above reports what it is: passed."""
+    from zstdlite_amd import _lib
     if torch.cuda.device_count() < 2:
         pytest.skip("one device: the slots shared it; the multi-device leg needs more")
+    L = _lib.lib()
+    n = (640 << 20) + 12345
+    host = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy()
+    one = _host_roundtrip(L, host, 2, 1, 1)[0]
     assert np.array_equal(_host_roundtrip(L, host, 2, 0, 1)[0], one)  # 0: every visible device
 
 

@@ -272,6 +272,31 @@ def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
     assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob) and ref.L.ZSTD_getFrameContentSize(blob, len(blob)) == n
     assert blob == z.zstd_compress(data)
     assert ref.decompress(blob, n) == data
+    # the flush that cannot release everything says so (zstd.h:841-880: non-zero = not fully flushed) -- once; repeated
+    # without new input it returns 0, so that the documented "until it returns 0" loop ends.  An unpledged session's flush does
+    # cut: everything written so far decodes from what it handed out.
+    L = _lib.lib()
+    hint = stream.Compressor(cctx._ptr, pledged=n)
+    held = hint.feed(data[:cut])
+    out = np.empty(1 << 20, dtype=np.uint8)
+    inb = stream._InBuffer(None, 0, 0)
+    rems = []
+    for _ in range(400):  # (drain what is complete)
+        outb = stream._OutBuffer(out.ctypes.data, out.size, 0)
+        rem = L.zl_compressStream2(cctx._ptr, C.byref(outb), C.byref(inb), stream.E_FLUSH)
+        assert not _lib.is_error(rem)
+        held += out[:outb.pos].tobytes()
+        rems.append((rem, outb.pos))
+        if rem == 0:
+            break
+    assert rems[-1][0] == 0 and len(rems) < 400
+    collected = cut - (64 << 20)  # one job is complete, the rest of the input stays collected
+    assert any(r >= collected for r, _ in rems), rems[:4]
+    assert len(held) > 0 and len(held) < len(blob)
+    loose = stream.Compressor(cctx._ptr)
+    first = loose.feed(data[:5 << 20]) + loose.flush()
+    assert z.zstd_decompress(first) == data[:5 << 20] and ref_stream_decompress(ref, first) == data[:5 << 20]
+    assert first + loose.finish(data[5 << 20:6 << 20]) != b""
     # more input than was pledged is an error, not a second frame (zstd.c:24140)
     over = stream.Compressor(cctx._ptr, pledged=1000)
     with pytest.raises(stream.ZstdStreamError, match="Src size is incorrect"):

@@ -43,9 +43,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
@@ -82,6 +82,7 @@ struct zl_cctx_s {
         bool emitted = false;   // a frame has been written in this session
         bool finishing = false; // ZL_e_end has compressed the rest; only handing out remains
         bool joined = false;    // the session's jobs are consecutive runs of blocks of ONE frame (decided when the first input arrives)
+        bool flush_told = false;  // a ZL_e_flush has reported the input that stays collected since input last arrived
         zlx::Xxh64 hash;        // joined session with ZL_c_checksumFlag: the content checksum runs through all jobs
         // round 4: a full job runs on a thread of its own while the caller's next pieces are collected (one job at a time; every
         // other entry that touches the context waits for it first: cs_wait)
@@ -229,6 +230,14 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         if (zl_launch_far_probe(&f, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stage_ok("far probe");
     }
+    // launch order: longest first (zl_launch_chunk_order), for launches that fill the device several times over
+    const u32* order = nullptr;
+    if (cnt >= 2048 && c->chunk_cap >= ZL_CHUNK && c->dict_use == 0) {  // (a dictionary frame's first chunk is a launch of its own)
+        if (!es.order.ensure((size_t)cnt * 8 + 64)) return kGpuUnavailable;
+        if (zl_launch_chunk_order((const zl_chunk_desc*)c->d_chunks.p + first, d_src, cnt, (u32*)es.order.p + cnt, (u32*)es.order.p, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        order = (const u32*)es.order.p;
+        stage_ok("order");
+    }
     zl_match_args m;
     m.chunks = (const zl_chunk_desc*)c->d_chunks.p + first;
     m.src = d_src;
@@ -252,6 +261,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.total = c->input_total;
     m.joined = joined ? 1u : 0u;
     m.pad1 = 0;
+    m.order = order;
     if (deep) m.lazy2 = dl.lazy2;
 #ifdef ZL_TRACE
     // development build: the match kernel stamps a timeline of one workgroup's iterations behind the 128 bytes of phase sums
@@ -309,6 +319,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.wlog = deep ? dl.wlog : (u32)ZL_FAR_WLOG;
     e.total_size = joined_total;
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
+    e.order = order;
     e.stats = m.stats ? m.stats + 8 : nullptr;
     if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     stage_ok("entropy");
@@ -1050,7 +1061,7 @@ size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
         c->cs.out_pos = 0;
         c->cs.pledged = ZL_CONTENTSIZE_UNKNOWN;
         c->cs.consumed = 0;
-        c->cs.started = c->cs.emitted = c->cs.finishing = c->cs.joined = false;
+        c->cs.started = c->cs.emitted = c->cs.finishing = c->cs.joined = c->cs.flush_told = false;
     }
     if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
         if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:22790
@@ -1158,6 +1169,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
             S.joined = S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.pledged > ZL_STREAM_JOB && use_one_frame(c, (size_t)S.pledged, true);
         input->pos += take;
         S.consumed += take;
+        if (take) S.flush_told = false;
         S.started = true;
         if (S.pledged != ZL_CONTENTSIZE_UNKNOWN && S.consumed > S.pledged) return ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:24140: more than was pledged
         if (S.stage.size() == ZL_STREAM_JOB) {
@@ -1189,12 +1201,14 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
     if (S.finishing && S.out.empty()) {  // session complete: the next call starts a new one
         S.pledged = ZL_CONTENTSIZE_UNKNOWN;
         S.consumed = 0;
-        S.started = S.emitted = S.finishing = S.joined = false;
+        S.started = S.emitted = S.finishing = S.joined = S.flush_told = false;
         return 0;
     }
     // ZL_e_flush inside a one-frame (pledged) session cuts no run: the input still collected is part of the answer, so that a caller
     // who reads 0 as "everything consumed so far can be decoded from the output" (zstd.h:841-880) is never told so wrongly
-    if (end_op == ZL_e_flush && S.joined && !S.finishing) return S.out.size() - S.out_pos + S.stage.size();
+    // -- ONCE per stretch of input: a caller that repeats the flush "until it returns 0" (the loop zstd.h documents) would spin for ever on
+    // bytes that only more input or ZL_e_end can release, so the same flush repeated without new input reports only what waits to be handed out.
+    if (end_op == ZL_e_flush && S.joined && !S.finishing && !S.stage.empty() && !S.flush_told) { S.flush_told = true; return S.out.size() - S.out_pos + S.stage.size(); }
     return S.out.size() - S.out_pos;
 }
 

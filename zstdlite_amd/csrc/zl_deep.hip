@@ -239,7 +239,7 @@ __device__ __forceinline__ u32 lds_common16(const u8* a, u32 oa, const u8* b, u3
 __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_args a, u32 nchunks) {
     __shared__ DeepShared S;
     const u32 t = threadIdx.x;
-    const u32 c = zl_spread(blockIdx.x, nchunks);
+    const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;

@@ -84,6 +84,7 @@ struct zl_match_args {
     u64 total;             // bytes of the whole input (the last readable byte of a chunk's section lies below it)
     u32 joined;            // the chunks are runs of blocks of ONE frame: a source may lie in front of its chunk (inside the chunk's section)
     u32 pad1;
+    const u32* order;      // launch order (zl_launch_chunk_order): workgroup w takes chunk order[zl_spread(w)], or null: chunk zl_spread(w)
 };
 
 // ---- the deep match finder (levels >= 6; zl_deep.hip).  Restates what the reference's lazy strategies search -- the most recent
@@ -144,6 +145,7 @@ struct zl_entropy_args {
     u32 wlog;          // window the header declares when the content is larger than it
     u64 total_size;    // content size of the whole frame
     const void* cdict; // zl_cdict* (device) or null: the dictionary's entropy tables, offered to frames of a single block
+    const u32* order;  // launch order of the chunks, as the match kernel's (or null)
     u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
 
@@ -159,6 +161,8 @@ extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipSt
 extern "C" size_t zl_deep_scratch_bytes(void);
 extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream);
 extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+// order[0 .. nchunks): the chunks by decreasing estimated cost (longest first), input order inside a class; scratch: nchunks words
+extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u8* src, u32 nchunks, u32* cost_scratch, u32* order, hipStream_t stream);
 extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_far_probe(const zl_far_args* a, u32 nchunks, hipStream_t stream);
 extern "C" hipError_t zl_launch_dict_hash(const u8* d_content, u32 n, u32* d_tables, hipStream_t stream);

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     __shared__ MatchSharedT<LLOG, SLOG, WB> S;
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
-    const u32 c = zl_spread(blockIdx.x, nchunks);
+    const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;
@@ -338,6 +338,15 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     u32 probed = 0, probed_lits = 0;
 #define tmin (smin > tmin0 ? smin : tmin0)  /* stride-1 bodies: shortest match a table candidate may be */
 
+    // ---- literals are not copied while a chunk has no sequence.  Random bytes, i.i.d. bytes over a few letters -- half of the bench
+    // mix -- yield none: their windows are emitted "as literals" seven times in eight without a search (below), and all that did was
+    // copy the chunk, 16 bytes per lane, into a buffer from which the entropy stage read it again (the kernel wrote
+    // 1.67 GB of intermediates per GiB).  While nseq == 0 every byte in front of the current window is a literal and nlit == ip: the
+    // windows without a match store nothing, the entropy kernel reads such a chunk's literals from the source itself
+    // (meta.nseq == 0), and the first window that does produce a sequence brings the bytes in front of it in, once.
+#define ZL_LITS_CATCH_UP(nlit_before_) do { if (nseq == 0 && tot_s != 0 && (nlit_before_) != 0) { const u32 cnt__ = (nlit_before_), body__ = cnt__ & ~15u; \
+        for (u32 q__ = t * 16; q__ < body__; q__ += ENC_THREADS * 16) { uint4 x__; __builtin_memcpy(&x__, src + q__, 16); __builtin_memcpy(lits + q__, &x__, 16); } \
+        if (t < cnt__ - body__) lits[body__ + t] = src[body__ + t]; } } while (0)
     u32 nseq = 0, nlit = 0;  // uniform running totals
     u32 miss = 0;            // consecutive windows without a sequence (uniform)
     u32 carry = 0;           // where the parse enters the next window, in bytes (uniform)
@@ -522,6 +531,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                 }
                 if (ph < 3) lds_barrier();
             }
+            ZL_LITS_CATCH_UP(nlit);
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
@@ -874,6 +884,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     if (ph < 3) lds_barrier();
                 }
             }
+            ZL_LITS_CATCH_UP(nlit);
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
             if (!any_match) {
                 // ---- a window without a single match -- the rule on data that does not repeat -- needs no parse: every node from
                 // the entry point on is on the path and gives its two bytes (what is left of them at the end of the chunk)
-                if (!covered && t >= carry_n) {
+                if (!covered && t >= carry_n && nseq != 0) {  // (a chunk without a sequence so far keeps its literals where they are: see lits_pending below)
                     const u32 ex = 2 * (t - carry_n);
                     if (in0) lits[nlit + ex] = (u8)v0;
                     if (in1) lits[nlit + ex + 1] = (u8)(v0 >> 8);
@@ -1128,6 +1139,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
                     if (ph < 3) lds_barrier();
                 }
             }
+            ZL_LITS_CATCH_UP(nlit);
             nseq += tot_s;
             nlit += tot_l;
             win_seqs = tot_s;
@@ -1152,7 +1164,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         ip += win;
         if (skip && ip < n) {
             const u32 to = (ip + skip * win < n) ? ip + skip * win : n;
-            {   // 16 bytes per thread and trip (global memory takes unaligned vectors)
+            if (nseq != 0) {   // 16 bytes per thread and trip (global memory takes unaligned vectors)
                 const u32 cnt = to - ip, body = cnt & ~15u;
                 for (u32 q = t * 16; q < body; q += ENC_THREADS * 16) { uint4 x; __builtin_memcpy(&x, src + ip + q, 16); __builtin_memcpy(lits + nlit + q, &x, 16); }
                 if (t < cnt - body) lits[nlit + body + t] = src[ip + body + t];
@@ -1174,6 +1186,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         }
     }
 #undef tmin
+#undef ZL_LITS_CATCH_UP
     if (prof) {
         atomicAdd((unsigned long long*)&a.stats[0], (unsigned long long)c_find);
         atomicAdd((unsigned long long*)&a.stats[1], (unsigned long long)c_parse);
@@ -2428,13 +2441,13 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
     __shared__ EntShared S;
     ZL_POISON(S, 8);
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const u32 c = zl_spread(blockIdx.x, nchunks);
+    const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;
-    const u8* lit = a.lits + (size_t)c * a.lit_stride;
     const zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
     const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
+    const u8* lit = nseq ? a.lits + (size_t)c * a.lit_stride : src;  // (a chunk without a sequence is all literals: the match kernels leave them where they are)
     // per-sequence scratch of the FSE chains, one array per table (ZL_SST_BYTES per sequence slot): the three codes as bytes,
     // the three states BEFORE each sequence as 16-bit words.  (Round 2 kept one 8-byte record per sequence; a chain lane then
     // needed a record per step, and its loop ran at the latency of those loads: one memory round trip per eight steps.  Now
@@ -3105,6 +3118,71 @@ __global__ __launch_bounds__(ENC_THREADS) void zl_gather_kernel(zl_gather_args a
     u8* d = a.dst + a.frame_off[c];
     const u32 n = a.frame_size[c];
     copy_wg(d, s, n);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Launch order: longest first.  A chunk of text costs the match kernel eight times what a chunk of random bytes costs (9.3 against
+// 1.1 ms per GiB); a launch whose expensive chunks come LAST ends with a few workgroups running while the device drains -- the
+// bench mix (a quarter each of random bytes, i.i.d. bytes, text, 20-bit integers, in that order) lost 0.5 of its 3.9 ms that way.
+// zl_chunk_cost_kernel looks at 1 KiB from the middle of every chunk: how many of its 1024 positions repeat eight bytes seen
+// earlier in the sample (a 4096-entry tag table in LDS, one wave per chunk, sixteen look-up-and-insert rounds) -- match-rich data
+// repeats there, match-poor data does not; zl_chunk_order_kernel sorts the chunks by that class, descending, input order inside
+// a class (a counting sort on one workgroup).  Only the schedule depends on it: every chunk's bytes are what they were.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void zl_chunk_cost_kernel(const zl_chunk_desc* chunks, const u8* src_base, u32 nchunks, u32* cost) {
+    __shared__ u32 tab[4096];
+    const u32 c = blockIdx.x, lane = threadIdx.x;
+    const zl_chunk_desc cd = chunks[c];
+    u32 hits = 0;
+    if (cd.src_size >= 4096) {
+        for (u32 i = lane; i < 4096; i += 64) tab[i] = 0;
+        const u8* p = src_base + cd.src_off + (cd.src_size >> 1) + 16 * lane;  // this lane's sixteen positions: bytes [0, 24)
+        const uint4 a = ld128(p);
+        const u64 b = ld64(p + 16);
+        const u64 w[3] = {(u64)a.x | ((u64)a.y << 32), (u64)a.z | ((u64)a.w << 32), b};
+        __syncthreads();
+#pragma unroll
+        for (u32 r = 0; r < 16; r++) {
+            const u64 v = r & 7 ? (w[r >> 3] >> (8 * (r & 7))) | (w[(r >> 3) + 1] << (64 - 8 * (r & 7))) : w[r >> 3];
+            const u64 h = v * 0x9E3779B185EBCA87ULL;
+            const u32 slot = (u32)(h >> 52), tag = (u32)(h >> 20) | 1u;
+            hits += tab[slot] == tag ? 1u : 0u;
+            __syncthreads();  // (one wave: orders the round's look-ups in front of its inserts)
+            tab[slot] = tag;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
+    }
+    if (lane == 0) cost[c] = hits >= 256 ? 3u : (hits >= 64 ? 2u : (hits >= 8 ? 1u : 0u));
+}
+
+#define ZL_ORDER_THREADS 1024
+__global__ __launch_bounds__(ZL_ORDER_THREADS) void zl_chunk_order_kernel(const u32* cost, u32 n, u32* order) {
+    __shared__ u32 cnt[4][ZL_ORDER_THREADS];  // per class and thread: chunks of that class in the thread's range, then where they go
+    const u32 t = threadIdx.x;
+    const u32 per = (n + ZL_ORDER_THREADS - 1) / ZL_ORDER_THREADS;
+    const u32 b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+    u32 k[4] = {0, 0, 0, 0};
+    for (u32 i = b; i < e; i++) k[cost[i] & 3]++;
+    for (int q = 0; q < 4; q++) cnt[q][t] = k[q];
+    __syncthreads();
+    if (t < 4) {  // class 3 first; inside a class the threads' ranges in order
+        u32 base = 0;
+        for (u32 q = 3; q > t; q--) for (u32 i = 0; i < ZL_ORDER_THREADS; i++) base += cnt[q][i];  // (a few thousand additions, once per launch)
+        for (u32 i = 0; i < ZL_ORDER_THREADS; i++) { const u32 v = cnt[t][i]; cnt[t][i] = base; base += v; }
+    }
+    __syncthreads();
+    u32 at[4] = {cnt[0][t], cnt[1][t], cnt[2][t], cnt[3][t]};
+    for (u32 i = b; i < e; i++) order[at[cost[i] & 3]++] = i;
+}
+
+extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u8* src, u32 nchunks, u32* cost_scratch, u32* order, hipStream_t stream) {
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(zl_chunk_cost_kernel, dim3(nchunks), dim3(64), 0, stream, chunks, src, nchunks, cost_scratch);
+    hipLaunchKernelGGL(zl_chunk_order_kernel, dim3(1), dim3(ZL_ORDER_THREADS), 0, stream, (const u32*)cost_scratch, nchunks, order);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
