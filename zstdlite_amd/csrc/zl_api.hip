@@ -1564,7 +1564,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.max_blocks = (u32*)d->d_counter.p + 8;
     f2.order = (u32*)d->d_order.p;  // (the 64-byte counter block is zeroed above; word 0 is the general kernel's queue head)
     f2.ext = nullptr;
-    f2.fuse1 = 3u;  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
+    f2.fuse1 = 3u | (ZL_QUAD_SPLIT ? 4u : 0u);  // single-block launches: literal and sequence lanes in one kernel (bit 0), sequence chains on quads of lanes (bit 1)
     f2.big = nullptr;
     f2.part = 0;
     f2.sym_first = 0;

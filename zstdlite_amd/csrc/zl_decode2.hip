@@ -659,6 +659,7 @@ struct SeqShared {
     short defn[3][64];  // predefined distributions (kind 0 LL, 1 OF, 2 ML), zstd.c:15480-15512
     u32 val_tab[3][64];  // quad chains: baseline of symbol s, one table per role (0 LL, 1 OF: 1 << s, 2 ML)
     u32 qpos[SEQ_FRAMES];  // quad chains: where the frame's bitstream starts this round (0xFFFFFFFF: no chain to run)
+    u32 cmd;               // two-wave chains: 1 = a chain phase follows the barrier, 0 = the role is over (wave 0 tells wave 1)
 };
 // Repcode history of a block that is decoded before its predecessor has finished: the three
 // unknown start values travel as symbols, 0x80000000 | k + 4 * (times "minus one" was applied)
@@ -1075,6 +1076,182 @@ __device__ __forceinline__ u32 seq_chain_quad(SeqShared& S, const SeqLane& L, u3
     return seq_tail(S, L, r, bs, bn, bp, i, sl, so, sm, r0, r1, r2, lit_used, out_used, oseq);
 }
 
+// ---- the quad chain on TWO waves (round 5; fuse1 bit 2).  A chain's time is its instruction count: a wave issues one vector
+// instruction every four cycles whatever the number of lanes at work, and of the 150 instructions of a step above only about 85
+// belong to what the NEXT step waits for -- the state's table entry, the bit cursor, the state bits.  The other 65 -- the three
+// values round the quad, the repeat-offset rules, the running totals, the record and its ring -- depend on nothing but the values.
+// So the workgroup has a second wave: wave 0 (PRODUCER) runs states and cursor and leaves every step's three values in LDS, sixteen
+// steps to a tile; wave 1 (CONSUMER, one lane per chain) follows a tile behind, turns values into records and, at the end of a
+// chain, runs the generic tail (seq_tail) from where the producer stopped.  Two tiles; one workgroup barrier per tile (the producer
+// may not start tile k + 2 before the consumer has left tile k, which is what the barrier of tile k + 1 says).  The tiles, the
+// consumer's record ring and the hand-over words live in S.ring, which the table builds have left by then.
+#define ZLQ_TS 16u
+struct QuadFin { u32 i; i32 bp; u32 sl, so, sm, err, act, pad; };
+struct QuadShare {                 // laid over S.ring (8 KiB)
+    uint4 ring[8][SEQ_FRAMES];     // the consumer's finished records: eight per chain, slot-major
+    u32 tile[2][ZLQ_TS][32];       // [tile][step][producer lane]: the step's value of that lane's role (LL, offset, ML; role 3: unused)
+    u32 tile_n[2][SEQ_FRAMES];     // steps of each chain in the tile
+    u32 more[2];                   // the producer goes on behind this tile
+    QuadFin fin[SEQ_FRAMES];       // where the producer stopped: sequence index, bit cursor, the three states; or its error
+};
+static_assert(sizeof(QuadShare) <= sizeof(uint4) * 8 * 64, "the hand-over fits the record ring's LDS");
+
+__device__ __forceinline__ void quad_produce(const zl2_args& a, SeqShared& S, u32 wg, u32 lane) {
+    QuadShare& Q = *(QuadShare*)&S.ring[0][0];
+    const u32 fq = (lane >> 2) & (SEQ_FRAMES - 1), role = lane & 3;
+    bool act = lane < 4 * SEQ_FRAMES && S.qpos[fq] != 0xFFFFFFFFu;
+    u32 err = 0, nseq = 0, i = 0, sl = 0, so = 0, sm = 0;
+    i32 bp = 0;
+    const u8* bs = nullptr;
+    u32 bn = 0;
+    if (act) {
+        const u32 f4 = a.order[wg * SEQ_FRAMES + fq];
+        const zl2_blk_rec r4 = a.brec[(size_t)f4 * ZL2_MAXB];
+        const u32 pos = S.qpos[fq];
+        bs = a.src + a.frames[f4].src_off + r4.src_off + r4.seq_off + pos;
+        bn = r4.seq_len - pos;
+        nseq = r4.nseq;
+        const u32 ll_log = S.logs[fq][0], of_log = S.logs[fq][1], ml_log = S.logs[fq][2];
+        bp = zl_bwd_init(bs, bn);
+        if (bp < 0) { err = ZL_E_CORRUPTION; act = false; }
+        else {
+            bp -= (i32)ll_log; sl = zl_bits_bwd(bs, bn, bp, ll_log);
+            bp -= (i32)of_log; so = zl_bits_bwd(bs, bn, bp, of_log);
+            bp -= (i32)ml_log; sm = zl_bits_bwd(bs, bn, bp, ml_log);
+            if (bp < 0) { err = ZL_E_CORRUPTION; act = false; }
+        }
+    }
+    const bool fast = act && bp >= 160;
+    // (everything the loop carries; meaningful in the lanes of a fast chain)
+    const u32 mis = fast ? (u32)((uintptr_t)bs & 3) : 0u;
+    const u32* w = (const u32*)(bs - mis);
+    u32 c = mis * 8 + (u32)bp;
+    u32 s = role == 0 ? sl : (role == 1 ? so : sm);
+    const u32 ebase = role == 0 ? 0u : (role == 1 ? 1024u : 512u);
+    const u32* vtab = &S.val_tab[role == 3 ? 2 : role][0];
+    u32 Dw = fast ? (c - 1) >> 5 : 0u;
+    zl_v4u32 x = {0u, 0u, 0u, 0u};
+    if (fast) x = *(const zl_v4u32*)(w + Dw - 3);
+    u32 m_a = role != 1 ? ~0u : 0u, m_b = (role == 0 || role == 3) ? ~0u : 0u, m_c = role != 0 ? ~0u : 0u, m_d = (role == 1 || role == 3) ? ~0u : 0u;
+    asm volatile("" : "+v"(m_a), "+v"(m_b), "+v"(m_c), "+v"(m_d));
+    typedef __attribute__((address_space(3))) const volatile u32 lds_cvu32;
+    const u32 ent_at = (u32)(uintptr_t)&S.L[fq].ent[ebase];
+    u32 ce = fast ? *(lds_cvu32*)(uintptr_t)(ent_at + 4 * s) : 0u;
+    bool told = false;
+    for (u32 k = 0;; k++) {
+        u32 n = 0;
+        if (fast) {
+            while (n < ZLQ_TS && i < nseq && Dw >= 4) {
+                const u32 sym = (ce >> 16) & 0xFF, e = ce >> 24, b = (ce >> 10) & 0xF;
+                const u32 pk = e | (b << 8);
+                const u32 p0 = quad_get<0>(pk), p1 = quad_get<1>(pk), p2 = quad_get<2>(pk);
+                const u32 e_ll = p0 & 0xFF, b_ll = p0 >> 8, e_of = p1 & 0xFF, b_of = p1 >> 8, e_ml = p2 & 0xFF, b_ml = p2 >> 8;
+                const u32 keep = (i + 1 == nseq) ? 0u : 0xFFFFFFFFu;  // the last sequence reads no state bits
+                const u32 e_all = e_of + e_ml + e_ll;
+                const u32 T = e_all + ((b_ll + b_ml + b_of) & keep);
+                const u32 above_e = (m_a & e_of) + (m_b & e_ml);
+                const u32 above_s = e_all + (m_c & b_ll) + (m_d & b_ml);
+                const u32 top = c - ((Dw - 3) << 5);
+                const u32 u = window_bits(x, top - above_s - (b & keep), b & keep);
+                s = (ce & 0x3FF) + u;
+                ce = *(lds_cvu32*)(uintptr_t)(ent_at + 4 * s);
+                const u32 extra = window_bits(x, top - above_e - e, e);
+                c -= T;
+                const u32 Dn = (c - 1) >> 5;
+                const zl_v4u32 xn = *(const zl_v4u32*)(w + (i32)Dn - 3);
+                Q.tile[k & 1][n][lane] = vtab[sym] + extra;
+                x = xn;
+                Dw = Dn;
+                i++;
+                n++;
+            }
+        }
+        const bool more = fast && i < nseq && Dw >= 4;
+        if (fast && !more && !told) {  // this chain's fast part is over: where the tail takes up
+            bp = (i32)c - (i32)(mis * 8);
+            sl = quad_get<0>(s);
+            so = quad_get<1>(s);
+            sm = quad_get<2>(s);
+        }
+        if (lane < 4 * SEQ_FRAMES && role == 0) {
+            Q.tile_n[k & 1][fq] = n;
+            if (!more && !told) { QuadFin fn; fn.i = i; fn.bp = bp; fn.sl = sl; fn.so = so; fn.sm = sm; fn.err = err; fn.act = (act || err) ? 1u : 0u; fn.pad = 0; Q.fin[fq] = fn; }
+        }
+        told = told || !more;
+        const bool any_more = __any(more);
+        if (lane == 0) Q.more[k & 1] = any_more ? 1u : 0u;
+        __syncthreads();  // tile k is the consumer's
+        if (!any_more) break;
+    }
+}
+
+__device__ __forceinline__ void quad_consume(const zl2_args& a, SeqShared& S, u32 wg, u32 lane /* of wave 1 */) {
+    QuadShare& Q = *(QuadShare*)&S.ring[0][0];
+    const u32 ch = lane & (SEQ_FRAMES - 1);
+    const bool mine = lane < SEQ_FRAMES && S.qpos[ch] != 0xFFFFFFFFu;
+    u32 f4 = 0;
+    zl2_blk_rec r4;
+    r4.type = 0; r4.nseq = 0; r4.seq_len = 0; r4.lit_size = 0;
+    uint4* oseq = nullptr;
+    bool symbolic = false;
+    if (mine) {
+        f4 = a.order[wg * SEQ_FRAMES + ch];
+        r4 = a.brec[(size_t)f4 * ZL2_MAXB];
+        oseq = (uint4*)a.seq_scratch + a.plan[f4].seq_off + r4.seq_dst;
+        symbolic = starts_symbolic(a, f4);
+    }
+    u32 r0 = symbolic ? ZL2_REP_SYM : 1u, r1 = symbolic ? (ZL2_REP_SYM | 1u) : 4u, r2 = symbolic ? (ZL2_REP_SYM | 2u) : 8u;
+    u32 lit_used = 0, out_used = 0, i = 0, bad = 0;
+    zl_v4u32* ring = (zl_v4u32*)&Q.ring[0][ch];
+    for (u32 k = 0;; k++) {
+        __syncthreads();  // tile k is ready
+        if (mine) {
+            const u32 n = Q.tile_n[k & 1][ch];
+            for (u32 j = 0; j < n; j++) {
+                const u32 ll = Q.tile[k & 1][j][4 * ch], ofv = Q.tile[k & 1][j][4 * ch + 1], ml = Q.tile[k & 1][j][4 * ch + 2];
+                // repcode rules (zstd.c:44291-44327); masks instead of ?: (see window_bits)
+                const u32 m_real = 0u - (u32)(ofv > 3);
+                const u32 ri = ofv - 1 + (u32)(ll == 0);
+                const u32 m1 = 0u - (u32)(ri == 1), m2 = 0u - (u32)(ri == 2), m3 = 0u - (u32)(ri == 3);
+                const u32 r0m = r0 + 5 * (r0 >> 31) - 1;
+                const u32 cand = (r1 & m1) | (r2 & m2) | (r0m & m3) | (r0 & ~(m1 | m2 | m3));
+                const u32 off = ((ofv - 3) & m_real) | (cand & ~m_real);
+                const u32 m_sh2 = m_real | m2 | m3, m_sh1 = m_sh2 | m1;
+                r2 = (r1 & m_sh2) | (r2 & ~m_sh2);
+                r1 = (r0 & m_sh1) | (r1 & ~m_sh1);
+                r0 = off;
+                bad |= (u32)(off == 0);
+                const zl_v4u32 rec = {lit_used, out_used, off, 0u};
+                lit_used += ll;
+                out_used += ll + ml;
+                bad |= (out_used > ZL_BLOCK_MAX) ? 1u : 0u;
+                ring[(i & 7) * SEQ_FRAMES] = rec;
+                if ((i & 7) == 7) {
+                    zl_v4u32* o = (zl_v4u32*)(oseq + (i - 7));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o[q] = ring[q * SEQ_FRAMES];
+                }
+                i++;
+            }
+        }
+        if (!Q.more[k & 1]) break;
+    }
+    if (mine) {
+        for (u32 k = i & ~7u; k < i; k++) { const zl_v4u32 v = ring[(k & 7) * SEQ_FRAMES]; oseq[k] = make_uint4(v.x, v.y, v.z, v.w); }
+        const QuadFin fn = Q.fin[ch];
+        u32 err = fn.err;
+        if (!err && fn.act) {
+            if (bad || fn.bp < 0 || fn.i != i) err = ZL_E_CORRUPTION;
+            else {
+                const u32 pos = S.qpos[ch];
+                const u8* bs = a.src + a.frames[f4].src_off + r4.src_off + r4.seq_off + pos;
+                err = seq_tail(S, S.L[ch], r4, bs, r4.seq_len - pos, fn.bp, i, fn.sl, fn.so, fn.sm, r0, r1, r2, lit_used, out_used, oseq);
+            }
+        }
+        if (err) set_err(a.frec + f4, err);
+    }
+}
+
 __device__ __forceinline__ void wave_sync() {  // the sequence role runs on one wave: LDS order is program order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1216,6 +1393,12 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
             if (b == 0) S.qpos[fi] = (mine && S.logs[fi][3] == 1 && fr->err == 0) ? pos : 0xFFFFFFFFu;
             wave_sync();
             const u32 fq = lane >> 2;
+            if (a.fuse1 & 4) {  // the chains on two waves: this one produces, wave 1 consumes (quad_produce / quad_consume)
+                if (lane == 0) S.cmd = 1;
+                __syncthreads();  // wave 1 wakes up
+                quad_produce(a, S, wg, lane);
+                __syncthreads();  // ... and has written its records, totals and errors
+            } else
             if (lane < 4 * SEQ_FRAMES && S.qpos[fq] != 0xFFFFFFFFu) {
                 const u32 f4 = a.order[wg * SEQ_FRAMES + fq];
                 const zl2_blk_rec r4 = a.brec[(size_t)f4 * ZL2_MAXB];
@@ -1231,6 +1414,10 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         }
         wave_sync();
         if (prof) { const u64 q2 = __builtin_amdgcn_s_memtime(); p_build += q1 - q0; p_chain += q2 - q1; p_parse += qp - q0; p_tab += qb - qp; }
+    }
+    if (QUAD && (a.fuse1 & 4)) {  // no more chains: wave 1 may go
+        if (lane == 0) S.cmd = 0;
+        __syncthreads();
     }
     // profile (slots of the general kernel's phase array, unused when no frame falls back): table builds, chains
     if (prof) {
@@ -1342,7 +1529,7 @@ __global__ __launch_bounds__(64) void zl2_seq_kernel(zl2_args a) {
 // workgroups has room for one sequence workgroup only, and the sequence chains are the longer pole).
 // Fused, the workgroups are dealt out in the pattern sequence, sequence, literal -- each list sorted
 // by decreasing cost -- which is what fits a CU: 2 x 50 + 41 KiB.
-__global__ __launch_bounds__(64) void zl2_entropy1_kernel(zl2_args a) {
+__global__ __launch_bounds__(128) void zl2_entropy1_kernel(zl2_args a) {
     __shared__ union U_ {
         SeqShared s;
         LitGroupT<1> g[LIT_FRAMES];
@@ -1353,6 +1540,20 @@ __global__ __launch_bounds__(64) void zl2_entropy1_kernel(zl2_args a) {
     u32 g0, g1; bool split;
     zl2_part_range(a, g0, g1, split);  // the part of the cost-sorted order this launch covers
     const u32 r = blockIdx.x % 3, g = blockIdx.x / 3;
+    if (threadIdx.x >= 64) {
+        // wave 1: the consumer of a sequence workgroup's two-wave chains; everywhere else it has nothing to do (a wave that has
+        // ended no longer counts for the workgroup's barriers)
+        const u32 sg = g0 + 2 * g + r;
+        if (r < 2 && sg < g1 && (a.fuse1 & 6) == 6) {
+            for (;;) {
+                __syncthreads();
+                if (U.s.cmd == 0) break;
+                quad_consume(a, U.s, sg, threadIdx.x - 64);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     if (r < 2) {
         const u32 sg = g0 + 2 * g + r;
         if (sg < g1) { if (a.fuse1 & 2) seq_role<true>(a, U.s, &rounds, sg); else seq_role<false>(a, U.s, &rounds, sg); }
@@ -1827,7 +2028,7 @@ static hipError_t zl2_launch_entropy(zl2_args a, u32 role, hipStream_t stream, h
     hipLaunchKernelGGL(zl2_seq_kernel, dim3(ng), dim3(64), 0, seq_stream, a);
     hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ng), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, a);
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ng), dim3(LIT_FRAMES * 4), 0, stream, a);
-    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ng), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ng), dim3(128), 0, stream, a);
     if (seq_stream != stream && (hipEventRecord(join, seq_stream) != hipSuccess || hipStreamWaitEvent(stream, join, 0) != hipSuccess)) return hipErrorUnknown;
     return hipGetLastError();
 }
@@ -1898,7 +2099,7 @@ extern "C" hipError_t zl2_launch_segments_entropy(const zl2_args* a, hipStream_t
     if (hipFuncSetAttribute((const void*)zl2_lit_kernel<ZL2_MAXB>, hipFuncAttributeMaxDynamicSharedMemorySize, ZL_LIT_PAD_BYTES) != hipSuccess) return hipErrorUnknown;
     hipLaunchKernelGGL(zl2_lit_kernel<ZL2_MAXB>, dim3(ngroups), dim3(LIT_FRAMES * ZL2_MAXB * 4), ZL_LIT_PAD_BYTES, stream, *a);
     hipLaunchKernelGGL(zl2_lit_kernel<1>, dim3(ngroups), dim3(LIT_FRAMES * 4), 0, stream, *a);
-    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ngroups), dim3(64), 0, stream, *a);
+    hipLaunchKernelGGL(zl2_entropy1_kernel, dim3(3 * ngroups), dim3(128), 0, stream, *a);
     if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess) return hipErrorUnknown;
     return hipGetLastError();
 }

@@ -1076,7 +1076,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
         a.ext = d.ext; a.big = (const zl3_big*)s->big.p;
         a.ext_shared = 0; a.ext_base = nullptr; a.dict_pre = nullptr; a.dict_end = nullptr; a.dict_len = 0; a.dict_id = 0; a.dict_rep[0] = 1; a.dict_rep[1] = 4; a.dict_rep[2] = 8;  // (the dictionary of a large frame travels in zl3_big)
-        a.fuse1 = 3u;
+        a.fuse1 = 3u | (ZL_QUAD_SPLIT ? 4u : 0u);
         a.part = 0;
         a.sym_first = (have_dict && hint->dict_formatted) ? 1u : 0u;
         stamp("alloc");

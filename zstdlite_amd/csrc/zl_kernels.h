@@ -5,6 +5,9 @@
 
 #include "zl_format.h"
 
+#ifndef ZL_QUAD_SPLIT
+#define ZL_QUAD_SPLIT 1  // the quad chains of single-block launches on two waves (zl_decode2.hip quad_produce / quad_consume); 0: one wave, as rounds 1-4
+#endif
 #define ZL_LIT_STRIDE (ZL_BLOCK_MAX + 256)
 #define ZL_SEQ_CAP 43776  // >= ZL_MAX_SEQ_PER_BLOCK, multiple of 64
 
@@ -106,7 +109,7 @@ struct zl2_args {
     u64* stats;  // optional (profiling): exec-kernel phase cycles {scan, literals, matches, flush, batches, blocks}
     u32* max_blocks;  // device words, zeroed before the launch: [0] the largest block count of a frame on the pipeline (set by zl2_index_kernel), [1] frames left to the general kernel
     u32* order;       // 2 x nframes entries: the frames sorted by decreasing sequence count, then by decreasing literal bytes (zl2_order_kernel)
-    u32 fuse1;        // launches whose frames all have one block: literal and sequence lanes in ONE kernel (zl2_entropy1_kernel); 0: two kernels (experiments)
+    u32 fuse1;        // launches whose frames all have one block: bit 0 literal and sequence lanes in ONE kernel (zl2_entropy1_kernel); bit 1 a chain on a quad of lanes; bit 2 ... and on two waves, producer and consumer (round 5); 0: two kernels (experiments)
     // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
     const zl2_blk_rec* ext;   // per segment 4 records of earlier blocks whose tables the segment inherits: [0] Huffman tree, [1..3] sequence tables in block order; type 0xFFFFFFFF: none.  Null on the ordinary path
     const struct zl3_big* big;  // execution state shared by the segments.  Null on the ordinary path
