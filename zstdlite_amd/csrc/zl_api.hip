@@ -202,10 +202,13 @@ const ZlCopyPair* zl_copy_pair(void) {
     std::lock_guard<std::mutex> l(m);
     ZlCopyPair& p = pairs[dev];
     if (made[dev]) return p.up && p.down ? &p : nullptr;
-    made[dev] = true;
     p.up = p.down = nullptr;
     p.duplex = 0;
-    if (hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&p.down, hipStreamNonBlocking) != hipSuccess) { p.up = p.down = nullptr; return nullptr; }
+    // (made only once both streams exist: a transient failure here must not switch the pipelined host entries off for the rest of
+    // the process, and the stream that was created goes back -- ADVICE r4)
+    if (hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking) != hipSuccess) { p.up = nullptr; return nullptr; }
+    if (hipStreamCreateWithFlags(&p.down, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(p.up); p.up = p.down = nullptr; return nullptr; }
+    made[dev] = true;
     const size_t probe = (size_t)16 << 20;
     void *pin = nullptr, *mem = nullptr;
     if (hipHostMalloc(&pin, 2 * probe, hipHostMallocDefault) == hipSuccess && hipMalloc(&mem, 2 * probe) == hipSuccess) {
@@ -214,7 +217,7 @@ const ZlCopyPair* zl_copy_pair(void) {
                 hipStream_t& again = (attempt & 1) ? p.down : p.up;
                 (void)hipStreamDestroy(again);
                 again = nullptr;
-                if (hipStreamCreateWithFlags(&again, hipStreamNonBlocking) != hipSuccess) { p.up = p.down = nullptr; break; }
+                if (hipStreamCreateWithFlags(&again, hipStreamNonBlocking) != hipSuccess) { hipStream_t& other = (attempt & 1) ? p.up : p.down; if (other) (void)hipStreamDestroy(other); p.up = p.down = nullptr; made[dev] = false; break; }
             }
             p.duplex = zl_bind_copy_pair(p.up, p.down, pin, mem, probe) ? 1 : 0;
 #ifdef ZL_DEV_SWITCHES
@@ -573,6 +576,8 @@ size_t zl_DCtx_getParameter(const zl_dctx* d, int param, int* value) {
     switch (param) {
     case ZL_d_forceIgnoreChecksum: *value = d->ignore_checksum; return 0;
     case ZL_d_stableOutBuffer: *value = 1; return 0;
+    case ZL_d_runBlocks: *value = d->run_blocks; return 0;
+    case ZL_d_slabMiB: *value = d->slab_mib; return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -1232,12 +1237,15 @@ size_t stream_frame_fallback(zl_dctx* d) {
     StreamFrame* F = (StreamFrame*)d->ds.big;
     auto& S = d->ds;
     (void)hipDeviceSynchronize();
+    // (bytes that were queued BEHIND the frame's end stay queued, behind the frame's own bytes -- ADVICE r4: they used to be dropped)
+    std::vector<u8> behind(S.acc.p, S.acc.p + S.acc.size());
     S.acc.clear();
     if (F->got) {
         u8* at = S.acc.grow((size_t)F->got);
         if (!at) return ZL_ERR(ZL_E_MEMORY);
         if (hipMemcpy(at, F->d_src.p, (size_t)F->got, hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
+    if (!behind.empty() && !S.acc.append(behind.data(), behind.size())) return ZL_ERR(ZL_E_MEMORY);
     S.skip = (size_t)F->handed;
     S.no_big = true;
     stream_frame_free_impl(F);
@@ -1403,7 +1411,13 @@ bool stream_frame_begin(zl_dctx* d, const FrameHeader& h) {
     const bool tiny = d->slab_mib != 0 && d->slab_mib < 64;
     F->per = d->run_blocks ? (size_t)d->run_blocks : 8192;
     F->run_bytes = tiny ? (u64)256 << 10 : (u64)64 << 20;  // (32 MiB: the same rate on the 1 GiB frame, within the noise)
-    // (room for the frame's bytes: what incompressible content takes, grown -- and moved -- should an encoder have spent more)
+    // (room for the frame's bytes: what incompressible content takes, grown -- and moved -- should an encoder have spent more.
+    // The header's claim is all there is to go by when the first bytes arrive: a claim above what the device has free sends the
+    // frame to the collecting route instead of pinning the memory -- ADVICE r4)
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (u64)h.content_size + (h.content_size >> 7) + ((u64)256 << 20) > (u64)free_b / 2) { delete F; return false; }
+    }
     if (!F->d_dst.ensure((size_t)h.content_size + 64) || !F->d_src.ensure((size_t)h.content_size + (size_t)(h.content_size >> 8) + ((size_t)64 << 10))) { stream_frame_free_impl(F); return false; }
     d->ds.big = F;
     return true;
@@ -2058,7 +2072,8 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     }
     if (!d->d_src.ensure(n + 16) || !d->d_dst.ensure(cap + 16)) return kGpuUnavailable;
     // ONE frame the host has walked, large enough: slab by slab.  Everything else: the whole input first (it is on its way already)
-    const bool slabs = early && table.size() == 1 && known[0] && !walks[0].blocks.empty() && table[0].dst_cap >= slab_min && table[0].dst_cap <= cap && dst;
+    const bool slabs = early && table.size() == 1 && known[0] && !walks[0].blocks.empty() && table[0].dst_cap >= slab_min && table[0].dst_cap <= cap && dst &&
+                       table[0].dst_cap > (u64)ZL2_MAXB * ZL_BLOCK_MAX;  // (a frame the lane pipeline takes is read whole: it must have arrived)
     if (early && !slabs) {
         if (!io.wait_uploaded(n)) return ZL_ERR(ZL_E_GENERIC);
     } else if (!early) {
@@ -2289,6 +2304,8 @@ size_t zl_DCtx_reset(zl_dctx* d, zl_ResetDirective reset) {
     if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
         if (!d->ds.acc.empty() || !d->ds.out.empty() || d->ds.big) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:42552
         d->ignore_checksum = 0;
+        d->run_blocks = 0;
+        d->slab_mib = 0;
         d->dict.clear();
         d->dict_id = 0;
         d->dict_formatted = d->dict_uploaded = false;
