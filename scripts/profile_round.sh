@@ -23,6 +23,13 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d gpu
 rm -rf /tmp/prof_n1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_n1 -- python3 scripts/n1_prof.py 1024 > gpurun_out/n1_run.log 2>&1
 cp "$(ls /tmp/prof_n1/*/*kernel_stats.csv | head -1)" gpurun_out/n1_kernel_stats.csv 2>/dev/null
+# the deep match finder of levels >= 6 (zl_deep.hip): level 9 on the bench mix, level 12 on text
+rm -rf /tmp/prof_deep
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_deep -- python3 scripts/dev/deep_prof.py 9 mix > gpurun_out/deep9_run.log 2>&1
+cp "$(ls /tmp/prof_deep/*/*kernel_stats.csv | head -1)" gpurun_out/deep9_kernel_stats.csv 2>/dev/null
+rm -rf /tmp/prof_deep
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_deep -- python3 scripts/dev/deep_prof.py 12 text > gpurun_out/deep12_run.log 2>&1
+cp "$(ls /tmp/prof_deep/*/*kernel_stats.csv | head -1)" gpurun_out/deep12_text_kernel_stats.csv 2>/dev/null
 # keep what travels back small: csv summaries only
 find gpurun_out -name "*.db" -delete 2>/dev/null
 du -sh gpurun_out

@@ -145,3 +145,16 @@ if l2csv:
     l2["_note"] = ("per full-grid launch of the headline command.  TCC_EA0_RDREQ counts the L2's read requests to the fabric; whether the fabric serves them from the "
                    "Infinity Cache or from HBM is decided behind the TCC block and is not visible to these counters (MI355X_MICROARCH.md: Infinity-Cache hits appear to be counted, not excluded)")
     json.dump(l2, open(os.path.join(P, f"{rnd}_l2_counters.json"), "w"), indent=1)
+
+# ---- the deep match finder of levels >= 6 (scripts/dev/deep_prof.py under rocprofv3 --kernel-trace --stats): its kernels and the radix sort's
+for name in ("deep9_kernel_stats.csv", "deep12_text_kernel_stats.csv"):
+    src = os.path.join(G, name)
+    if os.path.exists(src):
+        rows = [r for r in csv.DictReader(open(src)) if "zl" in r["Name"] or "radix" in r["Name"]]
+        for r in rows:
+            if "radix" in r["Name"]:
+                r["Name"] = "rocprim radix sort: " + ("onesweep" if "onesweep" in r["Name"] else "") + " " + r["Name"][-60:]
+        with open(os.path.join(P, f"{rnd}_{name}"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ["Name"])
+            w.writeheader()
+            w.writerows(rows)

@@ -43,9 +43,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order, handover;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order, &handover}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
@@ -320,6 +320,14 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.total_size = joined_total;
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.order = order;
+#ifndef ZL_ENT_SPLIT
+#define ZL_ENT_SPLIT 0  // 1: the entropy stage as two kernels with a register allocation each (zl_encode.hip zl_entropy_kernel<1>, <2>).  Measured, round 5, same bytes: no vector register spilled in either half (64 and 114 registers) -- and 1.98 ms per GiB of the mix against the one kernel's 1.75 (second half at 5 / 8 workgroups per CU: 1.88 / 2.03): the spills are not what the stage waits for
+#endif
+    e.handover = nullptr;
+    if (ZL_ENT_SPLIT && c->profile < 2) {  // (the in-kernel phase stamps of ZL_c_profile = 2 describe the one-kernel form)
+        if (!es.handover.ensure((size_t)cnt * ZL_ENT_HANDOVER + 64)) return kGpuUnavailable;
+        e.handover = (u8*)es.handover.p;
+    }
     e.stats = m.stats ? m.stats + 8 : nullptr;
     if (zl_launch_entropy(&e, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     stage_ok("entropy");

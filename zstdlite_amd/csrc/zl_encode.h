@@ -12,6 +12,7 @@
 #define ZL_ENC_BLOCKS 8                          // blocks per frame (they share one set of entropy tables)
 #define ZL_SEQ_STRIDE ((ZL_CHUNK / 4) + 8)       // sequences per chunk (min match 4)
 #define ZL_LIT_STRIDE_ENC (ZL_CHUNK + 64)
+#define ZL_ENT_HANDOVER 12288                   // bytes of shared state the two halves of the entropy stage hand over per chunk (zl_encode.hip EntShared behind its scratch regions)
 #define ZL_SST_BYTES 9                          // per sequence slot of the FSE-chain scratch: 3 code bytes + 3 16-bit states
 #define ZL_FRAME_OVERHEAD 24                     // magic 4 + FHD 1 + dictID 4 + FCS 4 + block header 3 + checksum 4 (+ slack)
 #define ZL_OUT_STRIDE (ZL_CHUNK + ZL_FRAME_OVERHEAD + 8)
@@ -146,6 +147,7 @@ struct zl_entropy_args {
     u64 total_size;    // content size of the whole frame
     const void* cdict; // zl_cdict* (device) or null: the dictionary's entropy tables, offered to frames of a single block
     const u32* order;  // launch order of the chunks, as the match kernel's (or null)
+    u8* handover;      // per chunk ZL_ENT_HANDOVER bytes: the stage runs as two kernels that hand their shared state over here (null: one kernel)
     u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
 

@@ -1715,6 +1715,7 @@ struct EntShared {
 };
 enum { T_LL = 0, T_OF = 1, T_ML = 2 };
 static_assert(offsetof(EntShared, hlen) >= 8192, "the XXH64 tile aliases the two shared 4 KiB regions");
+static_assert(offsetof(EntShared, hlen) == 8192 && sizeof(EntShared) - 8192 <= ZL_ENT_HANDOVER && sizeof(EntShared) % 16 == 0, "the hand-over between the two halves of the entropy stage covers everything behind the scratch regions");
 
 // serial LSB-first bit writer used by the table-description writers (one thread)
 struct BitW {
@@ -2437,7 +2438,15 @@ __device__ __noinline__ void exact_rep_codes(zl_seq* seqs, u32 first, u32 end, u
 #ifndef ZL_ENT_WGS
 #define ZL_ENT_WGS 8   // workgroups per CU the register budget is cut for (8: 64 VGPRs, the LDS footprint's own limit)
 #endif
-__global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
+// PHASE 0: the whole stage in one kernel.  PHASE 1 / 2: the same code as two kernels -- statistics, tables and FSE chains; then the
+// blocks' bit packing and the frame -- with the workgroup's shared state (everything in EntShared behind its two scratch regions, 11 KiB)
+// handed over through memory.  Each half gets a register allocation of its own: as ONE kernel the stage wants 115 vector registers and is held
+// to the 64 that eight workgroups per CU allow (65 spilled, 96 scalar ones).
+#ifndef ZL_ENT2_WGS
+#define ZL_ENT2_WGS 4   // ... the second half's register budget: 128 (it is the half that wants them: held to 64 it spills 250)
+#endif
+template <int PHASE>
+__global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS) void zl_entropy_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ EntShared S;
     ZL_POISON(S, 8);
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -2469,6 +2478,14 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
     const bool frame_first = !joined || a.chunk_base + c == 0, frame_last = !joined || a.chunk_base + c + 1 == a.total_chunks;
     const u32 fh = joined ? (frame_first ? joined_header_size(a.total_size, a.wlog, a.dict_id) : 0u)
                           : (n < 256 ? 6u : (n < 65536 + 256 ? 7u : 9u)) + dict_id_bytes(a.dict_id);
+    u32 nbk = (n >> 13) < 1 ? 1u : ((n >> 13) > ZL_ENC_BLOCKS ? (u32)ZL_ENC_BLOCKS : (n >> 13));
+    {
+        const u32 worth = (nseq * 4u + nlit) >> 12;
+        if (worth < nbk) nbk = worth ? worth : 1u;
+    }
+    const bool exact = a.exact_rep != 0;
+    u8* const handover = a.handover ? a.handover + (size_t)c * ZL_ENT_HANDOVER : nullptr;
+    if (PHASE != 2) {
     for (u32 i = t; i < 4 * 256; i += ENC_THREADS) (&S.hist[0][0])[i] = 0;
     for (u32 i = t; i < 3 * 64; i += ENC_THREADS) (&S.seq_hist[0][0])[i] = 0;
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
@@ -2484,11 +2501,6 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
     // (... and no more blocks than the chunk's content is worth: every block costs a header, two section headers and a stream
     // split, about 20 bytes, which a chunk that is a few hundred sequences of long matches -- records that repeat, ratio 100 and
     // more -- cannot carry eight times: one block per 4 KiB of sequences (counted at 4 bytes) and literals)
-    u32 nbk = (n >> 13) < 1 ? 1u : ((n >> 13) > ZL_ENC_BLOCKS ? (u32)ZL_ENC_BLOCKS : (n >> 13));
-    {
-        const u32 worth = (nseq * 4u + nlit) >> 12;
-        if (worth < nbk) nbk = worth ? worth : 1u;
-    }
     // The boundaries: for each, the first sequence whose match ends behind its byte target.  Searched WIDE: 256 threads sample the
     // sequences' ends at equal strides, every boundary then names its stride from the samples in LDS, and the threads test that
     // stride's sequences at once -- three memory round trips where a binary search per boundary made fifteen in a row while the
@@ -2535,7 +2547,6 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
     __syncthreads();
     // levels >= 6: a lane per block follows the decoder's repeat-offset history through its block (the other waves go on to the literal
     // histogram, which does not look at sequences; everybody meets again in front of the sequence statistics)
-    const bool exact = a.exact_rep != 0;
     if (exact && nseq && t < nbk) exact_rep_codes(const_cast<zl_seq*>(seqs), S.blk_seq[t], S.blk_seq[t + 1], S.blk_lit[t]);
 
     // =========================== statistics of the whole chunk: literal histogram, sequence codes and their histograms
@@ -2852,6 +2863,19 @@ __global__ __launch_bounds__(ENC_THREADS, ZL_ENT_WGS) void zl_entropy_kernel(zl_
         if (on) S.final_state[j][k] = st;
     }
     zl_sync_global();  // the saved states travel to the assembling threads through memory
+    }  // (PHASE != 2)
+    if (PHASE == 1) {  // hand the shared state over: everything behind the two scratch regions
+        const uint4* from = (const uint4*)((const u8*)&S + 8192);
+        uint4* to = (uint4*)handover;
+        for (u32 i = t; i < (sizeof(EntShared) - 8192 + 15) / 16; i += ENC_THREADS) to[i] = from[i];
+        if (prof) for (int k = 0; k < 6; k++) atomicAdd((unsigned long long*)&a.stats[k], (unsigned long long)pt[k]);
+        return;
+    }
+    if (PHASE == 2) {
+        const uint4* from = (const uint4*)handover;
+        uint4* to = (uint4*)((u8*)&S + 8192);
+        for (u32 i = t; i < (sizeof(EntShared) - 8192 + 15) / 16; i += ENC_THREADS) to[i] = from[i];
+    }
     // the tree nodes shared this region: staging words must be zero before bits are OR-ed in
     for (u32 i = t; i < 1024; i += ENC_THREADS) S.stage[i] = 0;
     __syncthreads();
@@ -3187,7 +3211,11 @@ extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_entropy_kernel, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    if (a->handover) {
+        hipLaunchKernelGGL(zl_entropy_kernel<1>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+        hipLaunchKernelGGL(zl_entropy_kernel<2>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
+    } else
+    hipLaunchKernelGGL(zl_entropy_kernel<0>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
     return hipGetLastError();
 }
 extern "C" hipError_t zl_launch_scan_sizes(const u32* frame_size, u64* frame_off, const u64* total_in, u64* total_out, u32 nchunks, hipStream_t stream) {
@@ -3204,7 +3232,7 @@ extern "C" hipError_t zl_launch_gather(const zl_gather_args* a, u32 nchunks, hip
 extern "C" int zl_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_match_auto_kernel<false, false, false, false>, ENC_THREADS, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel, ENC_THREADS, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zl_entropy_kernel<0>, ENC_THREADS, 0);
     return n;
 }
 
