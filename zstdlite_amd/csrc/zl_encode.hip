@@ -310,7 +310,8 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // Level 3 and below, chunks of large inputs in either layout (the level >= 5 instantiations, dictionaries and small inputs keep
     // the fixed minimum: their ratios are pinned); a pure function of the chunk's bytes.
     u32 smin = ZL_SPARSE_MIN;  // stride-2 body: shortest new-offset match kept (uniform)
-    bool cheap = false;
+    bool cheap = false, noisy = false;
+    bool dull = false;  // cheap or noisy bytes AND hardly a match in the chunk's first 4 KiB: the search acceleration below ramps up twice as fast and twice as far (uniform)
     if ((LEAN || (FAR && !HI)) && ZL_CHEAP_BITS && n >= 16384) {
         u32* const bins = S.cand;  // [256]
         bins[t] = 0;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         lds_barrier();
         const float total = __uint_as_float(S.scan_b[0]) + __uint_as_float(S.scan_b[1]) + __uint_as_float(S.scan_b[2]) + __uint_as_float(S.scan_b[3]);
         cheap = total * 10.0f < (float)ZL_CHEAP_BITS * 16384.0f;
+        noisy = total * 10.0f >= 78.0f * 16384.0f;  // 7.8 bits and more per byte: random for all an order-0 look can tell
         lds_barrier();
     }
     // (cheap bytes alone do not say it: records that repeat, a column of doubles are cheap byte for byte AND all matches, short
@@ -1156,11 +1158,13 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         // emitted as literals without searching or inserting.  A pure function of the data, so the
         // output stays deterministic.  Any sequence resets it.
         miss = (win_seqs == 0 && carry == 0) ? miss + 1 : 0;
-        u32 skip = (miss * (1u + a.accel)) >> 2;  // (negative levels: -accel)
+        // (a dull chunk -- see above -- ramps up twice as fast and skips up to 15 windows: the reference's step on such data grows with
+        // every 256 bytes without a match, zstd.c:30018, and reaches hundreds; 1 GiB of random bytes 0.80 -> 0.55 ms, of i.i.d. bytes over ten letters 1.80 -> 1.30 ms, same ratios)
+        u32 skip = (miss * (1u + a.accel)) >> (dull ? 1 : 2);  // (negative levels: -accel)
 #ifndef ZL_SKIP_MAX
 #define ZL_SKIP_MAX 7
 #endif
-        if (skip > ZL_SKIP_MAX) skip = ZL_SKIP_MAX;
+        if (skip > (dull ? 2u * ZL_SKIP_MAX + 1u : (u32)ZL_SKIP_MAX)) skip = dull ? 2u * ZL_SKIP_MAX + 1u : (u32)ZL_SKIP_MAX;
         ip += win;
         if (skip && ip < n) {
             const u32 to = (ip + skip * win < n) ? ip + skip * win : n;
@@ -1180,9 +1184,9 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
         else
 #endif
         dense = D != 0 || (!a.sparse_only && win_seqs * (WIN2 / win) >= (FAR ? ZL_DENSE_SEQS_FAR : ZL_DENSE_SEQS));
-        if (cheap && probed < 4096) {
+        if ((cheap || noisy) && probed < 4096) {
             probed += win; probed_lits += win_lits;
-            if (probed >= 4096 && (probed - probed_lits) * 10 < probed) smin = 8;
+            if (probed >= 4096 && (probed - probed_lits) * 10 < probed) { if (cheap) smin = 8; dull = true; }
         }
     }
 #undef tmin
