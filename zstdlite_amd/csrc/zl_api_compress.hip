@@ -321,7 +321,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.order = order;
 #ifndef ZL_ENT_SPLIT
-#define ZL_ENT_SPLIT 0  // 1: the entropy stage as two kernels with a register allocation each (zl_encode.hip zl_entropy_kernel<1>, <2>).  Measured, round 5, same bytes: no vector register spilled in either half (64 and 114 registers) -- and 1.98 ms per GiB of the mix against the one kernel's 1.75 (second half at 5 / 8 workgroups per CU: 1.88 / 2.03): the spills are not what the stage waits for
+#define ZL_ENT_SPLIT 0  // 1: the entropy stage as two kernels with a register allocation each (zl_encode.hip zl_entropy_kernel<1>, <2>).  Measured, round 5, same bytes: 18 and 0 vector registers spilled in the halves (64 and 114 registers) against the one kernel's 60 -- and 1.98 ms per GiB of the mix against the one kernel's 1.75 (second half at 5 / 8 workgroups per CU: 1.88 / 2.03): the spills are not what the stage waits for
 #endif
     e.handover = nullptr;
     if (ZL_ENT_SPLIT && c->profile < 2) {  // (the in-kernel phase stamps of ZL_c_profile = 2 describe the one-kernel form)
