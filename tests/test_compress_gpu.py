@@ -440,6 +440,37 @@ def test_levels_six_to_fifteen_track_the_reference_at_the_same_level(ref, level)
     assert z.zstd_cctx_settings(z.zstd_cctx(level=level))["level"] == level
 
 
+def test_negative_levels_store_their_literals_and_stay_valid(ref):
+    """Negative levels (zstd.c:29721: targetLength = -level; zstd.c:20675: literal compression is off for `fast` with a target length, i.e.
+    at every negative level): the frames carry Raw_Literals_Block sections only, decode through the reference, are larger than level 1's and
+    report the level they were asked for.  (Their speed is on the bench line: `levels`.)"""
+    import warnings
+    data = GENERATORS["text"](3 << 20, seed=4) + GENERATORS["iid10"](1 << 20, seed=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        l1 = z.zstd_compress(data, level=1)
+        for level in (-1, -5):
+            out = z.zstd_compress(data, level=level)
+            assert ref.decompress(out, len(data)) == data and z.zstd_decompress(out) == data
+            assert len(out) > len(l1)
+            assert z.zstd_cctx_settings(z.zstd_cctx(level=level))["level"] == level
+            frames = z.zstd_compress(data, level=level, frame_layout="frames")
+            # every block of the first frame: compressed blocks open with a literals section of type 0 (raw) or 1 (RLE), never Huffman
+            fhd = frames[4]
+            pos = 5 + (0 if (fhd >> 5) & 1 else 1) + {0: 1 if (fhd >> 5) & 1 else 0, 1: 2, 2: 4, 3: 8}[fhd >> 6]
+            seen = 0
+            while True:
+                h = int.from_bytes(frames[pos:pos + 3], "little")
+                last, btype, bsize = h & 1, (h >> 1) & 3, h >> 3
+                if btype == 2:
+                    assert frames[pos + 3] & 3 in (0, 1), (level, seen)
+                    seen += 1
+                pos += 3 + (1 if btype == 1 else bsize)
+                if last:
+                    break
+            assert seen >= 1
+
+
 def test_every_level_from_six_on_is_an_operating_point_of_its_own(ref):
     """zl_CCtx_getParameter reports 6 ... 15 as they were set, and a higher level never writes a larger frame than the one below it
     by more than noise (python sources, one frame)."""
