@@ -42,7 +42,7 @@ for rd in range(rounds):
             L.zl_CCtx_reset(cctx, int(rng.choice([1, 2])))  # session only / parameters (zstd.h:590; parameters also drops the dictionary)
             if rng.random() < 0.0:
                 pass
-        level = int(rng.choice([1, 3, 5]))
+        level = int(rng.choice([1, 3, 5, 7, 12, -1]))
         cs = int(rng.random() < 0.4)
         layout = int(rng.choice([0, 1, 2]))
         seek = int(rng.random() < 0.2)

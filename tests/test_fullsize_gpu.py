@@ -212,6 +212,43 @@ def test_device_slots_behind_the_host_entries():
     assert np.array_equal(got8, _host_roundtrip(L, host, 2, 1, 1)[0]) and used8[0] == 8
 
 
+def test_deep_levels_through_the_pipelined_host_entry():
+    """Levels >= 6 (csrc/zl_deep.hip) through the host entry's pipeline: sections of 64 MiB on three streams with a scratch set each (the
+    deep finder sorts a section at a time), and dealt out over device slots: the bytes must be those of the one-stream device entry, whatever
+    the staging, and the reference must read them -- one frame and independent frames."""
+    import zstdlite_amd as z
+    from zstdlite_amd import _lib
+    from zl_testlib import Ref
+    if not have_ref():
+        pytest.skip("needs the reference build (oracle/_ref)")
+    ref = Ref()
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    n = (300 << 20) + 4321
+    src = gen_mixed(n, dev)[0]
+    host = src.cpu().numpy()
+    for level, layout in ((9, 2), (6, 1)):
+        outs = []
+        for slots in (1, 3):
+            cctx = L.zl_createCCtx()
+            L.zl_CCtx_setParameter(cctx, 100, level); L.zl_CCtx_setParameter(cctx, 9003, layout); L.zl_CCtx_setParameter(cctx, 9007, slots)
+            cap = L.zl_compressBound(n)
+            buf = np.empty(cap, dtype=np.uint8)
+            r = L.zl_compress2(cctx, buf.ctypes.data, cap, host.ctypes.data, n)
+            assert not _lib.is_error(r), _lib.error_name(r)
+            outs.append(buf[:r].copy())
+            L.zl_freeCCtx(cctx)
+        assert np.array_equal(outs[0], outs[1]), (level, layout)
+        c = DeviceCodec(level=level, frame_layout={1: "frames", 2: "one_frame"}[layout])
+        comp, total, _ = c.compress(src)
+        assert total == len(outs[0]) and np.array_equal(comp[:total].cpu().numpy(), outs[0]), (level, layout)
+        c.close()
+        blob = outs[0].tobytes()
+        if layout == 2:
+            assert ref.decompress(blob, n) == host.tobytes()
+        assert z.zstd_decompress(blob) == host.tobytes()
+
+
 def test_device_slots_on_every_visible_device():
     """The multi-device leg of the test above (ZL_c_devices = 0: every visible device): needs more than one GPU; the pool's boxes
     have one, so it skips there -- on its own, so that the one-device body above reports what it is: passed."""
