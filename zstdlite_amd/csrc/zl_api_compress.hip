@@ -356,7 +356,9 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
 size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st, u64 joined_total = 0) {
     { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
     const bool joined = joined_total != 0;
-    const size_t group = enc_strides(c->chunk_cap).group;
+    // (levels >= 6: the deep match finder keeps a 64-bit word per input byte of a launch group -- groups of two sections, 128 MiB, hold that to 1 GiB)
+    // (a profiling context keeps one group: its per-kernel events time ONE launch of every kernel; the bytes do not depend on the grouping)
+    const size_t group = (deep_on(c) && !c->profile) ? std::min<size_t>(enc_strides(c->chunk_cap).group, 2 * ((size_t)1 << ZL_FAR_SECTION_LOG)) : enc_strides(c->chunk_cap).group;
     const size_t ngroups = (nchunks + group - 1) / group;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)))
