@@ -40,7 +40,7 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
  * src/cctx.c:265-284 and src/dctx.c:99,163 compile unchanged against the twins */
 #define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel.  Operating points: < 3 (every other position probed),
                                    * 3-4 (the double-hash parse), 5 (larger match tables, longer verification, denser far
-                                   * search), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 /
+                                   * search, two-step lazy rule, all three repeat offsets), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 /
                                    * 16 / 32 / 64 / 96 / 128 / 192 / 256 candidates per position --, lazy depth -- one step at 6
                                    * and 7, two from 8 -- and window -- 2 MiB up to 8, 4 MiB from 9 -- at that level,
                                    * zstd.c:29523-29550).  16 ... 22 run as 15 (the optimal parsers are not built).

@@ -249,7 +249,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.stats = nullptr;
     m.sparse_only = c->level < 3 ? 1u : 0u;
     m.hi = c->level >= 5 ? 1u : 0u;
-    m.lazy2 = c->level >= 6 ? 1u : 0u;
+    m.lazy2 = c->level >= 5 ? 1u : 0u;  // (level 5 too since round 5: with the one-step rule alone its python sources were 1.051x the reference's level 5)
     m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
     m.dict_len = c->dict_use;
     m.dict_hash = c->dict_use ? (const u32*)c->d_dict_hash.p : nullptr;
@@ -312,7 +312,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
     e.raw_lits = c->level < 0 ? 1u : 0u;
-    e.exact_rep = c->level >= 6 ? 1u : 0u;
+    e.exact_rep = c->level >= 5 ? 1u : 0u;
     e.joined = joined ? 1u : 0u;
     e.chunk_base = (u32)(frame_chunk0 + first);
     e.total_chunks = (u32)nchunks;

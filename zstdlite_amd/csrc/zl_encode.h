@@ -72,7 +72,7 @@ struct zl_match_args {
     u64* stats;  // optional (profiling): cycles {find, parse, emit, insert, iterations}
     u32 sparse_only;  // levels below 3: the stride-2 body throughout (faster, lower ratio on match-dense data)
     u32 hi;           // levels >= 5: larger match tables, longer per-lane verification (slower, higher ratio)
-    u32 lazy2;        // levels >= 6: the lazy rule also looks two positions on (zstd.c:31546 ZSTD_compressBlock_lazy_generic, depth 2)
+    u32 lazy2;        // levels >= 5: the lazy rule also looks two positions on (zstd.c:31546 ZSTD_compressBlock_lazy_generic, depth 2)
     u32 dict_len;     // dictionary content bytes that sit, as history, in front of every chunk (0: none)
     const u8* dict;   // those bytes
     const u32* dict_hash;  // the two match tables as they look after the dictionary's last byte (ZL_MATCH_TABLE_BYTES)
@@ -138,7 +138,7 @@ struct zl_entropy_args {
     u32 checksum;      // append XXH64 low 32 bits (ZSTD_c_checksumFlag)
     u32 dict_id;       // 0 = none
     u32 raw_lits;      // negative levels: literals are stored, not Huffman-coded (zstd.c:20675 ZSTD_literalsCompressionIsDisabled: strategy fast with a target length, i.e. every negative level)
-    u32 exact_rep;     // levels >= 6: the three-entry repeat-offset history of the decoder is followed sequence by sequence, codes 2 and 3 are emitted
+    u32 exact_rep;     // levels >= 5: the three-entry repeat-offset history of the decoder is followed sequence by sequence, codes 2 and 3 are emitted
     // single-frame layout: the chunks of this launch are consecutive runs of blocks of ONE frame
     u32 joined;        // 1: chunk 0 of the frame carries the frame header, only the frame's last chunk sets Last_Block, no per-chunk checksum
     u32 chunk_base;    // index, inside the frame, of this launch's first chunk
