@@ -304,6 +304,27 @@ def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
 
 
 @needs_ref
+@pytest.mark.parametrize("level", [9, -5])
+def test_streams_at_the_other_operating_points_write_what_the_one_shot_call_writes(ref, level):
+    """A pledged stream's jobs are whole sections of ONE frame (above): at the deep levels (csrc/zl_deep.hip sorts a section at a time; the
+    job's buffer holds its own range of the input only) and at the negative ones (stored literals) the bytes must still be zl_compress2's
+    for the whole input, and the reference must read them; an unpledged session's frames too."""
+    import torch
+    from zstdlite_amd.device import gen_mixed
+    n = (150 << 20) + 777
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    cctx = z.zstd_cctx(level=level)
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    blob = b"".join([comp.feed(data[off:off + 9999991]) for off in range(0, n, 9999991)] + [comp.finish()])
+    assert blob == z.zstd_compress(data, level=level)
+    assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob)
+    assert ref.decompress(blob, n) == data
+    loose = stream.Compressor(cctx._ptr)
+    blob2 = b"".join([loose.feed(data[off:off + 9999991]) for off in range(0, n, 9999991)] + [loose.finish()])
+    assert ref_stream_decompress(ref, blob2) == data and z.zstd_decompress(blob2) == data
+
+
+@needs_ref
 def test_a_large_frame_is_decoded_while_it_arrives(ref, oracle):
     """Round 4 ("streaming decode of a large frame is not streaming"): zl_decompressStream used to collect a frame
     to its last byte before the first one came out.  A frame whose header records ZL_d_slabMiB (32 MiB in a stream) of content or
