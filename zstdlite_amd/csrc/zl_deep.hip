@@ -470,6 +470,7 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
         u64* const best = a->best + (s0 - a->lo);
         if (a->k <= 16) hipLaunchKernelGGL((zl_deep_search_kernel<16>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
         else if (a->k <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
+        else if (a->k <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
         else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best);
         hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec);
         s0 = s1;
