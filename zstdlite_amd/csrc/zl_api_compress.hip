@@ -69,6 +69,8 @@ struct zl_cctx_s {
     bool far_valid = false;
     double far_ms = 0;
     bool ev_valid = false;
+    bool acc_valid = false;          // ... and the sums over a call's launch groups, when it had several (the deep levels)
+    double acc_ms[4] = {0, 0, 0, 0}, acc_far = 0;
     double kernel_ms[4] = {0, 0, 0, 0};
     DevBuf d_stats;
     u64 stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -356,24 +358,43 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
 size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipStream_t st, u64 joined_total = 0) {
     { const size_t pd = cctx_prepare_dict(c, st); if (ZL_IS_ERR(pd)) return pd; }
     const bool joined = joined_total != 0;
-    // (levels >= 6: the deep match finder keeps a 64-bit word per input byte of a launch group -- groups of two sections, 128 MiB, hold that to 1 GiB)
-    // (a profiling context keeps one group: its per-kernel events time ONE launch of every kernel; the bytes do not depend on the grouping)
-    const size_t group = (deep_on(c) && !c->profile) ? std::min<size_t>(enc_strides(c->chunk_cap).group, 2 * ((size_t)1 << ZL_FAR_SECTION_LOG)) : enc_strides(c->chunk_cap).group;
+    // (levels >= 6: the deep match finder keeps a 64-bit word per input byte of a launch group -- 8 GiB for a group of 1 GiB.  The group
+    // shrinks, down to two sections, until that fits into half of what the device has free: the bytes do not depend on the grouping
+    // (tests/test_fullsize_gpu.py), only the schedule does -- a launch over everything lets the expensive chunks of one kind of data
+    // run beside the cheap ones of another: the 1 GiB mix at level 9 as ONE group: parse 7.7 ms, as four groups of 256 MiB: 10.6)
+    size_t group = enc_strides(c->chunk_cap).group;
+    if (deep_on(c)) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t have = free_b + c->sets[0].deep_best.cap;  // (what the set already holds counts as available to it)
+        while (group > 2 * ((size_t)1 << ZL_FAR_SECTION_LOG) && std::min(group, nchunks) * (size_t)ZL_CHUNK * 8 > have / 2) group /= 2;
+    }
     const size_t ngroups = (nchunks + group - 1) / group;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
         !c->d_foff.ensure(nchunks * sizeof(u64)) || !c->d_totals.ensure((ngroups + 1) * sizeof(u64)))
         return kGpuUnavailable;
     if (hipMemcpyAsync(c->d_chunks.p, c->h_chunks.p, nchunks * sizeof(zl_chunk_desc), hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (hipMemsetAsync(c->d_totals.p, 0, sizeof(u64), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    const bool prof = c->profile && ngroups == 1;
+    // ZL_c_profile: per-kernel events around ONE launch group; a call of several groups (the deep levels: four sections each) drains the
+    // stream behind every group and adds the groups' times up (a diagnostic: the drains cost a few microseconds each)
+    const bool prof = c->profile && (ngroups == 1 || deep_on(c));
     if (prof && !c->ev[0]) for (auto& e : c->ev) (void)hipEventCreate(&e);
     if (prof && (joined || deep_on(c)) && !c->ev_far) (void)hipEventCreate(&c->ev_far);  // (the start of the far passes, or of the deep search)
     c->ev_valid = false;
+    c->acc_valid = false;
+    for (int k = 0; k < 4; k++) c->acc_ms[k] = 0;
+    c->acc_far = 0;
     for (size_t g = 0; g < ngroups; g++) {
         const size_t first = g * group;
         const u32 cnt = (u32)std::min<size_t>(group, nchunks - first);
         const size_t e = cctx_enqueue_group(c, c->sets[0], d_dst, d_src, first, cnt, nchunks, g, st, joined_total, prof, nullptr, nullptr);
         if (ZL_IS_ERR(e)) return e;
+        if (prof && ngroups > 1) {
+            if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+            for (int k = 0; k < 4; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]); c->acc_ms[k] += ms; }
+            if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->acc_far += ms; }
+            c->acc_valid = true;
+        }
     }
     if (!c->h_fsize.ensure(nchunks * sizeof(u32)) || !c->h_totals.ensure((ngroups + 1) * sizeof(u64))) return kGpuUnavailable;
     if (hipMemcpyAsync(c->h_fsize.p, c->d_fsize.p, nchunks * sizeof(u32), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -649,6 +670,7 @@ size_t zl_compress_device_finish(zl_cctx* c, size_t* frame_sizes) {
         }
         c->far_ms = 0;
         if (c->far_valid) { float ms = 0; (void)hipEventElapsedTime(&ms, c->ev_far, c->ev[0]); c->far_ms = ms; }
+        if (c->acc_valid) { for (int k = 0; k < 4; k++) c->kernel_ms[k] = c->acc_ms[k]; c->far_ms = c->acc_far; }  // (several launch groups: their sums)
         if (c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     }
     size_t total = (size_t)((const u64*)c->h_totals.p)[c->pending_groups];

@@ -79,35 +79,29 @@ template <int KMAX>
 __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64* sorted, u32 n, const u8* sec, u32 K, u32 window, u32 min_len, u32 frames, u64* best) {
     constexpr u32 E = DEEP_THREADS + KMAX;
     __shared__ uint4 rec[4][E];  // rec[j][e]: bytes [p - 8 + 16 j, p + 8 + 16 j) of entry e's position (one array per slice: consecutive lanes read consecutive slots)
-    __shared__ u32 spos[E + 1];
-    __shared__ u32 shash[E + 1];  // (one entry behind the block: does the last one have a twin?)
-    __shared__ u8 shave[E + 1];
+    __shared__ u64 skey[E + 1];  // hash << 32 | position of every entry (one entry behind the block: does the last one have a twin?); no entry: a hash no position has
+    static_assert(ZL_DEEP_HLOG < 32, "0xFFFFFFFF is not a hash");
     const u32 t = threadIdx.x;
     const u32 i0 = blockIdx.x * DEEP_THREADS;
     // positions and hashes first: an entry whose hash neither neighbour shares has no candidate and is nobody's candidate
     for (u32 e = t; e < E + 1; e += DEEP_THREADS) {
         const i64 idx = (i64)i0 + (i64)e - KMAX;
-        u32 pos = 0, h = 0xFFFFFFFFu;
-        bool have = false;
-        if (idx >= 0 && idx < (i64)n && (e >= (u32)KMAX || e + K >= (u32)KMAX)) {  // (of the entries in front only the K nearest are looked at)
-            const u64 key = sorted[idx];
-            pos = (u32)key;
-            h = (u32)(key >> 32);
-            have = true;
-        }
-        spos[e] = pos; shash[e] = h; shave[e] = have ? 1 : 0;
+        u64 key = 0xFFFFFFFF00000000ull;
+        if (idx >= 0 && idx < (i64)n && (e >= (u32)KMAX || e + K >= (u32)KMAX)) key = sorted[idx];  // (of the entries in front only the K nearest are looked at)
+        skey[e] = key;
     }
     __syncthreads();
     for (u32 e = t; e < E; e += DEEP_THREADS) {
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-        const u32 h = shash[e];
-        const bool twin = (e > 0 && shave[e - 1] && shash[e - 1] == h) || (shave[e + 1] && shash[e + 1] == h);
+        const u64 key = skey[e];
+        const u32 h = (u32)(key >> 32);
+        const bool twin = (e > 0 && (u32)(skey[e - 1] >> 32) == h) || (u32)(skey[e + 1] >> 32) == h;
 #if defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 2)
-        if (shave[e] && twin && spos[e] == 0x7FFFFFF1u) {  // (experiment: no record loads)
+        if (h != 0xFFFFFFFFu && twin && (u32)key == 0x7FFFFFF1u) {  // (experiment: no record loads)
 #else
-        if (shave[e] && twin) {
+        if (h != 0xFFFFFFFFu && twin) {
 #endif
-            const i32 a = (i32)spos[e] - 8;
+            const i32 a = (i32)(u32)key - 8;
             r0 = deep_ld16(sec, a, n); r1 = deep_ld16(sec, a + 16, n); r2 = deep_ld16(sec, a + 32, n); r3 = deep_ld16(sec, a + 48, n);
         }
         rec[0][e] = r0; rec[1][e] = r1; rec[2][e] = r2; rec[3][e] = r3;
@@ -115,7 +109,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
     __syncthreads();
     const u32 e = t + KMAX;
     if (i0 + t >= n) return;
-    const u32 p = spos[e], hme = shash[e];
+    const u32 p = (u32)skey[e], hme = (u32)(skey[e] >> 32);
     const uint4 m0 = rec[0][e], m1 = rec[1][e], m2 = rec[2][e], m3 = rec[3][e];
     const u32 chunk0 = p & ~(u32)(ZL_CHUNK - 1);  // (sections start on a chunk boundary)
     u32 lo = p > window ? p - window : 0u;
@@ -125,11 +119,13 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
     bool alive = true;
     for (u32 k = 1; k <= K; k++) {
         const u32 ce = e - k;
-        const u32 q = spos[ce];
-        alive = alive && shave[ce] && shash[ce] == hme && q >= lo && q < p;  // (positions ascend inside a hash value: the first one below the window ends the walk)
+        const u64 ck = skey[ce];
+        const u32 q = (u32)ck;
+        alive = alive && (u32)(ck >> 32) == hme && q >= lo && q < p;  // (positions ascend inside a hash value: the first one below the window ends the walk)
         if (!__any(alive)) break;
         if (alive) {
-            u32 len = cb64(m0.z, m0.w, rec[0][ce].z, rec[0][ce].w);
+            const uint2 c0 = *(const uint2*)&rec[0][ce].z;
+            u32 len = cb64(m0.z, m0.w, c0.x, c0.y);
             if (len == 8) {
                 u32 l = cb128(m1, rec[1][ce]);
                 len += l;
