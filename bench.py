@@ -225,7 +225,7 @@ def levels_leg(device, src, log):
     n = int(src.numel())
     samples = {"corpus": LONG_RANGE["corpus"](None), "text16M": GENERATORS["text"](16 << 20)}
     out = {}
-    for level in (-5, 1, 3, 5, 6, 9, 12, 15):
+    for level in (-5, 1, 3, 4, 5, 6, 9, 12, 15):
         codec = DeviceCodec(level=level, profile=True, frame_layout="one_frame")
         dst = torch.empty(codec.bound(n), dtype=torch.uint8, device=device)
         best = 1e9

@@ -38,15 +38,15 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
 
 /* parameter ids: numerically identical to ZSTD_cParameter / ZSTD_dParameter so that
  * src/cctx.c:265-284 and src/dctx.c:99,163 compile unchanged against the twins */
-#define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel.  Operating points: < 3 (every other position probed),
-                                   * 3-4 (the double-hash parse), 5 (larger match tables, longer verification, denser far
-                                   * search, two-step lazy rule, all three repeat offsets), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 /
-                                   * 16 / 32 / 64 / 96 / 128 / 192 / 256 candidates per position --, lazy depth -- one step at 6
-                                   * and 7, two from 8 -- and window -- 2 MiB up to 8, 4 MiB from 9 -- at that level,
-                                   * zstd.c:29523-29550).  16 ... 22 run as 15 (the optimal parsers are not built).
-                                   * zl_CCtx_getParameter reports the point a context runs at.  Contexts with a dictionary and
-                                   * the batch entries run levels >= 6 on the table-based parse at its deepest setting (the
-                                   * deep finder sorts the positions of ONE contiguous input). */
+#define ZL_c_compressionLevel 100 /* zstd.h:333  ZSTD_c_compressionLevel.  Operating points: negative levels and 1, 2 (every other position
+                                   * probed; negative levels store their literals and skip eagerly), 3 (the double-hash parse; 0 means 3), 4
+                                   * (larger match tables, longer verification), 5 (... denser far search, two-step lazy rule, all three repeat
+                                   * offsets), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 / 16 / 32 / 64 /
+                                   * 96 / 128 / 192 / 256 candidates per position --, lazy depth -- one step at 6 and 7, two from 8 -- and
+                                   * window -- 2 MiB up to 8, 4 MiB from 9 -- at that level, zstd.c:29523-29550).  16 ... 22 run as 15 (the
+                                   * optimal parsers are not built).  zl_CCtx_getParameter reports the point a context runs at.  Contexts with a
+                                   * dictionary and the batch entries run levels >= 6 on the table-based parse at its deepest setting (the deep
+                                   * finder sorts the positions of ONE contiguous input). */
 #define ZL_c_checksumFlag 201     /* zstd.h:440  ZSTD_c_checksumFlag     */
 #define ZL_c_nbWorkers 400        /* zstd.h:449  ZSTD_c_nbWorkers (accepted, ignored: the GPU path is always parallel) */
 #define ZL_c_stableInBuffer 1006  /* zstd.h:2083 ZSTD_c_stableInBuffer  (accepted, no-op) */

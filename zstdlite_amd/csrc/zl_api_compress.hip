@@ -250,7 +250,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.seq_stride = sd.seq;
     m.stats = nullptr;
     m.sparse_only = c->level < 3 ? 1u : 0u;
-    m.hi = c->level >= 5 ? 1u : 0u;
+    m.hi = c->level >= 4 ? 1u : 0u;  // (level 4, round 5: the larger tables and the longer verification without level 5's denser far search, second lazy step and repeat-offset history -- what level 5 was until then)
     m.lazy2 = c->level >= 5 ? 1u : 0u;  // (level 5 too since round 5: with the one-step rule alone its python sources were 1.051x the reference's level 5)
     m.dict = c->dict_use ? (const u8*)c->d_dict.p + c->dict.size() - c->dict_use : nullptr;
     m.dict_len = c->dict_use;
@@ -519,9 +519,12 @@ size_t zl_freeCCtx(zl_cctx* c) {
 // The encoder has these operating points, and a context remembers the one it runs at, not the number it was asked for
 // (zl_CCtx_getParameter and the host mirror's zstd_cctx_settings report that):
 //   levels < 3   every other position probed throughout (cf. the step of ZSTD_fast, zstd.c:29340); reported as given
-//   level 3, 4   the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
-//                in the one-frame layout one position in 8 takes part in the far search.  Reported as 3.
-//   level 5      the same parse with match tables four times the size (2^14 + 2^13 entries, three workgroups per CU instead
+//   level 3      the double-hash parse with the dense body where the data is rich in matches (cf. ZSTD_dfast, zstd.c:29529);
+//                in the one-frame layout one position in 8 takes part in the far search.
+//   level 4      ... with match tables four times the size and verification up to 72 bytes per lane (the reference's level 4 is its
+//                level 3 with larger tables too, zstd.c:29530)
+//   level 5      level 4 with one position in 4 in the far search, the two-step lazy rule and the decoder's exact repeat-offset history;
+//                its tables: four times the size (2^14 + 2^13 entries, three workgroups per CU instead
 //                of seven), verification up to 72 bytes per lane and one position in 4 in the far search.
 //   levels 6-15  the deep match finder (zl_deep.hip): every position's K most recent earlier occurrences inside the window,
 //                K, the lazy depth and the window as the reference has them at that level (deep_level above); python sources in
@@ -537,7 +540,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value >= 16 ? 15 : (value >= 5 ? value : (value >= 3 ? 3 : value));
+        c->level = value >= 16 ? 15 : (value == 0 ? 3 : value);  // (0: the default level, zstd.h:333 / zstd.c:29721)
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
