@@ -123,8 +123,18 @@ def test_batch_compress(oracle):
         [("text", 0), ("text", 300), ("iid10", 5000), ("rand", 777), ("int20", 70000), ("text", 200000), ("text", 131072)])]
     comps = z.zstd_compress_batch(items)
     singles = [z.zstd_compress(x, frame_layout="frames") for x in items]  # batch items are independent frames per chunk
-    assert comps == singles
-    assert [z.zstd_compress(x) for x in items if len(x) <= 131072] == [c for x, c in zip(items, comps) if len(x) <= 131072]
+    # (round 5: ONE input of 16 KiB - 16 MiB at levels 3 - 5 is searched by the deep match finder, which sorts one contiguous input;
+    # the objects of a batch keep the table parse.  Same bytes where both take the tables: small objects, and every size at level 1)
+    small = lambda x: len(x) <= 16384
+    assert [c for x, c in zip(items, comps) if small(x)] == [c for x, c in zip(items, singles) if small(x)]
+    assert [z.zstd_compress(x) for x in items if small(x)] == [c for x, c in zip(items, comps) if small(x)]
+    for x, c, s in zip(items, comps, singles):
+        assert len(c) <= len(s) * 1.10 + 16, (len(x), len(c), len(s))
+    fast = z.zstd_compress_batch(items, level=1)
+    assert fast == [z.zstd_compress(x, level=1, frame_layout="frames") for x in items]
+    assert [z.zstd_compress(x, level=1) for x in items if len(x) <= 131072] == [c for x, c in zip(items, fast) if len(x) <= 131072]
+    for x, c in zip(items, fast):
+        assert oracle.decompress(c, cap=len(x)) == x
     for x, c in zip(items, comps):
         assert oracle.decompress(c, cap=len(x)) == x
     assert z.zstd_decompress_batch([c for x, c in zip(items, comps) if len(x) <= 131072]) == [x for x in items if len(x) <= 131072]
@@ -383,7 +393,7 @@ def test_level_five_is_a_stronger_operating_point(ref):
         l3, l5 = z.zstd_compress(data, level=3), z.zstd_compress(data, level=5)
         f3, f5 = z.zstd_compress(data, level=3, frame_layout="frames"), z.zstd_compress(data, level=5, frame_layout="frames")
     assert len(l5) < len(l3) * 0.985, (len(l3), len(l5))
-    assert len(f5) < len(f3) * 0.96, (len(f3), len(f5))
+    assert len(f5) < len(f3) * 0.99, (len(f3), len(f5))  # (0.96 until round 5 gave levels 3 - 5 the deep match finder on inputs of this size: level 3 came down to it)
     assert len(l5) <= len(ref.compress(data, level=3)) * 1.01
     assert ref.decompress(l5, len(data)) == data and z.zstd_decompress(l5) == data
     assert z.zstd_decompress(f5) == data
@@ -435,7 +445,8 @@ def test_levels_six_to_fifteen_track_the_reference_at_the_same_level(ref, level)
     for name, data in (("corpus", corpus), ("text", text), ("records", records)):
         ours, theirs = len(outs[name, "auto"]), len(ref.compress(data, level=level))
         assert ours <= theirs * 1.05, (name, level, ours, theirs, ours / theirs)
-    assert len(outs["corpus", "auto"]) < len(c5) * 0.97
+    # (level 5 on an input of this size is the deep match finder six candidates deep since round 5: levels 6 and 7 sit right below it)
+    assert len(outs["corpus", "auto"]) < len(c5) * (1.0 if level <= 7 else 0.97)
     assert z.zstd_compress(corpus, level=level) == outs["corpus", "auto"]  # deterministic
     assert z.zstd_cctx_settings(z.zstd_cctx(level=level))["level"] == level
 
@@ -496,9 +507,9 @@ def test_chunks_of_cheap_bytes_keep_only_long_matches(ref):
     table = b"".join(lines[i] for i in rng.integers(0, 400, size=60000))                     # cheap bytes AND whole lines that repeat
     head = bytes(rng.integers(48, 58, size=6000, dtype=np.uint8)) + GENERATORS["text"](2 << 20, seed=3)  # the probe sees no match, the rest is text
     # ("table": 400 different lines, so a line's last occurrence lies 19 KiB back on average -- further than the 2^13-entry LDS tables
-    # remember at level 3 (mean age of an entry = the table's size): 1.17x the reference's size in round 3, 1.21x with round 4's
-    # smaller short table; a known weakness of the design, DESIGN.md section 9 -- the rule under test must not add to it)
-    for name, data, bar in (("iid10", iid, 1.0), ("digits", digits, 1.0), ("table", table, 1.25), ("digits_then_text", head, 1.05)):
+    # of the table parse remember: 1.17x the reference's size in round 3, 1.21 - 1.25x in round 4.  Round 5: an input of this size is
+    # searched by the deep match finder at level 3 too, which sees every occurrence inside the window: 1.016x)
+    for name, data, bar in (("iid10", iid, 1.0), ("digits", digits, 1.0), ("table", table, 1.05), ("digits_then_text", head, 1.05)):
         theirs = len(ref.compress(data, level=3))
         for layout in ("auto", "frames"):
             out = z.zstd_compress(data, frame_layout=layout)

@@ -43,9 +43,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order, handover;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order, handover, sub_lits, sub_seqs, sub_meta;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order, &handover}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order, &handover, &sub_lits, &sub_seqs, &sub_meta}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
@@ -115,13 +115,30 @@ inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_
 // windowLog 21 up to level 8, 22 from 9).  Levels 13 - 15 (btlazy2: a binary tree finds the longest match among more candidates
 // than a chain visits) search deeper still; the optimal parsers of levels 16 - 22 are not built: they run as 15.
 struct DeepLevel { u32 k, lazy2, wlog; };
-inline DeepLevel deep_level(int level) {
+// Levels 3 - 5 on an input of ZL_DEEP_SMALL_MIN .. ZL_DEEP_SMALL_MAX bytes search the same way, a few candidates deep (round 5): a call
+// that small is bound by its launches, not by its kernels -- the sort and the search of 1 MiB cost less than the far passes and the
+// table parse do (python sources, 1 MiB, host to host: 2.7 ms by the tables, 2.2 ms by the deep finder), and what it writes is
+// 4 - 8 % SMALLER than the reference's at the same level where the table parse wrote 8 - 12 % more.  Larger inputs (where the table
+// parse's 100 GB/s is the product) and the smallest (one sparse table pass, 0.15 ms a call) keep the table parse.
+#ifndef ZL_DEEP_SMALL_MIN
+#define ZL_DEEP_SMALL_MIN (16u << 10)
+#endif
+#ifndef ZL_DEEP_SMALL_MAX
+#define ZL_DEEP_SMALL_MAX (16u << 20)
+#endif
+#ifndef ZL_DEEP_SUB
+#define ZL_DEEP_SUB 8u  // workgroups that share a chunk in the deep parse of a small launch (a power of two; 1: never)
+#endif
+inline bool deep_small(int level, u64 total) { return level >= 3 && level <= 5 && total > ZL_DEEP_SMALL_MIN && total <= ZL_DEEP_SMALL_MAX; }
+inline DeepLevel deep_level(int level, u64 total) {
     static const DeepLevel tab[10] = {{8, 0, 21}, {16, 0, 21}, {16, 1, 21}, {16, 1, 22}, {32, 1, 22}, {64, 1, 22}, {96, 1, 22}, {128, 1, 22}, {192, 1, 22}, {256, 1, 22}};
+    static const DeepLevel small[3] = {{3, 0, 21}, {4, 0, 21}, {6, 0, 21}};
+    if (deep_small(level, total)) return small[level - 3];
     return tab[std::min(std::max(level, 6), 15) - 6];
 }
 // ... which needs ONE contiguous input and no dictionary (a dictionary's content is not part of what is sorted): batches of
 // objects and dictionary contexts at these levels run the table-based parse at its deepest setting instead
-inline bool deep_on(const zl_cctx* c) { return c->level >= 6 && c->one_input && c->dict_use == 0; }
+inline bool deep_on(const zl_cctx* c) { return (c->level >= 6 || deep_small(c->level, c->input_total)) && c->one_input && c->dict_use == 0; }
 
 inline u32 zl_rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
@@ -192,7 +209,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         !es.sst.ensure((size_t)cnt * sd.seq * ZL_SST_BYTES + 64) || !es.staged.ensure((size_t)cnt * sd.out))
         return kGpuUnavailable;
     const bool deep = deep_on(c);
-    const DeepLevel dl = deep_level(c->level);
+    const DeepLevel dl = deep_level(c->level, c->input_total);
     if (joined && !deep && (!es.far_table.ensure(ZL_FAR_TABLE_BYTES(cnt)) || !es.far_hints.ensure((size_t)cnt * ZL_FAR_HINT_WORDS * 4) || !es.far_lists.ensure(ZL_FAR_LIST_BYTES(cnt)))) return kGpuUnavailable;
     c->far_valid = false;
     u64 deep_lo = 0;
@@ -206,11 +223,11 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         d.total = c->input_total;
         d.k = dl.k;
         d.window = (1u << dl.wlog) - 1u;
-        d.mml = c->input_total > ((u64)256 << 10) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at these levels)
+        d.mml = (c->level < 6 || c->input_total > ((u64)256 << 10)) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at levels 6 and up; 5 throughout at 3 - 5)
         d.frames = joined ? 0u : 1u;
-        if (!es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(zl_deep_scratch_bytes())) return kGpuUnavailable;
+        if (!es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(zl_deep_scratch_bytes(d.hi - d.lo))) return kGpuUnavailable;
         d.scratch = es.deep_scratch.p;
-        d.scratch_bytes = zl_deep_scratch_bytes();
+        d.scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);
         d.best = (u64*)es.deep_best.p;
         if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
         if (zl_launch_deep_search(&d, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -262,9 +279,22 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     m.deep_lo = deep_lo;
     m.total = c->input_total;
     m.joined = joined ? 1u : 0u;
-    m.pad1 = 0;
+    m.sub = 0;
+    m.sub_lits = nullptr; m.sub_seqs = nullptr; m.sub_meta = nullptr;
     m.order = order;
-    if (deep) m.lazy2 = dl.lazy2;
+    if (deep) {
+        m.lazy2 = dl.lazy2;
+        // a launch that would leave most of the device idle: several workgroups share a chunk (zl_match_deep_kernel)
+        // (a function of the INPUT's size, not of the group's: every route a call can take -- one launch, sections through the
+        // upload slots, a stream's jobs -- writes the same bytes)
+        u32 parts = ZL_DEEP_SUB;
+        while (parts > 1 && chunks_of(c->input_total) * parts > 2048) parts >>= 1;
+        if (parts > 1 && c->chunk_cap >= ZL_CHUNK) {
+            if (!es.sub_lits.ensure((size_t)cnt * sd.lit) || !es.sub_seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) || !es.sub_meta.ensure((size_t)cnt * parts * 8 + 64)) return kGpuUnavailable;
+            m.sub = parts;
+            m.sub_lits = (u8*)es.sub_lits.p; m.sub_seqs = (zl_seq*)es.sub_seqs.p; m.sub_meta = (u32*)es.sub_meta.p;
+        }
+    }
 #ifdef ZL_TRACE
     // development build: the match kernel stamps a timeline of one workgroup's iterations behind the 128 bytes of phase sums
     if (prof && c->profile >= 2 && c->d_stats.ensure(128 + ZL_TRACE_BYTES)) {
@@ -314,7 +344,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.checksum = (u32)c->checksum;
     e.dict_id = c->dict_use ? c->dict_id : 0;  // (a raw-content dictionary has no id: zstd.c:27550)
     e.raw_lits = c->level < 0 ? 1u : 0u;
-    e.exact_rep = c->level >= 5 ? 1u : 0u;
+    e.exact_rep = (c->level >= 5 || deep) ? 1u : 0u;
     e.joined = joined ? 1u : 0u;
     e.chunk_base = (u32)(frame_chunk0 + first);
     e.total_chunks = (u32)nchunks;

@@ -215,6 +215,7 @@ struct DeepShared {
     u16 jump[DEEP_THREADS];
     u32 scan_a[4];
     u32 rep;                     // offset of the most recent sequence
+    u32 probe_good;              // cheap-bytes probe: sequences that were long, or used the offset of the one before
     u32 t_end[DEEP_THREADS], t_off[DEEP_THREADS];  // the merge pass
     alignas(16) u8 wbuf[DEEP_WBUF];
     alignas(16) u8 rbuf[DEEP_RBUF];
@@ -235,12 +236,24 @@ __device__ __forceinline__ u32 lds_common16(const u8* a, u32 oa, const u8* b, u3
 __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_args a, u32 nchunks) {
     __shared__ DeepShared S;
     const u32 t = threadIdx.x;
-    const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
+    // a.sub > 1 (a launch of few chunks, where a workgroup's walk over its chunk -- 512 windows, one behind the other -- is all the
+    // call waits for): `sub` workgroups share a chunk, each parses its part [p_lo, p_hi) as if the chunk began there (no repeat
+    // offset, no match running in from the part before; a match ends with the part) and leaves literals, sequences and counts where
+    // zl_deep_join_kernel collects them -- which also joins a match cut at a part's end with its continuation (zl_merge_pieces)
+    const u32 parts = a.sub > 1 ? a.sub : 1u;
+    const u32 part = parts > 1 ? blockIdx.x % parts : 0u;
+    const u32 c = parts > 1 ? blockIdx.x / parts : (a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks));
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;
-    u8* lits = a.lits + (size_t)c * a.lit_stride;
-    zl_seq* seqs = a.seqs + (size_t)c * a.seq_stride;
+    const u32 p_lo = part * (ZL_CHUNK / parts);
+    const u32 p_hi = parts > 1 ? (n < p_lo + ZL_CHUNK / parts ? n : p_lo + ZL_CHUNK / parts) : n;
+    if (parts > 1 && p_lo >= n) {
+        if (t == 0) { a.sub_meta[2 * blockIdx.x] = 0; a.sub_meta[2 * blockIdx.x + 1] = 0; }
+        return;
+    }
+    u8* lits = parts > 1 ? a.sub_lits + (size_t)c * a.lit_stride + p_lo : a.lits + (size_t)c * a.lit_stride;
+    zl_seq* seqs = parts > 1 ? a.sub_seqs + (size_t)c * a.seq_stride + (size_t)part * (a.seq_stride / parts) : a.seqs + (size_t)c * a.seq_stride;
     const u64* const best = a.deep_best + (size_t)(cd.src_off - a.deep_lo);
     // what may be read around the chunk: its section (no offset crosses one, zl_encode.h) and the input's end
     const u64 sec_off = cd.src_off & (DEEP_SEC_BYTES - 1);
@@ -257,13 +270,17 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         return make_uint4(w[0], w[1], w[2], w[3]);
     };
     if (t < 2) S.cand[DEEP_THREADS + t] = 0;
-    if (t == 0) S.rep = 0;
-    // ---- what is a match worth?  (zl_match_auto_kernel, zl_encode.hip, says it at length: a sequence with a new offset costs some 24
-    // bits, the literals it replaces cost what the chunk's bytes cost; where bytes are cheap -- i.i.d. data over a dozen symbols --
-    // new-offset matches of fewer than eight bytes lose bits, and the deep search finds MANY of them: every position of such data
-    // has sixteen earlier occurrences of its five bytes.)  Order-0 entropy of 16 KiB sampled from the chunk's four quarters; the
-    // rule starts behind the chunk's first 4 KiB, where matches covered less than a tenth of those bytes.
+    if (t == 0) { S.rep = 0; S.probe_good = 0; }
+    // ---- what is a match worth?  (zl_match_auto_kernel, zl_encode.hip, says it at length: a sequence with a new offset costs its
+    // offset's and its literal run's extra bits, the literals it replaces cost what the chunk's bytes cost; where bytes are cheap --
+    // i.i.d. data over a dozen symbols -- short new-offset matches lose bits, and the deep search finds MANY of them: behind a full
+    // history every position of such data has its five-byte twin, and nothing longer.)  Order-0 entropy of 16 KiB sampled from the
+    // chunk's four quarters; a cheap chunk (a part of one) looks at the sequences of its first window(s): where matches covered less
+    // than a tenth of the bytes, or fewer than half of the sequences were REGULAR -- eight bytes long, nearer than 64 bytes, or at the offset
+    // of the sequence before (a vector of doubles: seven-byte matches, every one at offset 8, one literal between them: ratio 8; cheap
+    // bytes by their histogram) -- only new-offset matches of smin_cheap bytes and more are kept from there on.
     bool cheap = false;
+    u32 smin_cheap = 8;
     if (n >= 16384) {
         u32* const bins = S.t_end;  // [256]
         bins[t] = 0;
@@ -283,17 +300,22 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         lds_barrier();
         const float total = __uint_as_float(S.scan_a[0]) + __uint_as_float(S.scan_a[1]) + __uint_as_float(S.scan_a[2]) + __uint_as_float(S.scan_a[3]);
         cheap = total * 10.0f < 36.0f * 16384.0f;  // below 3.6 bits per byte
+        // ... and the shortest match that pays: a sequence with a new offset inside such data costs some 45 bits (the offset's and the
+        // literal run's extra bits), the bytes it replaces cost total / 16384 bits each -- 14 bytes on ten equally likely symbols.  (The
+        // table parse asks for 8 and finds two such matches per chunk; this search finds all eighty of them: 0.8 % of the output)
+        if (cheap) { const u32 need = (u32)(45.0f * 16384.0f / fmaxf(total, 16384.0f)) + 1u; smin_cheap = need < 8u ? 8u : (need > 24u ? 24u : need); }
         lds_barrier();
     }
-    u32 smin = MIN_MATCH, probed = 0, probed_lits = 0;  // shortest new-offset match kept (uniform)
+    u32 smin = MIN_MATCH, probed = 0, probed_lits = 0, probed_seqs = 0;  // shortest new-offset match kept (uniform)
+    const u32 probe_len = parts > 1 ? 256u : 1024u;    // (every part of a shared chunk probes for itself: a shorter probe, or a quarter of the chunk keeps the short matches)
     u32 nseq = 0, nlit = 0, carry = 0;
     uint4 wb_cur = make_uint4(0, 0, 0, 0);
-    if (t < DEEP_WBUF / 16) wb_cur = ld16((i32)(16 * t));
-    u64 bw_cur = t < n ? best[t] : 0ull;
+    if (t < DEEP_WBUF / 16) wb_cur = ld16((i32)(p_lo + 16 * t));
+    u64 bw_cur = p_lo + t < p_hi ? best[p_lo + t] : 0ull;
     lds_barrier();
-    for (u32 ip = 0; ip < n; ip += DEEP_THREADS) {
+    for (u32 ip = p_lo; ip < p_hi; ip += DEEP_THREADS) {
         const u32 p = ip + t;
-        const bool in_range = p < n;
+        const bool in_range = p < p_hi;
         const u32 rep = S.rep;
         if (t < DEEP_WBUF / 16) *(uint4*)(S.wbuf + 16 * t) = wb_cur;
         // the bytes the repeat offset points at, for the whole window: [ip - rep - 8, + DEEP_RBUF)
@@ -301,9 +323,9 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         // the next window's bytes and words travel while this one is parsed
         uint4 wb_next = make_uint4(0, 0, 0, 0);
         u64 bw_next = 0;
-        if (ip + DEEP_THREADS < n) {
+        if (ip + DEEP_THREADS < p_hi) {
             if (t < DEEP_WBUF / 16) wb_next = ld16((i32)(ip + DEEP_THREADS + 16 * t));
-            if (p + DEEP_THREADS < n) bw_next = best[p + DEEP_THREADS];
+            if (p + DEEP_THREADS < p_hi) bw_next = best[p + DEEP_THREADS];
         }
         lds_barrier();
         const u64 v = lds64(S.wbuf, t);
@@ -311,11 +333,11 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         const u64 v_front = (u64)__shfl_up((u32)v, 8, 64) | ((u64)__shfl_up((u32)(v >> 32), 8, 64) << 32);
         u32 best_len = 0, best_off = 0, back = 0;
         if (in_range && carry < DEEP_THREADS) {  // (otherwise the whole window lies inside an earlier match)
-            const u32 room = n - p;
+            const u32 room = p_hi - p;
             u32 len_d = (u32)bw_cur & 0xFFFFu;
             const u32 off_d = (u32)(bw_cur >> 32), back_d = ((u32)bw_cur >> 16) & 0xFFu;
             if (len_d > room) len_d = room;
-            if (len_d < smin) len_d = 0;
+            if (len_d < smin && (smin == MIN_MATCH || off_d >= 64u)) len_d = 0;  // (near offsets are cheap to name: kept at any length)
             // the repeat offset: measured out of the two LDS buffers
             u32 l_r = 0;
             if (rep && p + reach >= rep) {
@@ -392,6 +414,14 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         // ---- compaction ranks from ballots; the four waves exchange their totals through LDS
         const u64 ms = __ballot(is_seq), ml = __ballot(is_lit);
         const u64 below = (1ull << (t & 63)) - 1;
+        if (cheap && probed < probe_len) {  // (uniform) the probe of the cheap-bytes rule: which of this window's sequences are regular?
+            const u32 lane = t & 63;
+            const u64 lower = ms & below;
+            const u32 prev = lower ? 63u - (u32)__builtin_clzll(lower) : lane;
+            const u32 off_prev = __shfl(best_off, (int)prev, 64);
+            const u64 mg = __ballot(is_seq && (best_len >= 8 || best_off < 64u || best_off == rep || (lower && off_prev == best_off)));
+            if (lane == 0) atomicAdd(&S.probe_good, (u32)__popcll(mg));
+        }
         if ((t & 63) == 0) S.scan_a[wave] = (u32)__popcll(ms) | ((u32)__popcll(ml) << 16);
         lds_barrier();
         u32 pre = 0, tot = 0;
@@ -415,15 +445,55 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
         }
         nseq += tot_s;
         nlit += tot_l;
-        if (cheap && probed < 4096) {
-            probed += DEEP_THREADS; probed_lits += tot_l;
-            if (probed >= 4096 && (probed - probed_lits) * 10 < probed) smin = 8;
+        if (cheap && probed < probe_len) {
+            probed += DEEP_THREADS; probed_lits += tot_l; probed_seqs += tot_s;
+            if (probed >= probe_len && ((probed - probed_lits) * 10 < probed || S.probe_good * 2 < probed_seqs)) smin = smin_cheap;
         }
         wb_cur = wb_next;
         bw_cur = bw_next;
         lds_barrier();
     }
+    if (parts > 1) {
+        if (t == 0) { a.sub_meta[2 * blockIdx.x] = nseq; a.sub_meta[2 * blockIdx.x + 1] = nlit; }
+        return;
+    }
     const u32 out_n = zl_merge_pieces(seqs, nseq, S.t_end, S.t_off, S.scan_a);
+    if (t == 0) {
+        a.meta[c].nseq = out_n;
+        a.meta[c].nlit = nlit;
+    }
+}
+
+// a.sub > 1: one workgroup per chunk puts the parts' literals and sequences behind one another where the entropy stage reads them
+// (literal counts become the chunk's running count), joins a match cut at a part's end with its continuation, and leaves the counts
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_join_kernel(zl_match_args a) {
+    __shared__ u32 t_end[DEEP_THREADS], t_off[DEEP_THREADS], scan_a[4];
+    const u32 t = threadIdx.x, c = blockIdx.x, parts = a.sub;
+    const u32* const sm = a.sub_meta + (size_t)2 * c * parts;
+    u8* const lits = a.lits + (size_t)c * a.lit_stride;
+    zl_seq* const seqs = a.seqs + (size_t)c * a.seq_stride;
+    u32 nseq = 0, nlit = 0;
+    for (u32 f = 0; f < parts; f++) nseq += sm[2 * f];
+    u32 s_at = 0;
+    for (u32 f = 0; f < parts; f++) {
+        const u32 ns = sm[2 * f], nl = sm[2 * f + 1];
+        const zl_seq* const from = a.sub_seqs + (size_t)c * a.seq_stride + (size_t)f * (a.seq_stride / parts);
+        for (u32 i = t; i < ns; i += DEEP_THREADS) {
+            zl_seq sq = from[i];
+            sq.lit_cum += nlit;
+            seqs[s_at + i] = sq;
+        }
+        if (nseq) {  // (a chunk without a sequence: the entropy stage reads its literals from the source)
+            const u8* const lf = a.sub_lits + (size_t)c * a.lit_stride + f * (ZL_CHUNK / parts);
+            for (u32 i = 16 * t; i < nl; i += 16 * DEEP_THREADS) {
+                if (i + 16 <= nl) { const uint4 x = ld128(lf + i); __builtin_memcpy(lits + nlit + i, &x, 16); }
+                else for (u32 b = i; b < nl; b++) lits[nlit + b] = lf[b];
+            }
+        }
+        s_at += ns;
+        nlit += nl;
+    }
+    const u32 out_n = zl_merge_pieces(seqs, nseq, t_end, t_off, scan_a);
     if (t == 0) {
         a.meta[c].nseq = out_n;
         a.meta[c].nlit = nlit;
@@ -434,25 +504,34 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_match_deep_kernel(zl_match_ar
 // host side
 // ---------------------------------------------------------------------------------------
 namespace {
-size_t g_sort_temp = 0;  // hipcub's temporary storage for a full section (a function of the item count only)
-size_t sort_temp_bytes() {
-    if (!g_sort_temp) {
-        size_t b = 0;
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, DEEP_SEC_MAX, 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
-        g_sort_temp = (b + 255) & ~(size_t)255;
-    }
-    return g_sort_temp;
+// hipcub's temporary storage for sorting n keys (a function of the item count only; no launch)
+size_t sort_temp_bytes(u32 n) {
+    static size_t full = 0;
+    if (n == DEEP_SEC_MAX && full) return full;
+    size_t b = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, n, 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
+    b = (b + 255) & ~(size_t)255;
+    if (n == DEEP_SEC_MAX) full = b;
+    return b;
 }
+// the longest section a search over `span` bytes sorts (sections end on multiples of DEEP_SEC_BYTES of the input; the first may be any part of one)
+inline u32 sec_cap(u64 span) { return (u32)std::min<u64>(std::max<u64>(span, 4096), DEEP_SEC_MAX); }
 }  // namespace
 
-extern "C" size_t zl_deep_scratch_bytes(void) { return 2 * (size_t)DEEP_SEC_MAX * sizeof(u64) + sort_temp_bytes() + 256; }
+// two key arrays of the longest section + the sort's temporary storage (with room to spare: a shorter last section may ask for a little more)
+extern "C" size_t zl_deep_scratch_bytes(u64 span) {
+    const u32 cap = sec_cap(span);
+    return 2 * (size_t)cap * sizeof(u64) + sort_temp_bytes(cap) + (64u << 10) + 256;
+}
 
 extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream) {
     if (a->hi <= a->lo) return hipSuccess;
-    if (a->scratch_bytes < zl_deep_scratch_bytes()) return hipErrorInvalidValue;
+    if (a->scratch_bytes < zl_deep_scratch_bytes(a->hi - a->lo)) return hipErrorInvalidValue;
+    const u32 cap = sec_cap(a->hi - a->lo);
     u64* const keys_a = (u64*)a->scratch;
-    u64* const keys_b = keys_a + DEEP_SEC_MAX;
-    void* const temp = keys_b + DEEP_SEC_MAX;
+    u64* const keys_b = keys_a + cap;
+    void* const temp = keys_b + cap;
+    const size_t temp_room = a->scratch_bytes - 2 * (size_t)cap * sizeof(u64);
     const u32 mml_shift = 64u - 8u * a->mml;
     for (u64 s0 = a->lo; s0 < a->hi;) {
         const u64 s1 = std::min<u64>(a->hi, (s0 & ~(DEEP_SEC_BYTES - 1)) + DEEP_SEC_BYTES);
@@ -460,7 +539,7 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
         const u8* sec = a->src + s0;
         const u32 blocks = (n + DEEP_THREADS - 1) / DEEP_THREADS;
         hipLaunchKernelGGL(zl_deep_key_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, sec, n, mml_shift, keys_a);
-        size_t tb = sort_temp_bytes();
+        size_t tb = temp_room;
         const hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, tb, (const u64*)keys_a, keys_b, n, 32, 32 + ZL_DEEP_HLOG, stream);
         if (e != hipSuccess) return e;
         u64* const best = a->best + (s0 - a->lo);
@@ -476,6 +555,8 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
 
 extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(zl_match_deep_kernel, dim3(nchunks), dim3(DEEP_THREADS), 0, stream, *a, nchunks);
+    const u32 parts = a->sub > 1 ? a->sub : 1u;
+    hipLaunchKernelGGL(zl_match_deep_kernel, dim3(nchunks * parts), dim3(DEEP_THREADS), 0, stream, *a, nchunks);
+    if (parts > 1) hipLaunchKernelGGL(zl_deep_join_kernel, dim3(nchunks), dim3(DEEP_THREADS), 0, stream, *a);
     return hipGetLastError();
 }

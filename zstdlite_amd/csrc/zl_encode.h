@@ -84,8 +84,12 @@ struct zl_match_args {
     u64 deep_lo;           // input position of deep_best[0]
     u64 total;             // bytes of the whole input (the last readable byte of a chunk's section lies below it)
     u32 joined;            // the chunks are runs of blocks of ONE frame: a source may lie in front of its chunk (inside the chunk's section)
-    u32 pad1;
+    u32 sub;               // deep parse of a launch that would not fill the device: 2, 4 or 8 workgroups share a chunk (zl_match_deep_kernel), 0 / 1: one each
     const u32* order;      // launch order (zl_launch_chunk_order): workgroup w takes chunk order[zl_spread(w)], or null: chunk zl_spread(w)
+    // sub > 1: where the parts of a chunk leave their literals and sequences (laid out as lits / seqs) and their counts (2 words per part), for zl_deep_join_kernel
+    u8* sub_lits;
+    zl_seq* sub_seqs;
+    u32* sub_meta;
 };
 
 // ---- the deep match finder (levels >= 6; zl_deep.hip).  Restates what the reference's lazy strategies search -- the most recent
@@ -107,7 +111,7 @@ struct zl_deep_args {
     u32 window;        // farthest offset
     u32 mml;           // bytes the hash covers (4, 5 or 6) = shortest match
     u32 frames;        // 1: independent frames -- a candidate must lie inside the position's own chunk
-    void* scratch;     // zl_deep_scratch_bytes()
+    void* scratch;     // zl_deep_scratch_bytes(hi - lo)
     size_t scratch_bytes;
     u64* best;         // out: one word per position, best[p - lo]
 };
@@ -160,7 +164,7 @@ struct zl_gather_args {
 };
 
 extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipStream_t stream);
-extern "C" size_t zl_deep_scratch_bytes(void);
+extern "C" size_t zl_deep_scratch_bytes(u64 span);  // for a search over `span` bytes of input
 extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream);
 extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream);
 // order[0 .. nchunks): the chunks by decreasing estimated cost (longest first), input order inside a class; scratch: nchunks words
