@@ -36,7 +36,9 @@
                                                  // upload, compress and download as one pipeline stage, and the output must not depend on how a call was staged
 #define ZL_FAR_TABLE_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)4 << ZL_FAR_BUCKET_LOG))   // one column of 2^ZL_FAR_BUCKET_LOG words per chunk
 #define ZL_FAR_LIST_CAP 40960u                    // sampled positions a chunk may list (expected: 16384 at one in eight, 32768 at one in four); what exceeds it is not probed
-#define ZL_FAR_LIST_BYTES(nchunks) ((size_t)(nchunks) * ((size_t)ZL_FAR_LIST_CAP * 8 + 64))
+#define ZL_FAR_SPARSE_CAP 255u                    // ... and the keys of one listed position in 256 (by tag), which zl_far_probe_kernel tries first
+#define ZL_FAR_LIST_WORDS (ZL_FAR_LIST_CAP * 2u + 16u + ZL_FAR_SPARSE_CAP + 1u)  // per chunk: 16 words of header, the pairs, the sparse keys' count and the keys
+#define ZL_FAR_LIST_BYTES(nchunks) ((size_t)(nchunks) * (size_t)ZL_FAR_LIST_WORDS * 4)
 #define ZL_FAR_HINT_WORDS (ZL_CHUNK >> ZL_FAR_HINT_LOG)
 
 #define ZL_TRACE_BYTES (1 << 20)                 // development builds (-DZL_TRACE=<chunk>): timeline of that chunk's match workgroup
@@ -123,7 +125,7 @@ struct zl_far_args {
     u32 chunk_base;        // index, inside the input, of chunks[0] (a multiple of ZL_FAR_GROUP)
     u32 sample_log;        // one position in 2^sample_log takes part (ZL_FAR_SAMPLE_LOG at level 3; higher levels sample more densely)
     u32* table;            // ZL_FAR_TABLE_BYTES(nchunks): per chunk a column of 2^ZL_FAR_BUCKET_LOG words, written whole by zl_launch_far_build
-    u32* lists;            // ZL_FAR_LIST_BYTES(nchunks): per chunk a count (16 words) and up to ZL_FAR_LIST_CAP pairs {bucket | tag << 14, position}
+    u32* lists;            // ZL_FAR_LIST_BYTES(nchunks): per chunk ZL_FAR_LIST_WORDS: a count (16 words), up to ZL_FAR_LIST_CAP pairs {bucket | tag << 14, position}, the sparse keys
     u32* hints;            // per chunk ZL_FAR_HINT_WORDS words, written by zl_launch_far_probe
 };
 

@@ -1283,16 +1283,17 @@ static_assert(ZL_FAR_BUCKET_LOG + 15 <= 32 - 3, "a list key holds bucket and tag
 __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_far_args a, u32 nchunks) {
     __shared__ u32 col[FAR_COL];
     __shared__ u32 wtot[2][FAR_BUILD_THREADS / 64];
-    __shared__ u32 count;
+    __shared__ u32 count, sparse_count;
     u32 running = 0;  // ordered pass: sampled positions so far (uniform)
     const u32 c = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 lim = far_limit(a, cd, a.chunk_base + c);
     const u32 sl = a.sample_log;
-    u32* list = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
+    u32* list = a.lists + (size_t)c * ZL_FAR_LIST_WORDS;
+    u32* const sparse = list + 16 + 2 * (size_t)ZL_FAR_LIST_CAP;  // [0] how many listed positions have a tag whose low byte is zero, then the keys of the first ZL_FAR_SPARSE_CAP to arrive (used only when all of them fit: which ones arrive first is not the content's business)
     for (u32 i = t; i < FAR_COL; i += FAR_BUILD_THREADS) col[i] = 0;
-    if (t == 0) count = 0;
+    if (t == 0) { count = 0; sparse_count = 0; }
     {   // the chunk's hint words start out empty (the probe kernel raises them with atomicMax)
         uint4* h4 = (uint4*)(a.hints + (size_t)c * ZL_FAR_HINT_WORDS);
         for (u32 i = t; i < ZL_FAR_HINT_WORDS / 4; i += FAR_BUILD_THREADS) h4[i] = make_uint4(0, 0, 0, 0);
@@ -1330,7 +1331,13 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
                     const bool on = p0 + j < lim && far_sampled(h, sl);
                     const u32 bucket = far_bucket(h, sl), tag = far_tag(h, sl);
                     keys[j] = bucket | (tag << ZL_FAR_BUCKET_LOG);
-                    if (on) { if (!ordered) atomicMax(&col[bucket], ((p0 + j) << 15) | tag); mine |= 1u << j; }
+                    if (on) {
+                        if (!ordered) {
+                            atomicMax(&col[bucket], ((p0 + j) << 15) | tag);
+                            if ((tag & 0xFFu) == 0) { const u32 i = atomicAdd(&sparse_count, 1u); if (i < ZL_FAR_SPARSE_CAP) sparse[1 + i] = keys[j]; }
+                        }
+                        mine |= 1u << j;
+                    }
                 }
                 u32 cnt = (u32)__popc(mine), inc = cnt;
 #pragma unroll
@@ -1362,7 +1369,7 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
         }
     }
     __syncthreads();  // (every position is in the column)
-    if (t == 0) list[0] = count < ZL_FAR_LIST_CAP ? count : ZL_FAR_LIST_CAP;
+    if (t == 0) { list[0] = count < ZL_FAR_LIST_CAP ? count : ZL_FAR_LIST_CAP; sparse[0] = sparse_count; }
     uint4* out = (uint4*)(a.table + (size_t)c * FAR_COL);
     const uint4* in = (const uint4*)col;
     for (u32 i = t; i < FAR_COL / 4; i += FAR_BUILD_THREADS) out[i] = in[i];
@@ -1379,6 +1386,9 @@ __global__ __launch_bounds__(FAR_BUILD_THREADS, 8) void zl_far_build_kernel(zl_f
 // (Runs, not one contiguous share per XCD: the chunks' costs differ with the data, and a share per XCD left most of the device
 // idle while the two XCDs that held the text quarter of the bench vector worked: 6.0 -> 8.9 ms.)
 #define FAR_XCDS 8u
+#ifndef ZL_FAR_GATE
+#define ZL_FAR_GATE 1  // a chunk's sampled positions are probed sparsely before the columns are streamed for it (zl_far_probe_kernel)
+#endif
 #ifndef FAR_XCD_RUN
 #define FAR_XCD_RUN 16u
 #endif
@@ -1399,6 +1409,9 @@ __global__ __launch_bounds__(FAR_PROBE_THREADS, 4) void zl_far_probe_kernel(zl_f
     // now happens inside the one: two column buffers, the next column's LDS-DMA in flight during the lookups in this one.
     __shared__ __align__(16) u32 colbuf[2][FAR_COL];
     __shared__ u32 still_open[ZL_FAR_GROUP + 2];  // per column step: does any wave hold an entry that is still looking
+#if ZL_FAR_GATE
+    __shared__ u32 pre_hits[2];
+#endif
     const u32 c0 = 2 * far_xcd_chunk(blockIdx.x), t = threadIdx.x;
     if (c0 >= nchunks) return;
     u32 back[2], count[2], lim[2];
@@ -1416,11 +1429,41 @@ __global__ __launch_bounds__(FAR_PROBE_THREADS, 4) void zl_far_probe_kernel(zl_f
             if (b > ZL_FAR_GROUP - 1) b = ZL_FAR_GROUP - 1;
             if (b > c) b = c;  // (columns exist for the launch's own chunks only)
             back[h] = b;
-            list[h] = a.lists + (size_t)c * (ZL_FAR_LIST_CAP * 2 + 16);
+            list[h] = a.lists + (size_t)c * ZL_FAR_LIST_WORDS;
             count[h] = b ? list[h][0] : 0u;
         }
     }
     if (back[0] == 0 && back[1] == 0) return;
+#if ZL_FAR_GATE
+    // ---- is there anything to find?  (round 5)  Random bytes, small integers, i.i.d. symbols: no sampled position of such a chunk has
+    // a twin further back, so none ever stops looking, and the chunk's whole list was read and all fifteen columns streamed for
+    // nothing -- those chunks, not the text, were half of what this kernel did on the bench mix.  One listed position in 256 (chosen
+    // by its tag: by content; the build kernel sets their keys aside) looks its bucket up in every column DIRECTLY in memory first: a
+    // thousand scattered words per chunk instead of a MiB of columns and 128 KiB of list.  A chunk that finds fewer than two tags
+    // there has at most a per cent of its positions matched further back and is left alone.
+    {
+        if (t < 2) pre_hits[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            if (!back[h] || !count[h]) continue;
+            const u32* const sparse = list[h] + 16 + 2 * (size_t)ZL_FAR_LIST_CAP;
+            const u32 ns = sparse[0];
+            if (ns > ZL_FAR_SPARSE_CAP) { if (t == 0) pre_hits[h] = 2; continue; }  // (long runs: every position is sampled alike)
+            u32 hits = 0;
+            for (u32 item = t; item < ns * back[h]; item += FAR_PROBE_THREADS) {
+                const u32 kk = sparse[1 + item / back[h]], k = 1 + item % back[h];
+                const u32 w = a.table[(size_t)(c0 + h - k) * FAR_COL + (kk & (FAR_COL - 1))];
+                hits += (w != 0 && (w & 0x7FFFu) == (kk >> ZL_FAR_BUCKET_LOG)) ? 1u : 0u;
+            }
+            if (hits) atomicAdd(&pre_hits[h], hits);
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) if (pre_hits[h] < 2) { count[h] = 0; back[h] = 0; }
+        if (back[0] == 0 && back[1] == 0) return;  // (uniform; the hint words stay as the build kernel left them: empty)
+    }
+#endif
     // the columns the pair wants: from the nearest one (c0 itself for chunk c0 + 1, else c0 - 1) down to the farthest
     const u32 j_hi = back[1] ? c0 : c0 - 1;
     u32 j_lo = j_hi;
