@@ -67,6 +67,57 @@ def test_high_levels_and_long_windows(ref):
 
 
 @needs_ref
+def test_large_frames_that_ride_on_the_dictionarys_tables(ref, oracle):
+    """the reference's level 3 with a trained dictionary writes first blocks with treeless literals and
+    Repeat_Mode sequence tables -- the DICTIONARY's (zstd.c:42053).  Until round 5 such a frame left the large-frame pipeline for
+    the general kernel's one workgroup (32 MiB: 3 s, 0.011 GB/s).  Its segments now inherit the dictionary's tables from the
+    synthetic block the lane pipeline already uses for small dictionary frames (zl_api.hip dctx_prepare_dict).  Several levels
+    and kinds of input, a raw-content dictionary beside the trained one; damaged frames get the oracle's verdict."""
+    t_ = GENERATORS["text"](1_300_000, seed=77)
+    trained = ref.train_dict([t_[i * 3000:(i + 1) * 3000] for i in range(400)], 20000)
+    assert trained[:4] == bytes([0x37, 0xA4, 0x30, 0xEC])
+    for D in (trained, t_[70000:110000]):
+        dctx = z.zstd_dctx(dict=D)
+        took = 0
+        for n, level, gen in [(4 << 20, 3, "text"), ((9 << 20) + 77, 3, "text"), (3 << 20, 1, "text"), (3 << 20, 6, "text"), (5 << 20, 3, "int20"), (2 << 20, 19, "text")]:
+            data = GENERATORS[gen](n, seed=n & 0xFFF)
+            comp = ref.compress(data, level=level, dict=D)
+            assert z.zstd_decompress(comp, dctx=dctx) == data, (len(D), n, level, gen)
+            took += 1
+            assert large_frames(dctx) == took, (len(D), n, level, gen)
+    # the wrong dictionary, no dictionary, flipped bytes: what the oracle says
+    data = GENERATORS["text"](3 << 20, seed=3)
+    comp = ref.compress(data, level=3, dict=trained)
+    dctx = z.zstd_dctx(dict=trained)
+    rng = np.random.default_rng(5)
+    cases = [comp[:len(comp) - 1], comp[:len(comp) // 3]]
+    for _ in range(30):
+        bad = bytearray(comp)
+        for _ in range(int(rng.integers(1, 3))):
+            bad[int(rng.integers(6, min(len(bad), 200000)))] ^= 1 << int(rng.integers(0, 8))
+        cases.append(bytes(bad))
+    errs = 0
+    for bad in cases:
+        try:
+            want = oracle.decompress(bad, cap=len(data), dict=trained)
+        except Exception:
+            want = None
+        try:
+            got = z.zstd_decompress(bad, dctx=dctx)
+        except z.ZstdError:
+            got = None
+        assert (got is None) == (want is None), "verdicts differ"
+        if got is not None:
+            assert got == want
+        else:
+            errs += 1
+    assert errs >= 8
+    with pytest.raises(z.ZstdError):
+        z.zstd_decompress(comp)  # (no dictionary: Dictionary_ID mismatch / tables missing)
+    assert z.zstd_decompress(comp, dctx=dctx) == data
+
+
+@needs_ref
 def test_checksummed_large_frame(ref):
     data = GENERATORS["text"](2 << 20, seed=3) + bytes(300000) + GENERATORS["rand"](400000, seed=3)
     comp = ref.compress(data, level=3, checksum=True)

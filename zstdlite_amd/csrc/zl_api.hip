@@ -1488,16 +1488,17 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
         zl3_hint hint;
         hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
         hint.tail = (d->run_headerless || d->run_not_last) ? d->run_tail : ZL3_TAIL_FROM_HEADER;  // (a run that is not the frame's last has no footer, whatever the header says)
-        hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0;
+        hint.dict_end = nullptr; hint.dict_len = 0; hint.dict_id = 0; hint.dict_formatted = 0; hint.dict_ext = nullptr; hint.dict_ext_base = nullptr;
         hint.dict_rep[0] = 1; hint.dict_rep[1] = 4; hint.dict_rep[2] = 8;
         hint.size_unknown = 0; hint.run_out = nullptr; hint.ndonors = 0; hint.donor[0] = hint.donor[1] = hint.donor[2] = hint.donor[3] = 0xFFFFFFFFu;
         hint.phase = 0; hint.reserve_blocks = 0; hint.reserve_span = 0;
-        if (has_dict) {  // the dictionary's content is history in front of the frame; its tables stay with the general kernel (zl_decode3.h)
+        if (has_dict) {  // the dictionary's content is history in front of the frame; its tables come as the lane pipeline's synthetic block (zl_decode3.h)
             hint.dict_len = (u32)(d->dict.size() - d->dict_content_off);
             hint.dict_end = (const u8*)d->d_dict.p + d->dict.size();
             hint.dict_id = d->dict_id;
             hint.dict_formatted = d->dict_formatted ? 1u : 0u;
             for (int k = 0; k < 3; k++) hint.dict_rep[k] = d->dict_rep[k];
+            if (d->dict_formatted && d->dict_ext_ok) { hint.dict_ext = (const zl2_blk_rec*)d->d_dict_ext.p; hint.dict_ext_base = (const u8*)d->d_dict_ext.p + 4 * sizeof(zl2_blk_rec); }
         }
         hint.sink_host = (n == 1 && d->sink_host) ? d->sink_host : nullptr;  // (a host entry decoding ONE frame: the output is downloaded as it is finished)
         hint.sunk = &d->sunk;
@@ -1582,7 +1583,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     f2.big = nullptr;
     f2.part = 0;
     f2.sym_first = 0;
-    f2.ext_shared = 0; f2.ext_base = nullptr; f2.dict_end = nullptr; f2.dict_len = 0; f2.dict_id = d->dict_id; f2.dict_pre = nullptr;
+    f2.ext_shared = 0; f2.ext_base = nullptr; f2.dict_ext_base = nullptr; f2.dict_end = nullptr; f2.dict_len = 0; f2.dict_id = d->dict_id; f2.dict_pre = nullptr;
     f2.dict_rep[0] = 1; f2.dict_rep[1] = 4; f2.dict_rep[2] = 8;
     if (has_dict) {
         f2.dict_end = (const u8*)d->d_dict.p + d->dict.size();

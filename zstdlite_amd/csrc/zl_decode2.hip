@@ -77,7 +77,9 @@ __device__ __forceinline__ void set_err(zl2_frame_rec* fr, u32 code) {
 // Inherited table descriptions (zl_kernels.h zl2_args::ext): four records per segment of a large frame, or ONE set of four for
 // every frame of a batch that starts from a dictionary (ext_shared), whose offsets count from ext_base.
 __device__ __forceinline__ const zl2_blk_rec& ext_rec(const zl2_args& a, u32 f, u32 k) { return a.ext[(a.ext_shared ? (size_t)0 : (size_t)f * 4) + k]; }
-__device__ __forceinline__ const u8* ext_src(const zl2_args& a, u32 f) { return a.ext_base ? a.ext_base : a.src + a.frames[f].src_off; }
+// (a record whose pad[0] is set describes the context's DICTIONARY -- the synthetic block of zl_api.hip dctx_prepare_dict -- among a
+// large frame's own donors: its offsets count from dict_ext_base)
+__device__ __forceinline__ const u8* ext_src(const zl2_args& a, u32 f, const zl2_blk_rec& r) { return r.pad[0] ? a.dict_ext_base : (a.ext_base ? a.ext_base : a.src + a.frames[f].src_off); }
 // does a chain of frame / segment f start from a history that the exec kernel fills in (symbols instead of numbers)?
 __device__ __forceinline__ bool starts_symbolic(const zl2_args& a, u32 f) { return a.ext != nullptr && (f != 0 || a.ext_shared != 0 || a.sym_first != 0); }
 
@@ -576,7 +578,7 @@ __device__ __forceinline__ void lit_role(const zl2_args& a, LitGroupT<MB>* G, u3
         if (ri == 0 ? ext_leader : (mine && (int)b == round && sub == 0)) {
             zl2_blk_rec lr = r;
             if (ri == 0) lr = ext_rec(a, f, 0);
-            const u8* blk = (ri == 0 ? ext_src(a, f) : src) + lr.src_off;
+            const u8* blk = (ri == 0 ? ext_src(a, f, lr) : src) + lr.src_off;
             u32 tree;
             if (ri == 0 && a.dict_pre != nullptr) {  // the dictionary's table, built once per context: copied
                 const zl2_dict_pre* P = a.dict_pre;
@@ -1350,7 +1352,7 @@ __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* r
         if (ext_lead || (mine && b + 4 == ri)) {  // leader: copy the table descriptions out of the frame, then parse them
             zl2_blk_rec lr = r;
             if (ext_lead) lr = ext_rec(a, f, 1 + ri);
-            const u8* sp = (ext_lead ? ext_src(a, f) : src) + lr.src_off + lr.seq_off;
+            const u8* sp = (ext_lead ? ext_src(a, f, lr) : src) + lr.src_off + lr.seq_off;
             const u32 sn = lr.seq_len, hn = sn < sizeof(B.hdr) ? sn : (u32)sizeof(B.hdr);
             {   // whole 16-byte pieces in one round trip, the last few bytes one by one
                 const u32 full = hn >> 4;

@@ -65,7 +65,8 @@ struct zl3_dev {  // device pointers of one large-frame decode
     u32* max_blocks;
     u32 cap_blocks;
     u32 dict_id;        // id of the dictionary loaded into the context (0: none, or raw content)
-    u32 dict_tables;    // the context holds a formatted dictionary: blocks may ride on ITS entropy tables (-> general kernel)
+    u32 dict_tables;    // the context holds a formatted dictionary: blocks may ride on ITS entropy tables ...
+    const zl2_blk_rec* dict_ext;  // ... which the segments inherit from these records (zl3_hint::dict_ext), or null: such frames go to the general kernel
     u32 have_dict;      // the context holds a dictionary of any kind
 };
 
@@ -531,7 +532,8 @@ __global__ __launch_bounds__(256) void zl3_plan_c_kernel(zl3_dev d, zl_frame_des
         none.type = ZL3_NONE;
         zl2_blk_rec* x = d.ext + (size_t)s * 4;
         x[0] = none; x[1] = none; x[2] = none; x[3] = none;
-        if (cur[0] != ZL3_NONE) x[0] = d.braw[cur[0]];
+        if (cur[0] != ZL3_NONE) { x[0] = d.braw[cur[0]]; x[0].pad[0] = 0; }  // (pad[0] of a donor record: 1 = the dictionary's, zl_decode2.hip ext_src; a block's own record keeps a byte count there)
+        else if (d.dict_ext) { x[0] = d.dict_ext[0]; x[0].pad[0] = 1; }  // (the dictionary's Huffman table is in force in front of the segment)
         {   // the (up to three) distinct defining blocks of the sequence tables, in block order
             u32 a0 = cur[1], a1 = cur[2], a2 = cur[3];
             const u32 nbk = info->nblocks;
@@ -542,22 +544,25 @@ __global__ __launch_bounds__(256) void zl3_plan_c_kernel(zl3_dev d, zl_frame_des
             if (ZL3_ORDER_KEY(a0) > ZL3_ORDER_KEY(a1)) { const u32 q = a0; a0 = a1; a1 = q; }
             #undef ZL3_ORDER_KEY
             u32 k = 1;
-            if (a0 != ZL3_NONE) x[k++] = d.braw[a0];
-            if (a1 != ZL3_NONE && a1 != a0) x[k++] = d.braw[a1];
-            if (a2 != ZL3_NONE && a2 != a1) x[k++] = d.braw[a2];
+            // (a table nobody has described yet is the dictionary's: its record spells out all three and comes first, the frame's own
+            // donors -- two at most, then -- override what they define)
+            if (d.dict_ext && (cur[1] == ZL3_NONE || cur[2] == ZL3_NONE || cur[3] == ZL3_NONE)) { x[k] = d.dict_ext[1]; x[k].pad[0] = 1; k++; }
+            if (a0 != ZL3_NONE) { x[k] = d.braw[a0]; x[k++].pad[0] = 0; }
+            if (a1 != ZL3_NONE && a1 != a0) { x[k] = d.braw[a1]; x[k++].pad[0] = 0; }
+            if (a2 != ZL3_NONE && a2 != a1) { x[k] = d.braw[a2]; x[k++].pad[0] = 0; }
         }
         for (u32 b = b0; b < b1; b++) {
             const zl2_blk_rec* r = d.braw + b;
             if (r->type != 2) continue;
-            // (with a formatted dictionary in the context such a block rides on the DICTIONARY's tables, zstd.c:42053: the general
-            // kernel knows those; this pipeline's lanes do not)
-            if (r->lit_mode == 3 && cur[0] == ZL3_NONE) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_DICT_CORRUPTED);
+            // (with a formatted dictionary in the context such a block rides on the DICTIONARY's tables, zstd.c:42053: x[] above names
+            // them when the context brought their records; without those the general kernel takes the frame)
+            if (r->lit_mode == 3 && cur[0] == ZL3_NONE && !d.dict_ext) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_DICT_CORRUPTED);
             if (r->lit_mode == 2) cur[0] = b;
             if (r->nseq > 0 && r->seq_modes != 0x100u) {
                 const u32 m = r->seq_modes;
                 const u32 mk[3] = {m >> 6, (m >> 4) & 3, (m >> 2) & 3};
                 for (int q = 0; q < 3; q++) {
-                    if (mk[q] == 3) { if (cur[1 + q] == ZL3_NONE) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_CORRUPTION); }
+                    if (mk[q] == 3) { if (cur[1 + q] == ZL3_NONE && !d.dict_ext) info_err(info, d.dict_tables ? ZL_E_FALLBACK : ZL_E_CORRUPTION); }
                     else cur[1 + q] = b;
                 }
             }
@@ -939,6 +944,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
     d.have_dict = have_dict ? 1u : 0u;
     d.dict_id = have_dict ? hint->dict_id : 0u;
     d.dict_tables = (have_dict && hint->dict_formatted) ? 1u : 0u;
+    d.dict_ext = d.dict_tables ? hint->dict_ext : nullptr;
     d.brec = nullptr; d.frec = nullptr; d.plan = nullptr; d.frames = nullptr; d.ext = nullptr; d.seg_tmp = nullptr;
     if (hipMemsetAsync(d.info, 0, sizeof(zl3_info), st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     // ---- the block table: uploaded from the host's walk, walked per chunk with the caller's chunk offsets, or walked by one lane
@@ -1075,7 +1081,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
         a.ext = d.ext; a.big = (const zl3_big*)s->big.p;
-        a.ext_shared = 0; a.ext_base = nullptr; a.dict_pre = nullptr; a.dict_end = nullptr; a.dict_len = 0; a.dict_id = 0; a.dict_rep[0] = 1; a.dict_rep[1] = 4; a.dict_rep[2] = 8;  // (the dictionary of a large frame travels in zl3_big)
+        a.ext_shared = 0; a.ext_base = nullptr; a.dict_ext_base = d.dict_ext ? hint->dict_ext_base : nullptr; a.dict_pre = nullptr; a.dict_end = nullptr; a.dict_len = 0; a.dict_id = 0; a.dict_rep[0] = 1; a.dict_rep[1] = 4; a.dict_rep[2] = 8;  // (the dictionary of a large frame travels in zl3_big)
         a.fuse1 = 3u | (ZL_QUAD_SPLIT ? 4u : 0u);
         a.part = 0;
         a.sym_first = (have_dict && hint->dict_formatted) ? 1u : 0u;

@@ -124,6 +124,7 @@ struct zl2_args {
     u32 dict_id;              // what a frame's Dictionary_ID must be when it has one (0: the context has no dictionary)
     u32 dict_rep[3];          // the history a frame starts with (1, 4, 8 without a formatted dictionary)
     const struct zl2_dict_pre* dict_pre;  // the dictionary's tables in the lanes' own formats, built once per context (null: the inheritance rounds build them from the synthetic block)
+    const u8* dict_ext_base;  // large frames (zl_decode3.hip): where the offsets of an ext record that describes the dictionary count from (zl_decode2.hip ext_src), or null
     // ---- a launch may cover a PART of the cost-sorted order (zl2_launch deals a large batch out in parts, see there).
     // 0: all of it.  Otherwise the launch's ROLE in the two-part schedule; which groups a role covers depends on the mode
     // the order kernel chose on the device (max_blocks[2]: ZL2_MODE_*).
