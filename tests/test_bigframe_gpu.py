@@ -67,6 +67,36 @@ def test_high_levels_and_long_windows(ref):
 
 
 @needs_ref
+def test_single_frames_of_two_to_eight_blocks_take_the_pipeline(ref):
+    """Round 5: ONE frame of 128 KiB - 1 MiB -- where zstd_serialize() of ordinary R objects lives -- went to the lane pipeline, which
+    gives a frame one sequence lane that walks its blocks one after the other (right for ten thousand frames side by side): 44 ms for
+    1 MiB of text the reference wrote, and this library's OWN one-frame output of that size (64 blocks: more than the lanes take) fell
+    through to the general kernel's one workgroup: 103 ms.  A call of a few frames now hands such frames to the large-frame
+    pipeline (blocks side by side): 4.7 and 2.4 ms.  A batch of many such frames keeps the lanes."""
+    import time
+    L = _lib.lib()
+    dctx = z.zstd_dctx()
+    took = 0
+    for n in (200_000, 512 << 10, 1 << 20):
+        data = GENERATORS["text"](n, seed=n & 0xFF)
+        for who, frame in (("reference", ref.compress(data, level=3)), ("own", z.zstd_compress(data))):
+            out = (C.c_char * n)()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter(); r = L.zl_decompressDCtx(dctx._ptr, out, n, frame, len(frame)); best = min(best, time.perf_counter() - t0)
+                took += 1
+            assert r == n and bytes(out) == data, (who, n)
+            assert large_frames(dctx) == took, (who, n)
+            assert best < 0.02, (who, n, best)  # (seconds; 0.012 - 0.103 before)
+    # many frames in one call: the lane pipeline, as before
+    items = [GENERATORS["text"](300_000, seed=i) for i in range(12)]
+    comps = [ref.compress(x, level=3) for x in items]
+    before = large_frames(dctx)
+    assert z.zstd_decompress_batch(comps, dctx=dctx) == items
+    assert large_frames(dctx) == before
+
+
+@needs_ref
 def test_large_frames_that_ride_on_the_dictionarys_tables(ref, oracle):
     """the reference's level 3 with a trained dictionary writes first blocks with treeless literals and
     Repeat_Mode sequence tables -- the DICTIONARY's (zstd.c:42053).  Until round 5 such a frame left the large-frame pipeline for
@@ -202,9 +232,10 @@ def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
 
 
 @needs_ref
-def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
-    """A SMALL frame (here four blocks) that does not record its size stays on the general kernel and still decodes; a large one
-    is bounded by its block count and takes the pipeline (test_large_frame_without_content_size_takes_the_pipeline)."""
+def test_small_frame_without_content_size(ref, oracle):
+    """A SMALL frame (here four blocks) that does not record its size: bounded by the room the caller gives, and -- since round 5,
+    as every single frame of two blocks and more -- decoded by the large-frame pipeline (until then: the general kernel); a large
+    one is bounded by its block count (test_large_frame_without_content_size_takes_the_pipeline).  Too little room is an error."""
     data = GENERATORS["text"](400000, seed=12)
     comp = bytearray(ref.compress(data, level=3))
     # rewrite the header: Single_Segment off, no Frame_Content_Size, explicit window descriptor (zstd.c:41050)
@@ -218,7 +249,10 @@ def test_frame_without_content_size_takes_the_general_kernel(ref, oracle):
     out = (C.c_char * len(data))()
     r = _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data), new, len(new))
     assert r == len(data) and bytes(out) == data
-    assert large_frames(dctx) == 0
+    assert large_frames(dctx) == 1
+    assert _lib.is_error(_lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data) - 1, new, len(new)))
+    r = _lib.lib().zl_decompressDCtx(dctx._ptr, out, len(data), new, len(new))
+    assert r == len(data) and bytes(out) == data
 
 
 def strip_content_size(comp):

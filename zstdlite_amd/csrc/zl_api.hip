@@ -1426,6 +1426,9 @@ bool stream_frame_begin(zl_dctx* d, const FrameHeader& h) {
 // enqueue the decode of `n` frames whose table sits in d->h_frames (pinned).  Frames of at most
 // one block size and without dictionary go through the lane-parallel pipeline (zl_decode2.hip);
 // the rest -- and whatever that pipeline hands back -- through the general kernel.
+#ifndef ZL_FEW_FRAMES
+#define ZL_FEW_FRAMES 4u  // a call of at most this many frames hands those of two blocks and more to the large-frame pipeline (below)
+#endif
 size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_t st) {
     size_t e = dctx_prepare_dict(d, st);
     if (ZL_IS_ERR(e)) return e;
@@ -1483,7 +1486,11 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // first, one after the other; it leaves each frame's result word on the device.
     d->took_big.assign(n, 0);
     for (size_t i = 0; i < n; i++) {
-        if ((tbl[i].dst_cap <= route_max && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
+        // (... and, in a call of a FEW frames, frames of two to eight blocks too -- round 5.  The lane pipeline gives a frame one sequence
+        // lane that walks its blocks one after the other: right for ten thousand frames side by side, 44 ms for ONE frame of 1 MiB of
+        // text the reference wrote (12 ms for 256 KiB).  The large-frame pipeline decodes the blocks side by side: 4.7 and 4.5 ms -- one block's chain of sequences.)
+        const u64 big_from = n <= ZL_FEW_FRAMES ? (u64)ZL_BLOCK_MAX : route_max;
+        if ((tbl[i].dst_cap <= big_from && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
         hint.host_blocks = nullptr; hint.nblocks = 0; hint.end_pos = 0; hint.d_chunk_off = nullptr; hint.nchunks = 0; hint.headerless = 0; hint.not_last = 0;
