@@ -44,7 +44,9 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
                                    * offsets), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 / 16 / 32 / 64 /
                                    * 96 / 128 / 192 / 256 candidates per position --, lazy depth -- one step at 6 and 7, two from 8 -- and
                                    * window -- 2 MiB up to 8, 4 MiB from 9 -- at that level, zstd.c:29523-29550).  16 ... 22 run as 15 (the
-                                   * optimal parsers are not built).  zl_CCtx_getParameter reports the point a context runs at.  Contexts with a
+                                   * optimal parsers are not built).  ONE input of 16 KiB ... 16 MiB is searched by the deep finder at levels 3, 4
+                                   * and 5 too (3 / 4 / 6 candidates, one step lazy: smaller output AND a shorter call than the tables give there;
+                                   * the batch entries and dictionary contexts keep the tables).  zl_CCtx_getParameter reports the point a context runs at.  Contexts with a
                                    * dictionary and the batch entries run levels >= 6 on the table-based parse at its deepest setting (the deep
                                    * finder sorts the positions of ONE contiguous input). */
 #define ZL_c_checksumFlag 201     /* zstd.h:440  ZSTD_c_checksumFlag     */
