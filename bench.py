@@ -211,6 +211,46 @@ def per_input_full_leg(codec, device, n, log):
     return out
 
 
+def single_object_leg(log):
+    """ONE object from host memory to host memory through the C entries alone (no Python in the timed region, output buffer made in
+    front), 64 KiB - 16 MiB, where zstd_serialize() of ordinary R objects lives: a call there is bound by its launches and by the
+    chain of ONE block, not by the device's throughput.  Wall time of zl_compress2 / zl_decompressDCtx (level 3, text; this library's
+    own frame and the reference's), next to the reference on one host core.  Round 5 found two cliffs here: the
+    table makes them visible."""
+    import zstdlite_amd as z
+    from zstdlite_amd import _lib
+    from zl_testlib import GENERATORS, Ref, have_ref
+    ref = Ref() if have_ref() else None
+    L = _lib.lib()
+    cctx, dctx = z.zstd_cctx(), z.zstd_dctx()
+    def best(f, reps=4):
+        b = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = f(); b = min(b, time.perf_counter() - t0)
+        return b, r
+    out = {}
+    for n in (64 << 10, 256 << 10, 1 << 20, 4 << 20, 16 << 20):
+        data = GENERATORS["text"](n, seed=5)
+        cap = L.zl_compressBound(n)
+        comp = (C.c_char * cap)()
+        back = (C.c_char * n)()
+        tc, csz = best(lambda: L.zl_compress2(cctx._ptr, comp, cap, data, n))
+        own = bytes(comp[:csz])
+        td, r = best(lambda: L.zl_decompressDCtx(dctx._ptr, back, n, own, len(own)))
+        assert r == n and bytes(back) == data
+        row = {"compress_ms": tc * 1e3, "decompress_own_frame_ms": td * 1e3, "ratio": n / csz}
+        if ref is not None:
+            trc, rframe = best(lambda: ref.compress(data, level=3), 2)
+            trd, _ = best(lambda: ref.decompress(rframe, n), 2)
+            tdr, r = best(lambda: L.zl_decompressDCtx(dctx._ptr, back, n, rframe, len(rframe)))
+            assert r == n and bytes(back) == data
+            row.update({"decompress_reference_frame_ms": tdr * 1e3, "reference_one_core": {"compress_ms": trc * 1e3, "decompress_ms": trd * 1e3, "ratio": n / len(rframe)}})
+        out[str(n)] = row
+        log(f"one object of {n >> 10} KiB host to host: compress {row['compress_ms']:.2f} ms, decompress {row['decompress_own_frame_ms']:.2f} ms"
+            + (f" (the reference's frame: {row['decompress_reference_frame_ms']:.2f}); reference on one core {row['reference_one_core']['compress_ms']:.2f} / {row['reference_one_core']['decompress_ms']:.2f} ms" if ref is not None else ""))
+    return out
+
+
 def levels_leg(device, src, log):
     """the operating points of zstd_cctx(level =) (R/cctx.R:10-14) on the bench vector, device-resident, ONE frame
     (the layout the reference's own zstd_compress() writes): compress rate, stage times (search = the far passes at levels <= 5, the
@@ -952,7 +992,7 @@ def main():
         if world == 1 and not args.no_extra:
             for name, leg in (("one_frame_layout", lambda: one_frame_leg(device, src, log)), ("per_input_full", lambda: per_input_full_leg(codec, device, n, log)),
                               ("long_range", lambda: long_range_leg(device, log)), ("levels", lambda: levels_leg(device, src, log)),
-                              ("c4_small_objects_dict", lambda: c4_leg(log))):
+                              ("c4_small_objects_dict", lambda: c4_leg(log)), ("single_object_host_to_host", lambda: single_object_leg(log))):
                 try:
                     out[name] = leg()
                 except Exception as e:  # informative legs; never lose the headline line to them
