@@ -50,7 +50,7 @@ bad = 0
 t0 = time.time()
 for rd in range(rounds):
     n = int(rng.integers(60 << 20, 700 << 20))
-    layout, cs, seek, level = int(rng.choice([0, 1, 2])), int(rng.random() < 0.3), int(rng.random() < 0.5), int(rng.choice([3, 3, 5, 6, 9, 12]))
+    layout, cs, seek, level = int(rng.choice([0, 1, 2])), int(rng.random() < 0.3), int(rng.random() < 0.5), int(rng.choice([3, 3, 5, 6, 9, 12, 17, 21]))
     s1, s2, s3 = 1, int(rng.choice([2, 3])), int(rng.choice([1, 2, 3]))
     print("round", rd, "MiB", n >> 20, dict(layout=layout, checksum=cs, seek=seek, level=level, slots=(s1, s2, s3)), flush=True)
     try:

@@ -494,6 +494,33 @@ def test_every_level_from_six_on_is_an_operating_point_of_its_own(ref):
     assert len(set(sizes)) >= 9, sizes
 
 
+def test_levels_sixteen_to_twenty_two_have_their_windows(ref):
+    """Levels 16 ... 22: level 15's search and parse inside the reference's WINDOW at that level (zstd.c:29542-29548: 2^22 at 16, 2^23
+    at 17 - 19, 2^25 at 20, 2^26 / 2^27 at 21 / 22 -- here at most a section, 2^26).  The deep match finder's sort hands a position
+    its most recent twins whatever the distance, so the window costs no time; what it buys: a repeat 6 MiB back is invisible at 15 and
+    found at 17, one 13 MiB back is found from 20 on.  The frames name their window, both decoders take them, and
+    zl_CCtx_getParameter reports the level as given (the optimal parsers are not built: the Python mirror says so)."""
+    import warnings
+    a, b = GENERATORS["text"](2 << 20, seed=31), GENERATORS["text"](4 << 20, seed=32)
+    near = a + b + a                                                   # the second copy lies 6 MiB behind the first
+    far = a + GENERATORS["text"](11 << 20, seed=33) + a                # ... 13 MiB
+    sizes = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, data, levels in (("near", near, (15, 16, 17, 19)), ("far", far, (19, 20, 22))):
+            for lv in levels:
+                out = z.zstd_compress(data, level=lv)
+                assert ref.decompress(out, len(data)) == data and z.zstd_decompress(out) == data, (name, lv)
+                sizes[name, lv] = len(out)
+                assert z.zstd_cctx_settings(z.zstd_cctx(level=lv))["level"] == lv
+    one_copy = len(z.zstd_compress(a, level=15))
+    assert sizes["near", 16] > sizes["near", 15] * 0.99                # (windows of 4 MiB both)
+    assert sizes["near", 17] < sizes["near", 15] - one_copy * 0.9      # the second copy costs next to nothing inside 8 MiB
+    assert sizes["near", 19] <= sizes["near", 17] * 1.001
+    assert sizes["far", 20] < sizes["far", 19] - one_copy * 0.9
+    assert sizes["far", 22] <= sizes["far", 20] * 1.001
+
+
 def test_chunks_of_cheap_bytes_keep_only_long_matches(ref):
     """Round 4: a chunk whose bytes cost less than 3.6 bits and whose first 4 KiB hardly match keeps only new-offset
     matches of eight bytes and more (and, in one frame, far hints of twelve and more) -- on i.i.d. bytes over ten letters the short

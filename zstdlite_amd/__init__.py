@@ -97,13 +97,12 @@ def _init_cctx_with_opts(opts, quiet=False):
                 raise ZstdError("init_cctx(): Bad compression level")
             got = C.c_int(0)
             L.zl_CCtx_getParameter(cctx._ptr, ZL_c_compressionLevel, C.byref(got))
-            if got.value != level and level > 3 and not quiet:
+            if level >= 16 and not quiet:
                 # levels 6 - 15 run the deep match finder with the reference's own search depth, lazy depth and window at that
                 # level; the optimal parsers of the reference's levels 16 - 22 are not built: say so instead of silently writing
                 # something else than was asked for
-                warnings.warn(f"init_cctx(): level {level} runs at this encoder's operating point {got.value} "
-                              "(operating points: < 3, 3, 5 and 6 ... 15 -- the reference's search depth, lazy depth and window at that level; "
-                              "the optimal parsers of levels 16 - 22 are not built; see include/zl_hip.h)")
+                warnings.warn(f"init_cctx(): level {level} runs level 15's search and parse inside level {got.value}'s window "
+                              "(the optimal parsers of the reference's levels 16 - 22 are not built; see include/zl_hip.h)")
         elif name == "num_threads":
             if int(val) > 1:
                 L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))

@@ -113,7 +113,8 @@ inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_
 // Levels 6 - 15: the deep match finder (zl_deep.hip) with the reference's own search depth, lazy depth and window at that level
 // (zstd.c:29523-29550: searchLog 3 / 4 / 4 / 4 / 5 / 6 / 6 at levels 6 - 12 -> 2^searchLog candidates; lazy at 6 - 7, lazy2 from 8;
 // windowLog 21 up to level 8, 22 from 9).  Levels 13 - 15 (btlazy2: a binary tree finds the longest match among more candidates
-// than a chain visits) search deeper still; the optimal parsers of levels 16 - 22 are not built: they run as 15.
+// than a chain visits) search deeper still; the optimal parsers of levels 16 - 22 are not built: those levels run 15's search and
+// parse inside their own, larger windows.
 struct DeepLevel { u32 k, lazy2, wlog; };
 // Levels 3 - 5 on an input of ZL_DEEP_SMALL_MIN .. ZL_DEEP_SMALL_MAX bytes search the same way, a few candidates deep (round 5): a call
 // that small is bound by its launches, not by its kernels -- the sort and the search of 1 MiB cost less than the far passes and the
@@ -131,10 +132,13 @@ struct DeepLevel { u32 k, lazy2, wlog; };
 #endif
 inline bool deep_small(int level, u64 total) { return level >= 3 && level <= 5 && total > ZL_DEEP_SMALL_MIN && total <= ZL_DEEP_SMALL_MAX; }
 inline DeepLevel deep_level(int level, u64 total) {
-    static const DeepLevel tab[10] = {{8, 0, 21}, {16, 0, 21}, {16, 1, 21}, {16, 1, 22}, {32, 1, 22}, {64, 1, 22}, {96, 1, 22}, {128, 1, 22}, {192, 1, 22}, {256, 1, 22}};
+    static const DeepLevel tab[17] = {{8, 0, 21}, {16, 0, 21}, {16, 1, 21}, {16, 1, 22}, {32, 1, 22}, {64, 1, 22}, {96, 1, 22}, {128, 1, 22}, {192, 1, 22}, {256, 1, 22},
+                                      // 16 - 22: level 15's search and parse inside the reference's WINDOW at that level (zstd.c:29540-29550: windowLog 22 / 23 / 23 / 23 / 25 / 26 / 27;
+                                      // here at most a section, 2^26).  The sort hands a position its K most recent twins whatever the distance, so the window costs nothing
+                                      {256, 1, 22}, {256, 1, 23}, {256, 1, 23}, {256, 1, 23}, {256, 1, 25}, {256, 1, 26}, {256, 1, 26}};
     static const DeepLevel small[3] = {{3, 0, 21}, {4, 0, 21}, {6, 0, 21}};
     if (deep_small(level, total)) return small[level - 3];
-    return tab[std::min(std::max(level, 6), 15) - 6];
+    return tab[std::min(std::max(level, 6), 22) - 6];
 }
 // ... which needs ONE contiguous input and no dictionary (a dictionary's content is not part of what is sorted): batches of
 // objects and dictionary contexts at these levels run the table-based parse at its deepest setting instead
@@ -561,7 +565,8 @@ size_t zl_freeCCtx(zl_cctx* c) {
 //                one frame 0.996 / 0.996 / 0.989 of the reference's size at 6 / 9 / 12 (round 4's table-based point 6: 1.085 /
 //                1.128 / 1.149).  Contexts with a dictionary and the batch entries run the table-based parse at its deepest
 //                setting (two-step lazy rule, all three repeat offsets) at these levels.
-//   levels 16-22 run as 15: the optimal parsers (zstd.c:34586-36163) are not built.
+//   levels 16-22 level 15's search and parse inside the reference's window at that level (8 MiB at 17 - 19, 32 MiB at 20, 64 MiB -- a
+//                section -- at 21 and 22); the optimal parsers (zstd.c:34586-36163) are not built.
 // Measured against the reference at the same level: within 5 % of its size at levels 1, 2, 3 and 6 ... 15
 // (tests/test_compress_gpu.py).
 size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
@@ -570,7 +575,7 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
     switch (param) {
     case ZL_c_compressionLevel:
         if (value < -131072 || value > 22) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
-        c->level = value >= 16 ? 15 : (value == 0 ? 3 : value);  // (0: the default level, zstd.h:333 / zstd.c:29721)
+        c->level = value > 22 ? 22 : (value == 0 ? 3 : value);  // (0: the default level, zstd.h:333 / zstd.c:29721; above 22: ZSTD_maxCLevel)
         return 0;
     case ZL_c_checksumFlag: c->checksum = value ? 1 : 0; return 0;
     case ZL_c_nbWorkers: c->nb_workers = value; return 0;
