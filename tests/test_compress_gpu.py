@@ -494,6 +494,30 @@ def test_every_level_from_six_on_is_an_operating_point_of_its_own(ref):
     assert len(set(sizes)) >= 9, sizes
 
 
+def test_levels_three_to_five_at_the_edges_of_the_small_input_route(ref):
+    """Levels 3 - 5 search ONE input of more than 16 KiB and at most 16 MiB with the deep match finder, everything else with the tables
+    (DESIGN.md 3.3): both sides of both edges, in both layouts, through both decoders; the routes' sizes stay close to each other
+    (an edge is not a cliff) and the python sources of a few hundred KB come out SMALLER than the reference's at the same level,
+    which the table parse missed by 9 - 24 %."""
+    from zl_testlib import LONG_RANGE
+    text = GENERATORS["text"]((16 << 20) + 64, seed=41)
+    for n in (16384, 16385, 16 << 20, (16 << 20) + 1):
+        data = text[:n]
+        for lv in (3, 5):
+            for layout in ("auto", "frames"):
+                out = z.zstd_compress(data, level=lv, frame_layout=layout)
+                assert z.zstd_decompress(out) == data, (n, lv, layout)
+                if layout == "auto":
+                    assert ref.decompress(out, n) == data, (n, lv)
+                    assert len(out) <= len(ref.compress(data, level=lv)) * 1.05, (n, lv)
+    corpus = LONG_RANGE["corpus"](None)
+    for n in (200_000, 1 << 20):
+        data = corpus[3_000_000:3_000_000 + n]
+        for lv in (3, 4, 5):
+            assert len(z.zstd_compress(data, level=lv)) <= len(ref.compress(data, level=lv)) * 1.07, (n, lv)
+        assert len(z.zstd_compress(data, level=3)) <= len(ref.compress(data, level=3)) * 0.99, n
+
+
 def test_levels_sixteen_to_twenty_two_have_their_windows(ref):
     """Levels 16 ... 22: level 15's search and parse inside the reference's WINDOW at that level (zstd.c:29542-29548: 2^22 at 16, 2^23
     at 17 - 19, 2^25 at 20, 2^26 / 2^27 at 21 / 22 -- here at most a section, 2^26).  The deep match finder's sort hands a position
