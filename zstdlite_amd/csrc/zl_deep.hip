@@ -27,6 +27,7 @@
 // the parse joins (zl_merge_pieces).  CPU model with the reference's entropy stage behind it: scripts/dev/sim/deep_sim.c
 // (python sources, one frame: 1.001 / 0.998 / 0.996 of the reference's size at levels 6 / 9 / 12).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -504,14 +505,18 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_join_kernel(zl_match_arg
 // host side
 // ---------------------------------------------------------------------------------------
 namespace {
-// hipcub's temporary storage for sorting n keys (a function of the item count only; no launch)
+// hipcub's temporary storage for sorting up to n keys: asked for once per power of two (the query walks rocPRIM's configuration
+// machinery: not something a call of a few hundred microseconds wants to repeat) and kept
 size_t sort_temp_bytes(u32 n) {
-    static size_t full = 0;
-    if (n == DEEP_SEC_MAX && full) return full;
-    size_t b = 0;
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, n, 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
-    b = (b + 255) & ~(size_t)255;
-    if (n == DEEP_SEC_MAX) full = b;
+    static std::atomic<size_t> known[33];
+    u32 lg = 12;
+    while (lg < 32 && ((u64)1 << lg) < n) lg++;
+    size_t b = known[lg].load(std::memory_order_acquire);
+    if (!b) {
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, (u32)std::min<u64>((u64)1 << lg, DEEP_SEC_MAX), 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
+        b = (b + 255) & ~(size_t)255;
+        known[lg].store(b, std::memory_order_release);
+    }
     return b;
 }
 // the longest section a search over `span` bytes sorts (sections end on multiples of DEEP_SEC_BYTES of the input; the first may be any part of one)
