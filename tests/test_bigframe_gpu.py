@@ -88,7 +88,12 @@ def test_single_frames_of_two_to_eight_blocks_take_the_pipeline(ref):
             assert r == n and bytes(out) == data, (who, n)
             assert large_frames(dctx) == took, (who, n)
             assert best < 0.02, (who, n, best)  # (seconds; 0.012 - 0.103 before)
-    # many frames in one call: the lane pipeline, as before
+    # a few such frames among many small ones: still the pipeline; many of them: side by side on the lanes, as before
+    small = [GENERATORS["text"](3000, seed=100 + i) for i in range(40)]
+    mid = [GENERATORS["text"](300_000, seed=i) for i in range(3)]
+    before = large_frames(dctx)
+    assert z.zstd_decompress_batch([ref.compress(x, level=3) for x in small + mid], dctx=dctx) == small + mid
+    assert large_frames(dctx) == before + 3
     items = [GENERATORS["text"](300_000, seed=i) for i in range(12)]
     comps = [ref.compress(x, level=3) for x in items]
     before = large_frames(dctx)

@@ -1427,7 +1427,7 @@ bool stream_frame_begin(zl_dctx* d, const FrameHeader& h) {
 // one block size and without dictionary go through the lane-parallel pipeline (zl_decode2.hip);
 // the rest -- and whatever that pipeline hands back -- through the general kernel.
 #ifndef ZL_FEW_FRAMES
-#define ZL_FEW_FRAMES 4u  // a call of at most this many frames hands those of two blocks and more to the large-frame pipeline (below)
+#define ZL_FEW_FRAMES 8u  // a call with at most this many frames of two to eight blocks' content hands them to the large-frame pipeline (below)
 #endif
 size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_t st) {
     size_t e = dctx_prepare_dict(d, st);
@@ -1485,11 +1485,16 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
     // (what the reference's zstd_compress() writes for large inputs), go through the large-frame pipeline
     // first, one after the other; it leaves each frame's result word on the device.
     d->took_big.assign(n, 0);
+    size_t n_mid = 0;  // frames whose content is more than one block and at most what the lanes take
+    for (size_t i = 0; i < n; i++) n_mid += (tbl[i].dst_cap > ZL_BLOCK_MAX && tbl[i].dst_cap <= route_max) ? 1 : 0;
     for (size_t i = 0; i < n; i++) {
-        // (... and, in a call of a FEW frames, frames of two to eight blocks too -- round 5.  The lane pipeline gives a frame one sequence
+        // (... and, when a call holds only a FEW of them, frames of two to eight blocks' content too -- round 5.  The lane pipeline gives a frame one sequence
         // lane that walks its blocks one after the other: right for ten thousand frames side by side, 44 ms for ONE frame of 1 MiB of
-        // text the reference wrote (12 ms for 256 KiB).  The large-frame pipeline decodes the blocks side by side: 4.7 and 4.5 ms -- one block's chain of sequences.)
-        const u64 big_from = n <= ZL_FEW_FRAMES ? (u64)ZL_BLOCK_MAX : route_max;
+        // text the reference wrote (12 ms for 256 KiB), and this library's own frame of that size -- 64 blocks -- fell through to the general
+        // kernel: 103 ms.  The large-frame pipeline decodes the blocks side by side: 4.7 / 4.5 and 2.4 ms -- one block's chain of sequences.
+        // One after the other they cost 2 - 5 ms each, so only a few: a hundred such frames side by side on the lanes or the general kernel
+        // are done in the time of the slowest.)
+        const u64 big_from = n_mid <= ZL_FEW_FRAMES ? (u64)ZL_BLOCK_MAX : route_max;
         if ((tbl[i].dst_cap <= big_from && !d->run_headerless) || tbl[i].dst_cap == ZL_CONTENTSIZE_UNKNOWN) continue;  // (dst_cap: the recorded size, or the room left for a frame that records none)
         if (!d->big && !(d->big = zl3_create())) return kGpuUnavailable;
         zl3_hint hint;
