@@ -398,7 +398,7 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     // (tests/test_fullsize_gpu.py), only the schedule does -- a launch over everything lets the expensive chunks of one kind of data
     // run beside the cheap ones of another: the 1 GiB mix at level 9 as ONE group: parse 7.7 ms, as four groups of 256 MiB: 10.6)
     size_t group = enc_strides(c->chunk_cap).group;
-    if (deep_on(c)) {
+    if (deep_on(c) && nchunks > 2 * ((size_t)1 << ZL_FAR_SECTION_LOG)) {  // (a call of two sections or fewer is one group whatever is free: no question to ask the driver)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         const size_t have = free_b + c->sets[0].deep_best.cap;  // (what the set already holds counts as available to it)
