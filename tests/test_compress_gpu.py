@@ -494,6 +494,23 @@ def test_every_level_from_six_on_is_an_operating_point_of_its_own(ref):
     assert len(set(sizes)) >= 9, sizes
 
 
+def test_far_probe_gate_keeps_copies_of_random_bytes(ref):
+    """Round 5: the far probe leaves a chunk alone when a sparse sample of its positions (one in 256, chosen by content) finds no
+    tag further back -- chunks of random bytes, small integers, i.i.d. symbols, which were half of the kernel's time on the bench
+    mix.  What must survive: random bytes that ARE a copy of something further back (no byte of them is cheap, every position has
+    its twin) -- and the sizes of inputs whose far matches carry the ratio."""
+    from zl_testlib import LONG_RANGE
+    rng = np.random.default_rng(77)
+    blob = bytes(rng.integers(0, 256, size=1 << 20, dtype=np.uint8))
+    filler = bytes(rng.integers(0, 256, size=17 << 20, dtype=np.uint8))          # (above 16 MiB in all: the table parse and its far passes)
+    data = blob + filler[: 600_000] + blob + filler[600_000:] + blob[: 300_000]   # copies 1.6 MiB and ~17 MiB back: the first inside the window
+    out = z.zstd_compress(data)
+    assert ref.decompress(out, len(data)) == data and z.zstd_decompress(out) == data
+    assert len(out) < len(data) - (1 << 20) + (64 << 10), (len(out), len(data))   # the near copy costs next to nothing
+    records = LONG_RANGE["records"](40 << 20)
+    assert len(z.zstd_compress(records)) <= len(ref.compress(records, level=3)) * 1.05
+
+
 def test_levels_three_to_five_at_the_edges_of_the_small_input_route(ref):
     """Levels 3 - 5 search ONE input of more than 16 KiB and at most 16 MiB with the deep match finder, everything else with the tables
     (DESIGN.md 3.3): both sides of both edges, in both layouts, through both decoders; the routes' sizes stay close to each other
