@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -30,6 +31,11 @@ struct zl_cctx_s {
     bool any_small = false;  // the chunk table being enqueued holds inputs of at most one chunk (zl_chunk_desc::flags bit 0)
     bool one_input = false;  // the chunk table being enqueued cuts ONE contiguous input, in order (what the deep match finder of levels >= 6 sorts)
     u64 input_total = 0;     // ... bytes of that input
+    // the deep match finder's scratch (a 64-bit word per input byte of a launch group, two key arrays and the sort's storage per
+    // section) did not fit, or the sort refused: deep_failed says so to the entry that made the call, which sets deep_denied, gives the deep
+    // buffers back and makes the call again on the table parse at its deepest setting -- levels >= 6 degrade instead of failing.  The denial
+    // lasts for the streaming session (a frame's header names ONE window), one-shot calls ask again every time.
+    bool deep_failed = false, deep_denied = false;
     int last_slots = 1;  // device slots the last zl_compress2 call used
     int devices = 1;     // ZL_c_devices: device slots zl_compress2 spreads a large input over (0: every visible device)
     std::vector<zl_cctx_s*> peers;  // one context per slot, created on first use
@@ -143,7 +149,28 @@ inline DeepLevel deep_level(int level, u64 total) {
 }
 // ... which needs ONE contiguous input and no dictionary (a dictionary's content is not part of what is sorted): batches of
 // objects and dictionary contexts at these levels run the table-based parse at its deepest setting instead
-inline bool deep_on(const zl_cctx* c) { return (c->level >= 6 || deep_small(c->level, c->input_total)) && c->one_input && c->dict_use == 0; }
+inline bool deep_on(const zl_cctx* c) { return (c->level >= 6 || deep_small(c->level, c->input_total)) && c->one_input && c->dict_use == 0 && !c->deep_denied; }
+// (tests: ZL_DEBUG_DEEP_OOM=1 in the environment makes every deep allocation "fail")
+inline bool deep_oom_switch() { static const bool on = getenv("ZL_DEBUG_DEEP_OOM") != nullptr; return on; }
+// what a denied deep call leaves behind goes back to the device before the call is made again
+inline void deep_release(zl_cctx* c) {
+    for (auto& es : c->sets) for (DevBuf* b : {&es.deep_best, &es.deep_scratch, &es.sub_lits, &es.sub_seqs, &es.sub_meta}) b->release();
+}
+// Runs `call` and, when the deep finder could not get what it needs, once more without it.
+template <class F>
+inline size_t with_deep_fallback(zl_cctx* c, F&& call) {
+    c->deep_failed = false;
+    size_t r = call();
+    if (ZL_IS_ERR(r) && c->deep_failed && !c->deep_denied) {
+        (void)hipDeviceSynchronize();  // (launch groups in front of the one that failed may still be running on the buffers given back below)
+        c->deep_denied = true;
+        c->deep_failed = false;
+        deep_release(c);
+        for (zl_cctx* p : c->peers) { p->deep_denied = true; deep_release(p); }
+        r = call();
+    }
+    return r;
+}
 
 inline u32 zl_rd32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
 
@@ -230,12 +257,23 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         d.window = (1u << dl.wlog) - 1u;
         d.mml = (c->level < 6 || c->input_total > ((u64)256 << 10)) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at levels 6 and up; 5 throughout at 3 - 5)
         d.frames = joined ? 0u : 1u;
-        if (!es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(zl_deep_scratch_bytes(d.hi - d.lo))) return kGpuUnavailable;
+        size_t scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);  // (0: the sort could not say what it needs)
+        if (scratch_bytes == 0 || deep_oom_switch() || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes)) { c->deep_failed = true; return kGpuUnavailable; }
         d.scratch = es.deep_scratch.p;
-        d.scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);
+        d.scratch_bytes = scratch_bytes;
         d.best = (u64*)es.deep_best.p;
         if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
-        if (zl_launch_deep_search(&d, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        hipError_t de = zl_launch_deep_search(&d, st);
+        if (de == hipErrorOutOfMemory) {
+            // the sort asked for more temporary storage at this section's size than its size class had said (zl_deep.hip sort_temp_bytes
+            // remembers the larger figure): once more with that; the buffer is replaced behind everything in flight (hipFree waits)
+            scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);
+            if (scratch_bytes == 0 || !es.deep_scratch.ensure(scratch_bytes)) { c->deep_failed = true; return kGpuUnavailable; }
+            d.scratch = es.deep_scratch.p;
+            d.scratch_bytes = scratch_bytes;
+            de = zl_launch_deep_search(&d, st);
+        }
+        if (de != hipSuccess) { c->deep_failed = true; return ZL_ERR(ZL_E_GENERIC); }
         stage_ok("deep search");
     } else if (joined) {
         if (prof) { (void)hipEventRecord(c->ev_far, st); c->far_valid = true; }
@@ -295,7 +333,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         u32 parts = ZL_DEEP_SUB;
         while (parts > 1 && chunks_of(c->input_total) * parts > 2048) parts >>= 1;
         if (parts > 1 && c->chunk_cap >= ZL_CHUNK) {
-            if (!es.sub_lits.ensure((size_t)cnt * sd.lit) || !es.sub_seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) || !es.sub_meta.ensure((size_t)cnt * parts * 8 + 64)) return kGpuUnavailable;
+            if (!es.sub_lits.ensure((size_t)cnt * sd.lit) || !es.sub_seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) || !es.sub_meta.ensure((size_t)cnt * parts * 8 + 64)) { c->deep_failed = true; return kGpuUnavailable; }
             m.sub = parts;
             m.sub_lits = (u8*)es.sub_lits.p; m.sub_seqs = (zl_seq*)es.sub_seqs.p; m.sub_meta = (u32*)es.sub_meta.p;
         }
@@ -401,8 +439,15 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
     if (deep_on(c) && nchunks > 2 * ((size_t)1 << ZL_FAR_SECTION_LOG)) {  // (a call of two sections or fewer is one group whatever is free: no question to ask the driver)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        const size_t have = free_b + c->sets[0].deep_best.cap;  // (what the set already holds counts as available to it)
-        while (group > 2 * ((size_t)1 << ZL_FAR_SECTION_LOG) && std::min(group, nchunks) * (size_t)ZL_CHUNK * 8 > have / 2) group /= 2;
+        // what a group of g chunks asks of the device: the candidate words (8 bytes per input byte), the per-chunk scratch of the parse and
+        // the entropy stage (enc_strides), and -- whatever the group -- one section's two key arrays and the sort's storage (the
+        // last two were not counted); what the set already holds counts as available to it
+        const zl_cctx_s::EncSet& s0 = c->sets[0];
+        const size_t have = free_b + s0.deep_best.cap + s0.deep_scratch.cap + s0.lits.cap + s0.seqs.cap + s0.sst.cap + s0.staged.cap;
+        const EncStrides sd = enc_strides(c->chunk_cap);
+        const size_t per_chunk = (size_t)ZL_CHUNK * 8 + sd.lit + (size_t)sd.seq * (sizeof(zl_seq) + ZL_SST_BYTES) + sd.out + sizeof(zl_chunk_meta);
+        const size_t fixed = zl_deep_scratch_bytes((u64)1 << 40);
+        while (group > ((size_t)1 << ZL_FAR_SECTION_LOG) && std::min(group, nchunks) * per_chunk + fixed > have / 2) group /= 2;
     }
     const size_t ngroups = (nchunks + group - 1) / group;
     if (!c->d_chunks.ensure(nchunks * sizeof(zl_chunk_desc)) || !c->d_fsize.ensure(nchunks * sizeof(u32)) ||
@@ -681,7 +726,8 @@ size_t zl_compress_device_async(zl_cctx* c, void* d_dst, size_t cap, const void*
     const size_t nchunks = fill_chunk_table(c, n);
     if (ZL_IS_ERR(nchunks)) return nchunks;
     const bool one = use_one_frame(c, n, false);
-    const size_t e = cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, one ? (u64)n : 0);
+    if (!c->cs.started) c->deep_denied = false;
+    const size_t e = with_deep_fallback(c, [&]() { return cctx_enqueue(c, (u8*)d_dst, (const u8*)d_src, nchunks, st, one ? (u64)n : 0); });
     if (ZL_IS_ERR(e)) return e;
     c->pending = true;
     c->pending_stream = st;
@@ -931,7 +977,7 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{hasher};
     run([&](int s) {
         zl_cctx* p = c->peers[s];
-        p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict;
+        p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict; p->deep_denied = c->deep_denied;
         if (p->dict != c->dict || p->dict_id != c->dict_id) { p->dict_uploaded = false; p->dict_formatted = c->dict_formatted; p->dict_id = c->dict_id; }
         const size_t cnt = first[s + 1] - first[s];
         bytes[s] = cnt ? compress2_pipelined(p, nullptr, 0, src + first[s] * (size_t)ZL_CHUNK, n, one_frame, first[s], cnt, nchunks) : 0;
@@ -971,13 +1017,18 @@ extern "C" {
 
 // replaces ZSTD_compress2 (zstd.h:599): host buffers in and out.
 static size_t compress2_impl(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n);
+static size_t compress2_body(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n);
 size_t zl_compress2(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     cs_wait(c);
+    if (!c->cs.started) c->deep_denied = false;  // (a one-shot call asks for the deep finder's memory afresh; a streaming session keeps what its first job got)
     return compress2_impl(c, dst, cap, src, n);
 }
 static size_t compress2_impl(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
+    return with_deep_fallback(c, [&]() { return compress2_body(c, dst, cap, src, n); });
+}
+static size_t compress2_body(zl_cctx* c, void* dst, size_t cap, const void* src, size_t n) {
     if (!device_ok()) return kGpuUnavailable;
     if (c->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
     if (cap && !dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
@@ -1133,6 +1184,7 @@ size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
         c->cs.pledged = ZL_CONTENTSIZE_UNKNOWN;
         c->cs.consumed = 0;
         c->cs.started = c->cs.emitted = c->cs.finishing = c->cs.joined = c->cs.flush_told = false;
+        c->deep_denied = false;
     }
     if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
         if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:22790
@@ -1190,19 +1242,31 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         auto body = [c, n, bound, pledged, consumed_end, joined, dev]() {
             (void)hipSetDevice(dev);
             auto& T = c->cs;
-            T.job_ret = joined ? compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash)
+            const zlx::Xxh64 hash0 = T.hash;  // (a call made a second time hashes its bytes a second time: from the same start)
+            T.job_ret = joined ? with_deep_fallback(c, [&]() { T.hash = hash0; return compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash); })
                                : compress2_impl(c, T.job_out.p, bound, T.job_in.p, n);
         };
-        try { S.job = std::thread(body); S.job_on = true; }
-        catch (...) {  // no thread to be had: the job runs here, and what it wrote becomes what waits to be handed out (as collect() would make it)
+        static const int fail_from = getenv("ZL_DEBUG_NO_JOB_THREAD") ? atoi(getenv("ZL_DEBUG_NO_JOB_THREAD")) : 0;  // (tests: from the k-th job of the process on, thread creation "fails")
+        static std::atomic<int> jobs_seen{0};
+        try {
+            if (fail_from > 0 && ++jobs_seen >= fail_from) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            S.job = std::thread(body);
+            S.job_on = true;
+        } catch (...) {  // no thread to be had: the job runs here.  collect() above may just have put the job BEFORE this one into S.out
+                         // (hand_out() only runs when this returns), so these bytes go BEHIND what waits there, as run_job() appends
             body();
             const size_t r = S.job_ret;
             S.job_in.clear();
             if (ZL_IS_ERR(r)) { S.job_out.clear(); return r; }
-            S.job_out.n = r;
-            std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
+            if (S.out.empty()) {
+                S.job_out.n = r;
+                std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
+                S.out_pos = 0;
+            } else if (!S.out.append(S.job_out.p, r)) {
+                S.job_out.clear();
+                return ZL_ERR(ZL_E_MEMORY);
+            }
             S.job_out.clear();
-            S.out_pos = 0;
             S.emitted = true;
         }
         return 0;
@@ -1222,7 +1286,8 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         size_t r;
         if (S.joined) {
             if ((S.consumed - n) % ZL_STREAM_JOB != 0 || !(n == ZL_STREAM_JOB || S.consumed == pledged)) { S.out.n = old; return ZL_ERR(ZL_E_STAGE_WRONG); }
-            r = compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &S.hash);
+            const zlx::Xxh64 hash0 = S.hash;
+            r = with_deep_fallback(c, [&]() { S.hash = hash0; return compress2_pipelined(c, at, bound, S.stage.p, (size_t)pledged, true, (size_t)((S.consumed - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &S.hash); });
         } else
             r = compress2_impl(c, at, bound, S.stage.p, n);
         S.out.n = old + (ZL_IS_ERR(r) ? 0 : r);
@@ -1273,6 +1338,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.pledged = ZL_CONTENTSIZE_UNKNOWN;
         S.consumed = 0;
         S.started = S.emitted = S.finishing = S.joined = S.flush_told = false;
+        c->deep_denied = false;
         return 0;
     }
     // ZL_e_flush inside a one-frame (pledged) session cuts no run: the input still collected is part of the answer, so that a caller

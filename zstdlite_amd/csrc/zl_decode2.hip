@@ -1265,6 +1265,9 @@ __device__ __forceinline__ void wave_sync() {  // the sequence role runs on one 
 // round r builds block r's tables, then every lane whose leader is r runs its chain.  Frames from
 // the HIP encoder share one table set per frame and finish in one round with all lanes busy.
 // QUAD (launches of single-block frames): the chain of a frame runs on four lanes, seq_chain_quad.
+// Barriers: this role is ONE wave and orders its LDS traffic with wave_sync().  The only workgroup barriers (__syncthreads) it may hold are
+// the two-wave chains' protocol -- cmd = 1 / barrier / quad_produce / barrier per chain phase, cmd = 0 / barrier at the end -- because
+// zl2_entropy1_kernel's second wave counts them; no path may leave the role in front of the last one.
 template <bool QUAD>
 __device__ __forceinline__ void seq_role(const zl2_args& a, SeqShared& S, u32* rounds, u32 wg) {
     const u32 lane = threadIdx.x;
@@ -1542,6 +1545,10 @@ __global__ __launch_bounds__(128) void zl2_entropy1_kernel(zl2_args a) {
     u32 g0, g1; bool split;
     zl2_part_range(a, g0, g1, split);  // the part of the cost-sorted order this launch covers
     const u32 r = blockIdx.x % 3, g = blockIdx.x / 3;
+    // The consumer below counts workgroup barriers in step with seq_role's and reads `cmd` behind each: the word starts out as "the role
+    // is over", so that a producer that ever ended without its last barrier (a wave that has ended no longer counts for a barrier) would
+    // release the consumer into a break, not into a chain phase on whatever the LDS held
+    if (r < 2) { if (threadIdx.x == 0) U.s.cmd = 0; __syncthreads(); }
     if (threadIdx.x >= 64) {
         // wave 1: the consumer of a sequence workgroup's two-wave chains; everywhere else it has nothing to do (a wave that has
         // ended no longer counts for the workgroup's barriers)

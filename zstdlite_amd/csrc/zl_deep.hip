@@ -507,17 +507,26 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_join_kernel(zl_match_arg
 namespace {
 // hipcub's temporary storage for sorting up to n keys: asked for once per power of two (the query walks rocPRIM's configuration
 // machinery: not something a call of a few hundred microseconds wants to repeat) and kept
+// (the figure of 2^lg items is taken for every n up to 2^lg -- rocPRIM picks its configuration by size and promises no
+// monotonicity.  Should a sort ever refuse its storage, zl_launch_deep_search asks for that n exactly and raises `sort_floor`, which every
+// later answer includes; the caller then sizes the scratch again.  0: the query itself failed -- no deep search.)
+std::atomic<size_t> sort_floor{0};
+size_t sort_query(u32 n) {
+    size_t b = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, n, 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr) != hipSuccess) return 0;
+    return (std::max<size_t>(b, 1) + 255) & ~(size_t)255;
+}
 size_t sort_temp_bytes(u32 n) {
     static std::atomic<size_t> known[33];
     u32 lg = 12;
     while (lg < 32 && ((u64)1 << lg) < n) lg++;
     size_t b = known[lg].load(std::memory_order_acquire);
     if (!b) {
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, b, (const u64*)nullptr, (u64*)nullptr, (u32)std::min<u64>((u64)1 << lg, DEEP_SEC_MAX), 32, 32 + ZL_DEEP_HLOG, (hipStream_t) nullptr);
-        b = (b + 255) & ~(size_t)255;
+        b = sort_query((u32)std::min<u64>((u64)1 << lg, DEEP_SEC_MAX));
+        if (!b) return 0;
         known[lg].store(b, std::memory_order_release);
     }
-    return b;
+    return std::max(b, sort_floor.load(std::memory_order_acquire));
 }
 // the longest section a search over `span` bytes sorts (sections end on multiples of DEEP_SEC_BYTES of the input; the first may be any part of one)
 inline u32 sec_cap(u64 span) { return (u32)std::min<u64>(std::max<u64>(span, 4096), DEEP_SEC_MAX); }
@@ -526,12 +535,14 @@ inline u32 sec_cap(u64 span) { return (u32)std::min<u64>(std::max<u64>(span, 409
 // two key arrays of the longest section + the sort's temporary storage (with room to spare: a shorter last section may ask for a little more)
 extern "C" size_t zl_deep_scratch_bytes(u64 span) {
     const u32 cap = sec_cap(span);
-    return 2 * (size_t)cap * sizeof(u64) + sort_temp_bytes(cap) + (64u << 10) + 256;
+    const size_t temp = sort_temp_bytes(cap);
+    if (!temp) return 0;
+    return 2 * (size_t)cap * sizeof(u64) + temp + (64u << 10) + 256;
 }
 
 extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream) {
     if (a->hi <= a->lo) return hipSuccess;
-    if (a->scratch_bytes < zl_deep_scratch_bytes(a->hi - a->lo)) return hipErrorInvalidValue;
+    if (a->scratch_bytes == 0 || a->scratch_bytes < zl_deep_scratch_bytes(a->hi - a->lo)) return hipErrorInvalidValue;
     const u32 cap = sec_cap(a->hi - a->lo);
     u64* const keys_a = (u64*)a->scratch;
     u64* const keys_b = keys_a + cap;
@@ -546,7 +557,17 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
         hipLaunchKernelGGL(zl_deep_key_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, sec, n, mml_shift, keys_a);
         size_t tb = temp_room;
         const hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, tb, (const u64*)keys_a, keys_b, n, 32, 32 + ZL_DEEP_HLOG, stream);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            // too little storage for THIS n (see sort_temp_bytes)?  Then say what it takes and let the caller come back with it
+            const size_t need = sort_query(n);
+            if (need > temp_room) {
+                size_t f = sort_floor.load();
+                while (f < need && !sort_floor.compare_exchange_weak(f, need)) {}
+                (void)hipGetLastError();
+                return hipErrorOutOfMemory;
+            }
+            return e;
+        }
         u64* const best = a->best + (s0 - a->lo);
         if (a->k <= 16) hipLaunchKernelGGL((zl_deep_search_kernel<16>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
         else if (a->k <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
