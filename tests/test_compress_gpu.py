@@ -801,4 +801,5 @@ def test_deep_levels_degrade_to_the_table_parse_when_their_scratch_cannot_be_had
     denied = [int(x) for x in out.stdout.split("sizes")[1].split()[:3]]
     text = GENERATORS["text"](3 << 20, seed=5)
     deep = [len(z.zstd_compress(text, level=level)) for level in (3, 9, 15)]
-    assert all(d >= s for d, s in zip(denied, deep)) and denied[1] > deep[1], (denied, deep)
+    # (level 3 on this synthetic text is the one place where the tables write a little LESS than three candidates of the deep finder: DESIGN 3.3)
+    assert denied[1] > deep[1] and denied[2] > deep[2] and denied[0] < 1.05 * deep[0], (denied, deep)
