@@ -43,9 +43,11 @@ typedef struct zl_dctx_s zl_dctx; /* replaces ZSTD_DCtx (zstd.h:278) */
                                    * (larger match tables, longer verification), 5 (... denser far search, two-step lazy rule, all three repeat
                                    * offsets), 6 ... 15 (the deep match finder: the reference's own search depth -- 8 / 16 / 16 / 16 / 32 / 64 /
                                    * 96 / 128 / 192 / 256 candidates per position --, lazy depth -- one step at 6 and 7, two from 8 -- and
-                                   * window -- 2 MiB up to 8, 4 MiB from 9 -- at that level, zstd.c:29523-29550).  16 ... 22: level 15's search and parse inside the reference's window at
-                                   * that level -- 4 / 8 / 8 / 8 / 32 / 64 / 64 MiB (the reference's 128 MiB at 22 is cut to a section) --: the
-                                   * optimal parsers are not built.  ONE input of 16 KiB ... 16 MiB is searched by the deep finder at levels 3, 4
+                                   * window -- 2 MiB up to 8, 4 MiB from 9 -- at that level, zstd.c:29523-29550).  16 ... 22: level 15's search inside the reference's window at
+                                   * that level -- 4 / 8 / 8 / 8 / 32 / 64 / 64 MiB (the reference's 128 MiB at 22 is cut to a section) -- and, round 6, the
+                                   * PRICE-BASED parse (csrc/zl_opt.hip; the reference's btopt / btultra / btultra2, zstd.c:34586-36163): every position's
+                                   * nearest offset per length, a forward pass over arrival prices taken from the chunk's own symbol statistics, twice.
+                                   * ONE input of 16 KiB ... 16 MiB is searched by the deep finder at levels 3, 4
                                    * and 5 too (3 / 4 / 6 candidates, one step lazy: smaller output AND a shorter call than the tables give there;
                                    * the batch entries and dictionary contexts keep the tables).  zl_CCtx_getParameter reports the point a context runs at.  Contexts with a
                                    * dictionary and the batch entries run levels >= 6 on the table-based parse at its deepest setting (the deep

@@ -49,7 +49,7 @@ bad = 0
 t0 = time.time()
 for rd in range(rounds):
     x = make()
-    opts = {"level": int(rng.choice([1, 2, 3, 3, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, -5, -1, 0, 4, 19, 22]))}  # (src/cctx.c:261-268: -5 .. 22; the operating points are < 3, 3, 5, 6 ... 15)
+    opts = {"level": int(rng.choice([1, 2, 3, 3, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, -5, -1, 0, 4, 16, 17, 19, 19, 20, 22]))}  # (src/cctx.c:261-268: -5 .. 22; every level is an operating point: 16 ... 22 the price-based parse)
     if rng.random() < 0.3:
         opts["include_checksum"] = True
     d = None

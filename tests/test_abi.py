@@ -82,19 +82,17 @@ def test_context_options_mirror_reference_glue():
     with pytest.warns(UserWarning, match="init_dctx\\(\\): Unknown option 'bogus'"):
         z._init_dctx_with_opts({"bogus": 1})
     # the glue clamps to -5..22 (src/cctx.c:261-263); the context then reports the operating point it actually runs
-    # at (include/zl_hip.h).  Levels 16 ... 22 are level 15's search and parse inside their own windows -- operating points
-    # of their own, reported as given -- but not the reference's optimal parsers: the mirror says so
+    # at (include/zl_hip.h).  Every level of the range is one of its own since round 6 (16 ... 22: the price-based parse of
+    # csrc/zl_opt.hip; rounds 2 - 5 warned there), so the mirror has nothing to say
     # (round 1 echoed the number back and silently wrote level-3 output for level 19)
-    with pytest.warns(UserWarning, match="level 22 runs level 15's search and parse inside level 22's window"):
-        assert z.zstd_cctx_settings(z.zstd_cctx(level=99))["level"] == 22
-    assert z.zstd_cctx_settings(z.zstd_cctx(level=-99))["level"] == -5
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")  # levels the encoder implements as asked: no warning
-        for lv in (-5, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+        assert z.zstd_cctx_settings(z.zstd_cctx(level=99))["level"] == 22
+        assert z.zstd_cctx_settings(z.zstd_cctx(level=-99))["level"] == -5
+        for lv in (-5, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22):
             assert z.zstd_cctx_settings(z.zstd_cctx(level=lv))["level"] == lv
         assert z.zstd_cctx_settings(z.zstd_cctx(level=0))["level"] == 3  # 0 = the default level (zstd.h:333)
-    with pytest.warns(UserWarning, match="level 16 runs level 15's search and parse inside level 16's window"):
         s = z.zstd_cctx_settings(z.zstd_cctx(level=16, include_checksum=True, num_threads=4))
     assert s == {"level": 16, "num_threads": 4, "include_checksum": 1}
     assert z.zstd_dctx_settings(z.zstd_dctx(validate_checksum=False))["validate_checksum"] == 1  # inverted, src/dctx.c:233

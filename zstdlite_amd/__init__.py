@@ -95,14 +95,8 @@ def _init_cctx_with_opts(opts, quiet=False):
             level = max(-5, min(22, int(val)))  # src/cctx.c:261-263
             if is_error(L.zl_CCtx_setParameter(cctx._ptr, ZL_c_compressionLevel, level)):
                 raise ZstdError("init_cctx(): Bad compression level")
-            got = C.c_int(0)
-            L.zl_CCtx_getParameter(cctx._ptr, ZL_c_compressionLevel, C.byref(got))
-            if level >= 16 and not quiet:
-                # levels 6 - 15 run the deep match finder with the reference's own search depth, lazy depth and window at that
-                # level; the optimal parsers of the reference's levels 16 - 22 are not built: say so instead of silently writing
-                # something else than was asked for
-                warnings.warn(f"init_cctx(): level {level} runs level 15's search and parse inside level {got.value}'s window "
-                              "(the optimal parsers of the reference's levels 16 - 22 are not built; see include/zl_hip.h)")
+            # (every level of the reference's range is an operating point of its own since round 6 -- 16 ... 22 run the price-based parse of
+            # csrc/zl_opt.hip --: the mirror has nothing to warn of; zl_CCtx_getParameter reports the point a context runs at)
         elif name == "num_threads":
             if int(val) > 1:
                 L.zl_CCtx_setParameter(cctx._ptr, ZL_c_nbWorkers, int(val))

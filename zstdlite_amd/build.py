@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzl_hip.so")
-SOURCES = ["zl_decode.hip", "zl_decode2.hip", "zl_decode3.hip", "zl_encode.hip", "zl_deep.hip", "zl_api.hip", "zl_api_compress.hip"]
+SOURCES = ["zl_decode.hip", "zl_decode2.hip", "zl_decode3.hip", "zl_encode.hip", "zl_deep.hip", "zl_opt.hip", "zl_api.hip", "zl_api_compress.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 

@@ -49,9 +49,9 @@ struct zl_cctx_s {
     // per-launch-group scratch.  Set 0 serves the one-stream paths; the host entries' pipeline (zl_compress2 of a large
     // input) keeps ZL_PIPE_SETS groups in flight, each on its own stream with its own set.
     struct EncSet {
-        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, order, handover, sub_lits, sub_seqs, sub_meta;
+        DevBuf lits, seqs, sst, meta, staged, far_table, far_hints, far_lists, deep_best, deep_scratch, deep_chain, order, handover, sub_lits, sub_seqs, sub_meta;
         hipStream_t st = nullptr;
-        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &order, &handover, &sub_lits, &sub_seqs, &sub_meta}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
+        void release() { for (DevBuf* b : {&lits, &seqs, &sst, &meta, &staged, &far_table, &far_hints, &far_lists, &deep_best, &deep_scratch, &deep_chain, &order, &handover, &sub_lits, &sub_seqs, &sub_meta}) b->release(); if (st) (void)hipStreamDestroy(st); st = nullptr; }
     };
     EncSet sets[3];
     hipStream_t copy_stream = nullptr, down_stream = nullptr;  // the process's pair for this context's device (zl_copy_pair.h): not owned
@@ -119,9 +119,10 @@ inline size_t chunks_of(size_t n) { return n == 0 ? 1 : (n + ZL_CHUNK - 1) / ZL_
 // Levels 6 - 15: the deep match finder (zl_deep.hip) with the reference's own search depth, lazy depth and window at that level
 // (zstd.c:29523-29550: searchLog 3 / 4 / 4 / 4 / 5 / 6 / 6 at levels 6 - 12 -> 2^searchLog candidates; lazy at 6 - 7, lazy2 from 8;
 // windowLog 21 up to level 8, 22 from 9).  Levels 13 - 15 (btlazy2: a binary tree finds the longest match among more candidates
-// than a chain visits) search deeper still; the optimal parsers of levels 16 - 22 are not built: those levels run 15's search and
-// parse inside their own, larger windows.
-struct DeepLevel { u32 k, lazy2, wlog; };
+// than a chain visits) search deeper still.  Levels 16 - 22 (round 6): 15's search inside the reference's window at that level, every
+// position's CHAIN kept beside its best candidate, 15's lazy parse to have statistics, and then the price-based parse of zl_opt.hip
+// (`opt` passes of it: the reference's btopt / btultra / btultra2, zstd.c:34586-36163).
+struct DeepLevel { u32 k, lazy2, wlog, opt; };
 // Levels 3 - 5 on an input of ZL_DEEP_SMALL_MIN .. ZL_DEEP_SMALL_MAX bytes search the same way, a few candidates deep (round 5): a call
 // that small is bound by its launches, not by its kernels -- the sort and the search of 1 MiB cost less than the far passes and the
 // table parse do (python sources, 1 MiB, host to host: 2.7 ms by the tables, 2.2 ms by the deep finder), and what it writes is
@@ -137,13 +138,16 @@ struct DeepLevel { u32 k, lazy2, wlog; };
 #define ZL_DEEP_SUB 8u  // workgroups that share a chunk in the deep parse of a small launch (a power of two; 1: never).  16 and 32 were measured: 6 - 9 % off a small call's
                         // time, and config C1's buffer repeated to 1 MiB 1.098 -> 1.174x the reference's size (every part starts without a repeat offset and probes for itself)
 #endif
+#ifndef ZL_OPT_PASSES
+#define ZL_OPT_PASSES 2u  // price-based passes at levels 16 - 22 (the model, python sources at level 16: 1.011 / 1.002 / 1.000 of the reference's size with one / two / three; 0: level 15's parse, as round 5)
+#endif
 inline bool deep_small(int level, u64 total) { return level >= 3 && level <= 5 && total > ZL_DEEP_SMALL_MIN && total <= ZL_DEEP_SMALL_MAX; }
 inline DeepLevel deep_level(int level, u64 total) {
-    static const DeepLevel tab[17] = {{8, 0, 21}, {16, 0, 21}, {16, 1, 21}, {16, 1, 22}, {32, 1, 22}, {64, 1, 22}, {96, 1, 22}, {128, 1, 22}, {192, 1, 22}, {256, 1, 22},
+    static const DeepLevel tab[17] = {{8, 0, 21, 0}, {16, 0, 21, 0}, {16, 1, 21, 0}, {16, 1, 22, 0}, {32, 1, 22, 0}, {64, 1, 22, 0}, {96, 1, 22, 0}, {128, 1, 22, 0}, {192, 1, 22, 0}, {256, 1, 22, 0},
                                       // 16 - 22: level 15's search and parse inside the reference's WINDOW at that level (zstd.c:29540-29550: windowLog 22 / 23 / 23 / 23 / 25 / 26 / 27;
                                       // here at most a section, 2^26).  The sort hands a position its K most recent twins whatever the distance, so the window costs nothing
-                                      {256, 1, 22}, {256, 1, 23}, {256, 1, 23}, {256, 1, 23}, {256, 1, 25}, {256, 1, 26}, {256, 1, 26}};
-    static const DeepLevel small[3] = {{3, 0, 21}, {4, 0, 21}, {6, 0, 21}};
+                                      {256, 1, 22, ZL_OPT_PASSES}, {256, 1, 23, ZL_OPT_PASSES}, {256, 1, 23, ZL_OPT_PASSES}, {256, 1, 23, ZL_OPT_PASSES}, {256, 1, 25, ZL_OPT_PASSES}, {256, 1, 26, ZL_OPT_PASSES}, {256, 1, 26, ZL_OPT_PASSES}};
+    static const DeepLevel small[3] = {{3, 0, 21, 0}, {4, 0, 21, 0}, {6, 0, 21, 0}};
     if (deep_small(level, total)) return small[level - 3];
     return tab[std::min(std::max(level, 6), 22) - 6];
 }
@@ -154,7 +158,7 @@ inline bool deep_on(const zl_cctx* c) { return (c->level >= 6 || deep_small(c->l
 inline bool deep_oom_switch() { static const bool on = getenv("ZL_DEBUG_DEEP_OOM") != nullptr; return on; }
 // what a denied deep call leaves behind goes back to the device before the call is made again
 inline void deep_release(zl_cctx* c) {
-    for (auto& es : c->sets) for (DevBuf* b : {&es.deep_best, &es.deep_scratch, &es.sub_lits, &es.sub_seqs, &es.sub_meta}) b->release();
+    for (auto& es : c->sets) for (DevBuf* b : {&es.deep_best, &es.deep_scratch, &es.deep_chain, &es.sub_lits, &es.sub_seqs, &es.sub_meta}) b->release();
 }
 // Runs `call` and, when the deep finder could not get what it needs, once more without it.
 template <class F>
@@ -258,7 +262,9 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         d.mml = (c->level < 6 || c->input_total > ((u64)256 << 10)) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at levels 6 and up; 5 throughout at 3 - 5)
         d.frames = joined ? 0u : 1u;
         size_t scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);  // (0: the sort could not say what it needs)
-        if (scratch_bytes == 0 || deep_oom_switch() || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes)) { c->deep_failed = true; return kGpuUnavailable; }
+        if (scratch_bytes == 0 || deep_oom_switch() || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes) ||
+            (dl.opt && !es.deep_chain.ensure((size_t)(d.hi - d.lo) * 8 * ZL_DEEP_CHAIN + 64))) { c->deep_failed = true; return kGpuUnavailable; }
+        d.chain = dl.opt ? (u64*)es.deep_chain.p : nullptr;
         d.scratch = es.deep_scratch.p;
         d.scratch_bytes = scratch_bytes;
         d.best = (u64*)es.deep_best.p;
@@ -332,6 +338,10 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         // upload slots, a stream's jobs -- writes the same bytes)
         u32 parts = ZL_DEEP_SUB;
         while (parts > 1 && chunks_of(c->input_total) * parts > 2048) parts >>= 1;
+        if (dl.opt) {  // the price-based parse of levels 16+ walks whole chunks, and writes beside the parse it prices itself by (zl_opt.hip): the parts' arrays
+            if (!es.sub_lits.ensure((size_t)cnt * sd.lit) || !es.sub_seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq))) { c->deep_failed = true; return kGpuUnavailable; }
+            m.sub_lits = (u8*)es.sub_lits.p; m.sub_seqs = (zl_seq*)es.sub_seqs.p;
+        } else
         if (parts > 1 && c->chunk_cap >= ZL_CHUNK) {
             if (!es.sub_lits.ensure((size_t)cnt * sd.lit) || !es.sub_seqs.ensure((size_t)cnt * sd.seq * sizeof(zl_seq)) || !es.sub_meta.ensure((size_t)cnt * parts * 8 + 64)) { c->deep_failed = true; return kGpuUnavailable; }
             m.sub = parts;
@@ -353,6 +363,9 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     if (prof) (void)hipEventRecord(c->ev[0], st);
     if (deep) {
         if (zl_launch_match_deep(&m, cnt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        // levels 16 - 22: the lazy parse's sequences seed the statistics of the price-based one, which replaces them (the best words' buffer,
+        // which the lazy parse has read, takes the arrivals)
+        if (dl.opt && zl_launch_opt_parse(&m, (const u64*)es.deep_chain.p, (u64*)es.deep_best.p, cnt, dl.opt, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     } else if (joined && c->dict_use) {
         // ONE frame with a dictionary (zstd.c:27550: the dictionary's content is history in front of the frame's first byte):
         // the frame's first chunk is searched with the dictionary in front of it, exactly as a dictionary frame of its own
@@ -443,9 +456,9 @@ size_t cctx_enqueue(zl_cctx* c, u8* d_dst, const u8* d_src, size_t nchunks, hipS
         // the entropy stage (enc_strides), and -- whatever the group -- one section's two key arrays and the sort's storage (the
         // last two were not counted); what the set already holds counts as available to it
         const zl_cctx_s::EncSet& s0 = c->sets[0];
-        const size_t have = free_b + s0.deep_best.cap + s0.deep_scratch.cap + s0.lits.cap + s0.seqs.cap + s0.sst.cap + s0.staged.cap;
+        const size_t have = free_b + s0.deep_best.cap + s0.deep_scratch.cap + s0.deep_chain.cap + s0.lits.cap + s0.seqs.cap + s0.sst.cap + s0.staged.cap;
         const EncStrides sd = enc_strides(c->chunk_cap);
-        const size_t per_chunk = (size_t)ZL_CHUNK * 8 + sd.lit + (size_t)sd.seq * (sizeof(zl_seq) + ZL_SST_BYTES) + sd.out + sizeof(zl_chunk_meta);
+        const size_t per_chunk = (size_t)ZL_CHUNK * 8 * (1 + (deep_level(c->level, c->input_total).opt ? ZL_DEEP_CHAIN : 0)) + sd.lit + (size_t)sd.seq * (sizeof(zl_seq) + ZL_SST_BYTES) + sd.out + sizeof(zl_chunk_meta);
         const size_t fixed = zl_deep_scratch_bytes((u64)1 << 40);
         while (group > ((size_t)1 << ZL_FAR_SECTION_LOG) && std::min(group, nchunks) * per_chunk + fixed > have / 2) group /= 2;
     }

@@ -77,7 +77,7 @@ __device__ __forceinline__ u32 cb128(const uint4& a, const uint4& b) {
 // search: entry i of the sorted order against entries i - 1 ... i - K
 // ---------------------------------------------------------------------------------------
 template <int KMAX>
-__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64* sorted, u32 n, const u8* sec, u32 K, u32 window, u32 min_len, u32 frames, u64* best) {
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64* sorted, u32 n, const u8* sec, u32 K, u32 window, u32 min_len, u32 frames, u64* best, u64* chain) {
     constexpr u32 E = DEEP_THREADS + KMAX;
     __shared__ uint4 rec[4][E];  // rec[j][e]: bytes [p - 8 + 16 j, p + 8 + 16 j) of entry e's position (one array per slice: consecutive lanes read consecutive slots)
     __shared__ u64 skey[E + 1];  // hash << 32 | position of every entry (one entry behind the block: does the last one have a twin?); no entry: a hash no position has
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
     u32 bl = 0, bo = 0, be = 0;
     int bg = -1000000;
     bool alive = true;
+    // levels 16+ (chain != null): every candidate longer than all nearer ones, the ZL_DEEP_CHAIN longest kept -- ascending, the longest last
+    u32 ch_l[ZL_DEEP_CHAIN], ch_o[ZL_DEEP_CHAIN];
+#pragma unroll
+    for (int j = 0; j < ZL_DEEP_CHAIN; j++) { ch_l[j] = 0; ch_o[j] = 0; }
     for (u32 k = 1; k <= K; k++) {
         const u32 ce = e - k;
         const u64 ck = skey[ce];
@@ -139,6 +143,11 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
             if (len >= min_len) {
                 const int g = 4 * (int)len - (int)(31 - __clz(p - q + 1));
                 if (g > bg) { bg = g; bl = len; bo = p - q; be = ce; }  // (ties: the nearer one, met first)
+                if (chain && len > ch_l[ZL_DEEP_CHAIN - 1]) {
+#pragma unroll
+                    for (int j = 0; j + 1 < ZL_DEEP_CHAIN; j++) { ch_l[j] = ch_l[j + 1]; ch_o[j] = ch_o[j + 1]; }
+                    ch_l[ZL_DEEP_CHAIN - 1] = len; ch_o[ZL_DEEP_CHAIN - 1] = p - q;
+                }
             }
         }
     }
@@ -161,6 +170,12 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
 #else
     best[p] = word;
 #endif
+    if (chain) {
+        static_assert(ZL_DEEP_CHAIN == 4, "two 16-byte stores");
+        uint4* const to = (uint4*)(chain + (size_t)ZL_DEEP_CHAIN * p);
+        to[0] = make_uint4(ch_l[0], ch_o[0], ch_l[1], ch_o[1]);
+        to[1] = make_uint4(ch_l[2], ch_o[2], ch_l[3], ch_o[3]);
+    }
 }
 
 
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
 // measures a head's next ZL_DEEP_EXT bytes at once, sixteen per lane.  (python sources, 1 MB of one file, level 9: 1.069 -> 1.03 of
 // the reference's size -- scripts/dev/sim/deep_sim.c cap=56 / 255.)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_extend_kernel(u64* best, u32 n, const u8* sec) {
+__global__ __launch_bounds__(DEEP_THREADS) void zl_deep_extend_kernel(u64* best, u32 n, const u8* sec, u64* chain) {
     const u32 p = blockIdx.x * DEEP_THREADS + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
     const u64 w = p < n ? best[p] : 0ull;
@@ -203,6 +218,11 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_extend_kernel(u64* best,
         const u32 d = lane - h;
         const u32 total = ZL_DEEP_CAP + (h_ext > d ? h_ext - d : 0u);
         best[p] = (w & ~0xFFFFull) | total;
+        if (chain) {  // the chain's entry of the same offset (a full one is the longest or shares its length with it) learns its real length too
+            u64* const ch = chain + (size_t)ZL_DEEP_CHAIN * p;
+#pragma unroll
+            for (int j = 0; j < ZL_DEEP_CHAIN; j++) { const u64 cwj = ch[j]; if ((u32)(cwj >> 32) == off && ((u32)cwj & 0xFFFFu) == ZL_DEEP_CAP) ch[j] = (cwj & ~0xFFFFull) | total; }
+        }
     }
 }
 
@@ -569,11 +589,12 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
             return e;
         }
         u64* const best = a->best + (s0 - a->lo);
-        if (a->k <= 16) hipLaunchKernelGGL((zl_deep_search_kernel<16>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
-        else if (a->k <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
-        else if (a->k <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best);
-        else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best);
-        hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec);
+        u64* const chain = a->chain ? a->chain + (size_t)ZL_DEEP_CHAIN * (s0 - a->lo) : nullptr;
+        if (a->k <= 16) hipLaunchKernelGGL((zl_deep_search_kernel<16>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best, chain);
+        else if (a->k <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best, chain);
+        else if (a->k <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best, chain);
+        else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best, chain);
+        hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec, chain);
         s0 = s1;
     }
     return hipGetLastError();

@@ -105,6 +105,10 @@ struct zl_match_args {
 #define ZL_DEEP_BACK 8         // ... and up to this many bytes in front of both
 #define ZL_DEEP_EXT 1024       // a match that fills the record is measured on, this many bytes at most (zl_deep_extend_kernel)
 // best word (64 bits): [15:0] length (0: no candidate), [23:16] bytes that agree in front of both, [63:32] offset
+// Levels 16 ... 22 (zl_opt.hip) also want a position's CHAIN: among its K most recent twins, nearest first, every one that is longer
+// than all nearer ones -- "the nearest offset per length", what the reference's binary tree hands its optimal parser (zstd.c:34300
+// ZSTD_insertBtAndGetAllMatches).  The longest ZL_DEEP_CHAIN of them, ascending, the longest in the last slot; a word: [15:0] length, [63:32] offset, 0: none.
+#define ZL_DEEP_CHAIN 4
 struct zl_deep_args {
     const u8* src;     // the input (positions below are offsets into it)
     u64 lo, hi;        // the positions this call covers: whole chunks of ONE input, in order; sections of 2^(17 + ZL_FAR_SECTION_LOG) bytes are searched one after the other
@@ -116,6 +120,7 @@ struct zl_deep_args {
     void* scratch;     // zl_deep_scratch_bytes(hi - lo)
     size_t scratch_bytes;
     u64* best;         // out: one word per position, best[p - lo]
+    u64* chain;        // out, or null: ZL_DEEP_CHAIN words per position, chain[ZL_DEEP_CHAIN * (p - lo) ...]
 };
 
 struct zl_far_args {
@@ -169,6 +174,9 @@ extern "C" hipError_t zl_launch_match(const zl_match_args* a, u32 nchunks, hipSt
 extern "C" size_t zl_deep_scratch_bytes(u64 span);  // for a search over `span` bytes of input
 extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t stream);
 extern "C" hipError_t zl_launch_match_deep(const zl_match_args* a, u32 nchunks, hipStream_t stream);
+// levels 16 ... 22: the price-based parse over the chains, `passes` times (zl_opt.hip); the lazy parse has run (its sequences seed the statistics);
+// arrivals: scratch, one word per input byte from deep_lo on (the best words' buffer: the lazy parse is done with it)
+extern "C" hipError_t zl_launch_opt_parse(const zl_match_args* a, const u64* chain, u64* arrivals, u32 nchunks, u32 passes, hipStream_t stream);
 // order[0 .. nchunks): the chunks by decreasing estimated cost (longest first), input order inside a class; scratch: nchunks words
 extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u8* src, u32 nchunks, u32* cost_scratch, u32* order, hipStream_t stream);
 extern "C" hipError_t zl_launch_far_build(const zl_far_args* a, u32 nchunks, hipStream_t stream);
