@@ -100,7 +100,7 @@ __device__ __forceinline__ u32 win_byte(u32 win, u32 o, u32 lane) {
 
 // chain: OPT_TOPC words per input byte from position deep_lo on; word: [15:0] length, [63:32] offset, 0: none; ascending lengths, the longest in slot OPT_TOPC - 1
 // arrivals: one word per input byte (the buffer the lazy parse read its candidates from: it is done with them)
-__global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args a, const u64* __restrict__ chain_all, u64* __restrict__ arrivals_all, u32 nchunks, u32 passes) {
+__global__ __launch_bounds__(OPT_THREADS, 8) void zl_opt_parse_kernel(zl_match_args a, const u64* __restrict__ chain_all, u64* __restrict__ arrivals_all, u32 nchunks, u32 passes) {
     __shared__ OptShared S;
     const u32 lane = threadIdx.x;
     const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
@@ -205,46 +205,84 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
         for (u32 i = lane; i < OPT_RING; i += OPT_THREADS) S.arr[i] = OPT_NONE;
         lds_sync();
         // ------------------------------------------------------------------ forward
+        // Per lane, once per pass: the match-length price of the length this lane stands for in a first round of pushes, and the tables a
+        // uniform look-up reads with v_readlane instead of an LDS round trip
+        const u32 pml_lane = S.p_ml[opt_ml_code(OPT_MINM + lane - 3)];
+        const u32 v_pll = lane < 36 ? (u32)S.p_ll[lane] : 0u;
+        const u32 pll0 = S.p_ll[0], pof0 = S.p_of[0], pof1 = S.p_of[1];
+        auto pll_of = [&](u32 litlen) -> u32 { const u32 cc = opt_ll_code(litlen); return (u32)__builtin_amdgcn_readlane((int)v_pll, (int)__builtin_amdgcn_readfirstlane((int)(cc > 35 ? 35 : cc))); };
         u32 i = 0;                       // the node in hand (chunk offset)
-        u32 price = S.p_ll[0];           // what it costs to stand here, the pending literal run's length code included
+        u32 price = pll0;                // what it costs to stand here, the pending literal run's length code included
         u32 litlen = 0;                  // literals pending
+        u32 pll_cur = pll0;              // ... and what that run's length code costs
         u32 r0 = 0, r1 = 0, r2 = 0;      // the history (0: none yet)
+        u64 cur_w = 0x80000000ull;       // how the node in hand was reached (stored when something will ask: it arrived by a match, or it pushes)
+        bool cur_stored = true;
         i32 wb = 0;                      // window base (chunk offset, a multiple of 4)
         u32 w_cur = load_win(0), w_r0 = 0, w_r1 = 0, w_r2 = 0;
         u32 cb = 0;                      // chain batch: lane l holds word l & 3 of position cb + (l >> 2)
         u64 cw = chain[lane];
         u64 cw_next = (size_t)64 + lane < (size_t)n * OPT_TOPC ? chain[64 + lane] : 0ull;
+        auto word_price = [&](u64 w) -> u32 { const u32 off = (u32)(w >> 32); return off ? (u32)S.p_of[opt_hb(off + 3) & 31] : 0u; };
+        u32 cpo = word_price(cw);        // the offset-code price of every word of the batch
+        u64 candmask = __ballot(((u32)cw & 0xFFFFu) >= OPT_MINM);  // bit 4 k + 3: position cb + k has a candidate
         u64 end_w = 0x80000000ull;       // how the chunk's end is reached (position n's word would be the next chunk's first: kept here)
-        if (lane == 0) { S.rep[0][0] = 0x80000000u; S.rep[0][1] = 0; S.rep[0][2] = 0; }
+        u32 far = 0;                     // the farthest position a pushed match lands on
+        // per 64 positions from mb on: where each repeat offset matches four bytes, and every position's literal price
+        u32 mb = 0, plit64 = 0;
+        u64 rm0 = 0, rm1 = 0, rm2 = 0;
+        bool dirty = true;
         while (i < n) {
-            // ---- windows and the chain batch keep up with the position
-            u32 o = i - (u32)wb;
-            if (o > 188u) {
-                wb = (i32)(i & ~3u);
-                o = i - (u32)wb;
-                w_cur = load_win(wb);
-                if (r0) w_r0 = load_win(wb - (i32)r0);
-                if (r1) w_r1 = load_win(wb - (i32)r1);
-                if (r2) w_r2 = load_win(wb - (i32)r2);
+            // ---- the windows, the per-position masks and the chain batch keep up with the position
+            if (dirty || i - mb >= 64u) {
+                if (i - (u32)wb > 124u) {
+                    wb = (i32)(i & ~3u);
+                    w_cur = load_win(wb);
+                    w_r0 = r0 ? load_win(wb - (i32)r0) : 0u; w_r1 = r1 ? load_win(wb - (i32)r1) : 0u; w_r2 = r2 ? load_win(wb - (i32)r2) : 0u;
+                }
+                mb = i;
+                const u32 x = i - (u32)wb + lane;  // this lane's position inside the windows (x + 4 <= 256)
+                const u32 k0 = x >> 2, sh = x & 3;
+                auto lane4 = [&](u32 win) -> u32 { const u32 d0 = (u32)__shfl((int)win, (int)(k0 & 63), 64), d1 = (u32)__shfl((int)win, (int)((k0 + 1) & 63), 64); return __builtin_amdgcn_alignbyte(d1, d0, sh); };
+                const u32 c4 = lane4(w_cur);
+                const bool room4 = i + lane + OPT_MINM <= n;
+                rm0 = r0 ? __ballot(room4 && lane4(w_r0) == c4) : 0ull;
+                rm1 = r1 ? __ballot(room4 && lane4(w_r1) == c4) : 0ull;
+                rm2 = r2 ? __ballot(room4 && lane4(w_r2) == c4) : 0ull;
+                plit64 = S.p_lit[c4 & 0xFFu];
+                dirty = false;
             }
             if (i - cb >= 16u) {
                 if (i - cb < 32u) { cb += 16; cw = cw_next; }
                 else { cb = i & ~15u; cw = (size_t)cb * OPT_TOPC + lane < (size_t)n * OPT_TOPC ? chain[(size_t)cb * OPT_TOPC + lane] : 0ull; }
                 const size_t nx = (size_t)(cb + 16) * OPT_TOPC + lane;
                 cw_next = nx < (size_t)n * OPT_TOPC ? chain[nx] : 0ull;
+                cpo = word_price(cw);
+                candmask = __ballot(((u32)cw & 0xFFFFu) >= OPT_MINM);
             }
+            const u32 j = (u32)__builtin_amdgcn_readfirstlane((int)(i - mb));
+            const u32 q = (u32)__builtin_amdgcn_readfirstlane((int)(4u * (i - cb)));
             const u32 room = n - i;
             const bool ll0 = litlen == 0;
-            const u32 base = price;  // (the next run's length code, for no literal, is in every price from here: S.p_ll[0] added where a match lands)
-            // ---- repeat offsets (zstd.c:19680: with no literal pending the codes mean the second, the third, and the first less one -- the last is not tried)
-            {
-                const u32 cur4 = win4(w_cur, o);
+            const u32 base = price;
+            // which repeat offsets are worth measuring here (zstd.c:19680: with no literal pending the codes mean the second, the third, and the
+            // first less one -- the last is not tried)
+            const bool t0 = !ll0 && ((rm0 >> j) & 1), t1 = ((rm1 >> j) & 1) && !(ll0 && r1 == r0), t2 = ((rm2 >> j) & 1) && !(ll0 && r2 == r0);
+            const bool has_c = ((candmask >> (q + 3)) & 1) && room >= OPT_MINM;
+            u32 jump_len = 0, jump_off = 0;
+            if (t0 || t1 || t2 || has_c) {
+                // this node is somebody's source: its history and how it was reached are kept
+                if (lane == 0) {
+                    S.rep[i & (OPT_RING - 1)][0] = r0 | (ll0 ? 0x80000000u : 0u); S.rep[i & (OPT_RING - 1)][1] = r1; S.rep[i & (OPT_RING - 1)][2] = r2;
+                    if (!cur_stored && i) arrivals[i] = cur_w;
+                }
+                cur_stored = true;
+                const u32 o = i - (u32)wb;
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
+                    if (!(r == 0 ? t0 : r == 1 ? t1 : t2)) continue;  // (uniform)
                     const u32 off = r == 0 ? r0 : r == 1 ? r1 : r2;
-                    if (off == 0 || off > i + reach || (ll0 && r == 0) || (ll0 && off == r0)) continue;  // (uniform)
                     const u32 wr = r == 0 ? w_r0 : r == 1 ? w_r1 : w_r2;
-                    if (win4(wr, o) != cur4 || room < OPT_MINM) continue;
                     const bool differs = win_byte(w_cur, o, lane) != win_byte(wr, o, lane);
                     const u64 dm = __ballot(differs);
                     u32 L = dm ? (u32)__builtin_ctzll(dm) : 64u;
@@ -257,62 +295,73 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                     }
                     if (L > room) L = room;
                     if (L > OPT_CAP) L = OPT_CAP;
+                    if (L < OPT_MINM) continue;
                     const u32 code = ll0 ? (u32)r - 1u : (r == 0 ? 0u : 1u);  // (r = 1 with no literal pending is code 0, r = 2 code 1)
-                    const u32 pc = base + S.p_of[code ? 1 : 0] + S.p_ll[0];
-                    for (u32 lb = OPT_MINM; lb <= L; lb += 64) {
+                    const u32 pc = base + (code ? pof1 : pof0) + pll0;
+                    if (i + L > far) far = i + L;
+                    {
+                        const u32 l = OPT_MINM + lane;
+                        if (l <= L) atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)(pc + pml_lane) << 36) | ((u64)l << 28) | off);
+                    }
+                    for (u32 lb = OPT_MINM + 64; lb <= L; lb += 64) {
                         const u32 l = lb + lane;
-                        if (l <= L) {
-                            const u32 pr = pc + S.p_ml[opt_ml_code(l - 3)];
-                            atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)pr << 36) | ((u64)l << 28) | off);
-                        }
+                        if (l <= L) atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)(pc + S.p_ml[opt_ml_code(l - 3)]) << 36) | ((u64)l << 28) | off);
                     }
                 }
-            }
-            // ---- the chain's candidates: lengths OPT_MINM .. the longest, each from the nearest entry that reaches it
-            u32 jump_len = 0, jump_off = 0;
-            {
-                const u32 q = (u32)__builtin_amdgcn_readfirstlane((int)(4u * (i - cb)));
-                const u32 w0l = (u32)__builtin_amdgcn_readlane((int)(u32)cw, (int)q), w1l = (u32)__builtin_amdgcn_readlane((int)(u32)cw, (int)(q + 1));
-                const u32 w2l = (u32)__builtin_amdgcn_readlane((int)(u32)cw, (int)(q + 2)), w3l = (u32)__builtin_amdgcn_readlane((int)(u32)cw, (int)(q + 3));
-                u32 L3 = w3l & 0xFFFFu;
-                if (L3 > room) L3 = room;
-                if (L3 >= OPT_MINM) {
-                    const u32 O0 = (u32)__builtin_amdgcn_readlane((int)(u32)(cw >> 32), (int)q), O1 = (u32)__builtin_amdgcn_readlane((int)(u32)(cw >> 32), (int)(q + 1));
-                    const u32 O2 = (u32)__builtin_amdgcn_readlane((int)(u32)(cw >> 32), (int)(q + 2)), O3 = (u32)__builtin_amdgcn_readlane((int)(u32)(cw >> 32), (int)(q + 3));
-                    const u32 L0 = w0l & 0xFFFFu, L1 = w1l & 0xFFFFu, L2 = w2l & 0xFFFFu;
+                // ---- the chain's candidates: lengths OPT_MINM .. the longest, each from the nearest entry that reaches it
+                if (has_c) {
+                    const u32 lo32 = (u32)cw, hi32 = (u32)(cw >> 32);
+                    u32 L3 = (u32)__builtin_amdgcn_readlane((int)lo32, (int)(q + 3)) & 0xFFFFu;
+                    const u32 O3 = (u32)__builtin_amdgcn_readlane((int)hi32, (int)(q + 3));
+                    if (L3 > room) L3 = room;
                     if (L3 > OPT_CAP) { jump_len = L3; jump_off = O3; }
                     else {
-                        const u32 ll_0 = S.p_ll[0];
-                        const u32 pc0 = base + ll_0 + (O0 ? S.p_of[opt_hb(O0 + 3) & 31] : 0u), pc1 = base + ll_0 + (O1 ? S.p_of[opt_hb(O1 + 3) & 31] : 0u);
-                        const u32 pc2 = base + ll_0 + (O2 ? S.p_of[opt_hb(O2 + 3) & 31] : 0u), pc3 = base + ll_0 + S.p_of[opt_hb(O3 + 3) & 31];
-                        for (u32 lb = OPT_MINM; lb <= L3; lb += 64) {
+                        const u32 L0 = (u32)__builtin_amdgcn_readlane((int)lo32, (int)q) & 0xFFFFu, L1 = (u32)__builtin_amdgcn_readlane((int)lo32, (int)(q + 1)) & 0xFFFFu, L2 = (u32)__builtin_amdgcn_readlane((int)lo32, (int)(q + 2)) & 0xFFFFu;
+                        const u32 O0 = (u32)__builtin_amdgcn_readlane((int)hi32, (int)q), O1 = (u32)__builtin_amdgcn_readlane((int)hi32, (int)(q + 1)), O2 = (u32)__builtin_amdgcn_readlane((int)hi32, (int)(q + 2));
+                        const u32 b0 = base + pll0;
+                        const u32 pc0 = b0 + (u32)__builtin_amdgcn_readlane((int)cpo, (int)q), pc1 = b0 + (u32)__builtin_amdgcn_readlane((int)cpo, (int)(q + 1));
+                        const u32 pc2 = b0 + (u32)__builtin_amdgcn_readlane((int)cpo, (int)(q + 2)), pc3 = b0 + (u32)__builtin_amdgcn_readlane((int)cpo, (int)(q + 3));
+                        if (i + L3 > far) far = i + L3;
+                        {
+                            const u32 l = OPT_MINM + lane;
+                            if (l <= L3) {
+                                const u32 off = L0 >= l ? O0 : L1 >= l ? O1 : L2 >= l ? O2 : O3;
+                                const u32 pc = L0 >= l ? pc0 : L1 >= l ? pc1 : L2 >= l ? pc2 : pc3;
+                                atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)(pc + pml_lane) << 36) | ((u64)l << 28) | off);
+                            }
+                        }
+                        for (u32 lb = OPT_MINM + 64; lb <= L3; lb += 64) {
                             const u32 l = lb + lane;
                             if (l <= L3) {
                                 const u32 off = L0 >= l ? O0 : L1 >= l ? O1 : L2 >= l ? O2 : O3;
                                 const u32 pc = L0 >= l ? pc0 : L1 >= l ? pc1 : L2 >= l ? pc2 : pc3;
-                                const u32 pr = pc + S.p_ml[opt_ml_code(l - 3)];
-                                atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)pr << 36) | ((u64)l << 28) | off);
+                                atomicMin((unsigned long long*)&S.arr[(i + l) & (OPT_RING - 1)], ((u64)(pc + S.p_ml[opt_ml_code(l - 3)]) << 36) | ((u64)l << 28) | off);
                             }
                         }
                     }
                 }
+                lds_sync();
             }
-            lds_sync();
             // ---- the next node: a match taken whole, or position i + 1 by a literal or by the best match that lands there
             u32 ni, nprice, nlitlen, nr0 = r0, nr1 = r1, nr2 = r2, m_len = 0, m_off = 0, m_src = i;
             bool src_ll0 = ll0;
             if (jump_len) {
                 ni = i + jump_len;
                 m_len = jump_len; m_off = jump_off;
-                nprice = base + S.p_ll[0] + S.p_of[opt_hb(jump_off + 3) & 31] + S.p_ml[opt_ml_code(jump_len - 3) > 52 ? 52 : opt_ml_code(jump_len - 3)];
+                const u32 mc = opt_ml_code(jump_len - 3);
+                nprice = base + pll0 + S.p_of[opt_hb(jump_off + 3) & 31] + S.p_ml[mc > 52 ? 52 : mc];
                 nlitlen = 0;
                 for (u32 k = lane; k < OPT_RING; k += OPT_THREADS) S.arr[k] = OPT_NONE;  // whatever was on its way into the match, or over it, is dropped (as the reference restarts its table behind such a match)
+                far = ni;
             } else {
                 ni = i + 1;
-                const u32 b = (win4(w_cur, o)) & 0xFFu;
-                const i32 lit_price = (i32)base + (i32)S.p_lit[b] + (i32)S.p_ll[opt_ll_code(litlen + 1) > 35 ? 35 : opt_ll_code(litlen + 1)] - (i32)S.p_ll[opt_ll_code(litlen) > 35 ? 35 : opt_ll_code(litlen)];
-                const u64 aw = S.arr[ni & (OPT_RING - 1)];
-                if (lane == 0) S.arr[ni & (OPT_RING - 1)] = OPT_NONE;
+                const u32 pll_next = pll_of(litlen + 1);
+                const i32 lit_price = (i32)base + (i32)__builtin_amdgcn_readlane((int)plit64, (int)j) + (i32)pll_next - (i32)pll_cur;
+                u64 aw = OPT_NONE;
+                if (ni <= far) {
+                    aw = S.arr[ni & (OPT_RING - 1)];
+                    if (aw != OPT_NONE && lane == 0) S.arr[ni & (OPT_RING - 1)] = OPT_NONE;
+                }
                 const u32 a_price = (u32)(aw >> 36);
                 if (aw != OPT_NONE && (i32)a_price < lit_price) {
                     m_len = (u32)(aw >> 28) & 0xFFu; m_off = (u32)aw & 0x0FFFFFFFu;
@@ -324,7 +373,7 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                         nr0 = s0 & 0x7FFFFFFFu; nr1 = S.rep[m_src & (OPT_RING - 1)][1]; nr2 = S.rep[m_src & (OPT_RING - 1)][2];
                         src_ll0 = (s0 >> 31) != 0;
                     }
-                } else { nprice = (u32)lit_price; nlitlen = litlen + 1; }
+                } else { nprice = (u32)lit_price; nlitlen = litlen + 1; pll_cur = pll_next; }
             }
             if (m_len) {
                 // the history behind a match (by value: the decoder's rules, zstd.c:19680): the offset in hand stays, the second swaps, anything else pushes --
@@ -335,7 +384,7 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                 else { nr0 = m_off; nr1 = h0; nr2 = h1; }
                 // the windows follow the history: what is kept moves, what is new is loaded
                 const u32 k0 = w_r0, k1 = w_r1, k2 = w_r2;
-                if (jump_len || ni - (u32)wb > 188u) {  // (the windows are about to move anyway: reloaded at the top of the loop with these offsets)
+                if (jump_len || ni - (u32)wb > 124u) {
                     wb = (i32)(ni & ~3u);
                     w_cur = load_win(wb);
                     w_r0 = nr0 ? load_win(wb - (i32)nr0) : 0u; w_r1 = nr1 ? load_win(wb - (i32)nr1) : 0u; w_r2 = nr2 ? load_win(wb - (i32)nr2) : 0u;
@@ -343,16 +392,15 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                     auto pick = [&](u32 off) -> u32 { return off == 0 ? 0u : off == r0 ? k0 : off == r1 ? k1 : off == r2 ? k2 : load_win(wb - (i32)off); };
                     w_r0 = pick(nr0); w_r1 = pick(nr1); w_r2 = pick(nr2);
                 }
-            }
-            if (lane == 0) {
-                S.rep[ni & (OPT_RING - 1)][0] = nr0 | (nlitlen == 0 ? 0x80000000u : 0u);
-                S.rep[ni & (OPT_RING - 1)][1] = nr1;
-                S.rep[ni & (OPT_RING - 1)][2] = nr2;
+                dirty = nr0 != r0 || nr1 != r1 || nr2 != r2 || jump_len != 0;
+                pll_cur = pll0;
             }
             {
                 const u64 w = m_len ? ((u64)m_len | ((u64)m_off << 32)) : (0x80000000ull | nlitlen);
-                if (ni < n) { if (lane == 0) arrivals[ni] = w; }
-                else end_w = w;
+                if (ni >= n) end_w = w;
+                cur_w = w;
+                cur_stored = false;
+                if (m_len && ni < n) { if (lane == 0) arrivals[ni] = w; cur_stored = true; }  // (the backward pass steps from match to match: every match's arrival is kept)
             }
             i = ni; price = nprice; litlen = nlitlen; r0 = nr0; r1 = nr1; r2 = nr2;
         }
