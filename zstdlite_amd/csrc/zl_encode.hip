@@ -248,6 +248,12 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     ZL_POISON(S, 4);
     const u32 t = threadIdx.x;
     const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
+#if ZL_MATCH_PRIO
+    // (schedule only) Longest first leaves the expensive chunks that did not fit into the launch's first round -- 2048 chunks of text on 1792
+    // resident workgroups: 256 of them -- running beside cheap ones, and the launch lasts as long as they do.  Their waves go first where a
+    // SIMD has to choose: the chunk's class sits behind the order (zl_launch_chunk_order: cost_scratch = order + nchunks).
+    if (a.order && a.order[nchunks + c] >= 3u) __builtin_amdgcn_s_setprio(ZL_MATCH_PRIO);
+#endif
     const zl_chunk_desc cd = a.chunks[c];
     const u8* src = a.src + cd.src_off;
     const u32 n = cd.src_size;

@@ -5,6 +5,9 @@
 
 #include "zl_format.h"
 
+#ifndef ZL_MATCH_PRIO
+#define ZL_MATCH_PRIO 0  // wave priority (s_setprio) of the match kernel's most expensive chunk class (zl_encode.hip zl_match_auto_kernel); 0: none.  Measured, round 6, 1 GiB mix, same bytes: 3.31 - 3.32 ms without, 3.30 - 3.37 at 2, 3.34 at 3 -- the stragglers of the launch's second round do not wait for issue slots the cheap chunks take
+#endif
 #ifndef ZL_QUAD_SPLIT
 #define ZL_QUAD_SPLIT 1  // the quad chains of single-block launches on two waves (zl_decode2.hip quad_produce / quad_consume); 0: one wave, as rounds 1-4
 #endif

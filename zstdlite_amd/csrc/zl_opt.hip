@@ -100,7 +100,7 @@ __device__ __forceinline__ u32 win_byte(u32 win, u32 o, u32 lane) {
 
 // chain: OPT_TOPC words per input byte from position deep_lo on; word: [15:0] length, [63:32] offset, 0: none; ascending lengths, the longest in slot OPT_TOPC - 1
 // arrivals: one word per input byte (the buffer the lazy parse read its candidates from: it is done with them)
-__global__ __launch_bounds__(OPT_THREADS, 8) void zl_opt_parse_kernel(zl_match_args a, const u64* __restrict__ chain_all, u64* __restrict__ arrivals_all, u32 nchunks, u32 passes) {
+__global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args a, const u64* __restrict__ chain_all, u64* __restrict__ arrivals_all, u32 nchunks, u32 passes) {
     __shared__ OptShared S;
     const u32 lane = threadIdx.x;
     const u32 c = a.order ? a.order[zl_spread(blockIdx.x, nchunks)] : zl_spread(blockIdx.x, nchunks);
