@@ -144,6 +144,27 @@ __device__ __forceinline__ void insert16_pair(u32* tl, u32 bl, u32 old_l, u32* t
 // function of the data (sequences found in the previous window), so the output stays deterministic.
 // ---------------------------------------------------------------------------------------
 #define WIN2 (2 * ENC_THREADS)
+// Round 6: the bulk instantiation at EIGHT workgroups per CU -- 2^12 + 2^12 entries (18.4 KiB of LDS with the rest; 2^13 + 2^11 was 22.4: seven) and 64
+// vector registers (65 before: __launch_bounds__' second argument asks for them).  Not for the latency it hides (text alone: 9.15 -> 8.90 ms per GiB)
+// but for what a launch is made of: the chunks of a kind take equally long, a launch whose expensive kind has more chunks than the device has
+// places runs that kind in two rounds, and the second round is a handful of workgroups on an empty device -- the 1 GiB mix has 2048 chunks of text
+// for 1792 places: 3.33 ms where its four kinds add up to 3.0.  With 2048 places: 2.93 ms.  The long table's half costs text 2.9 % of ratio, the short
+// table's double gives 1.8 back (4.257 -> 4.210; the mix 1.634 -> 1.633); 2^12 + 2^11 (ten places by LDS, eight by registers): 2.88 ms, text 4.133.
+#ifndef LONG_LOG_BULK
+#define LONG_LOG_BULK 12
+#endif
+// ... and the one-frame (windowed) instantiation likewise: 2^12 + 2^12 entries and 64 vector registers (two spilled) = eight workgroups per CU where 2^13 + 2^12 and 76
+// registers gave six.  1 GiB mix in one frame: match 4.84 -> 4.17 ms, 64 MiB of text 0.997 -> 1.021 of the reference's size, the python sources (three copies:
+// above the deep finder's 16 MiB) 1.017 -> 1.028, records unchanged.  (Round 5 tried SEVEN through the short table alone: 4.88 -> 4.75 ms, not taken.)
+#ifndef LONG_LOG_FAR
+#define LONG_LOG_FAR 12
+#endif
+#ifndef ZL_FAR_MIN_BLOCKS
+#define ZL_FAR_MIN_BLOCKS 8
+#endif
+#ifndef ZL_BULK_MIN_BLOCKS
+#define ZL_BULK_MIN_BLOCKS 8    // __launch_bounds__' second argument for the bulk instantiation: workgroups per CU the register allocation must allow
+#endif
 #ifndef ZL_MATCH_SGPRS
 #define ZL_MATCH_SGPRS 88  // a CU admits seven 256-thread workgroups up to 96 scalar registers per wave (six from 97; MI355X_MICROARCH.md, Residency); the lean body took the bulk instantiation to 97
 #endif
@@ -229,10 +250,9 @@ __device__ __forceinline__ bool worth_it(u32 len, u32 off, u32 rep) {
 // CU instead of seven) and verification up to 72 bytes per lane.  The CPU model of the parse (scripts/dev/sim/sim.c) gives
 // text +3.2 %, python sources +5.3 % of ratio for it; what the device gives and costs is in DESIGN.md 3.3.
 template <bool DICT, bool PROF, bool FAR, bool INTRA, bool HI = false>
-__global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATCH_SGPRS))) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
+__global__ __launch_bounds__(ENC_THREADS, (!DICT && !PROF && !FAR && !INTRA && !HI) ? ZL_BULK_MIN_BLOCKS : ((!DICT && !PROF && FAR && !HI) ? ZL_FAR_MIN_BLOCKS : 1)) __attribute__((amdgpu_num_sgpr(ZL_MATCH_SGPRS))) void zl_match_auto_kernel(zl_match_args a, u32 nchunks) {
     static_assert(!(DICT && HI), "the dictionary's table image has the base sizes");
-    constexpr int LLOG = HI ? LONG_LOG_HI : LONG_LOG;
-    constexpr u32 lshift = 64u - (u32)LLOG;
+    constexpr int LLOG = HI ? LONG_LOG_HI : ((!DICT && !FAR && !INTRA) ? LONG_LOG_BULK : (FAR ? LONG_LOG_FAR : LONG_LOG));
     constexpr u32 lane_cap = (FAR || HI) ? LANE_MATCH_CAP_FAR : LANE_MATCH_CAP;
     // The bulk path (no dictionary, independent frames, inputs larger than a chunk) runs with half the short table: its
     // candidates are nearer (mean age = table size), so their gathers hit closer caches -- 1 GiB mix: match 5.74 -> 4.98 ms
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(ENC_THREADS) __attribute__((amdgpu_num_sgpr(ZL_MATC
     // (a launch that mixes small inputs with chunks of large ones -- a batch -- must write for every chunk what a launch of
     // its own would: the chunks of large inputs hash as the bulk instantiation does)
     const u32 sshift = (INTRA && !DICT && !FAR && !HI && !intra_on) ? 64u - SHORT_LOG_BULK : 64u - (u32)SLOG;
+    const u32 lshift = (INTRA && !DICT && !FAR && !HI && !intra_on) ? 64u - LONG_LOG_BULK : 64u - (u32)LLOG;  // (likewise the long table, should the bulk path's ever be the smaller)
     // Inputs of at most 16 KiB (no dictionary): the short table hashes FOUR bytes and a table candidate of four bytes is a match, as
     // the reference's level 3 does for such inputs (zstd.c:29607: minMatch 4 up to 16 KiB); other single-chunk inputs hash five
     // (zstd.c:29581).  A pickled data frame of 1 KiB held 9 sequences against the reference's 56 (1.29x its size): its repeats are

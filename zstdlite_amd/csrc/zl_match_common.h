@@ -55,7 +55,7 @@ __device__ __forceinline__ u32 hash_long(u64 v, u32 shift /* 64 - log2 of the ta
                            // Round 4, 1 GiB mix in one frame: match 7.55 -> 7.07 ms for 0.9 % of the python sources (4.390 -> 4.353; the reference's level 3: 4.428)
 #endif
 #ifndef SHORT_LOG_BULK
-#define SHORT_LOG_BULK 11  // the bulk instantiation of the match kernel (zl_encode.hip says why)
+#define SHORT_LOG_BULK 12  // the bulk instantiation of the match kernel (zl_encode.hip says why; 11 until round 6, beside a long table of 2^13)
 #endif
 template <bool FAR>
 __device__ __forceinline__ u32 hash_short(u64 v, u32 shift /* 64 - log2 of the table's entries */) {
