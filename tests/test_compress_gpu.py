@@ -460,8 +460,9 @@ def test_levels_sixteen_to_twenty_two_price_their_parse(ref, level):
     backwards (the reference's btopt / btultra / btultra2, zstd.c:34586-36163).  The REFERENCE decoder must regenerate every input bit for
     bit, in both layouts, from nothing to many chunks; the output is deterministic; and the bar of north_star holds AT THE SAME LEVEL
     on real text (the python sources) and on the long-range records: at most 1.05x the reference's size (level 15's parse at these
-    levels, round 5: 1.07 - 1.11x).  The synthetic text -- random words of a vocabulary of forty, every one with thousands of twins -- wants
-    more than the 256 most recent candidates (the reference's binary tree looks at all of them): held to 1.12x, and said so in DESIGN 3.3."""
+    levels, round 5: 1.07 - 1.11x).  The synthetic text -- random words of a small vocabulary, every one with thousands of twins -- wants
+    more than the 256 most recent twins of FOUR bytes (the reference's binary tree looks at all of them): a second search pass over an
+    eight-byte hash is merged into the chains (1.09 - 1.10x -> 1.04 - 1.05x); held to 1.08x, and said so in DESIGN 3.3."""
     import warnings
     from zl_testlib import LONG_RANGE
     from ratio_inputs import INPUTS
@@ -490,7 +491,7 @@ def test_levels_sixteen_to_twenty_two_price_their_parse(ref, level):
                     assert b"".join(got) == data, (name, layout)
                 assert z.zstd_decompress(out) == data, (name, layout)
         c15 = z.zstd_compress(corpus, level=15)
-    for name, data, bar in (("corpus", corpus, 1.05), ("records", records, 1.05), ("iid10", cases[3][1], 1.05), ("text", text, 1.12)):
+    for name, data, bar in (("corpus", corpus, 1.05), ("records", records, 1.05), ("iid10", cases[3][1], 1.05), ("text", text, 1.08)):
         ours, theirs = len(outs[name, "auto"]), len(ref.compress(data, level=level))
         assert ours <= theirs * bar, (name, level, ours, theirs, ours / theirs)
     assert len(outs["corpus", "auto"]) < len(c15) * 0.96  # what the prices buy over level 15's lazy parse of the same candidates

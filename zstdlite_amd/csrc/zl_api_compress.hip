@@ -138,6 +138,9 @@ struct DeepLevel { u32 k, lazy2, wlog, opt; };
 #define ZL_DEEP_SUB 8u  // workgroups that share a chunk in the deep parse of a small launch (a power of two; 1: never).  16 and 32 were measured: 6 - 9 % off a small call's
                         // time, and config C1's buffer repeated to 1 MiB 1.098 -> 1.174x the reference's size (every part starts without a repeat offset and probes for itself)
 #endif
+#ifndef ZL_OPT_K2
+#define ZL_OPT_K2 256u    // levels 16 - 22: candidates per position of the second search pass (eight-byte hash; zl_deep.hip); 0: one pass
+#endif
 #ifndef ZL_OPT_PASSES
 #define ZL_OPT_PASSES 2u  // price-based passes at levels 16 - 22 (the model, python sources at level 16: 1.011 / 1.002 / 1.000 of the reference's size with one / two / three; 0: level 15's parse, as round 5)
 #endif
@@ -265,6 +268,8 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         if (scratch_bytes == 0 || deep_oom_switch() || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes) ||
             (dl.opt && !es.deep_chain.ensure((size_t)(d.hi - d.lo) * 8 * ZL_DEEP_CHAIN + 64))) { c->deep_failed = true; return kGpuUnavailable; }
         d.chain = dl.opt ? (u64*)es.deep_chain.p : nullptr;
+        d.k2 = dl.opt ? ZL_OPT_K2 : 0u;
+        d.mml2 = 8;
         d.scratch = es.deep_scratch.p;
         d.scratch_bytes = scratch_bytes;
         d.best = (u64*)es.deep_best.p;

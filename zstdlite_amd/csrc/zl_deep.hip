@@ -113,6 +113,10 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
     const u32 p = (u32)skey[e], hme = (u32)(skey[e] >> 32);
     const uint4 m0 = rec[0][e], m1 = rec[1][e], m2 = rec[2][e], m3 = rec[3][e];
     const u32 chunk0 = p & ~(u32)(ZL_CHUNK - 1);  // (sections start on a chunk boundary)
+    // frames: bit 0 -- independent frames (a candidate lies inside the position's own chunk); bit 1 -- a SECOND pass over the section,
+    // sorted by a longer hash (levels 16+): what it finds is merged into the chain the first pass left, the best words stay as they are
+    const bool merge = (frames & 2u) != 0;
+    frames &= 1u;
     u32 lo = p > window ? p - window : 0u;
     if (frames && lo < chunk0) lo = chunk0;
     u32 bl = 0, bo = 0, be = 0;
@@ -150,6 +154,42 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
                 }
             }
         }
+    }
+    if (merge) {
+        // The two chains -- this pass's and the one in memory -- are each ascending in length and descending in offset; together the entries that no
+        // other one beats at both (at least as long AND at least as near) are the nearest offset per length over all candidates of both passes.  The
+        // ZL_DEEP_CHAIN longest of them stay.
+        static_assert(ZL_DEEP_CHAIN == 4, "two 16-byte words each way");
+        if (ch_l[ZL_DEEP_CHAIN - 1] == 0) return;  // nothing new
+        uint4* const at = (uint4*)(chain + (size_t)ZL_DEEP_CHAIN * p);
+        const uint4 e0 = at[0], e1 = at[1];
+        u32 L[8] = {e0.x, e0.z, e1.x, e1.z, ch_l[0], ch_l[1], ch_l[2], ch_l[3]};
+        u32 O[8] = {e0.y, e0.w, e1.y, e1.w, ch_o[0], ch_o[1], ch_o[2], ch_o[3]};
+        bool dead[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            bool d = (L[x] & 0xFFFFu) == 0;
+#pragma unroll
+            for (int y = 0; y < 8; y++) if (y != x) {
+                const u32 lx = L[x] & 0xFFFFu, ly = L[y] & 0xFFFFu;
+                // y beats x: at least as long and at least as near (of two equal entries the first stays)
+                d = d || (ly != 0 && ly >= lx && O[y] <= O[x] && (ly > lx || O[y] < O[x] || y < x));
+            }
+            dead[x] = d;
+        }
+        u32 nl[4] = {0, 0, 0, 0}, no[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int slot = 3; slot >= 0; slot--) {  // the longest survivor not yet taken, four times
+            u32 bestl = 0, besto = 0; int which = -1;
+#pragma unroll
+            for (int x = 0; x < 8; x++) { const u32 lx = L[x] & 0xFFFFu; if (!dead[x] && lx > bestl) { bestl = lx; besto = O[x]; which = x; } }
+#pragma unroll
+            for (int x = 0; x < 8; x++) if (x == which) dead[x] = true;
+            nl[slot] = bestl; no[slot] = besto;
+        }
+        at[0] = make_uint4(nl[0], no[0], nl[1], no[1]);
+        at[1] = make_uint4(nl[2], no[2], nl[3], no[3]);
+        return;
     }
     u64 word = 0;
     if (bl) {
@@ -595,6 +635,18 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
         else if (a->k <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best, chain);
         else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best, chain);
         hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec, chain);
+        if (chain && a->k2) {
+            // levels 16+: the section once more, sorted by a hash of mml2 bytes -- the K most recent twins of a LONG prefix reach where the K most recent
+            // of minMatch bytes end (a word of a small vocabulary has thousands of twins, the phrase around it a few) --, merged into the chains
+            hipLaunchKernelGGL(zl_deep_key_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, sec, n, 64u - 8u * a->mml2, keys_a);
+            size_t tb2 = temp_room;
+            const hipError_t e2 = hipcub::DeviceRadixSort::SortKeys(temp, tb2, (const u64*)keys_a, keys_b, n, 32, 32 + ZL_DEEP_HLOG, stream);
+            if (e2 != hipSuccess) return e2;
+            const u32 fl = a->frames | 2u;
+            if (a->k2 <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k2, a->window, a->mml2, fl, best, chain);
+            else if (a->k2 <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k2, a->window, a->mml2, fl, best, chain);
+            else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k2, 256u), a->window, a->mml2, fl, best, chain);
+        }
         s0 = s1;
     }
     return hipGetLastError();

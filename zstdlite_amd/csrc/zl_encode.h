@@ -121,6 +121,7 @@ struct zl_deep_args {
     size_t scratch_bytes;
     u64* best;         // out: one word per position, best[p - lo]
     u64* chain;        // out, or null: ZL_DEEP_CHAIN words per position, chain[ZL_DEEP_CHAIN * (p - lo) ...]
+    u32 k2, mml2;      // with a chain: a second pass over every section, sorted by a hash of mml2 bytes, k2 candidates deep, merged into the chains (0: none)
 };
 
 struct zl_far_args {
