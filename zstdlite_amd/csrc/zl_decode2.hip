@@ -177,6 +177,27 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
 #ifndef ZL2_SPLIT_MIN
 #define ZL2_SPLIT_MIN 1024   // frames from which on a batch may be cut in two (zl2_launch)
 #endif
+// One LDS add for all the lanes of a wave that name the same bucket (a batch of 100 000 small objects has a handful of costs: every lane of
+// every wave used to queue on the same three words -- 287 us for config C4's batch; any permutation inside a bucket is correct).  Up to four
+// buckets per wave this way, whoever is left adds alone.  Returns the lane's slot (the bucket's old count + the lane's rank among its peers).
+__device__ __forceinline__ u32 order_bucket_add(u32* cnt, u32 bucket, bool on) {
+    const u32 lane = threadIdx.x & 63;
+    u64 todo = __ballot(on);
+    u32 slot = 0;
+    for (int r = 0; r < 4 && todo; r++) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 lb = (u32)__shfl((int)bucket, leader, 64);
+        const u64 same = __ballot(on && bucket == lb) & todo;
+        u32 base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cnt[lb], (u32)__popcll(same));
+        base = (u32)__shfl((int)base, leader, 64);
+        if ((same >> lane) & 1) slot = base + (u32)__popcll(same & ((1ull << lane) - 1));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1) slot = atomicAdd(&cnt[bucket], 1u);
+    return slot;
+}
+
 __global__ __launch_bounds__(1024) void zl2_order_kernel(zl2_args a) {
     __shared__ u32 cnt[1024];
     __shared__ u32 part[16];
@@ -185,9 +206,10 @@ __global__ __launch_bounds__(1024) void zl2_order_kernel(zl2_args a) {
         const u32 shift = pass == 0 ? 5 : 7;
         cnt[t] = 0;
         __syncthreads();
-        for (u32 f = t; f < n; f += 1024) {
-            const u32 key = (pass == 0 ? a.frec[f].cost : a.frec[f].lit_cost) >> shift;
-            atomicAdd(&cnt[1023 - (key > 1023 ? 1023 : key)], 1u);
+        for (u32 f0 = 0; f0 < n; f0 += 1024) {  // (every wave stays whole: the ballots want all of its lanes)
+            const u32 f = f0 + t;
+            const u32 key = f < n ? (pass == 0 ? a.frec[f].cost : a.frec[f].lit_cost) >> shift : 0u;
+            (void)order_bucket_add(cnt, 1023 - (key > 1023 ? 1023 : key), f < n);
         }
         __syncthreads();
         // exclusive scan over the 1024 buckets
@@ -215,9 +237,11 @@ __global__ __launch_bounds__(1024) void zl2_order_kernel(zl2_args a) {
             a.max_blocks[2] = gs;
         }
         __syncthreads();
-        for (u32 f = t; f < n; f += 1024) {
-            const u32 key = (pass == 0 ? a.frec[f].cost : a.frec[f].lit_cost) >> shift;
-            a.order[pass * n + atomicAdd(&cnt[1023 - (key > 1023 ? 1023 : key)], 1u)] = f;
+        for (u32 f0 = 0; f0 < n; f0 += 1024) {
+            const u32 f = f0 + t;
+            const u32 key = f < n ? (pass == 0 ? a.frec[f].cost : a.frec[f].lit_cost) >> shift : 0u;
+            const u32 slot = order_bucket_add(cnt, 1023 - (key > 1023 ? 1023 : key), f < n);
+            if (f < n) a.order[pass * n + slot] = f;
         }
         __syncthreads();
     }
