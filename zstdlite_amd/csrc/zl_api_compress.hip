@@ -413,10 +413,15 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
     e.total_size = joined_total;
     e.cdict = (c->dict_use && c->dict_formatted && !joined) ? c->d_cdict.p : nullptr;
     e.order = order;
+#ifndef ZL_ENT_SMALL
+#define ZL_ENT_SMALL 1  // 0: every object through zl_entropy_kernel, as rounds 1-5
+#endif
 #ifndef ZL_ENT_SPLIT
 #define ZL_ENT_SPLIT 0  // 1: the entropy stage as two kernels with a register allocation each (zl_encode.hip zl_entropy_kernel<1>, <2>).  Measured, round 5, same bytes: 18 and 0 vector registers spilled in the halves (64 and 114 registers) against the one kernel's 60 -- and 1.98 ms per GiB of the mix against the one kernel's 1.75 (second half at 5 / 8 workgroups per CU: 1.88 / 2.03): the spills are not what the stage waits for
 #endif
     e.handover = nullptr;
+    // small objects on a dictionary's entropy tables (zl_encode.hip zl_entropy_small_kernel): levels 3 and 4 (repeat offset 1 only), no checksum, literals Huffman-coded
+    e.small_done = (ZL_ENT_SMALL && e.cdict != nullptr && !e.exact_rep && !e.raw_lits && !e.checksum && !e.joined && e.order == nullptr && c->chunk_cap < 16384u) ? 1u : 0u;
     if (ZL_ENT_SPLIT && c->profile < 2) {  // (the in-kernel phase stamps of ZL_c_profile = 2 describe the one-kernel form)
         if (!es.handover.ensure((size_t)cnt * ZL_ENT_HANDOVER + 64)) return kGpuUnavailable;
         e.handover = (u8*)es.handover.p;

@@ -1058,7 +1058,9 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // still: 1 GiB of them, runs of 1 / 2 / 3 / 4 / 5 / 8 segments: 12.5 / 11.3 / 10.4 / 10.8 / 11.5 / 12.1 ms; the reference's
         // single-block segments: 27.7 / 23.5 / 22.3 / 22.4 / 23.5 / 20.9 ms, best at 6 - 8)
         const u32 run_cap = info.nblocks >= 4u * info.nsegs ? 3u : (u32)ZL3_EXEC_RUN;
-        u32 exec_run = std::max<u32>(1u, std::min<u32>(run_cap, info.nsegs / (3u * (u32)g_num_cu)));
+        // (round 6: segments of several small blocks fill the device at TWO workgroups per CU -- the runs of 1024 chunks that a frame from host memory is decoded in take two
+        // chunks per workgroup instead of one: half the bytes that cross a run's edge and wait for the ordered copies.  1 GiB host to host, runs of 1 / 2 / 3 / 4: 29.0 / 27.5 / 28.5 / 29.1 ms)
+        u32 exec_run = std::max<u32>(1u, std::min<u32>(run_cap, info.nsegs / ((run_cap == 3u ? 2u : 3u) * (u32)g_num_cu)));
 #ifdef ZL_DEV_SWITCHES
         if (getenv("ZL_EXEC_RUN")) exec_run = (u32)atoi(getenv("ZL_EXEC_RUN"));
 #endif

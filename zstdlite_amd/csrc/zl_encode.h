@@ -160,6 +160,7 @@ struct zl_entropy_args {
     const void* cdict; // zl_cdict* (device) or null: the dictionary's entropy tables, offered to frames of a single block
     const u32* order;  // launch order of the chunks, as the match kernel's (or null)
     u8* handover;      // per chunk ZL_ENT_HANDOVER bytes: the stage runs as two kernels that hand their shared state over here (null: one kernel)
+    u32 small_done;    // 1: zl_entropy_small_kernel runs first (small objects on a dictionary's tables, a wave each); zl_entropy_kernel does what it left (frame_size 0xFFFFFFFF)
     u64* stats;        // optional (profiling): cycles {statistics, tree | tables, codes + stream bits, block literals, block sequences, chains | tree description + tail, chunks}
 };
 

@@ -2236,7 +2236,7 @@ __device__ __noinline__ u32 huf_write_tree_wave(EntShared& S, u8* dst, u32 lane)
 // One backward Huffman stream by one wave (zstd.c:17690 HUF_compress1X_usingCTable_internal):
 // the last symbol is written first.  Tiles of 512 symbols; each lane codes 8 consecutive
 // symbols, a wave scan places its bits, LDS atomicOr assembles words, whole bytes are flushed.
-__device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed */, const u8* lit, u32 cnt, u8* out) {
+__device__ u32 huf_encode_stream(const u8* hlen /* LDS */, const u16* hcode /* LDS */, u32* stage /* 256 words, zeroed */, const u8* lit, u32 cnt, u8* out) {
     const u32 lane = threadIdx.x & 63;
     u32 written = 0, carry_bits = 0;
     // the 8 symbols of a lane are 8 consecutive bytes (read back to front): one load, fetched a tile ahead
@@ -2256,8 +2256,8 @@ __device__ u32 huf_encode_stream(EntShared& S, u32* stage /* 256 words, zeroed *
         for (u32 j = 0; j < 8; j++) {
             if (first + j < cnt) {
                 const u32 sym = (u32)(v >> (56 - 8 * j)) & 0xFF;  // byte cnt-1-(first+j)
-                const u32 len = S.hlen[sym];
-                const u64 code = S.hcode[sym];
+                const u32 len = hlen[sym];
+                const u64 code = hcode[sym];
                 if (j < 4) { lo |= code << nlo; nlo += len; }
                 else { hi |= code << nhi; nhi += len; }
             }
@@ -2539,6 +2539,7 @@ __global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS)
     u8* const code_k[3] = {sst_base, sst_base + a.seq_stride, sst_base + 2 * (size_t)a.seq_stride};                    // T_LL, T_OF, T_ML
     unsigned short* const state_k[3] = {(unsigned short*)(sst_base + 3 * (size_t)a.seq_stride), (unsigned short*)(sst_base + 5 * (size_t)a.seq_stride),
                                         (unsigned short*)(sst_base + 7 * (size_t)a.seq_stride)};
+    if (a.small_done && a.frame_size[c] != 0xFFFFFFFFu) return;  // (zl_entropy_small_kernel wrote this one's frame)
     u8* out = a.out + (size_t)c * a.out_stride;
     const u32 out_limit = a.out_stride - 16;  // what a frame may occupy while it is being built
     const bool prof = a.stats != nullptr && t == 0;
@@ -3004,9 +3005,9 @@ __global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS)
                 u32 off = 6;
                 for (u32 k = 0; k < wave; k++) off += (S.sbits[j][k] + 8) >> 3;
                 const u32 s0 = wave * seg, cnt = (wave == 3) ? nl - 3 * seg : seg;
-                huf_encode_stream(S, S.stage + 256 * wave, blit + s0, cnt, p + off);
+                huf_encode_stream(S.hlen, S.hcode, S.stage + 256 * wave, blit + s0, cnt, p + off);
             } else if (wave == 0) {
-                huf_encode_stream(S, S.stage, blit, nl, p);
+                huf_encode_stream(S.hlen, S.hcode, S.stage, blit, nl, p);
             }
             tree_out = true;
         } else if (mode == 1) {
@@ -3190,6 +3191,160 @@ __global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS)
 }
 
 
+// ---------------------------------------------------------------------------------------
+// zl_entropy_small_kernel (round 6): the entropy stage of a SMALL object that rides on a dictionary's tables -- config C4's
+// shape: 100 000 objects of a few hundred bytes, one frame each.  zl_entropy_kernel gives every object a workgroup of 256 threads,
+// zeroes and ranks four histograms, builds a Huffman tree and three FSE tables and then finds, for nearly every such object, that the
+// dictionary's tables are cheaper than its own plus their descriptions: 110 000 cycles of barriers and one-lane phases per object,
+// 2.3 of the 4.1 ms a call of 100 000 objects spends in kernels.  The reference does not ask either: with a dictionary whose tables
+// are valid, literals of at most 1 KiB take the dictionary's Huffman table as it is (zstd.c:18020 HUF_compress_internal: preferRepeat
+// below the lazy strategies) and fewer than 1000 sequences take its FSE tables in Repeat_Mode (zstd.c:21034 ZSTD_selectEncodingType).
+// Here: ONE WAVE per object, four objects per workgroup, the dictionary's tables copied into LDS once per workgroup, no workgroup
+// barrier behind that copy.  Eligible: a dictionary with entropy tables, no checksum, levels 3 - 4 (repeat offset 1 only), content below
+// 16 KiB (one block), at most 1023 literals (one Huffman stream, a 3-byte section header), at most 127 sequences, every literal and
+// every code present in the dictionary's tables.  Everything else gets frame_size = 0xFFFFFFFF and is done by zl_entropy_kernel
+// behind this launch (a.small_done).
+//   literals    Treeless_Literals_Block on the dictionary's table when that beats raw (from 6 literals up, zstd.c:20745), else raw
+//   sequences   the bitstream of zstd.c:21146 written front to back by all lanes in step (uniform: the three states and the bit
+//               container are the same in every lane; lane 0 stores), the sequence's fields handed round with lane shuffles
+// ---------------------------------------------------------------------------------------
+#define SMALL_OBJECTS 4
+#define SMALL_MAX_LIT 1023u
+#define SMALL_MAX_SEQ 127u
+#define SMALL_SEQ_BYTES 1664  // 127 sequences x (27 state bits + up to 59 extra bits) / 8 + the flushed states + slack
+struct SmallShared {
+    u16 state[3][512];
+    i32 dnb[3][56], dfs[3][56];
+    u32 log[3];
+    u8 hlen[256];
+    u16 hcode[256];
+    u32 stage[SMALL_OBJECTS][256];
+    alignas(8) u8 seqbuf[SMALL_OBJECTS][SMALL_SEQ_BYTES];
+};
+
+__global__ __launch_bounds__(64 * SMALL_OBJECTS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
+    __shared__ SmallShared S;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const zl_cdict* const cd_ = (const zl_cdict*)a.cdict;
+    for (u32 i = t; i < 3 * 512; i += 64 * SMALL_OBJECTS) S.state[i >> 9][i & 511] = cd_->ct[i >> 9].state[i & 511];
+    for (u32 i = t; i < 3 * 56; i += 64 * SMALL_OBJECTS) { S.dnb[i / 56][i % 56] = cd_->ct[i / 56].dnb[i % 56]; S.dfs[i / 56][i % 56] = cd_->ct[i / 56].dfs[i % 56]; }
+    if (t < 3) S.log[t] = cd_->ct[t].log;
+    for (u32 i = t; i < 256; i += 64 * SMALL_OBJECTS) { S.hlen[i] = cd_->hlen[i]; S.hcode[i] = cd_->hcode[i]; }
+    for (u32 i = t; i < SMALL_OBJECTS * 256; i += 64 * SMALL_OBJECTS) (&S.stage[0][0])[i] = 0;
+    __syncthreads();
+    const u32 c = blockIdx.x * SMALL_OBJECTS + wave;
+    if (c >= nchunks) return;
+    const zl_chunk_desc cd = a.chunks[c];
+    const u32 n = cd.src_size;
+    const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
+    const u8* const src = a.src + cd.src_off;
+    const zl_seq* const seqs = a.seqs + (size_t)c * a.seq_stride;
+    const u8* const lit = nseq ? a.lits + (size_t)c * a.lit_stride : src;
+    bool ok = cd_->ok != 0 && cd_->huf_ok != 0 && n >= 1 && n < 16384 && nlit <= SMALL_MAX_LIT && nseq <= SMALL_MAX_SEQ && S.log[0] != 0 && S.log[1] != 0 && S.log[2] != 0;
+    // ---- the literals' bits under the dictionary's codes
+    u32 lbits = 0, lbad = 0;
+    for (u32 i = lane; i < nlit; i += 64) { const u32 l = S.hlen[lit[i]]; lbits += l; lbad |= l == 0 ? 1u : 0u; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lbits += __shfl_xor(lbits, d, 64); lbad |= __shfl_xor(lbad, d, 64); }
+    // ---- the sequences' fields: this lane holds sequences lane and 64 + lane
+    u32 f_ll[2] = {0, 0}, f_mb[2] = {0, 0}, f_ob[2] = {0, 0}, f_cd[2] = {0, 0};  // literal length, match length - 3, offset value (zstd.c:19680), the three codes packed
+    u32 sbad = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const u32 i = 64 * h + lane;
+        if (i < nseq) {
+            const zl_seq q = seqs[i];
+            const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u, prev_off = i ? seqs[i - 1].offset : 0u;
+            const u32 ll = q.lit_cum - prev_cum;
+            const u32 ob = (ll > 0 && q.offset == prev_off) ? 1u : q.offset + 3;  // (repeat offset 1 only, as zl_entropy_kernel below level 5)
+            const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(q.match_len);
+            f_ll[h] = ll; f_mb[h] = q.match_len - 3; f_ob[h] = ob; f_cd[h] = cl | (co << 8) | (cm << 16);
+            if (!((cd_->sym_mask[T_LL] >> cl) & 1) || !((cd_->sym_mask[T_OF] >> co) & 1) || !((cd_->sym_mask[T_ML] >> cm) & 1)) sbad = 1;
+        }
+    }
+    sbad = __any((int)sbad) ? 1u : 0u;
+    if (!ok || lbad || sbad) {  // (uniform) not this kernel's: the general one takes it
+        if (lane == 0) a.frame_size[c] = 0xFFFFFFFFu;
+        return;
+    }
+    u8* const out = a.out + (size_t)c * a.out_stride;
+    const u32 fh = (n < 256 ? 6u : 7u) + dict_id_bytes(a.dict_id);
+    if (lane == 0) write_frame_header(out, n, 0, a.dict_id);
+    u8* const blk = out + fh + 3;
+    // ---- literals section
+    const u32 csize = (lbits + 8) >> 3;
+    const u32 lhs_r = 1 + (nlit >= 32);
+    const bool huf = nlit >= 6 && 3 + csize < lhs_r + nlit;
+    u32 lit_sec;
+    if (huf) {
+        lit_sec = 3 + csize;
+        if (lane == 0) wr_le(blk, 3ull | ((u64)nlit << 4) | ((u64)csize << 14), 3);  // Treeless_Literals_Block, one stream, 10-bit sizes
+        (void)huf_encode_stream(S.hlen, S.hcode, S.stage[wave], lit, nlit, blk + 3);
+    } else {
+        lit_sec = lhs_r + nlit;
+        if (lane == 0) wr_le(blk, 0u | ((lhs_r == 1 ? 0u : 1u) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4)), lhs_r);
+        for (u32 i = lane; i < nlit; i += 64) blk[lhs_r + i] = lit[i];
+    }
+    // ---- sequences section
+    u8* const sq = blk + lit_sec;
+    u32 seq_sec = 1;
+    if (nseq == 0) { if (lane == 0) sq[0] = 0; }
+    else {
+        // every lane runs the same chain (zstd.c:21146 ZSTD_encodeSequences): sequence k's fields come from lane k & 63 by shuffle
+        u8* const sb = S.seqbuf[wave];
+        u64 acc = 0; u32 nb = 0, wr = 0;
+        auto put = [&](u32 v, u32 bits) { acc |= (u64)(v & ((bits < 32 ? (1u << bits) : 0u) - 1u)) << nb; nb += bits; };
+        auto flush = [&]() { if (nb >= 32) { if (lane == 0) { const u32 w = (u32)acc; __builtin_memcpy(sb + wr, &w, 4); } wr += 4; acc >>= 32; nb -= 32; } };
+        auto field = [&](const u32 (&f)[2], u32 k) -> u32 { const u32 lo = (u32)__shfl((int)f[0], (int)(k & 63), 64), hi = (u32)__shfl((int)f[1], (int)(k & 63), 64); return k < 64 ? lo : hi; };
+        u32 st_ll, st_of, st_ml;
+        {
+            const u32 k = nseq - 1, cdw = field(f_cd, k);
+            const u32 cl = cdw & 0xFF, co = (cdw >> 8) & 0xFF, cm = cdw >> 16;
+            st_ml = fse_init_state(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm]);
+            st_of = fse_init_state(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co]);
+            st_ll = fse_init_state(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl]);
+            put(field(f_ll, k), e_LL_bits[cl]); flush();
+            put(field(f_mb, k), e_ML_bits[cm]); flush();
+            put(field(f_ob, k), co); flush();
+        }
+        for (u32 k = nseq - 1; k-- > 0;) {
+            const u32 cdw = field(f_cd, k);
+            const u32 cl = cdw & 0xFF, co = (cdw >> 8) & 0xFF, cm = cdw >> 16;
+            const u32 eo = fse_encode(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co], st_of);
+            put(eo & 0xFFFF, eo >> 16); flush();
+            const u32 em = fse_encode(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm], st_ml);
+            put(em & 0xFFFF, em >> 16); flush();
+            const u32 el = fse_encode(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl], st_ll);
+            put(el & 0xFFFF, el >> 16); flush();
+            put(field(f_ll, k), e_LL_bits[cl]); flush();
+            put(field(f_mb, k), e_ML_bits[cm]); flush();
+            put(field(f_ob, k), co); flush();
+        }
+        put(st_ml, S.log[T_ML]); flush();
+        put(st_of, S.log[T_OF]); flush();
+        put(st_ll, S.log[T_LL]); flush();
+        put(1, 1);  // the end mark
+        const u32 tail = (nb + 7) >> 3;
+        if (lane == 0) for (u32 b = 0; b < tail; b++) sb[wr + b] = (u8)(acc >> (8 * b));
+        const u32 total = wr + tail;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) { sq[0] = (u8)nseq; sq[1] = 0xFC; }  // Repeat_Mode three times
+        for (u32 i = lane; i < total; i += 64) sq[2 + i] = sb[i];
+        seq_sec = 2 + total;
+    }
+    // ---- the block: compressed where that is smaller than the content (zstd.c:26880), else raw
+    u32 bsize = lit_sec + seq_sec;
+    if (bsize >= n) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = lane; i < n; i += 64) blk[i] = src[i];
+        if (lane == 0) wr_le(out + fh, ((u64)n << 3) | 1u, 3);
+        bsize = n;
+    } else if (lane == 0) wr_le(out + fh, ((u64)bsize << 3) | (2u << 1) | 1u, 3);
+    if (lane == 0) a.frame_size[c] = fh + 3 + bsize;
+}
+
 // exclusive scan of frame sizes: one workgroup of 1024 threads walks tiles of 4096 sizes, four consecutive ones per thread (coalesced), a running
 // total from tile to tile.  (Rounds 1-5 gave every thread of 256 a contiguous range: strided loads, 190 us for the 100 000 sizes of config C4's batch.)
 #define ZL_SCAN_THREADS 1024
@@ -3295,6 +3450,7 @@ extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
+    if (a->small_done) hipLaunchKernelGGL(zl_entropy_small_kernel, dim3((nchunks + SMALL_OBJECTS - 1) / SMALL_OBJECTS), dim3(64 * SMALL_OBJECTS), 0, stream, *a, nchunks);
     if (a->handover) {
         hipLaunchKernelGGL(zl_entropy_kernel<1>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         hipLaunchKernelGGL(zl_entropy_kernel<2>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
