@@ -174,6 +174,9 @@ __global__ __launch_bounds__(64) void zl2_index_kernel(zl2_args a) {
 // (measured on 10 000 reference-made 64 KiB frames of three kinds in turn: 12.9 -> ms below for the
 // literal + sequence lanes).  Only the schedule depends on it: any permutation is correct.
 // ---------------------------------------------------------------------------------------
+#ifndef ZL2_SMALL
+#define ZL2_SMALL 1  // 0: every frame through the lanes, as rounds 1-5 (zl2_small_kernel)
+#endif
 #ifndef ZL2_SPLIT_MIN
 #define ZL2_SPLIT_MIN 1024   // frames from which on a batch may be cut in two (zl2_launch)
 #endif
@@ -2084,10 +2087,208 @@ static hipError_t zl2_launch_exec(zl2_args a, u32 role, hipStream_t stream) {
 //   starves the literal workgroups, which need 113 KiB of a CU's LDS to themselves and find exec workgroups sitting there
 //   (entropy 1.96 -> 3.80 ms, decode 3.84 -> 4.80 ms).  Even an EMPTY launch of that kernel on the critical path costs: it
 //   is not dispatched before a CU has the LDS free (seen as 5.7 instead of 2.6 ms in front of the exec kernel).
+// ---------------------------------------------------------------------------------------
+// zl2_small_kernel (round 6): SMALL frames that ride on a dictionary's tables, a WAVE each -- config C4's shape (100 000 frames of a few
+// hundred bytes).  The lane pipeline gives such a frame a sequence lane, four literal lanes and an exec workgroup of 512 threads, and every
+// group of eight frames copies the dictionary's tables (9 KiB in the lanes' formats) into its LDS per frame: 2.5 of the 2.9 ms a call of
+// 100 000 objects spends in kernels are those fixed costs.  Here four frames share a workgroup and ONE copy of the tables (zl2_dict_pre);
+// a wave stages its frame's block in LDS, decodes the literals (raw, RLE, or one Huffman stream on the dictionary's table: symbol after
+// symbol, every lane in step, lane 0 storing), then the sequences on the dictionary's three FSE tables (Repeat_Mode), executing each into
+// an LDS image of the output as it is decoded -- literals and match bytes copied by all lanes, a source in front of the frame read from the
+// dictionary's content --, and writes the image out in one piece.
+// It only ever ACCEPTS: a frame it cannot take (several blocks, a checksum, its own tables, more than 2 KiB of content, four streams) or
+// that fails ANY check on the way (a stream not consumed to its last bit, an offset too far, a size that does not add up) is left exactly
+// as the index kernel described it, and the lanes decode it -- or name its error -- as before.  Same verdicts as the oracle by construction.
+// ---------------------------------------------------------------------------------------
+#define SMALLD_FRAMES 4
+// A backward bit reader over a stream that lies in LDS: 64 bits of it in registers -- bits [lo, lo + 64), lo a multiple of 32 --, loaded as
+// aligned dwords and funnel-shifted (the stream starts at any byte of its buffer); bits in front of the stream's first read as zero, what lies
+// behind its last bit is never asked for.  get(bp, n): the n <= 32 bits below position bp.
+struct SmallBits {
+    const u32* words;   // the dword that holds the stream's first byte
+    u32 sh;             // ... and that byte's place in it (0 .. 3)
+    i32 lo;
+    u64 w;
+    __device__ __forceinline__ void open(const u8* buf_aligned16, u32 byte_off) { words = (const u32*)buf_aligned16 + (byte_off >> 2); sh = byte_off & 3; lo = 0x40000000; w = 0; }
+    __device__ __forceinline__ void fill(i32 bp) {
+        lo = (bp & ~31) - 32;
+        const i32 k = lo >> 5;  // the stream's dword index of bit lo (negative: in front of the stream)
+        const u32 d0 = k >= 0 ? words[k] : 0u, d1 = k + 1 >= 0 ? words[k + 1] : 0u, d2 = k + 2 >= 0 ? words[k + 2] : 0u;
+        w = (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+        if (k < 0 && sh) w &= k + 1 < 0 ? 0ull : ~0xFFFFFFFFull;  // (the dword in front of the stream's first is not the stream's: with a byte shift it would leak in)
+    }
+    __device__ __forceinline__ u32 get(i32 bp, u32 n) {
+        if (n == 0) return 0;
+        if (bp - (i32)n < lo || bp > lo + 64) fill(bp);
+        return (u32)(w >> (u32)(bp - (i32)n - lo)) & (u32)((1ull << n) - 1);
+    }
+};
+#define SMALLD_BLK 752u    // bytes of the frame's block, of its literals and of its content the wave keeps in LDS: sized for objects of a few hundred bytes, so that eight
+#define SMALLD_LIT 496u    // workgroups share a CU (18.6 KiB each); larger frames take the lanes
+#define SMALLD_OUT 1008u
+struct SmallDecShared {
+    u16 tab[2048];
+    u32 ent[1280];
+    u32 ll_tab[36], ml_tab[53];
+    alignas(16) u8 blk[SMALLD_FRAMES][SMALLD_BLK + 16];
+    alignas(16) u8 lit[SMALLD_FRAMES][SMALLD_LIT + 16];
+    alignas(16) u8 out[SMALLD_FRAMES][SMALLD_OUT + 16];
+};
+__global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_args a) {
+    __shared__ SmallDecShared S;
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const zl2_dict_pre* const P = a.dict_pre;
+    for (u32 i = t; i < 2048; i += 64 * SMALLD_FRAMES) S.tab[i] = P->tab[i];
+    for (u32 i = t; i < 1280; i += 64 * SMALLD_FRAMES) S.ent[i] = P->ent[i];
+    if (t < 36) S.ll_tab[t] = k_LL_base[t] | ((u32)k_LL_bits[t] << 24);
+    if (t < 53) S.ml_tab[t] = k_ML_base[t] | ((u32)k_ML_bits[t] << 24);
+    __syncthreads();
+    // (one wave's LDS traffic is served in the order it was issued: what must not happen is the compiler moving it.  A workgroup-scope fence would
+    // also wait for every global access in flight)
+    auto lds_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    const u32 f = blockIdx.x * SMALLD_FRAMES + wave;
+    if (f >= a.nframes) return;
+    zl2_frame_rec* const fr = a.frec + f;
+    if (fr->err != 0 || fr->skippable || fr->nblocks != 1 || fr->has_checksum) return;
+    const u64 fcs = fr->fcs;
+    const zl_frame_desc fd = a.frames[f];
+    if (fcs == ZL_CONTENTSIZE_UNKNOWN || fcs > SMALLD_OUT || fcs > fd.dst_cap) return;
+    const zl2_blk_rec r = a.brec[(size_t)f * ZL2_MAXB];
+    const u8* const src = a.src + fd.src_off + r.src_off;
+    u8* const dst = a.dst + fd.dst_off;
+    u8* const ob = S.out[wave];
+    u32 produced = 0;
+    if (r.type == 0) {  // a raw block
+        if (r.size != fcs) return;
+        for (u32 i = lane; i < r.size; i += 64) dst[i] = src[i];
+        produced = r.size;
+    } else if (r.type == 1) {  // a run of one byte
+        if (r.size != fcs) return;
+        const u8 b = src[0];
+        for (u32 i = lane; i < r.size; i += 64) dst[i] = b;
+        produced = r.size;
+    } else {
+        if (r.size > SMALLD_BLK || r.lit_size > SMALLD_LIT || r.lit_mode == 2 || r.nseq > 1023) return;
+        if (r.lit_mode == 3 && (P->huf_ok != 1 || r.streams != 1)) return;
+        if (r.nseq && (r.seq_modes != 0xFCu || P->seq_ok != 1)) return;
+        u8* const blk = S.blk[wave];
+        for (u32 i = 16 * lane; i < r.size; i += 16 * 64) {
+            if (i + 16 <= r.size) { uint4 x; __builtin_memcpy(&x, src + i, 16); *(uint4*)(blk + i) = x; }
+            else for (u32 b = i; b < r.size; b++) blk[b] = src[b];
+        }
+        u8* const lit = S.lit[wave];
+        lds_sync();
+        // ---- literals
+        const u32 nlit = r.lit_size;
+        if (r.lit_mode == 0) { for (u32 i = lane; i < nlit; i += 64) lit[i] = blk[r.lit_a + i]; }
+        else if (r.lit_mode == 1) { for (u32 i = lane; i < nlit; i += 64) lit[i] = (u8)r.lit_a; }
+        else {
+            // one Huffman stream, read from its end (zstd.c:38653): the table's `log` top bits name a cell {symbol, length}
+            const u8* const hs = blk + r.lit_a;
+            const u32 hn = r.lit_b, log = P->huf_log;
+            i32 bp = zl_bwd_init(hs, hn);
+            if (bp < 0 || log == 0 || log > 11) return;
+            SmallBits rd;
+            rd.open(blk, r.lit_a);
+            for (u32 i = 0; i < nlit; i++) {
+                const u32 cell = S.tab[rd.get(bp, log)];
+                bp -= (i32)(cell >> 8);
+                if (lane == 0) lit[i] = (u8)cell;
+                if (bp < 0) return;  // (uniform) ran out of bits
+            }
+            if (bp != 0) return;  // every stream is consumed exactly (the oracle's rule)
+        }
+        lds_sync();
+        // ---- sequences, executed as they are decoded
+        u32 lit_used = 0, pos = 0;
+        if (r.nseq) {
+            const u8* const bs = blk + r.seq_off + 1;  // (behind the mode byte: three times Repeat_Mode)
+            if (r.seq_len < 1) return;
+            const u32 bn = r.seq_len - 1;
+            i32 bp = zl_bwd_init(bs, bn);
+            if (bp < 0) return;
+            SmallBits rd;
+            rd.open(blk, r.seq_off + 1);
+            const u32 ll_log = P->seq_log[0], of_log = P->seq_log[1], ml_log = P->seq_log[2];
+            u32 sl = rd.get(bp, ll_log); bp -= (i32)ll_log;
+            u32 so = rd.get(bp, of_log); bp -= (i32)of_log;
+            u32 sm = rd.get(bp, ml_log); bp -= (i32)ml_log;
+            if (bp < 0) return;
+            u32 r0 = a.dict_rep[0], r1 = a.dict_rep[1], r2 = a.dict_rep[2];
+            const u32 dict_len = a.dict_len;
+            for (u32 i = 0; i < r.nseq; i++) {
+                const u32 cl = S.ent[sl], cm = S.ent[512 + sm], co = S.ent[1024 + so];
+                const u32 yl = (cl >> 16) & 0xFF, ym = (cm >> 16) & 0xFF, yo = (co >> 16) & 0xFF;
+                if (yl > ZL_MAX_LL || ym > ZL_MAX_ML || yo > ZL_MAX_OF) return;
+                const u32 tl = S.ll_tab[yl], tm = S.ml_tab[ym];
+                const u32 nl = tl >> 24, nm = tm >> 24;
+                const u32 ofv = (1u << yo) + rd.get(bp, yo); bp -= (i32)yo;
+                const u32 ml = (tm & 0xFFFFFF) + rd.get(bp, nm); bp -= (i32)nm;
+                const u32 ll = (tl & 0xFFFFFF) + rd.get(bp, nl); bp -= (i32)nl;
+                if (bp < 0) return;
+                u32 off;
+                if (ofv > 3) { off = ofv - 3; r2 = r1; r1 = r0; r0 = off; }
+                else {
+                    const u32 idx = ofv - 1 + (ll == 0);
+                    if (idx == 0) off = r0;
+                    else {
+                        off = (idx == 3) ? r0 - 1 : (idx == 1 ? r1 : r2);
+                        if (off == 0) return;
+                        if (idx != 1) r2 = r1;
+                        r1 = r0;
+                        r0 = off;
+                    }
+                }
+                if (lit_used + ll > nlit || (u64)pos + ll + ml > fcs || off > pos + ll + dict_len) return;
+                // the literals, then the match: its source is in front of it -- in the image, or (in front of position 0) in the dictionary's content;
+                // a source that overlaps the match repeats its first `off` bytes
+                for (u32 j = lane; j < ll; j += 64) ob[pos + j] = lit[lit_used + j];
+                pos += ll; lit_used += ll;
+                lds_sync();
+                for (u32 j = lane; j < ml; j += 64) {
+                    const u32 k = off >= ml ? j : j % off;     // (byte j copies byte j - off, which copied j - 2 off ...: the first `off` bytes, round and round)
+                    const i32 at = (i32)pos - (i32)off + (i32)k;
+                    ob[pos + j] = at >= 0 ? ob[at] : a.dict_end[at];  // (the dictionary's last 8 KiB kept in LDS instead: measured SLOWER, 1.35 -> 1.64 ms per 100 000 frames -- a copy per workgroup and a fifth fewer of them per CU; the reads hit the caches and other waves cover them)
+                }
+                pos += ml;
+                lds_sync();
+                if (i + 1 < r.nseq) {
+                    u32 nb = (cl >> 10) & 0xF;
+                    sl = (cl & 0x3FF) + rd.get(bp, nb); bp -= (i32)nb;
+                    nb = (cm >> 10) & 0xF;
+                    sm = (cm & 0x3FF) + rd.get(bp, nb); bp -= (i32)nb;
+                    nb = (co >> 10) & 0xF;
+                    so = (co & 0x3FF) + rd.get(bp, nb); bp -= (i32)nb;
+                    if (bp < 0) return;
+                }
+            }
+            if (bp != 0) return;  // zstd.c:44690
+        }
+        // the literals behind the last sequence
+        const u32 rest = nlit - lit_used;
+        if ((u64)pos + rest != fcs) return;
+        for (u32 j = lane; j < rest; j += 64) ob[pos + j] = lit[lit_used + j];
+        pos += rest;
+        lds_sync();
+        for (u32 i = 16 * lane; i < pos; i += 16 * 64) {
+            if (i + 16 <= pos) { const uint4 x = *(const uint4*)(ob + i); __builtin_memcpy(dst + i, &x, 16); }
+            else for (u32 b = i; b < pos; b++) dst[b] = ob[b];
+        }
+        produced = pos;
+    }
+    if (lane == 0) {
+        a.results[f] = produced;
+        fr->cost = 0; fr->lit_cost = 0;
+        fr->err = ZL_E_DONE;  // (the lanes and the exec kernel leave such a frame alone: zl2_index_kernel's word for "decoded before this launch")
+    }
+}
+
 extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl2_side* side, hipEvent_t* ev /* optional: 4 events, recorded after index / entropy / exec */) {
     if (a->nframes == 0) return hipSuccess;
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
+    if (ZL2_SMALL && a->dict_pre != nullptr && a->dict_end != nullptr && a->big == nullptr)  // small frames on a dictionary's tables: a wave each, in front of the lanes
+        hipLaunchKernelGGL(zl2_small_kernel, dim3((n + SMALLD_FRAMES - 1) / SMALLD_FRAMES), dim3(64 * SMALLD_FRAMES), 0, stream, *a);
     hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
     {   // the literal kernel's dynamic LDS has to be allowed once per DEVICE (one process may drive several: ZL_d_devices)

@@ -3209,6 +3209,9 @@ __global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS)
 //               container are the same in every lane; lane 0 stores), the sequence's fields handed round with lane shuffles
 // ---------------------------------------------------------------------------------------
 #define SMALL_OBJECTS 4
+#ifndef ZL_SMALL_MIN_BLOCKS
+#define ZL_SMALL_MIN_BLOCKS 6  // workgroups per CU the register allocation must allow (__launch_bounds__): 118 registers and four per CU without; 80 (18 spilled) and six: kernels of a 100 000-object call 2.30 -> 2.09 ms; 64 (28 spilled) and eight: 2.26
+#endif
 #define SMALL_MAX_LIT 1023u
 #define SMALL_MAX_SEQ 127u
 #define SMALL_SEQ_BYTES 1664  // 127 sequences x (27 state bits + up to 59 extra bits) / 8 + the flushed states + slack
@@ -3222,7 +3225,7 @@ struct SmallShared {
     alignas(8) u8 seqbuf[SMALL_OBJECTS][SMALL_SEQ_BYTES];
 };
 
-__global__ __launch_bounds__(64 * SMALL_OBJECTS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
+__global__ __launch_bounds__(64 * SMALL_OBJECTS, ZL_SMALL_MIN_BLOCKS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ SmallShared S;
     const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const zl_cdict* const cd_ = (const zl_cdict*)a.cdict;
