@@ -2239,7 +2239,7 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         in_total += (sizes[i] + 15) & ~(size_t)15;
     }
     if (!d->h_stage_in.ensure(in_total + 16) || !d->d_src.ensure(in_total + 16)) return kGpuUnavailable;
-    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
             FrameHeader h;
             const u8* s = (const u8*)srcs[i];
@@ -2271,7 +2271,7 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     tp[4] = now_ms();
     const u64* r = (const u64*)d->h_results.p;
-    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
             if (pre[i]) { results[i] = pre[i]; continue; }
             results[i] = (size_t)r[i];

@@ -1123,7 +1123,7 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         largest = std::max(largest, sizes[i]);
         if (chunks_of(sizes[i]) == 1) c->any_small = true;
     }
-    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
             if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
             const size_t k = chunks_of(sizes[i]);
@@ -1158,7 +1158,7 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         results[i] = sz;
         off += sz;
     }
-    zl_parallel_for(n, 8192, [&](size_t b, size_t e) {
+    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; i++) {
             if (results[i] > caps[i]) results[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
             else memcpy(dsts[i], (const u8*)c->h_stage_out.p + out_off[i], results[i]);

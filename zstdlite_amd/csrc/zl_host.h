@@ -167,7 +167,7 @@ static inline bool zl_bind_copy_pair(hipStream_t up, hipStream_t down, void* pin
 // library is linked with -z nodelete: unloading it would unmap the code they sleep in); a forked child has none of them and
 // runs its loops on the calling thread.
 struct __attribute__((visibility("hidden"))) ZlPool {
-    static const size_t kWorkers = 7;
+    static const size_t kWorkers = 15;  // (seven until round 6: pack + unpack of a 100 000-object call 1.5 -> ms; a host with fewer cores uses as many as it has)
     std::mutex m, user;
     std::condition_variable cv_work, cv_done;
     void (*fn)(void*, size_t) = nullptr;
@@ -219,7 +219,7 @@ __attribute__((visibility("hidden"))) inline ZlPool* zl_pool() {
 
 namespace {
 
-// f(begin, end) over [0, n) on up to 8 host threads (the calling one among them); ranges of at least `grain` items, so
+// f(begin, end) over [0, n) on up to 16 host threads (the calling one among them); ranges of at least `grain` items, so
 // small batches stay on the caller.
 template <class F>
 static inline void zl_parallel_for(size_t n, size_t grain, F f) {
