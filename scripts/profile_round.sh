@@ -30,6 +30,14 @@ cp "$(ls /tmp/prof_deep/*/*kernel_stats.csv | head -1)" gpurun_out/deep9_kernel_
 rm -rf /tmp/prof_deep
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_deep -- python3 scripts/dev/deep_prof.py 12 text > gpurun_out/deep12_run.log 2>&1
 cp "$(ls /tmp/prof_deep/*/*kernel_stats.csv | head -1)" gpurun_out/deep12_text_kernel_stats.csv 2>/dev/null
+# the price-based parse of levels 16 - 22 (zl_opt.hip): level 16 on the bench mix
+rm -rf /tmp/prof_deep
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_deep -- python3 scripts/dev/deep_prof.py 16 mix > gpurun_out/opt16_run.log 2>&1
+cp "$(ls /tmp/prof_deep/*/*kernel_stats.csv | head -1)" gpurun_out/opt16_kernel_stats.csv 2>/dev/null
+# config C4: 100 000 small objects with a dictionary through the batch entries (the small-object kernels of round 6)
+rm -rf /tmp/prof_c4
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c4 -- python3 scripts/dev/c4_quick.py > gpurun_out/c4_run.log 2>&1
+cp "$(ls /tmp/prof_c4/*/*kernel_stats.csv | head -1)" gpurun_out/c4_kernel_stats.csv 2>/dev/null
 # keep what travels back small: csv summaries only
 find gpurun_out -name "*.db" -delete 2>/dev/null
 du -sh gpurun_out

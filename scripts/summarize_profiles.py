@@ -147,7 +147,7 @@ if l2csv:
     json.dump(l2, open(os.path.join(P, f"{rnd}_l2_counters.json"), "w"), indent=1)
 
 # ---- the deep match finder of levels >= 6 (scripts/dev/deep_prof.py under rocprofv3 --kernel-trace --stats): its kernels and the radix sort's
-for name in ("deep9_kernel_stats.csv", "deep12_text_kernel_stats.csv"):
+for name in ("deep9_kernel_stats.csv", "deep12_text_kernel_stats.csv", "opt16_kernel_stats.csv", "c4_kernel_stats.csv"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         rows = [r for r in csv.DictReader(open(src)) if "zl" in r["Name"] or "radix" in r["Name"]]

@@ -2100,7 +2100,9 @@ static hipError_t zl2_launch_exec(zl2_args a, u32 role, hipStream_t stream) {
 // that fails ANY check on the way (a stream not consumed to its last bit, an offset too far, a size that does not add up) is left exactly
 // as the index kernel described it, and the lanes decode it -- or name its error -- as before.  Same verdicts as the oracle by construction.
 // ---------------------------------------------------------------------------------------
-#define SMALLD_FRAMES 4
+#define SMALLD_FRAMES 8    // frames per workgroup ...
+#define SMALLD_G 16        // ... of SMALLD_G lanes each: FOUR frames share a wave.  A frame's chains are serial -- a wave spends the same instructions on them whether 64 lanes follow or 16 --
+                           // and only the copies use the lanes: with a wave per frame the kernel was bound by instruction issue (100 000 frames: 1.0 ms)
 // A backward bit reader over a stream that lies in LDS: 64 bits of it in registers -- bits [lo, lo + 64), lo a multiple of 32 --, loaded as
 // aligned dwords and funnel-shifted (the stream starts at any byte of its buffer); bits in front of the stream's first read as zero, what lies
 // behind its last bit is never asked for.  get(bp, n): the n <= 32 bits below position bp.
@@ -2134,12 +2136,12 @@ struct SmallDecShared {
     alignas(16) u8 lit[SMALLD_FRAMES][SMALLD_LIT + 16];
     alignas(16) u8 out[SMALLD_FRAMES][SMALLD_OUT + 16];
 };
-__global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_args a) {
+__global__ __launch_bounds__(SMALLD_G * SMALLD_FRAMES) void zl2_small_kernel(zl2_args a) {
     __shared__ SmallDecShared S;
-    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u32 t = threadIdx.x, lane = t & (SMALLD_G - 1), wave = t / SMALLD_G;  // ("lane": the lane inside its frame's group; "wave": the group's slot in the workgroup)
     const zl2_dict_pre* const P = a.dict_pre;
-    for (u32 i = t; i < 2048; i += 64 * SMALLD_FRAMES) S.tab[i] = P->tab[i];
-    for (u32 i = t; i < 1280; i += 64 * SMALLD_FRAMES) S.ent[i] = P->ent[i];
+    for (u32 i = t; i < 2048; i += SMALLD_G * SMALLD_FRAMES) S.tab[i] = P->tab[i];
+    for (u32 i = t; i < 1280; i += SMALLD_G * SMALLD_FRAMES) S.ent[i] = P->ent[i];
     if (t < 36) S.ll_tab[t] = k_LL_base[t] | ((u32)k_LL_bits[t] << 24);
     if (t < 53) S.ml_tab[t] = k_ML_base[t] | ((u32)k_ML_bits[t] << 24);
     __syncthreads();
@@ -2160,19 +2162,19 @@ __global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_ar
     u32 produced = 0;
     if (r.type == 0) {  // a raw block
         if (r.size != fcs) return;
-        for (u32 i = lane; i < r.size; i += 64) dst[i] = src[i];
+        for (u32 i = lane; i < r.size; i += SMALLD_G) dst[i] = src[i];
         produced = r.size;
     } else if (r.type == 1) {  // a run of one byte
         if (r.size != fcs) return;
         const u8 b = src[0];
-        for (u32 i = lane; i < r.size; i += 64) dst[i] = b;
+        for (u32 i = lane; i < r.size; i += SMALLD_G) dst[i] = b;
         produced = r.size;
     } else {
         if (r.size > SMALLD_BLK || r.lit_size > SMALLD_LIT || r.lit_mode == 2 || r.nseq > 1023) return;
         if (r.lit_mode == 3 && (P->huf_ok != 1 || r.streams != 1)) return;
         if (r.nseq && (r.seq_modes != 0xFCu || P->seq_ok != 1)) return;
         u8* const blk = S.blk[wave];
-        for (u32 i = 16 * lane; i < r.size; i += 16 * 64) {
+        for (u32 i = 16 * lane; i < r.size; i += 16 * SMALLD_G) {
             if (i + 16 <= r.size) { uint4 x; __builtin_memcpy(&x, src + i, 16); *(uint4*)(blk + i) = x; }
             else for (u32 b = i; b < r.size; b++) blk[b] = src[b];
         }
@@ -2180,8 +2182,8 @@ __global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_ar
         lds_sync();
         // ---- literals
         const u32 nlit = r.lit_size;
-        if (r.lit_mode == 0) { for (u32 i = lane; i < nlit; i += 64) lit[i] = blk[r.lit_a + i]; }
-        else if (r.lit_mode == 1) { for (u32 i = lane; i < nlit; i += 64) lit[i] = (u8)r.lit_a; }
+        if (r.lit_mode == 0) { for (u32 i = lane; i < nlit; i += SMALLD_G) lit[i] = blk[r.lit_a + i]; }
+        else if (r.lit_mode == 1) { for (u32 i = lane; i < nlit; i += SMALLD_G) lit[i] = (u8)r.lit_a; }
         else {
             // one Huffman stream, read from its end (zstd.c:38653): the table's `log` top bits name a cell {symbol, length}
             const u8* const hs = blk + r.lit_a;
@@ -2242,10 +2244,10 @@ __global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_ar
                 if (lit_used + ll > nlit || (u64)pos + ll + ml > fcs || off > pos + ll + dict_len) return;
                 // the literals, then the match: its source is in front of it -- in the image, or (in front of position 0) in the dictionary's content;
                 // a source that overlaps the match repeats its first `off` bytes
-                for (u32 j = lane; j < ll; j += 64) ob[pos + j] = lit[lit_used + j];
+                for (u32 j = lane; j < ll; j += SMALLD_G) ob[pos + j] = lit[lit_used + j];
                 pos += ll; lit_used += ll;
                 lds_sync();
-                for (u32 j = lane; j < ml; j += 64) {
+                for (u32 j = lane; j < ml; j += SMALLD_G) {
                     const u32 k = off >= ml ? j : j % off;     // (byte j copies byte j - off, which copied j - 2 off ...: the first `off` bytes, round and round)
                     const i32 at = (i32)pos - (i32)off + (i32)k;
                     ob[pos + j] = at >= 0 ? ob[at] : a.dict_end[at];  // (the dictionary's last 8 KiB kept in LDS instead: measured SLOWER, 1.35 -> 1.64 ms per 100 000 frames -- a copy per workgroup and a fifth fewer of them per CU; the reads hit the caches and other waves cover them)
@@ -2267,10 +2269,10 @@ __global__ __launch_bounds__(64 * SMALLD_FRAMES, 8) void zl2_small_kernel(zl2_ar
         // the literals behind the last sequence
         const u32 rest = nlit - lit_used;
         if ((u64)pos + rest != fcs) return;
-        for (u32 j = lane; j < rest; j += 64) ob[pos + j] = lit[lit_used + j];
+        for (u32 j = lane; j < rest; j += SMALLD_G) ob[pos + j] = lit[lit_used + j];
         pos += rest;
         lds_sync();
-        for (u32 i = 16 * lane; i < pos; i += 16 * 64) {
+        for (u32 i = 16 * lane; i < pos; i += 16 * SMALLD_G) {
             if (i + 16 <= pos) { const uint4 x = *(const uint4*)(ob + i); __builtin_memcpy(dst + i, &x, 16); }
             else for (u32 b = i; b < pos; b++) dst[b] = ob[b];
         }
@@ -2288,7 +2290,7 @@ extern "C" hipError_t zl2_launch(const zl2_args* a, hipStream_t stream, const zl
     const u32 n = a->nframes;
     hipLaunchKernelGGL(zl2_index_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, *a);
     if (ZL2_SMALL && a->dict_pre != nullptr && a->dict_end != nullptr && a->big == nullptr)  // small frames on a dictionary's tables: a wave each, in front of the lanes
-        hipLaunchKernelGGL(zl2_small_kernel, dim3((n + SMALLD_FRAMES - 1) / SMALLD_FRAMES), dim3(64 * SMALLD_FRAMES), 0, stream, *a);
+        hipLaunchKernelGGL(zl2_small_kernel, dim3((n + SMALLD_FRAMES - 1) / SMALLD_FRAMES), dim3(SMALLD_G * SMALLD_FRAMES), 0, stream, *a);
     hipLaunchKernelGGL(zl2_order_kernel, dim3(1), dim3(1024), 0, stream, *a);
     if (ev) (void)hipEventRecord(ev[0], stream);
     {   // the literal kernel's dynamic LDS has to be allowed once per DEVICE (one process may drive several: ZL_d_devices)
