@@ -852,3 +852,71 @@ def test_deep_levels_degrade_to_the_table_parse_when_their_scratch_cannot_be_had
     deep = [len(z.zstd_compress(text, level=level)) for level in (3, 9, 15)]
     # (level 3 on this synthetic text is the one place where the tables write a little LESS than three candidates of the deep finder: DESIGN 3.3)
     assert denied[1] > deep[1] and denied[2] > deep[2] and denied[0] < 1.05 * deep[0], (denied, deep)
+
+
+def test_small_objects_on_a_dictionary_at_the_edges_of_the_wave_kernels(ref, oracle):
+    """Round 6 (config C4): a batch of small objects with a dictionary is encoded by zl_entropy_small_kernel (a wave per object: treeless
+    literals and Repeat_Mode sequences on the dictionary's tables) and decoded by zl2_small_kernel (four frames per wave), with the
+    general kernels behind them for whatever those cannot take.  Objects around every limit of the two -- 1023 / 1024 literals, 127 / 128
+    sequences, 1008 / 1009 bytes of content, 16 KiB, bytes the dictionary's Huffman table cannot code, runs, nothing at all -- must come out as
+    frames the REFERENCE decodes with the dictionary, the oracle too, and this library's batch decoder; a batch is deterministic and an
+    object's bytes do not depend on its neighbours (the one-object entry writes the same); damaged frames get the oracle's verdict."""
+    import pickle
+    rng = np.random.default_rng(17)
+    names = [f"name_{i:02d}_{'x' * (i % 7)}" for i in range(50)]
+
+    def obj(k):
+        perm = rng.permutation(50)[:k]
+        return pickle.dumps({names[j]: int(rng.integers(0, 1000)) for j in perm}, protocol=4)
+    train = [obj(int(rng.integers(10, 40))) for _ in range(1500)]
+    d = ref.train_dict(train, 5000)
+    base = b"".join(train[:60])
+    items = [obj(k) for k in (1, 2, 5, 10, 25, 39, 50)] * 3
+    items += [base[:k] for k in (1, 2, 3, 5, 6, 7, 63, 64, 255, 256, 257, 1007, 1008, 1009, 1023, 1024, 1025, 2047, 2048, 4000, 16383, 16384, 16385, 40000)]
+    items += [bytes(rng.integers(0, 256, int(k), dtype=np.uint8)) for k in (1, 6, 100, 1023, 1024, 3000)]            # no table codes these: raw
+    items += [bytes(rng.integers(97, 123, int(k), dtype=np.uint8)) for k in (50, 700, 1023, 1024, 1500)]             # literals only, all codable
+    items += [b"ab" * k for k in (3, 40, 500, 600)] + [b"x" * k for k in (1, 7, 64, 1000, 5000)] + [b"", bytes(300)]
+    items += [b"".join(train[i][:9] + bytes([i & 255]) for i in range(k)) for k in (100, 126, 127, 128, 129, 200)]   # many short sequences
+    cctx = z.zstd_cctx(dict=d)
+    frames = z.zstd_compress_batch(items, cctx=cctx)
+    assert frames == z.zstd_compress_batch(items, cctx=cctx)
+    assert frames[:12] == [z.zstd_compress(x, cctx=cctx) for x in items[:12]]
+    for x, f in zip(items, frames):
+        assert ref.decompress(f, max(len(x), 1), dict=d) == x, len(x)
+        assert oracle.decompress(f, cap=max(len(x), 1), dict=d) == x, len(x)
+    assert z.zstd_decompress_batch(frames, dict=d) == items
+    # what the REFERENCE writes for the same objects (its own choice of tables and streams) through the batch decoder
+    theirs = [ref.compress(x, level=3, dict=d) for x in items]
+    assert z.zstd_decompress_batch(theirs, dict=d) == items
+    # damaged frames (one to three flipped bits), ours and the reference's, through the batch entry: accepted exactly when the oracle accepts
+    # them, and then the same bytes (zl2_small_kernel only ever accepts: what fails any of its checks is decoded -- or named -- by the lanes)
+    import ctypes as C
+    from zstdlite_amd import _lib
+    from zl_testlib import is_error
+    damaged = []
+    for f, x in list(zip(frames, items)) + list(zip(theirs, items)):
+        if len(x) > 3000 or len(f) < 12:
+            continue
+        for _ in range(12):
+            b = bytearray(f)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(4, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            damaged.append((bytes(b), len(x)))
+    m = len(damaged)
+    outs = [np.zeros(max(n, 1), dtype=np.uint8) for _, n in damaged]
+    srcs = [np.frombuffer(f, dtype=np.uint8) for f, _ in damaged]
+    res = (C.c_size_t * m)()
+    dctx = z.zstd_dctx(dict=d)
+    r = _lib.lib().zl_decompress_batch(dctx._ptr, m, (C.c_void_p * m)(*[x.ctypes.data for x in outs]), (C.c_size_t * m)(*[n for _, n in damaged]),
+                                       (C.c_void_p * m)(*[x.ctypes.data for x in srcs]), (C.c_size_t * m)(*[len(f) for f, _ in damaged]), res)
+    assert not is_error(r)
+    accepted = 0
+    for i, (f, n) in enumerate(damaged):
+        code, out = oracle.decompress_code(f, n, dict=d)
+        if is_error(res[i]):
+            assert is_error(code), (i, _lib.error_name(res[i]), code)
+        else:
+            assert not is_error(code), (i, res[i], code)
+            assert res[i] == code and outs[i][:res[i]].tobytes() == out, i
+            accepted += 1
+    assert 0 < accepted < m
