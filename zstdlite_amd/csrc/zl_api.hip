@@ -272,6 +272,7 @@ struct zl_dctx_s {
     DevBuf d_src, d_dst, d_frames, d_results, d_counter, d_lit, d_seq, d_dict, d_dict_tables, d_order;
     DevBuf d_plan, d_frec, d_brec, d_lit2, d_seq2;  // lane-parallel pipeline (zl_decode2.hip)
     PinBuf h_frames, h_results, h_stage_in, h_stage_out, h_plan;
+    std::vector<hipEvent_t> batch_events;  // zl_decompress_batch: one behind every piece of the output that comes down (grow-only)
     // pending device-resident call
     hipStream_t pending_stream = nullptr;
     size_t pending_n = 0;
@@ -517,6 +518,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     PinBuf* pins[] = {&d->h_frames, &d->h_results, &d->h_stage_in, &d->h_stage_out, &d->h_plan};
     for (PinBuf* b : pins) b->release();
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->batch_events) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
     if (d->side.fork) (void)hipEventDestroy(d->side.fork);
     if (d->side.join) (void)hipEventDestroy(d->side.join);
@@ -2239,7 +2241,12 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         in_total += (sizes[i] + 15) & ~(size_t)15;
     }
     if (!d->h_stage_in.ensure(in_total + 16) || !d->d_src.ensure(in_total + 16)) return kGpuUnavailable;
-    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
+    // (round 6: packed, uploaded, brought down and unpacked in PIECES -- zl_compress_batch says why; the frame table's offsets are the caller's sizes' running sum)
+    const size_t pieces = (prof || n < 16384) ? 1 : 4;
+    for (size_t pc = 0; pc < pieces; pc++) {
+    const size_t pb0 = n * pc / pieces, pb1 = n * (pc + 1) / pieces;
+    zl_parallel_for(pb1 - pb0, 4096, [&](size_t b_, size_t e_) {
+        const size_t b = pb0 + b_, e = pb0 + e_;
         for (size_t i = b; i < e; i++) {
             FrameHeader h;
             const u8* s = (const u8*)srcs[i];
@@ -2255,29 +2262,46 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
             if (table[i].src_size) memcpy((u8*)d->h_stage_in.p + table[i].src_off, s, table[i].src_size);
         }
     });
+    {
+        const size_t o0 = table[pb0].src_off, o1 = pb1 < n ? table[pb1].src_off : in_total;
+        if (o1 > o0 && hipMemcpyAsync((u8*)d->d_src.p + o0, (const u8*)d->h_stage_in.p + o0, o1 - o0, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
+    }  // (pieces)
     for (size_t i = 0; i < n; i++) {
         table[i].dst_off = out_total;
         out_total += (table[i].dst_cap + 15) & ~(size_t)15;
     }
     if (!d->h_stage_out.ensure(out_total + 16) || !d->d_dst.ensure(out_total + 16)) return kGpuUnavailable;
     tp[1] = now_ms();
-    if (hipMemcpyAsync(d->d_src.p, d->h_stage_in.p, in_total, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
     size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, n, st);
     if (ZL_IS_ERR(e)) return e;
     if (prof) { (void)hipStreamSynchronize(st); tp[3] = now_ms(); }
     if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (out_total && hipMemcpyAsync(d->h_stage_out.p, d->d_dst.p, out_total, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    if (hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    tp[4] = now_ms();
+    while (d->batch_events.size() < pieces) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
+        d->batch_events.push_back(ev);
+    }
+    for (size_t pc = 0; pc < pieces; pc++) {
+        const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
+        const size_t o0 = table[b0].dst_off, o1 = b1 < n ? table[b1].dst_off : out_total;
+        if (o1 > o0 && hipMemcpyAsync((u8*)d->h_stage_out.p + o0, (const u8*)d->d_dst.p + o0, o1 - o0, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipEventRecord(d->batch_events[pc], st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+    }
     const u64* r = (const u64*)d->h_results.p;
-    zl_parallel_for(n, 4096, [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; i++) {
-            if (pre[i]) { results[i] = pre[i]; continue; }
-            results[i] = (size_t)r[i];
-            if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
-        }
-    });
+    for (size_t pc = 0; pc < pieces; pc++) {
+        const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
+        if (hipEventSynchronize(d->batch_events[pc]) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (pc + 1 == pieces) tp[4] = now_ms();
+        zl_parallel_for(b1 - b0, 4096, [&](size_t b, size_t e) {
+            for (size_t i = b0 + b; i < b0 + e; i++) {
+                if (pre[i]) { results[i] = pre[i]; continue; }
+                results[i] = (size_t)r[i];
+                if (!ZL_IS_ERR(r[i]) && r[i]) memcpy(dsts[i], (const u8*)d->h_stage_out.p + table[i].dst_off, (size_t)r[i]);
+            }
+        });
+    }
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) d->batch_ms[k] = tp[k + 1] - tp[k]; }
     if (d->profile >= 2 && d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 128, hipMemcpyDeviceToHost);
     return 0;
