@@ -3208,65 +3208,59 @@ __global__ __launch_bounds__(ENC_THREADS, PHASE == 2 ? ZL_ENT2_WGS : ZL_ENT_WGS)
 //   sequences   the bitstream of zstd.c:21146 written front to back by all lanes in step (uniform: the three states and the bit
 //               container are the same in every lane; lane 0 stores), the sequence's fields handed round with lane shuffles
 // ---------------------------------------------------------------------------------------
-#define SMALL_OBJECTS 4
-#ifndef ZL_SMALL_MIN_BLOCKS
-#define ZL_SMALL_MIN_BLOCKS 6  // workgroups per CU the register allocation must allow (__launch_bounds__): 118 registers and four per CU without; 80 (18 spilled) and six: kernels of a 100 000-object call 2.30 -> 2.09 ms; 64 (28 spilled) and eight: 2.26
-#endif
+#define SMALL_G 16            // lanes per object: FOUR objects share a wave.  What an object costs is its serial chains -- a wave spends the same instructions on them whether
+#define SMALL_OBJECTS 16      // 64 lanes follow or 16 -- and with a wave per object the kernel was bound by instruction issue (100 000 objects: 0.73 ms at six waves per SIMD)
 #define SMALL_MAX_LIT 1023u
 #define SMALL_MAX_SEQ 127u
-#define SMALL_SEQ_BYTES 1664  // 127 sequences x (27 state bits + up to 59 extra bits) / 8 + the flushed states + slack
+#define SMALL_STAGE_WORDS 360 // one Huffman stream of at most 1023 codes of at most 11 bits, and its end mark
 struct SmallShared {
     u16 state[3][512];
     i32 dnb[3][56], dfs[3][56];
     u32 log[3];
     u8 hlen[256];
     u16 hcode[256];
-    u32 stage[SMALL_OBJECTS][256];
-    alignas(8) u8 seqbuf[SMALL_OBJECTS][SMALL_SEQ_BYTES];
+    u32 stage[SMALL_OBJECTS][SMALL_STAGE_WORDS];
 };
 
-__global__ __launch_bounds__(64 * SMALL_OBJECTS, ZL_SMALL_MIN_BLOCKS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
+__global__ __launch_bounds__(SMALL_G * SMALL_OBJECTS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ SmallShared S;
-    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const u32 t = threadIdx.x, lane = t & (SMALL_G - 1), slot = t / SMALL_G;  // (lane: inside the object's group)
     const zl_cdict* const cd_ = (const zl_cdict*)a.cdict;
-    for (u32 i = t; i < 3 * 512; i += 64 * SMALL_OBJECTS) S.state[i >> 9][i & 511] = cd_->ct[i >> 9].state[i & 511];
-    for (u32 i = t; i < 3 * 56; i += 64 * SMALL_OBJECTS) { S.dnb[i / 56][i % 56] = cd_->ct[i / 56].dnb[i % 56]; S.dfs[i / 56][i % 56] = cd_->ct[i / 56].dfs[i % 56]; }
+    for (u32 i = t; i < 3 * 512; i += SMALL_G * SMALL_OBJECTS) S.state[i >> 9][i & 511] = cd_->ct[i >> 9].state[i & 511];
+    for (u32 i = t; i < 3 * 56; i += SMALL_G * SMALL_OBJECTS) { S.dnb[i / 56][i % 56] = cd_->ct[i / 56].dnb[i % 56]; S.dfs[i / 56][i % 56] = cd_->ct[i / 56].dfs[i % 56]; }
     if (t < 3) S.log[t] = cd_->ct[t].log;
-    for (u32 i = t; i < 256; i += 64 * SMALL_OBJECTS) { S.hlen[i] = cd_->hlen[i]; S.hcode[i] = cd_->hcode[i]; }
-    for (u32 i = t; i < SMALL_OBJECTS * 256; i += 64 * SMALL_OBJECTS) (&S.stage[0][0])[i] = 0;
+    for (u32 i = t; i < 256; i += SMALL_G * SMALL_OBJECTS) { S.hlen[i] = cd_->hlen[i]; S.hcode[i] = cd_->hcode[i]; }
+    for (u32 i = t; i < SMALL_OBJECTS * SMALL_STAGE_WORDS; i += SMALL_G * SMALL_OBJECTS) (&S.stage[0][0])[i] = 0;
     __syncthreads();
-    const u32 c = blockIdx.x * SMALL_OBJECTS + wave;
+    const u32 c = blockIdx.x * SMALL_OBJECTS + slot;
     if (c >= nchunks) return;
+    // (an object's group: LDS traffic of one wave is served in the order it was issued; what must not happen is the compiler moving it)
+    auto group_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    // sums and ORs over the group's sixteen lanes
+    auto gsum = [&](u32 v) -> u32 { v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64); return v; };
     const zl_chunk_desc cd = a.chunks[c];
     const u32 n = cd.src_size;
     const u32 nseq = a.meta[c].nseq, nlit = a.meta[c].nlit;
     const u8* const src = a.src + cd.src_off;
     const zl_seq* const seqs = a.seqs + (size_t)c * a.seq_stride;
     const u8* const lit = nseq ? a.lits + (size_t)c * a.lit_stride : src;
-    bool ok = cd_->ok != 0 && cd_->huf_ok != 0 && n >= 1 && n < 16384 && nlit <= SMALL_MAX_LIT && nseq <= SMALL_MAX_SEQ && S.log[0] != 0 && S.log[1] != 0 && S.log[2] != 0;
-    // ---- the literals' bits under the dictionary's codes
-    u32 lbits = 0, lbad = 0;
-    for (u32 i = lane; i < nlit; i += 64) { const u32 l = S.hlen[lit[i]]; lbits += l; lbad |= l == 0 ? 1u : 0u; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { lbits += __shfl_xor(lbits, d, 64); lbad |= __shfl_xor(lbad, d, 64); }
-    // ---- the sequences' fields: this lane holds sequences lane and 64 + lane
-    u32 f_ll[2] = {0, 0}, f_mb[2] = {0, 0}, f_ob[2] = {0, 0}, f_cd[2] = {0, 0};  // literal length, match length - 3, offset value (zstd.c:19680), the three codes packed
-    u32 sbad = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const u32 i = 64 * h + lane;
-        if (i < nseq) {
+    const bool ok = cd_->ok != 0 && cd_->huf_ok != 0 && n >= 1 && n < 16384 && nlit <= SMALL_MAX_LIT && nseq <= SMALL_MAX_SEQ && S.log[0] != 0 && S.log[1] != 0 && S.log[2] != 0;
+    // ---- the literals' bits under the dictionary's codes; every sequence's codes against what the dictionary's tables can say
+    u32 lbits = 0, bad = 0;
+    if (ok) {
+        for (u32 i = lane; i < nlit; i += SMALL_G) { const u32 l = S.hlen[lit[i]]; lbits += l; bad |= l == 0 ? 1u : 0u; }
+        for (u32 i = lane; i < nseq; i += SMALL_G) {
             const zl_seq q = seqs[i];
             const u32 prev_cum = i ? seqs[i - 1].lit_cum : 0u, prev_off = i ? seqs[i - 1].offset : 0u;
             const u32 ll = q.lit_cum - prev_cum;
             const u32 ob = (ll > 0 && q.offset == prev_off) ? 1u : q.offset + 3;  // (repeat offset 1 only, as zl_entropy_kernel below level 5)
             const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(q.match_len);
-            f_ll[h] = ll; f_mb[h] = q.match_len - 3; f_ob[h] = ob; f_cd[h] = cl | (co << 8) | (cm << 16);
-            if (!((cd_->sym_mask[T_LL] >> cl) & 1) || !((cd_->sym_mask[T_OF] >> co) & 1) || !((cd_->sym_mask[T_ML] >> cm) & 1)) sbad = 1;
+            if (!((cd_->sym_mask[T_LL] >> cl) & 1) || !((cd_->sym_mask[T_OF] >> co) & 1) || !((cd_->sym_mask[T_ML] >> cm) & 1)) bad = 1;
         }
     }
-    sbad = __any((int)sbad) ? 1u : 0u;
-    if (!ok || lbad || sbad) {  // (uniform) not this kernel's: the general one takes it
+    lbits = gsum(lbits);
+    bad = gsum(bad);
+    if (!ok || bad) {  // (the same in all of the group's lanes) not this kernel's: the general one takes it
         if (lane == 0) a.frame_size[c] = 0xFFFFFFFFu;
         return;
     }
@@ -3282,66 +3276,83 @@ __global__ __launch_bounds__(64 * SMALL_OBJECTS, ZL_SMALL_MIN_BLOCKS) void zl_en
     if (huf) {
         lit_sec = 3 + csize;
         if (lane == 0) wr_le(blk, 3ull | ((u64)nlit << 4) | ((u64)csize << 14), 3);  // Treeless_Literals_Block, one stream, 10-bit sizes
-        (void)huf_encode_stream(S.hlen, S.hcode, S.stage[wave], lit, nlit, blk + 3);
+        // the stream (zstd.c:17890 HUF_compress1X): the LAST literal's code in the lowest bits, the first literal's just below the end mark.  A lane
+        // takes four literals a round, the round's sixty-four codes are placed by a scan over the group's lanes
+        u32* const stage = S.stage[slot];
+        u32 at = 0;  // bits placed so far
+        for (u32 e0 = 0; e0 < nlit; e0 += 4 * SMALL_G) {
+            u64 bits = 0; u32 nb = 0;
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) {
+                const u32 e = e0 + 4 * lane + j;  // emission index: literal nlit - 1 - e
+                if (e < nlit) { const u32 sym = lit[nlit - 1 - e]; bits |= (u64)S.hcode[sym] << nb; nb += S.hlen[sym]; }
+            }
+            u32 inc = nb;
+#pragma unroll
+            for (int d = 1; d < SMALL_G; d <<= 1) { const u32 x = __shfl_up(inc, d, SMALL_G); if ((int)lane >= d) inc += x; }
+            stage_or(stage, at + inc - nb, bits, nb);
+            at += (u32)__shfl((int)inc, SMALL_G - 1, SMALL_G);
+        }
+        if (lane == 0) stage_or(stage, at, 1, 1);  // the end mark
+        group_sync();
+        u8* const p = blk + 3;
+        const u8* const sb = (const u8*)stage;
+        for (u32 i = lane; i < csize; i += SMALL_G) p[i] = sb[i];
     } else {
         lit_sec = lhs_r + nlit;
         if (lane == 0) wr_le(blk, 0u | ((lhs_r == 1 ? 0u : 1u) << 2) | ((u64)nlit << (lhs_r == 1 ? 3 : 4)), lhs_r);
-        for (u32 i = lane; i < nlit; i += 64) blk[lhs_r + i] = lit[i];
+        for (u32 i = lane; i < nlit; i += SMALL_G) blk[lhs_r + i] = lit[i];
     }
     // ---- sequences section
     u8* const sq = blk + lit_sec;
     u32 seq_sec = 1;
     if (nseq == 0) { if (lane == 0) sq[0] = 0; }
     else {
-        // every lane runs the same chain (zstd.c:21146 ZSTD_encodeSequences): sequence k's fields come from lane k & 63 by shuffle
-        u8* const sb = S.seqbuf[wave];
+        // every lane of the group runs the same chain (zstd.c:21146 ZSTD_encodeSequences), last sequence first; a sequence's record is read from memory by
+        // all of them (one address: one transaction), the one in front of it -- which its literal count and its repeat test need -- a step ahead
+        u8* const sbp = sq + 2;
         u64 acc = 0; u32 nb = 0, wr = 0;
         auto put = [&](u32 v, u32 bits) { acc |= (u64)(v & ((bits < 32 ? (1u << bits) : 0u) - 1u)) << nb; nb += bits; };
-        auto flush = [&]() { if (nb >= 32) { if (lane == 0) { const u32 w = (u32)acc; __builtin_memcpy(sb + wr, &w, 4); } wr += 4; acc >>= 32; nb -= 32; } };
-        auto field = [&](const u32 (&f)[2], u32 k) -> u32 { const u32 lo = (u32)__shfl((int)f[0], (int)(k & 63), 64), hi = (u32)__shfl((int)f[1], (int)(k & 63), 64); return k < 64 ? lo : hi; };
-        u32 st_ll, st_of, st_ml;
-        {
-            const u32 k = nseq - 1, cdw = field(f_cd, k);
-            const u32 cl = cdw & 0xFF, co = (cdw >> 8) & 0xFF, cm = cdw >> 16;
-            st_ml = fse_init_state(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm]);
-            st_of = fse_init_state(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co]);
-            st_ll = fse_init_state(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl]);
-            put(field(f_ll, k), e_LL_bits[cl]); flush();
-            put(field(f_mb, k), e_ML_bits[cm]); flush();
-            put(field(f_ob, k), co); flush();
-        }
-        for (u32 k = nseq - 1; k-- > 0;) {
-            const u32 cdw = field(f_cd, k);
-            const u32 cl = cdw & 0xFF, co = (cdw >> 8) & 0xFF, cm = cdw >> 16;
-            const u32 eo = fse_encode(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co], st_of);
-            put(eo & 0xFFFF, eo >> 16); flush();
-            const u32 em = fse_encode(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm], st_ml);
-            put(em & 0xFFFF, em >> 16); flush();
-            const u32 el = fse_encode(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl], st_ll);
-            put(el & 0xFFFF, el >> 16); flush();
-            put(field(f_ll, k), e_LL_bits[cl]); flush();
-            put(field(f_mb, k), e_ML_bits[cm]); flush();
-            put(field(f_ob, k), co); flush();
+        auto flush = [&]() { if (nb >= 32) { if (lane == 0) { const u32 w = (u32)acc; __builtin_memcpy(sbp + wr, &w, 4); } wr += 4; acc >>= 32; nb -= 32; } };
+        u32 st_ll = 0, st_of = 0, st_ml = 0;
+        zl_seq cur = seqs[nseq - 1];
+        for (u32 k = nseq; k-- > 0;) {
+            zl_seq prev; prev.lit_cum = 0; prev.offset = 0; prev.match_len = 0; prev.pos = 0;
+            if (k) prev = seqs[k - 1];
+            const u32 ll = cur.lit_cum - prev.lit_cum;
+            const u32 ob = (ll > 0 && k && cur.offset == prev.offset) ? 1u : cur.offset + 3;
+            const u32 cl = ll_code(ll), co = hb32(ob), cm = ml_code(cur.match_len);
+            if (k == nseq - 1) {
+                st_ml = fse_init_state(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm]);
+                st_of = fse_init_state(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co]);
+                st_ll = fse_init_state(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl]);
+            } else {
+                const u32 eo = fse_encode(S.state[T_OF], S.dnb[T_OF][co], S.dfs[T_OF][co], st_of);
+                put(eo & 0xFFFF, eo >> 16); flush();
+                const u32 em = fse_encode(S.state[T_ML], S.dnb[T_ML][cm], S.dfs[T_ML][cm], st_ml);
+                put(em & 0xFFFF, em >> 16); flush();
+                const u32 el = fse_encode(S.state[T_LL], S.dnb[T_LL][cl], S.dfs[T_LL][cl], st_ll);
+                put(el & 0xFFFF, el >> 16); flush();
+            }
+            put(ll, e_LL_bits[cl]); flush();
+            put(cur.match_len - 3, e_ML_bits[cm]); flush();
+            put(ob, co); flush();
+            cur = prev;
         }
         put(st_ml, S.log[T_ML]); flush();
         put(st_of, S.log[T_OF]); flush();
         put(st_ll, S.log[T_LL]); flush();
         put(1, 1);  // the end mark
         const u32 tail = (nb + 7) >> 3;
-        if (lane == 0) for (u32 b = 0; b < tail; b++) sb[wr + b] = (u8)(acc >> (8 * b));
-        const u32 total = wr + tail;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { sq[0] = (u8)nseq; sq[1] = 0xFC; }  // Repeat_Mode three times
-        for (u32 i = lane; i < total; i += 64) sq[2 + i] = sb[i];
-        seq_sec = 2 + total;
+        if (lane == 0) { for (u32 bq = 0; bq < tail; bq++) sbp[wr + bq] = (u8)(acc >> (8 * bq)); sq[0] = (u8)nseq; sq[1] = 0xFC; }  // Repeat_Mode three times
+        seq_sec = 2 + wr + tail;
     }
     // ---- the block: compressed where that is smaller than the content (zstd.c:26880), else raw
     u32 bsize = lit_sec + seq_sec;
     if (bsize >= n) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        for (u32 i = lane; i < n; i += 64) blk[i] = src[i];
+        for (u32 i = lane; i < n; i += SMALL_G) blk[i] = src[i];
         if (lane == 0) wr_le(out + fh, ((u64)n << 3) | 1u, 3);
         bsize = n;
     } else if (lane == 0) wr_le(out + fh, ((u64)bsize << 3) | (2u << 1) | 1u, 3);
@@ -3453,7 +3464,7 @@ extern "C" hipError_t zl_launch_chunk_order(const zl_chunk_desc* chunks, const u
 
 extern "C" hipError_t zl_launch_entropy(const zl_entropy_args* a, u32 nchunks, hipStream_t stream) {
     if (nchunks == 0) return hipSuccess;
-    if (a->small_done) hipLaunchKernelGGL(zl_entropy_small_kernel, dim3((nchunks + SMALL_OBJECTS - 1) / SMALL_OBJECTS), dim3(64 * SMALL_OBJECTS), 0, stream, *a, nchunks);
+    if (a->small_done) hipLaunchKernelGGL(zl_entropy_small_kernel, dim3((nchunks + SMALL_OBJECTS - 1) / SMALL_OBJECTS), dim3(SMALL_G * SMALL_OBJECTS), 0, stream, *a, nchunks);
     if (a->handover) {
         hipLaunchKernelGGL(zl_entropy_kernel<1>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
         hipLaunchKernelGGL(zl_entropy_kernel<2>, dim3(nchunks), dim3(ENC_THREADS), 0, stream, *a, nchunks);
