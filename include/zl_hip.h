@@ -305,6 +305,10 @@ size_t zl_DStreamOutSize(void);
  * fills ms[0..4] = {whole decode, frame/block index, literal+sequence lanes, execution, general
  * kernel}.  Return 0, or an error code when profiling was not enabled.  A value of 2 additionally makes
  * the kernels count shader cycles per phase (global atomics: slows them down; development only). */
+#define ZL_c_faultInjection 9098 /* TESTS ONLY (the library reads no environment variables): bit 0 -- the deep match finder's allocations "fail", so that the
+                                  * call is made again on the table parse (levels >= 6 degrade instead of failing); bits 4 and up: k -- from the k-th full job
+                                  * of a streaming session on, the job's thread "cannot be had" and the job runs on the caller (tests/test_stream_gpu.py,
+                                  * tests/test_compress_gpu.py).  0: off. */
 #define ZL_c_profile 9001
 #define ZL_d_profile 9002
 size_t zl_cctx_kernel_ms(const zl_cctx *cctx, double *ms);

@@ -802,56 +802,41 @@ def test_a_seek_table_with_a_damaged_content_field_is_not_believed(layout, ref):
     assert z.zstd_decompress(bytes(comp)) == data
 
 
-_DEEP_DENIED_SCRIPT = r"""
-import sys, os
-sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import torch
-import zstdlite_amd as z
-from zstdlite_amd import stream
-from zstdlite_amd.device import gen_mixed
-from zl_testlib import GENERATORS, Ref
-ref = Ref()
-text = GENERATORS["text"](3 << 20, seed=5)
-sizes = {}
-for level in (3, 9, 15):
-    comp = z.zstd_compress(text, level=level)
-    assert ref.decompress(comp, len(text)) == text and z.zstd_decompress(comp) == text
-    sizes[level] = len(comp)
-# a pledged stream of several jobs with a content checksum: every job is made twice (the deep attempt, then the table parse), the
-# running XXH64 must cover the bytes once
-n = (150 << 20) + 5
-data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
-cctx = z.zstd_cctx(level=9, include_checksum=True)
-comp = stream.Compressor(cctx._ptr, pledged=n)
-blob = b"".join([comp.feed(data[off:off + 40000003]) for off in range(0, n, 40000003)] + [comp.finish()])
-assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob)
-assert ref.decompress(blob, n) == data  # (the reference verifies the checksum)
-# the device-resident entry
-from zstdlite_amd.device import DeviceCodec
-import numpy as np
-codec = DeviceCodec(level=9, frame_layout="one_frame")
-src = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).cuda()
-dst, total, _ = codec.compress(src)
-assert ref.decompress(bytes(dst[:total].cpu().numpy()), len(text)) == text
-print("sizes", sizes[3], sizes[9], sizes[15])
-"""
-
-
 def test_deep_levels_degrade_to_the_table_parse_when_their_scratch_cannot_be_had(ref):
     """a deep-level call whose scratch does not fit (8 bytes per input byte, a section's key arrays, the sort's storage)
     or whose sort refuses used to FAIL with a memory error.  Now the entry makes the call again on the table parse at its deepest
-    setting: valid frames, a little larger.  ZL_DEBUG_DEEP_OOM=1 makes every deep allocation "fail"."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZL_DEBUG_DEEP_OOM="1")
-    out = subprocess.run([sys.executable, "-c", _DEEP_DENIED_SCRIPT], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert out.returncode == 0 and "sizes" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-    denied = [int(x) for x in out.stdout.split("sizes")[1].split()[:3]]
+    setting: valid frames, a little larger.  ZL_c_faultInjection bit 0 makes every deep allocation "fail"."""
+    import torch
+    from zstdlite_amd import _lib, stream
+    from zstdlite_amd.device import DeviceCodec, gen_mixed
+    L = _lib.lib()
     text = GENERATORS["text"](3 << 20, seed=5)
-    deep = [len(z.zstd_compress(text, level=level)) for level in (3, 9, 15)]
+    denied, deep = [], []
+    for level in (3, 9, 15, 19):
+        cctx = z.zstd_cctx(level=level)
+        assert L.zl_CCtx_setParameter(cctx._ptr, 9098, 1) == 0
+        comp = z.zstd_compress(text, cctx=cctx)
+        assert ref.decompress(comp, len(text)) == text and z.zstd_decompress(comp) == text
+        denied.append(len(comp))
+        deep.append(len(z.zstd_compress(text, level=level)))
     # (level 3 on this synthetic text is the one place where the tables write a little LESS than three candidates of the deep finder: DESIGN 3.3)
-    assert denied[1] > deep[1] and denied[2] > deep[2] and denied[0] < 1.05 * deep[0], (denied, deep)
+    assert denied[1] > deep[1] and denied[2] > deep[2] and denied[3] > deep[3] and denied[0] < 1.05 * deep[0], (denied, deep)
+    # a pledged stream of several jobs with a content checksum: every job is made twice (the deep attempt, then the table parse), the
+    # running XXH64 must cover the bytes once
+    n = (150 << 20) + 5
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    cctx = z.zstd_cctx(level=9, include_checksum=True)
+    assert L.zl_CCtx_setParameter(cctx._ptr, 9098, 1) == 0
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    blob = b"".join([comp.feed(data[off:off + 40000003]) for off in range(0, n, 40000003)] + [comp.finish()])
+    assert ref.L.ZSTD_findFrameCompressedSize(blob, len(blob)) == len(blob)
+    assert ref.decompress(blob, n) == data  # (the reference verifies the checksum)
+    # the device-resident entry
+    codec = DeviceCodec(level=9, frame_layout="one_frame")
+    assert L.zl_CCtx_setParameter(codec.cctx, 9098, 1) == 0
+    src = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).cuda()
+    dst, total, _ = codec.compress(src)
+    assert ref.decompress(bytes(dst[:total].cpu().numpy()), len(text)) == text
 
 
 def test_small_objects_on_a_dictionary_at_the_edges_of_the_wave_kernels(ref, oracle):

@@ -324,37 +324,25 @@ def test_streams_at_the_other_operating_points_write_what_the_one_shot_call_writ
     assert ref_stream_decompress(ref, blob2) == data and z.zstd_decompress(blob2) == data
 
 
-_NO_THREAD_SCRIPT = r"""
-import sys, torch
-import zstdlite_amd as z
-from zstdlite_amd import stream
-from zstdlite_amd.device import gen_mixed
-n = (200 << 20) + 4321
-data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
-want = z.zstd_compress(data)
-cctx = z.zstd_cctx()
-# ONE call brings three jobs' worth of input: job 1 runs on its thread, job 2's thread "cannot be had" -- collect() has just put
-# job 1's bytes where they wait to be handed out, and job 2's must go behind them
-comp = stream.Compressor(cctx._ptr, pledged=n)
-blob = comp.feed(data) + comp.finish()
-assert blob == want, (len(blob), len(want))
-loose = stream.Compressor(cctx._ptr)
-blob2 = loose.feed(data) + loose.finish()
-assert z.zstd_decompress(blob2) == data
-print("no job lost")
-"""
-
-
 def test_a_job_whose_thread_cannot_be_started_loses_nothing():
     """ADVICE r5 (medium): when std::thread fails (EAGAIN) a full job runs inline; what it wrote used to REPLACE the bytes of the job
     before it, which collect() had just moved to where they wait for hand_out(): a run missing from a pledged one-frame stream, a whole
-    frame from an unpledged one.  ZL_DEBUG_NO_JOB_THREAD=2 lets the first job of the process have its thread and fails every later one."""
-    import subprocess
-    import sys
-    env = dict(os.environ, ZL_DEBUG_NO_JOB_THREAD="2")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _NO_THREAD_SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert out.returncode == 0 and "no job lost" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    frame from an unpledged one.  ZL_c_faultInjection = 2 << 4 lets the first job of a session have its thread and fails every later one."""
+    import torch
+    from zstdlite_amd.device import gen_mixed
+    n = (200 << 20) + 4321
+    data = gen_mixed(n, torch.device("cuda", 0))[0].cpu().numpy().tobytes()
+    want = z.zstd_compress(data)
+    cctx = z.zstd_cctx()
+    assert _lib.lib().zl_CCtx_setParameter(cctx._ptr, 9098, 2 << 4) == 0
+    # ONE call brings three jobs' worth of input: job 1 runs on its thread, job 2's thread "cannot be had" -- collect() has just put
+    # job 1's bytes where they wait to be handed out, and job 2's must go behind them
+    comp = stream.Compressor(cctx._ptr, pledged=n)
+    blob = comp.feed(data) + comp.finish()
+    assert blob == want, (len(blob), len(want))
+    loose = stream.Compressor(cctx._ptr)
+    blob2 = loose.feed(data) + loose.finish()
+    assert z.zstd_decompress(blob2) == data
 
 
 @needs_ref

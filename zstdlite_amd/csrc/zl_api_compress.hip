@@ -36,6 +36,9 @@ struct zl_cctx_s {
     // buffers back and makes the call again on the table parse at its deepest setting -- levels >= 6 degrade instead of failing.  The denial
     // lasts for the streaming session (a frame's header names ONE window), one-shot calls ask again every time.
     bool deep_failed = false, deep_denied = false;
+    // ZL_c_faultInjection (tests): bit 0 -- every allocation of the deep finder "fails"; bits 4 and up: k -- from the k-th full job of a streaming
+    // session on, the job's thread "cannot be had" (jobs_started counts them; reset with the session)
+    int fault = 0, jobs_started = 0;
     int last_slots = 1;  // device slots the last zl_compress2 call used
     int devices = 1;     // ZL_c_devices: device slots zl_compress2 spreads a large input over (0: every visible device)
     std::vector<zl_cctx_s*> peers;  // one context per slot, created on first use
@@ -157,8 +160,6 @@ inline DeepLevel deep_level(int level, u64 total) {
 // ... which needs ONE contiguous input and no dictionary (a dictionary's content is not part of what is sorted): batches of
 // objects and dictionary contexts at these levels run the table-based parse at its deepest setting instead
 inline bool deep_on(const zl_cctx* c) { return (c->level >= 6 || deep_small(c->level, c->input_total)) && c->one_input && c->dict_use == 0 && !c->deep_denied; }
-// (tests: ZL_DEBUG_DEEP_OOM=1 in the environment makes every deep allocation "fail")
-inline bool deep_oom_switch() { static const bool on = getenv("ZL_DEBUG_DEEP_OOM") != nullptr; return on; }
 // what a denied deep call leaves behind goes back to the device before the call is made again
 inline void deep_release(zl_cctx* c) {
     for (auto& es : c->sets) for (DevBuf* b : {&es.deep_best, &es.deep_scratch, &es.deep_chain, &es.sub_lits, &es.sub_seqs, &es.sub_meta}) b->release();
@@ -265,7 +266,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         d.mml = (c->level < 6 || c->input_total > ((u64)256 << 10)) ? 5u : 4u;  // (zstd.c:29523-29600: minMatch 5 above 256 KiB, 4 below, at levels 6 and up; 5 throughout at 3 - 5)
         d.frames = joined ? 0u : 1u;
         size_t scratch_bytes = zl_deep_scratch_bytes(d.hi - d.lo);  // (0: the sort could not say what it needs)
-        if (scratch_bytes == 0 || deep_oom_switch() || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes) ||
+        if (scratch_bytes == 0 || (c->fault & 1) || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes) ||
             (dl.opt && !es.deep_chain.ensure((size_t)(d.hi - d.lo) * 8 * ZL_DEEP_CHAIN + 64))) { c->deep_failed = true; return kGpuUnavailable; }
         d.chain = dl.opt ? (u64*)es.deep_chain.p : nullptr;
         d.k2 = dl.opt ? ZL_OPT_K2 : 0u;
@@ -661,6 +662,11 @@ size_t zl_CCtx_setParameter(zl_cctx* c, int param, int value) {
         if (value < 0 || value > 64) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
         c->devices = value;
         return 0;
+    case ZL_c_faultInjection:
+        if (value < 0 || value > 0xFFFF) return ZL_ERR(ZL_E_PARAM_OUTOFBOUND);
+        c->fault = value;
+        c->jobs_started = 0;
+        return 0;
     default: return ZL_ERR(ZL_E_PARAM_UNSUPPORTED);
     }
 }
@@ -1000,7 +1006,7 @@ size_t compress2_sharded(zl_cctx* c, u8* dst, size_t cap, const u8* src, size_t 
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{hasher};
     run([&](int s) {
         zl_cctx* p = c->peers[s];
-        p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict; p->deep_denied = c->deep_denied;
+        p->level = c->level; p->checksum = c->checksum; p->layout = c->layout; p->dict = c->dict; p->deep_denied = c->deep_denied; p->fault = c->fault & 1;
         if (p->dict != c->dict || p->dict_id != c->dict_id) { p->dict_uploaded = false; p->dict_formatted = c->dict_formatted; p->dict_id = c->dict_id; }
         const size_t cnt = first[s + 1] - first[s];
         bytes[s] = cnt ? compress2_pipelined(p, nullptr, 0, src + first[s] * (size_t)ZL_CHUNK, n, one_frame, first[s], cnt, nchunks) : 0;
@@ -1231,6 +1237,7 @@ size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
         c->cs.consumed = 0;
         c->cs.started = c->cs.emitted = c->cs.finishing = c->cs.joined = c->cs.flush_told = false;
         c->deep_denied = false;
+        c->jobs_started = 0;
     }
     if (reset == ZL_reset_parameters || reset == ZL_reset_session_and_parameters) {
         if (c->cs.started || c->cs.finishing) return ZL_ERR(ZL_E_STAGE_WRONG);  // zstd.c:22790
@@ -1292,10 +1299,9 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
             T.job_ret = joined ? with_deep_fallback(c, [&]() { T.hash = hash0; return compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash); })
                                : compress2_impl(c, T.job_out.p, bound, T.job_in.p, n);
         };
-        static const int fail_from = getenv("ZL_DEBUG_NO_JOB_THREAD") ? atoi(getenv("ZL_DEBUG_NO_JOB_THREAD")) : 0;  // (tests: from the k-th job of the process on, thread creation "fails")
-        static std::atomic<int> jobs_seen{0};
+        const int fail_from = c->fault >> 4;  // (ZL_c_faultInjection: from the k-th job of the session on, thread creation "fails")
         try {
-            if (fail_from > 0 && ++jobs_seen >= fail_from) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+            if (fail_from > 0 && ++c->jobs_started >= fail_from) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
             S.job = std::thread(body);
             S.job_on = true;
         } catch (...) {  // no thread to be had: the job runs here.  collect() above may just have put the job BEFORE this one into S.out
@@ -1385,6 +1391,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.consumed = 0;
         S.started = S.emitted = S.finishing = S.joined = S.flush_told = false;
         c->deep_denied = false;
+        c->jobs_started = 0;
         return 0;
     }
     // ZL_e_flush inside a one-frame (pledged) session cuts no run: the input still collected is part of the answer, so that a caller
