@@ -382,8 +382,8 @@ def c4_leg(log, nitems=100000):
     # ZL_d_profile = 1 drains the stream between the phases of a call to time them, so the phases come from calls of their own behind the timed ones
     tc = td = 1e9
     cms, dms = (C.c_double * 5)(), (C.c_double * 5)()
-    for it in range(7):
-        prof = 1 if it >= 5 else 0
+    for it in range(14):
+        prof = 1 if it >= 12 else 0
         L.zl_CCtx_setParameter(cctx, 9001, prof); L.zl_DCtx_setParameter(dctx, 9002, prof)
         t1 = time.perf_counter()
         r = L.zl_compress_batch(cctx, B.n, B.p_comp.ctypes.data_as(vp), B.caps.ctypes.data_as(sp), B.p_src.ctypes.data_as(vp), B.sizes.ctypes.data_as(sp), B.csize.ctypes.data_as(sp))
