@@ -382,6 +382,9 @@ def c4_leg(log, nitems=100000):
     # ZL_d_profile = 1 drains the stream between the phases of a call to time them, so the phases come from calls of their own behind the timed ones
     tc = td = 1e9
     cms, dms = (C.c_double * 5)(), (C.c_double * 5)()
+    # (the legs in front have given back tens of GiB of device memory, which the driver wipes with the copy engines: copies that start right behind
+    # it run at half their rate for some hundred milliseconds -- DESIGN section 6; a call of 4 ms is all copies and launches)
+    time.sleep(1.0)
     for it in range(14):
         prof = 1 if it >= 12 else 0
         L.zl_CCtx_setParameter(cctx, 9001, prof); L.zl_DCtx_setParameter(dctx, 9002, prof)
