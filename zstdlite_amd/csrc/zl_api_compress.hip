@@ -95,12 +95,18 @@ struct zl_cctx_s {
         bool joined = false;    // the session's jobs are consecutive runs of blocks of ONE frame (decided when the first input arrives)
         bool flush_told = false;  // a ZL_e_flush has reported the input that stays collected since input last arrived
         zlx::Xxh64 hash;        // joined session with ZL_c_checksumFlag: the content checksum runs through all jobs
-        // round 4: a full job runs on a thread of its own while the caller's next pieces are collected (one job at a time; every
-        // other entry that touches the context waits for it first: cs_wait)
-        std::thread job;
-        bool job_on = false;
-        ByteBuf job_in, job_out;  // the running job's input and what it wrote
-        size_t job_ret = 0;       // ... its byte count or error code
+        // round 4: a full job runs on a thread of its own while the caller's next pieces are collected; every other entry that touches the
+        // context waits for the threads first (cs_wait).  Round 6: TWO jobs in flight -- a job is an upload, a few kernels and a download, one
+        // behind the other (2.6 ms for 64 MiB), and the link carries both directions at once: the second job's upload runs beside the first
+        // one's kernels and download.  Each slot has a WORKER context of its own (device buffers, scratch sets, streams); the jobs' bytes are
+        // handed out in the order the jobs were started.  (One at a time where ONE content checksum runs through all jobs of a frame.)
+        struct Job {
+            std::thread th;
+            ByteBuf in, out;   // the job's input and what it wrote
+            size_t ret = 0;    // ... its byte count or error code
+        } job[2];
+        int job_head = 0, job_count = 0;  // the oldest job not yet collected; jobs started and not yet collected
+        zl_cctx_s* worker[2] = {nullptr, nullptr};
     } cs;
 };
 
@@ -108,7 +114,7 @@ namespace {
 
 // a streaming job that runs beside the caller (zl_compressStream2) is finished before anything else uses the context
 inline void cs_wait(zl_cctx* c) {
-    if (c->cs.job_on) { c->cs.job.join(); c->cs.job_on = false; }
+    for (auto& j : c->cs.job) if (j.th.joinable()) j.th.join();
 }
 
 hipStream_t cctx_stream(zl_cctx* c, void* user) {
@@ -607,6 +613,7 @@ size_t zl_freeCCtx(zl_cctx* c) {
     if (c->ev_far) (void)hipEventDestroy(c->ev_far);
     for (zl_cctx* p : c->peers) (void)zl_freeCCtx(p);
     c->peers.clear();
+    for (auto& w : c->cs.worker) { if (w) (void)zl_freeCCtx(w); w = nullptr; }
     for (auto& es : c->sets) es.release();
     for (hipEvent_t e : c->pipe_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&c->d_src, &c->d_dst, &c->d_chunks, &c->d_dict, &c->d_dict_tables, &c->d_dict_hash, &c->d_cdict, &c->d_fsize, &c->d_foff, &c->d_totals, &c->d_stats};
@@ -1227,9 +1234,8 @@ size_t zl_CCtx_reset(zl_cctx* c, zl_ResetDirective reset) {
     if (!c) return ZL_ERR(ZL_E_GENERIC);
     cs_wait(c);
     if (reset == ZL_reset_session_only || reset == ZL_reset_session_and_parameters) {
-        c->cs.job_in.clear();
-        c->cs.job_out.clear();
-        c->cs.job_ret = 0;
+        for (auto& j : c->cs.job) { j.in.clear(); j.out.clear(); j.ret = 0; }
+        c->cs.job_head = c->cs.job_count = 0;
         c->cs.stage.clear();
         c->cs.out.clear();
         c->cs.out_pos = 0;
@@ -1264,61 +1270,82 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
         S.out_pos += k;
         if (S.out_pos == S.out.size()) { S.out.clear(); S.out_pos = 0; }
     };
-    // what a job that ran beside the caller wrote becomes what waits to be handed out (S.out is empty whenever this is called)
+    // what the OLDEST job that ran beside the caller wrote becomes what waits to be handed out (behind whatever still waits there)
     auto collect = [&]() -> size_t {
-        if (!S.job_on) return 0;
-        cs_wait(c);
-        const size_t r = S.job_ret;
-        S.job_in.clear();
-        if (ZL_IS_ERR(r)) { S.job_out.clear(); return r; }
-        S.job_out.n = r;
-        std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
-        S.job_out.clear();
-        S.out_pos = 0;
+        if (S.job_count == 0) return 0;
+        auto& J = S.job[S.job_head];
+        if (J.th.joinable()) J.th.join();
+        zl_cctx* const w = S.worker[S.job_head];
+        if (w && w->deep_denied) c->deep_denied = true;  // (the denial lasts for the session: a frame's header names ONE window)
+        S.job_head ^= 1;
+        S.job_count--;
+        const size_t r = J.ret;
+        J.in.clear();
+        if (ZL_IS_ERR(r)) { J.out.clear(); return r; }
+        if (S.out.empty()) {
+            J.out.n = r;
+            std::swap(S.out.p, J.out.p); std::swap(S.out.n, J.out.n); std::swap(S.out.cap, J.out.cap);
+            S.out_pos = 0;
+        } else if (!S.out.append(J.out.p, r)) { J.out.clear(); return ZL_ERR(ZL_E_MEMORY); }
+        J.out.clear();
         S.emitted = true;
         return 0;
     };
-    // a FULL job: on a thread of its own, so that the caller's next pieces are copied while it is uploaded, compressed and brought
-    // down (the job before it is collected first: one at a time)
+    // a FULL job: on a thread and a worker context of its own, so that the caller's next pieces are copied while it is uploaded, compressed
+    // and brought down -- and the job behind it started
     auto start_job = [&]() -> size_t {
-        { const size_t e = collect(); if (ZL_IS_ERR(e)) return e; }
-        std::swap(S.stage.p, S.job_in.p); std::swap(S.stage.n, S.job_in.n); std::swap(S.stage.cap, S.job_in.cap);
+        const int limit = (S.joined && c->checksum) ? 1 : 2;
+        if (S.job_count >= limit) { const size_t e = collect(); if (ZL_IS_ERR(e)) return e; }
+        const int slot = (S.job_head + S.job_count) & 1;
+        auto& J = S.job[slot];
+        if (!S.worker[slot]) S.worker[slot] = zl_createCCtx();
+        zl_cctx* const w = S.worker[slot];
+        if (!w) return ZL_ERR(ZL_E_MEMORY);
+        {   // the worker compresses as this context would
+            w->level = c->level; w->checksum = c->checksum; w->layout = c->layout; w->pipeline = c->pipeline; w->devices = c->devices; w->seek_table = c->seek_table;
+            w->nb_workers = c->nb_workers; w->fault = c->fault & 1; w->deep_denied = c->deep_denied;
+            if (w->dict != c->dict || w->dict_id != c->dict_id || w->dict_formatted != c->dict_formatted) { w->dict = c->dict; w->dict_id = c->dict_id; w->dict_formatted = c->dict_formatted; w->dict_uploaded = false; }
+        }
+        std::swap(S.stage.p, J.in.p); std::swap(S.stage.n, J.in.n); std::swap(S.stage.cap, J.in.cap);
         S.stage.clear();
-        const size_t n = S.job_in.size(), bound = zl_compressBound(n);
-        S.job_out.clear();
-        if (!S.job_out.reserve(bound)) return ZL_ERR(ZL_E_MEMORY);
+        const size_t n = J.in.size(), bound = zl_compressBound(n);
+        J.out.clear();
+        if (!J.out.reserve(bound)) return ZL_ERR(ZL_E_MEMORY);
         const u64 pledged = S.pledged, consumed_end = S.consumed;
         const bool joined = S.joined;
         if (joined && ((consumed_end - n) % ZL_STREAM_JOB != 0 || !(n == ZL_STREAM_JOB || consumed_end == pledged))) return ZL_ERR(ZL_E_STAGE_WRONG);
         int dev = 0;
         (void)hipGetDevice(&dev);
-        auto body = [c, n, bound, pledged, consumed_end, joined, dev]() {
+        auto* const hash = &S.hash;
+        auto* const Jp = &J;
+        auto body = [w, Jp, hash, n, bound, pledged, consumed_end, joined, dev]() {
             (void)hipSetDevice(dev);
-            auto& T = c->cs;
-            const zlx::Xxh64 hash0 = T.hash;  // (a call made a second time hashes its bytes a second time: from the same start)
-            T.job_ret = joined ? with_deep_fallback(c, [&]() { T.hash = hash0; return compress2_pipelined(c, T.job_out.p, bound, T.job_in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), &T.hash); })
-                               : compress2_impl(c, T.job_out.p, bound, T.job_in.p, n);
+            const zlx::Xxh64 hash0 = *hash;  // (a call made a second time hashes its bytes a second time: from the same start)
+            Jp->ret = joined ? with_deep_fallback(w, [&]() { *hash = hash0; return compress2_pipelined(w, Jp->out.p, bound, Jp->in.p, (size_t)pledged, true, (size_t)((consumed_end - n) / ZL_CHUNK), chunks_of(n), chunks_of((size_t)pledged), hash); })
+                             : compress2_impl(w, Jp->out.p, bound, Jp->in.p, n);
         };
         const int fail_from = c->fault >> 4;  // (ZL_c_faultInjection: from the k-th job of the session on, thread creation "fails")
         try {
             if (fail_from > 0 && ++c->jobs_started >= fail_from) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-            S.job = std::thread(body);
-            S.job_on = true;
-        } catch (...) {  // no thread to be had: the job runs here.  collect() above may just have put the job BEFORE this one into S.out
-                         // (hand_out() only runs when this returns), so these bytes go BEHIND what waits there, as run_job() appends
+            J.th = std::thread(body);
+            S.job_count++;
+        } catch (...) {  // no thread to be had: the job runs here -- behind every job that is still under way, whose bytes go out first (they used
+                         // to be replaced by this job's)
+            while (S.job_count) { const size_t e = collect(); if (ZL_IS_ERR(e)) return e; }
             body();
-            const size_t r = S.job_ret;
-            S.job_in.clear();
-            if (ZL_IS_ERR(r)) { S.job_out.clear(); return r; }
+            if (w->deep_denied) c->deep_denied = true;
+            const size_t r = J.ret;
+            J.in.clear();
+            if (ZL_IS_ERR(r)) { J.out.clear(); return r; }
             if (S.out.empty()) {
-                S.job_out.n = r;
-                std::swap(S.out.p, S.job_out.p); std::swap(S.out.n, S.job_out.n); std::swap(S.out.cap, S.job_out.cap);
+                J.out.n = r;
+                std::swap(S.out.p, J.out.p); std::swap(S.out.n, J.out.n); std::swap(S.out.cap, J.out.cap);
                 S.out_pos = 0;
-            } else if (!S.out.append(S.job_out.p, r)) {
-                S.job_out.clear();
+            } else if (!S.out.append(J.out.p, r)) {
+                J.out.clear();
                 return ZL_ERR(ZL_E_MEMORY);
             }
-            S.job_out.clear();
+            J.out.clear();
             S.emitted = true;
         }
         return 0;
@@ -1366,7 +1393,7 @@ size_t zl_compressStream2(zl_cctx* c, zl_outBuffer* output, zl_inBuffer* input, 
             hand_out();
         }
     }
-    if (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && S.job_on) {  // the job that is still running comes out first
+    while (end_op != ZL_e_continue && input->pos == input->size && S.out.empty() && S.job_count) {  // the jobs that are still running come out first, oldest first
         const size_t e = collect();
         if (ZL_IS_ERR(e)) return e;
         hand_out();

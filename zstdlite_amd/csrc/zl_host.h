@@ -222,9 +222,9 @@ namespace {
 // f(begin, end) over [0, n) on up to 16 host threads (the calling one among them); ranges of at least `grain` items, so
 // small batches stay on the caller.
 template <class F>
-static inline void zl_parallel_for(size_t n, size_t grain, F f) {
+static inline void zl_parallel_for(size_t n, size_t grain, F f, size_t max_threads = ZlPool::kWorkers + 1) {
     const size_t hw = std::thread::hardware_concurrency();
-    const size_t t = std::min<size_t>(std::min<size_t>(ZlPool::kWorkers + 1, hw ? hw : 1), grain ? n / grain : 1);
+    const size_t t = std::min<size_t>(std::min<size_t>(std::min<size_t>(ZlPool::kWorkers + 1, max_threads), hw ? hw : 1), grain ? n / grain : 1);
     ZlPool* pool = t > 1 ? zl_pool() : nullptr;
     if (!pool || !pool->user.try_lock()) { f((size_t)0, n); return; }
     struct Ctx { F* f; size_t n, per; } cx{&f, n, (n + t - 1) / t};
@@ -240,7 +240,8 @@ static inline void zl_parallel_for(size_t n, size_t grain, F f) {
 // buffers ran at (64 MiB in and 40 MiB out per job, 8 ms of an 11 ms job); small blocks stay on the caller.
 static inline void zl_memcpy_mt(void* dst, const void* src, size_t n) {
     if (n < ((size_t)2 << 20)) { if (n) memcpy(dst, src, n); return; }
-    zl_parallel_for(n, (size_t)512 << 10, [&](size_t b, size_t e) { memcpy((u8*)dst + b, (const u8*)src + b, e - b); });
+    // (eight threads, as rounds 1-5: the streaming entries copy pieces of a few MiB, and waking sixteen threads for each of them cost the pledged stream a tenth of its rate)
+    zl_parallel_for(n, (size_t)512 << 10, [&](size_t b, size_t e) { memcpy((u8*)dst + b, (const u8*)src + b, e - b); }, 8);
 }
 
 inline bool ByteBuf::append(const void* src, size_t k) {
