@@ -227,7 +227,7 @@ def test_deep_levels_through_the_pipelined_host_entry():
     n = (300 << 20) + 4321
     src = gen_mixed(n, dev)[0]
     host = src.cpu().numpy()
-    for level, layout in ((9, 2), (6, 1)):
+    for level, layout in ((9, 2), (6, 1), (17, 2)):  # (17: the price-based parse of csrc/zl_opt.hip over two search passes, round 6)
         outs = []
         for slots in (1, 3):
             cctx = L.zl_createCCtx()

@@ -304,7 +304,7 @@ def test_flush_inside_a_pledged_one_frame_session_keeps_the_stream_valid(ref):
 
 
 @needs_ref
-@pytest.mark.parametrize("level", [9, -5])
+@pytest.mark.parametrize("level", [9, -5, 19])
 def test_streams_at_the_other_operating_points_write_what_the_one_shot_call_writes(ref, level):
     """A pledged stream's jobs are whole sections of ONE frame (above): at the deep levels (csrc/zl_deep.hip sorts a section at a time; the
     job's buffer holds its own range of the input only) and at the negative ones (stored literals) the bytes must still be zl_compress2's
