@@ -25,7 +25,7 @@ for rd in range(rounds):
     n = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 24 << 20))
     layout = str(rng.choice(["frames", "one_frame"]))
     cs = bool(rng.random() < 0.3)
-    level = int(rng.choice([1, 3, 3, 5, 6, 9, -5]))
+    level = int(rng.choice([1, 3, 3, 5, 6, 9, -5, 16, 19]))
     key = (layout, cs, level)
     try:
         if key not in codecs:
