@@ -147,6 +147,9 @@ struct DeepLevel { u32 k, lazy2, wlog, opt; };
 #define ZL_DEEP_SUB 8u  // workgroups that share a chunk in the deep parse of a small launch (a power of two; 1: never).  16 and 32 were measured: 6 - 9 % off a small call's
                         // time, and config C1's buffer repeated to 1 MiB 1.098 -> 1.174x the reference's size (every part starts without a repeat offset and probes for itself)
 #endif
+#ifndef ZL_BT_K2
+#define ZL_BT_K2 256u     // levels 13 - 15 (the reference's btlazy2: a binary tree finds the longest match): candidates of a second search pass over an eight-byte hash whose best replaces the first pass's where it gains more (16 MiB of the synthetic text at level 15: 1.095 -> 1.039 of the reference's size, the python sources 1.012 -> 1.006, for 8 -> 14 ms of the call); 0: one pass
+#endif
 #ifndef ZL_OPT_K2
 #define ZL_OPT_K2 256u    // levels 16 - 22: candidates per position of the second search pass (eight-byte hash; zl_deep.hip); 0: one pass
 #endif
@@ -275,7 +278,7 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
         if (scratch_bytes == 0 || (c->fault & 1) || !es.deep_best.ensure((size_t)(d.hi - d.lo) * 8 + 64) || !es.deep_scratch.ensure(scratch_bytes) ||
             (dl.opt && !es.deep_chain.ensure((size_t)(d.hi - d.lo) * 8 * ZL_DEEP_CHAIN + 64))) { c->deep_failed = true; return kGpuUnavailable; }
         d.chain = dl.opt ? (u64*)es.deep_chain.p : nullptr;
-        d.k2 = dl.opt ? ZL_OPT_K2 : 0u;
+        d.k2 = dl.opt ? ZL_OPT_K2 : ((c->level >= 13 && deep_level(c->level, c->input_total).k >= 96) ? ZL_BT_K2 : 0u);
         d.mml2 = 8;
         d.scratch = es.deep_scratch.p;
         d.scratch_bytes = scratch_bytes;

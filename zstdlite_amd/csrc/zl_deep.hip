@@ -155,7 +155,26 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
             }
         }
     }
+    // the best candidate's word: its length, the bytes that agree in FRONT of both (the sequence may start there if the parse leaves those literals free), its offset
+    auto best_word = [&]() -> u64 {
+        const u64 mine = (u64)m0.x | ((u64)m0.y << 32), theirs = (u64)rec[0][be].x | ((u64)rec[0][be].y << 32);
+        const u64 x = mine ^ theirs;
+        u32 back = x ? (u32)(__builtin_clzll(x) >> 3) : 8u;
+        const u32 q = p - bo;
+        const u32 lo_src = frames ? chunk0 : 0u;  // the source may not start in front of this (the section, or the frame)
+        if (back > q - lo_src) back = q - lo_src;
+        if (back > p - chunk0) back = p - chunk0;  // nor the sequence in front of its chunk
+        return (u64)(bl | (back << 16)) | ((u64)bo << 32);
+    };
     if (merge) {
+        // the best word: this pass's best by the same gain against the one the first pass left (whose length may have been measured on since)
+        if (bl) {
+            const u64 old = best[p];
+            const u32 ol = (u32)old & 0xFFFFu, oo = (u32)(old >> 32);
+            const int og = ol ? 4 * (int)ol - (int)(31 - __clz(oo + 1)) : -1000000;
+            if (bg > og) best[p] = best_word();
+        }
+        if (chain == nullptr) return;
         // The two chains -- this pass's and the one in memory -- are each ascending in length and descending in offset; together the entries that no
         // other one beats at both (at least as long AND at least as near) are the nearest offset per length over all candidates of both passes.  The
         // ZL_DEEP_CHAIN longest of them stay.
@@ -192,17 +211,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void zl_deep_search_kernel(const u64*
         return;
     }
     u64 word = 0;
-    if (bl) {
-        // bytes that agree in front of both: the sequence may start there if the parse leaves those literals free
-        const u64 mine = (u64)m0.x | ((u64)m0.y << 32), theirs = (u64)rec[0][be].x | ((u64)rec[0][be].y << 32);
-        const u64 x = mine ^ theirs;
-        u32 back = x ? (u32)(__builtin_clzll(x) >> 3) : 8u;
-        const u32 q = p - bo;
-        const u32 lo_src = frames ? chunk0 : 0u;  // the source may not start in front of this (the section, or the frame)
-        if (back > q - lo_src) back = q - lo_src;
-        if (back > p - chunk0) back = p - chunk0;  // nor the sequence in front of its chunk
-        word = (u64)(bl | (back << 16)) | ((u64)bo << 32);
-    }
+    if (bl) word = best_word();
 #if defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 1)
     if (word == 0x123456789ABCDEFull) best[p] = word;  // (experiment: no scattered store)
 #elif defined(ZL_DEEP_EXP) && (ZL_DEEP_EXP & 4)
@@ -635,7 +644,7 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
         else if (a->k <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k, a->window, a->mml, a->frames, best, chain);
         else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k, 256u), a->window, a->mml, a->frames, best, chain);
         hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec, chain);
-        if (chain && a->k2) {
+        if (a->k2) {
             // levels 16+: the section once more, sorted by a hash of mml2 bytes -- the K most recent twins of a LONG prefix reach where the K most recent
             // of minMatch bytes end (a word of a small vocabulary has thousands of twins, the phrase around it a few) --, merged into the chains
             hipLaunchKernelGGL(zl_deep_key_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, sec, n, 64u - 8u * a->mml2, keys_a);
@@ -646,6 +655,7 @@ extern "C" hipError_t zl_launch_deep_search(const zl_deep_args* a, hipStream_t s
             if (a->k2 <= 64) hipLaunchKernelGGL((zl_deep_search_kernel<64>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k2, a->window, a->mml2, fl, best, chain);
             else if (a->k2 <= 128) hipLaunchKernelGGL((zl_deep_search_kernel<128>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, a->k2, a->window, a->mml2, fl, best, chain);
             else hipLaunchKernelGGL((zl_deep_search_kernel<256>), dim3(blocks), dim3(DEEP_THREADS), 0, stream, (const u64*)keys_b, n, sec, std::min<u32>(a->k2, 256u), a->window, a->mml2, fl, best, chain);
+            hipLaunchKernelGGL(zl_deep_extend_kernel, dim3(blocks), dim3(DEEP_THREADS), 0, stream, best, n, sec, chain);  // (a best word the second pass wrote may fill its record too)
         }
         s0 = s1;
     }
