@@ -1078,6 +1078,10 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         // frame, 1.2 ms that used to stand in front of it; joined again in front of the exec kernel)
         fill_st = (side && side->part_stream[2] && s->fill_fork && s->fill_join) ? side->part_stream[2] : st;
         if (fill_st != st && (hipEventRecord(s->fill_fork, st) != hipSuccess || hipStreamWaitEvent(fill_st, s->fill_fork, 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
+#ifdef ZL_DEV_SWITCHES
+        if (!getenv("ZL_DEV_NO_FILL"))  // (experiment, round 6: what the fill costs the stages beside it -- this library's 1 GiB frame: entropy 3.33 -> 2.83 ms, exec 2.83 -> 2.59, the decode 10.2 -> 9.5 ms; the output is then wrong.
+                                        // Doing without it means links written for every byte of every region that holds a waiting one, and a flag read per hop of the ordered copies: not built)
+#endif
         if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (fill_st != st && hipEventRecord(s->fill_join, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
