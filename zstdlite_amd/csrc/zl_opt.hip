@@ -410,6 +410,7 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
         OptRec* const recs = (OptRec*)seqs;  // (zl_seq and OptRec are both four words)
         const u32 stride = a.seq_stride;
         u32 found = 0, trailing = 0, lit_total = 0;
+        bool broken = false;  // (a word that does not step backwards: cannot happen -- and must not hang the device if it ever does: the pass is dropped)
         {
             u32 at = n;
             bool first = true;
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                 const u64 w = at == n ? end_w : arrivals[at];
                 if ((u32)w & 0x80000000u) {  // a run of literals ends here
                     const u32 k = (u32)w & 0x7FFFFFFFu;
+                    if (k == 0 || k > at) { broken = true; break; }
                     if (first) trailing = k;
                     lit_total += k;
                     at -= k;
@@ -425,11 +427,13 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                 }
                 first = false;
                 const u32 len = (u32)w & 0xFFFFu, off = (u32)(w >> 32);
+                if (len == 0 || len > at) { broken = true; break; }
                 const u32 start = at - len;
                 u32 k = 0;
                 if (start > 0) {
                     const u64 w2 = arrivals[start];
                     if ((u32)w2 & 0x80000000u) k = (u32)w2 & 0x7FFFFFFFu;
+                    if (k > start) { broken = true; break; }
                 }
                 if (found < stride) {
                     if (lane == 0) { OptRec r; r.pos = start; r.len = len; r.off = off; r.litlen = k; recs[stride - 1 - found] = r; }
@@ -437,10 +441,12 @@ __global__ __launch_bounds__(OPT_THREADS) void zl_opt_parse_kernel(zl_match_args
                     lit_total += k;
                     at = start - k;
                 } else {  // (cannot happen: a sequence takes four bytes and the array holds one per four)
+                    broken = true;
                     break;
                 }
             }
         }
+        if (broken) break;  // (the best parse so far stands)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_sync();
         // ------------------------------------------------------------------ emit: turned round, literal counts summed, literals copied
