@@ -2242,10 +2242,17 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     }
     if (!d->h_stage_in.ensure(in_total + 16) || !d->d_src.ensure(in_total + 16)) return kGpuUnavailable;
     // (round 6: packed, uploaded, brought down and unpacked in PIECES -- zl_compress_batch says why; the frame table's offsets are the caller's sizes' running sum)
-    const size_t pieces = (prof || n < 16384) ? 1 : 4;
+    const size_t pieces = (prof || n < 16384) ? 1 : ZL_BATCH_PIECES;
+    const ZlCopyPair* const pair = zl_copy_pair();  // (the copies on the process's copy pair, as in zl_compress_batch)
+    const hipStream_t up = pair ? pair->up : st, down = pair ? pair->down : st;
+    while (d->batch_events.size() < pieces + 2) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
+        d->batch_events.push_back(ev);
+    }
     for (size_t pc = 0; pc < pieces; pc++) {
     const size_t pb0 = n * pc / pieces, pb1 = n * (pc + 1) / pieces;
-    zl_parallel_for(pb1 - pb0, 4096, [&](size_t b_, size_t e_) {
+    zl_parallel_for(pb1 - pb0, ZL_BATCH_GRAIN, [&](size_t b_, size_t e_) {
         const size_t b = pb0 + b_, e = pb0 + e_;
         for (size_t i = b; i < e; i++) {
             FrameHeader h;
@@ -2264,37 +2271,36 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
     });
     {
         const size_t o0 = table[pb0].src_off, o1 = pb1 < n ? table[pb1].src_off : in_total;
-        if (o1 > o0 && hipMemcpyAsync((u8*)d->d_src.p + o0, (const u8*)d->h_stage_in.p + o0, o1 - o0, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (o1 > o0 && hipMemcpyAsync((u8*)d->d_src.p + o0, (const u8*)d->h_stage_in.p + o0, o1 - o0, hipMemcpyHostToDevice, up) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     }  // (pieces)
+    if (up != st && (hipEventRecord(d->batch_events[pieces], up) != hipSuccess || hipStreamWaitEvent(st, d->batch_events[pieces], 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
     for (size_t i = 0; i < n; i++) {
         table[i].dst_off = out_total;
         out_total += (table[i].dst_cap + 15) & ~(size_t)15;
     }
     if (!d->h_stage_out.ensure(out_total + 16) || !d->d_dst.ensure(out_total + 16)) return kGpuUnavailable;
     tp[1] = now_ms();
-    if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
+    if (prof) { (void)hipStreamSynchronize(st); }
+    tp[2] = now_ms();
     size_t e = dctx_enqueue(d, (u8*)d->d_dst.p, (const u8*)d->d_src.p, n, st);
     if (ZL_IS_ERR(e)) return e;
-    if (prof) { (void)hipStreamSynchronize(st); tp[3] = now_ms(); }
-    if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-    while (d->batch_events.size() < pieces) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
-        d->batch_events.push_back(ev);
-    }
+    if (prof) { (void)hipStreamSynchronize(st); }
+    tp[3] = now_ms();
+    if (down != st && (hipEventRecord(d->batch_events[pieces + 1], st) != hipSuccess || hipStreamWaitEvent(down, d->batch_events[pieces + 1], 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
+    if (hipMemcpyAsync(d->h_results.p, d->d_results.p, n * sizeof(u64), hipMemcpyDeviceToHost, down) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     for (size_t pc = 0; pc < pieces; pc++) {
         const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
         const size_t o0 = table[b0].dst_off, o1 = b1 < n ? table[b1].dst_off : out_total;
-        if (o1 > o0 && hipMemcpyAsync((u8*)d->h_stage_out.p + o0, (const u8*)d->d_dst.p + o0, o1 - o0, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (hipEventRecord(d->batch_events[pc], st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (o1 > o0 && hipMemcpyAsync((u8*)d->h_stage_out.p + o0, (const u8*)d->d_dst.p + o0, o1 - o0, hipMemcpyDeviceToHost, down) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipEventRecord(d->batch_events[pc], down) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     const u64* r = (const u64*)d->h_results.p;
     for (size_t pc = 0; pc < pieces; pc++) {
         const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
         if (hipEventSynchronize(d->batch_events[pc]) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (pc + 1 == pieces) tp[4] = now_ms();
-        zl_parallel_for(b1 - b0, 4096, [&](size_t b, size_t e) {
+        zl_parallel_for(b1 - b0, ZL_BATCH_GRAIN, [&](size_t b, size_t e) {
             for (size_t i = b0 + b; i < b0 + e; i++) {
                 if (pre[i]) { results[i] = pre[i]; continue; }
                 results[i] = (size_t)r[i];
@@ -2303,6 +2309,9 @@ size_t zl_decompress_batch(zl_dctx* d, size_t n, void* const* dsts, const size_t
         });
     }
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) d->batch_ms[k] = tp[k + 1] - tp[k]; }
+#ifdef ZL_DEV_SWITCHES
+    else if (pieces > 1) { tp[5] = now_ms(); fprintf(stderr, "[zl d-batch] packed + issued %.3f | enqueued %.3f | last piece down %.3f | unpacked %.3f\n", tp[2] - tp[0], tp[3] - tp[0], tp[4] - tp[0], tp[5] - tp[0]); }
+#endif
     if (d->profile >= 2 && d->d_stats.p) (void)hipMemcpy(d->stats, d->d_stats.p, 128, hipMemcpyDeviceToHost);
     return 0;
 }

@@ -1142,10 +1142,19 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
     // Round 6: a large batch is packed in PIECES, each piece's upload issued as soon as it lies in the pinned buffer -- the pool packs the next piece
     // while the link carries this one (and, below, unpacks a piece while the next comes down): pack + upload of a 100 000-object call 1.4 -> ms.
     // (ZL_c_profile keeps one piece: its phases are measured with the stream drained between them.)
-    const size_t pieces = (prof || n < 16384) ? 1 : 4;
+    const size_t pieces = (prof || n < 16384) ? 1 : ZL_BATCH_PIECES;
+    // The copies ride the process's copy pair (zl_copy_pair.h), not the kernels' stream: a stream keeps the copy engine of its first copy, and
+    // the context's own was seen to carry 30 MB up at 26 GB/s where the pair -- made with both directions checked for their rate -- carries 50.
+    const ZlCopyPair* const pair = zl_copy_pair();
+    const hipStream_t up = pair ? pair->up : st, down = pair ? pair->down : st;
+    while (c->pipe_events.size() < pieces + 1) {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
+        c->pipe_events.push_back(ev);
+    }
     for (size_t pc = 0; pc < pieces; pc++) {
         const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
-        zl_parallel_for(b1 - b0, 4096, [&](size_t b, size_t e) {
+        zl_parallel_for(b1 - b0, ZL_BATCH_GRAIN, [&](size_t b, size_t e) {
             for (size_t i = b0 + b; i < b0 + e; i++) {
                 if (sizes[i]) memcpy((u8*)c->h_stage_in.p + in_off[i], srcs[i], sizes[i]);
                 const size_t k = chunks_of(sizes[i]);
@@ -1159,9 +1168,11 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         });
         if (pc == 0) tp[1] = now_ms();
         const size_t o0 = in_off[b0], o1 = b1 < n ? in_off[b1] : in_total;
-        if (o1 > o0 && hipMemcpyAsync((u8*)c->d_src.p + o0, (const u8*)c->h_stage_in.p + o0, o1 - o0, hipMemcpyHostToDevice, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (o1 > o0 && hipMemcpyAsync((u8*)c->d_src.p + o0, (const u8*)c->h_stage_in.p + o0, o1 - o0, hipMemcpyHostToDevice, up) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
-    if (prof) { (void)hipStreamSynchronize(st); tp[2] = now_ms(); }
+    if (up != st && (hipEventRecord(c->pipe_events[pieces], up) != hipSuccess || hipStreamWaitEvent(st, c->pipe_events[pieces], 0) != hipSuccess)) return ZL_ERR(ZL_E_GENERIC);
+    if (prof) { (void)hipStreamSynchronize(st); }
+    tp[2] = now_ms();
     c->chunk_cap = (u32)std::min<size_t>(largest, ZL_CHUNK);  // small objects: small scratch per object, one launch group (enc_strides)
     const size_t e = cctx_enqueue(c, (u8*)c->d_dst.p, (const u8*)c->d_src.p, nchunks, st);
     c->chunk_cap = ZL_CHUNK;
@@ -1180,23 +1191,18 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         off += sz;
     }
     if (off != total) return ZL_ERR(ZL_E_GENERIC);
-    // the frames come down piece by piece, a piece is unpacked while the next one travels
-    while (c->pipe_events.size() < pieces) {
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return kGpuUnavailable;
-        c->pipe_events.push_back(ev);
-    }
+    // the frames come down piece by piece, a piece is unpacked while the next one travels (the kernels' stream has been drained above)
     for (size_t pc = 0; pc < pieces; pc++) {
         const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
         const size_t o0 = out_off[b0], o1 = b1 < n ? out_off[b1] : total;
-        if (o1 > o0 && hipMemcpyAsync((u8*)c->h_stage_out.p + o0, (const u8*)c->d_dst.p + o0, o1 - o0, hipMemcpyDeviceToHost, st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
-        if (hipEventRecord(c->pipe_events[pc], st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (o1 > o0 && hipMemcpyAsync((u8*)c->h_stage_out.p + o0, (const u8*)c->d_dst.p + o0, o1 - o0, hipMemcpyDeviceToHost, down) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (hipEventRecord(c->pipe_events[pc], down) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
     }
     for (size_t pc = 0; pc < pieces; pc++) {
         const size_t b0 = n * pc / pieces, b1 = n * (pc + 1) / pieces;
         if (hipEventSynchronize(c->pipe_events[pc]) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         if (pc + 1 == pieces) tp[4] = now_ms();
-        zl_parallel_for(b1 - b0, 4096, [&](size_t b, size_t e) {
+        zl_parallel_for(b1 - b0, ZL_BATCH_GRAIN, [&](size_t b, size_t e) {
             for (size_t i = b0 + b; i < b0 + e; i++) {
                 if (results[i] > caps[i]) results[i] = ZL_ERR(ZL_E_DSTSIZE_TOO_SMALL);
                 else memcpy(dsts[i], (const u8*)c->h_stage_out.p + out_off[i], results[i]);
@@ -1204,6 +1210,9 @@ size_t zl_compress_batch(zl_cctx* c, size_t n, void* const* dsts, const size_t* 
         });
     }
     if (prof) { tp[5] = now_ms(); for (int k = 0; k < 5; k++) c->batch_ms[k] = tp[k + 1] - tp[k]; }
+#ifdef ZL_DEV_SWITCHES
+    else if (pieces > 1) { tp[5] = now_ms(); fprintf(stderr, "[zl c-batch] first piece packed %.3f | all issued %.3f | kernels done %.3f | last piece down %.3f | unpacked %.3f\n", tp[1] - tp[0], tp[2] - tp[0], tp[3] - tp[0], tp[4] - tp[0], tp[5] - tp[0]); }
+#endif
     if (c->profile >= 2 && c->ev_valid && c->d_stats.p) (void)hipMemcpy(c->stats, c->d_stats.p, 128, hipMemcpyDeviceToHost);
     return 0;
 }

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(1024) void zl2_order_kernel(zl2_args a) {
     __shared__ u32 cnt[1024];
     __shared__ u32 part[16];
     const u32 t = threadIdx.x, n = a.nframes;
+    // Every frame already decoded by zl2_small_kernel (config C4: 100 000 small objects on a dictionary): nothing to sort, and the
+    // entropy and exec launches behind this one return at once (zl2_part_range) -- they used to walk 100 000 finished frames, 0.6 ms.
+    if (a.big == nullptr && a.max_blocks[3] == n) { if (t == 0) a.max_blocks[2] = ZL2_MODE_NONE; return; }
     for (u32 pass = 0; pass < 2; pass++) {  // 0: by sequences (order[0..n)), 1: by literal bytes (order[n..2n))
         const u32 shift = pass == 0 ? 5 : 7;
         cnt[t] = 0;
@@ -2282,6 +2285,7 @@ __global__ __launch_bounds__(SMALLD_G * SMALLD_FRAMES) void zl2_small_kernel(zl2
         a.results[f] = produced;
         fr->cost = 0; fr->lit_cost = 0;
         fr->err = ZL_E_DONE;  // (the lanes and the exec kernel leave such a frame alone: zl2_index_kernel's word for "decoded before this launch")
+        atomicAdd(a.max_blocks + 3, 1u);  // (a batch this kernel finished on its own: zl2_order_kernel calls the lanes off)
     }
 }
 

@@ -236,6 +236,15 @@ static inline void zl_parallel_for(size_t n, size_t grain, F f, size_t max_threa
     pool->user.unlock();
 }
 
+// The batch entries (zl_compress_batch, zl_decompress_batch) pack and unpack their objects on the pool: in pieces, a piece's copy issued as
+// soon as it is packed; objects per task of a piece.
+#ifndef ZL_BATCH_PIECES
+#define ZL_BATCH_PIECES 4
+#endif
+#ifndef ZL_BATCH_GRAIN
+#define ZL_BATCH_GRAIN 1024
+#endif
+
 // memcpy of a large block on the pool's threads: one core copies at 10 - 15 GB/s, which is what the streaming entries' job
 // buffers ran at (64 MiB in and 40 MiB out per job, 8 ms of an 11 ms job); small blocks stay on the caller.
 static inline void zl_memcpy_mt(void* dst, const void* src, size_t n) {

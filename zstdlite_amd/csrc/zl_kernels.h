@@ -110,7 +110,7 @@ struct zl2_args {
     u32* seq_scratch;
     u32 ignore_checksum;
     u64* stats;  // optional (profiling): exec-kernel phase cycles {scan, literals, matches, flush, batches, blocks}
-    u32* max_blocks;  // device words, zeroed before the launch: [0] the largest block count of a frame on the pipeline (set by zl2_index_kernel), [1] frames left to the general kernel
+    u32* max_blocks;  // device words, zeroed before the launch: [0] the largest block count of a frame on the pipeline (set by zl2_index_kernel), [1] frames left to the general kernel, [2] the schedule (ZL2_MODE_*, set by zl2_order_kernel), [3] frames zl2_small_kernel finished
     u32* order;       // 2 x nframes entries: the frames sorted by decreasing sequence count, then by decreasing literal bytes (zl2_order_kernel)
     u32 fuse1;        // launches whose frames all have one block: bit 0 literal and sequence lanes in ONE kernel (zl2_entropy1_kernel); bit 1 a chain on a quad of lanes; bit 2 ... and on two waves, producer and consumer (round 5); 0: two kernels (experiments)
     // ---- large-frame pipeline only (zl_decode3.hip): the "frames" are segments (1 to ZL2_MAXB consecutive blocks) of ONE frame
@@ -143,11 +143,13 @@ struct zl2_args {
 #define ZL2_ROLE_X1 4u   // exec kernel, main stream (behind E1)
 #define ZL2_ROLE_XS 5u   // exec kernel, second stream (behind ES)
 #define ZL2_MODE_WHOLE 0u   // the batch is not cut: E1 and X1 cover everything, the other launches return at once
+#define ZL2_MODE_NONE 2u    // every frame was decoded in front of the lanes (zl2_small_kernel): every launch returns at once
 #define ZL2_MODE_HALVES 1u  // single-block frames: the expensive half of the order on the main stream (E1, X1), the cheap half -- entropy and exec -- beside it (ES, XS)
 // the groups (of ZL2_WG_FRAMES frames of the sequence order) a launch covers: [g0, g1)
 __device__ __forceinline__ void zl2_part_range(const zl2_args& a, u32& g0, u32& g1, bool& split) {
     const u32 all = (a.nframes + 7) / 8;
     g0 = 0; g1 = all; split = false;
+    if (a.big == nullptr && a.max_blocks[2] == ZL2_MODE_NONE) { g1 = 0; return; }
     if (!a.part) return;
     const u32 mode = a.max_blocks[2];
     split = mode != ZL2_MODE_WHOLE;
