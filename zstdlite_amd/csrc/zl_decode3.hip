@@ -741,6 +741,16 @@ __global__ __launch_bounds__(64 * ZL3_OFF_WAVES) void zl3_offsets_kernel(zl3_dev
 #ifndef ZL3_COPY_SLICE
 #define ZL3_COPY_SLICE 1024u                   // output bytes per workgroup: four per thread (4096: every thread made four rounds one behind the other; 23.0 -> 21.8 ms on the 1 GiB reference frame)
 #endif
+// Round 6, measured on the 1 GiB reference frame (ordered copies 3.9 of its 19.6 ms; 192 launches of 17 - 20 us) and taken out again:
+//  * with the walks and the byte reads compiled out the launches take 0.6 ms together, with the walks alone out 2.4: the time is the
+//    dependent trips to memory, not the scan of the links;
+//  * several quads per thread travelling TOGETHER (all their links asked for at once, walks in step; 2048 / 1024 workgroups per launch
+//    instead of 4096): 1 / 2 / 4 quads 19.7 / 19.9 / 20.6 ms, this library's own frame 10.4 / 10.6 / 11.3 -- a wave walks as long as
+//    the longest of its bytes' chains;
+//  * a quad that waits for four consecutive positions (the inside of a match) moved by ONE 16-byte link read and ONE 4-byte read: no change;
+//  * the walks of ALL groups in one launch up front (they only read and shorten links: no order among them), the ordered launches
+//    left with link -> byte -> store: the ordered launches 19.7 -> 11.9 us each, but the walk launch takes 2.2 ms -- the walks are bound
+//    by their number (one 64-byte line per link read of a short match), not by the order: 3.96 -> 4.5 ms.
 __global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* dst, const u32* link, const u32* tile_flag, u64 gstart, zl3_info* info) {
     const u64 n = info->produced;
     const u64 s0 = gstart + (u64)blockIdx.x * ZL3_COPY_SLICE;
