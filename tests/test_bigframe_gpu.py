@@ -237,6 +237,43 @@ def test_damaged_large_frames_agree_with_the_oracle(ref, oracle):
 
 
 @needs_ref
+def test_the_link_array_is_kept_between_decodes(ref):
+    """One context, frames of different sizes one after the other, a damaged one in between: the large-frame pipeline keeps its
+    per-byte links between decodes (all "final" again once a decode has ended well, zl3_state_s::link_clean) and fills them only
+    after an error, for a frame larger than what has been filled, or on new memory -- every decode must come out as if on a fresh context."""
+    text = GENERATORS["text"](3 << 20, seed=31)
+    far = GENERATORS["text"](2 << 20, seed=32)
+    a = text
+    b = far + GENERATORS["iid10"](1 << 20, seed=33) + far[:1 << 20] + GENERATORS["rand"](1 << 20, seed=34) + far  # copies from megabytes back: bytes that wait
+    ca, cb = ref.compress(a, level=3), ref.compress(b, level=9)
+    bad = bytearray(cb)
+    bad[len(bad) // 2] ^= 0x10
+    dctx = z.zstd_dctx()
+    took = 0
+    for which in ["a", "b", "a", "bad", "b", "b", "a", "bad", "a", "b"]:
+        if which == "bad":
+            try:
+                got = z.zstd_decompress(bytes(bad), dctx=dctx)
+            except z.ZstdError:
+                got = None
+            assert got is None or got != b  # (a flipped bit in the middle of a frame: an error, or other bytes -- never a hang)
+            continue
+        comp, plain = (ca, a) if which == "a" else (cb, b)
+        assert z.zstd_decompress(comp, dctx=dctx) == plain, which
+        took += 1
+    assert large_frames(dctx) >= took
+    # the device-resident entry, the same frames on one codec
+    import torch
+    from zstdlite_amd.device import DeviceCodec
+    codec = DeviceCodec(level=3)
+    for comp, plain in [(cb, b), (ca, a), (cb, b), (cb, b), (ca, a)]:
+        d_src = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+        d_dst = torch.zeros(len(plain), dtype=torch.uint8, device="cuda")
+        total, _ = codec.decompress(d_src, codec.frame_table([len(comp)], [len(plain)]), d_dst)
+        assert total == len(plain) and bytes(d_dst.cpu().numpy()) == plain
+
+
+@needs_ref
 def test_small_frame_without_content_size(ref, oracle):
     """A SMALL frame (here four blocks) that does not record its size: bounded by the room the caller gives, and -- since round 5,
     as every single frame of two blocks and more -- decoded by the large-frame pipeline (until then: the general kernel); a large

@@ -738,6 +738,10 @@ __global__ __launch_bounds__(64 * ZL3_OFF_WAVES) void zl3_offsets_kernel(zl3_dev
 #define ZL3_GROUP_LOG 22                       // 4 MiB of output per launch (measured 8 / 4 / 2 / 1 MiB on the 1 GiB reference frame: 7.0 / 5.8 / 6.6 / 8.5 ms)
 #endif
 #define ZL3_COPY_THREADS 256
+#define ZL3_NO_RESET (~0ull)
+#ifndef ZL3_KEEP_LINKS
+#define ZL3_KEEP_LINKS 1   // 0: the link array is filled in front of every decode, as rounds 1-5
+#endif
 #ifndef ZL3_COPY_SLICE
 #define ZL3_COPY_SLICE 1024u                   // output bytes per workgroup: four per thread (4096: every thread made four rounds one behind the other; 23.0 -> 21.8 ms on the 1 GiB reference frame)
 #endif
@@ -751,10 +755,25 @@ __global__ __launch_bounds__(64 * ZL3_OFF_WAVES) void zl3_offsets_kernel(zl3_dev
 //  * the walks of ALL groups in one launch up front (they only read and shorten links: no order among them), the ordered launches
 //    left with link -> byte -> store: the ordered launches 19.7 -> 11.9 us each, but the walk launch takes 2.2 ms -- the walks are bound
 //    by their number (one 64-byte line per link read of a short match), not by the order: 3.96 -> 4.5 ms.
-__global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* dst, const u32* link, const u32* tile_flag, u64 gstart, zl3_info* info) {
+__global__ __launch_bounds__(ZL3_COPY_THREADS) void zl3_group_copy_kernel(u8* dst, u32* link, const u32* tile_flag, u64 gstart, u64 reset_start, zl3_info* info) {
     const u64 n = info->produced;
+    if (info->err) return;
+    // The group that was copied by the launch in front of this one gets its links back to "final": every one of its bytes is, nothing in
+    // this launch reads a link in front of gstart, and a link array that is all ZL3_ROOT when a decode ends needs no fill when the next one
+    // begins (zl3_state_s::link_clean; the fill of 4 GiB for a 1 GiB frame ran beside the entropy stage and cost this library's own frame
+    // 0.7 of its 10.2 ms there).
+    if (reset_start != ZL3_NO_RESET) {
+        const u64 r0 = reset_start + (u64)blockIdx.x * ZL3_COPY_SLICE;
+        if (r0 < n && tile_flag[r0 >> ZL3_TILE_LOG]) {
+            const u64 q = r0 + threadIdx.x * 4;
+            if (q < n) {
+                const uint4 v = *(const uint4*)(link + q);
+                if (v.x < ZL3_MARK_MIN || v.y < ZL3_MARK_MIN || v.z < ZL3_MARK_MIN || v.w < ZL3_MARK_MIN) *(uint4*)(link + q) = make_uint4(ZL3_ROOT, ZL3_ROOT, ZL3_ROOT, ZL3_ROOT);
+            }
+        }
+    }
     const u64 s0 = gstart + (u64)blockIdx.x * ZL3_COPY_SLICE;
-    if (s0 >= n || info->err) return;
+    if (s0 >= n) return;
     if (!tile_flag[s0 >> ZL3_TILE_LOG]) return;  // (a slice lies inside one 16 KiB tile)
     for (u64 q = s0 + threadIdx.x * 4; q < s0 + ZL3_COPY_SLICE && q < n; q += ZL3_COPY_THREADS * 4) {
         const uint4 v = *(const uint4*)(link + q);  // (the link buffer is padded: reading a few entries past the end is fine)
@@ -850,10 +869,19 @@ struct zl3_state_s {
     hipEvent_t sink_ev[ZL3_SINK_EVENTS] = {};
     hipEvent_t sink_done[ZL3_SINK_EVENTS] = {};  // behind the download of each piece (zl3_hint::sink_hash)
     hipEvent_t fill_fork = nullptr, fill_join = nullptr;  // around the link fill that runs beside the entropy stage
+    bool link_clean = false;   // the first link_clean_bytes of the link array hold ZL3_ROOT throughout: the decode before this one ended well and its ordered copies put every link back
+    size_t link_clean_bytes = 0;
     // what phase 1 of a run in two calls leaves for phase 2 (zl3_hint::phase)
     struct Saved { zl3_dev d; zl2_args a; zl3_info info; u64 span = 0; hipStream_t fill_st = nullptr; bool valid = false; } sv;
 };
 
+static bool zl3_link_ensure(zl3_state_s* s, size_t bytes) {
+    const void* const p0 = s->link.p;
+    const size_t c0 = s->link.cap;
+    if (!s->link.ensure(bytes)) { s->link_clean = false; s->link_clean_bytes = 0; return false; }
+    if (s->link.p != p0 || s->link.cap != c0) { s->link_clean = false; s->link_clean_bytes = 0; }  // (new memory: nothing is known about it)
+    return true;
+}
 extern "C" zl3_state* zl3_create(void) { return new (std::nothrow) zl3_state_s(); }
 extern "C" void zl3_free(zl3_state* s) {
     if (!s) return;
@@ -1057,7 +1085,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         const u64 rspan = std::max<u64>(span, hint ? std::min<u64>(hint->reserve_span, 0xFFFFD000ull) : 0);
         // (the sequence records of later runs are not known yet: room for half as many again)
         if (!s->lit.ensure(std::max<u64>(info.lit_total, hint && hint->reserve_span ? rspan : 0) + 64) || !s->seq.ensure((hint && hint->reserve_span && s->seq.cap < info.seq_total * 16 + 64 ? info.seq_total * 24 : info.seq_total * 16) + 64) ||
-            !s->link.ensure(rspan * 4 + 64) || !s->tile_flag.ensure(((rspan >> ZL3_TILE_LOG) + 1) * 4) || !s->tot.ensure((size_t)d.cap_blocks * 16))
+            !zl3_link_ensure(s, rspan * 4 + 64) || !s->tile_flag.ensure(((rspan >> ZL3_TILE_LOG) + 1) * 4) || !s->tot.ensure((size_t)d.cap_blocks * 16))
             return ZL_OOM_HERE;
         }
         // An exec workgroup works through a RUN of consecutive segments; what a run's bytes copy from in front of the run waits for
@@ -1092,7 +1120,11 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (!getenv("ZL_DEV_NO_FILL"))  // (experiment, round 6: what the fill costs the stages beside it -- this library's 1 GiB frame: entropy 3.33 -> 2.83 ms, exec 2.83 -> 2.59, the decode 10.2 -> 9.5 ms; the output is then wrong.
                                         // Doing without it means links written for every byte of every region that holds a waiting one, and a flag read per hop of the ordered copies: not built)
 #endif
+        if (!(ZL3_KEEP_LINKS && s->link_clean && span * 4 + 64 <= s->link_clean_bytes)) {
         if (hipMemsetAsync(s->link.p, 0xFF, span * 4 + 64, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        s->link_clean_bytes = std::max<size_t>(s->link_clean && ZL3_KEEP_LINKS ? s->link_clean_bytes : 0, (size_t)(span * 4 + 64));
+        }
+        s->link_clean = false;  // (until this decode has ended well)
         if (fill_st != st && hipEventRecord(s->fill_join, fill_st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         a.frames = d.frames; a.plan = d.plan; a.frec = d.frec; a.brec = d.brec; a.nframes = info.nsegs; a.src = d_src; a.dst = d_dst; a.results = nullptr;
         a.lit_scratch = (u8*)s->lit.p; a.seq_scratch = (u32*)s->seq.p; a.ignore_checksum = 1; a.stats = nullptr; a.max_blocks = d.max_blocks; a.order = (u32*)s->order.p;
@@ -1140,10 +1172,18 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
             if (hipMemcpyAsync(s->h_gflag.p, s->gflag.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
             gflags = (const u32*)s->h_gflag.p;
         }
+        // Putting the links back costs the ordered launches a second look at every group's links (the 1 GiB reference frame: 19.5 -> 19.8 ms)
+        // and saves the decode behind this one its fill -- which costs a frame of small blocks 0.6 - 0.9 ms (its literal and sequence lanes
+        // read and write memory all the time: this library's own 1 GiB frame 10.2 -> 9.6 - 9.9 ms) and a frame of 128 KiB blocks next to
+        // nothing (the fill runs beside chains of 22 000 sequences that leave the memory system idle).  So: frames whose segments hold
+        // several blocks leave their links clean, the others leave them as they are and the next decode fills.
+        const bool keep = ZL3_KEEP_LINKS && (u64)info.nsegs * 2 <= info.nblocks;
+        u64 launched = ZL3_NO_RESET;  // the group of the launch in front: its links are put back by the next launch (zl3_group_copy_kernel)
         for (u64 g = 0; g < span; g += (u64)1 << glog) {
             if (gflags && !gflags[g >> glog]) continue;
             hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << glog) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
-                               d_dst + fd.dst_off, (const u32*)s->link.p, (const u32*)s->tile_flag.p, g, d.info);
+                               d_dst + fd.dst_off, (u32*)s->link.p, (const u32*)s->tile_flag.p, g, keep ? launched : ZL3_NO_RESET, d.info);
+            launched = g;
             const u64 done = g + ((u64)1 << glog);
             if (sink && (done & (((u64)1 << ZL3_SINK_LOG) - 1)) == 0 && done < span && nsink < ZL3_SINK_EVENTS) {
                 if (!s->sink_ev[nsink] && hipEventCreateWithFlags(&s->sink_ev[nsink], hipEventDisableTiming) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
@@ -1151,6 +1191,9 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
                 nsink++;
             }
         }
+        if (keep && launched != ZL3_NO_RESET)  // (the last group's links: a launch that copies nothing)
+            hipLaunchKernelGGL(zl3_group_copy_kernel, dim3((1u << glog) / ZL3_COPY_SLICE), dim3(ZL3_COPY_THREADS), 0, st,
+                               d_dst + fd.dst_off, (u32*)s->link.p, (const u32*)s->tile_flag.p, (u64)1 << 62, launched, d.info);
         // the download of what is finished, piece by piece behind the events, on a stream of its own (the host thread waits in
         // these calls when the memory is pageable; the copy kernels are all queued by now).  With a content checksum to check
         // (sink_hash) a second thread runs the XXH64 chain over every piece as soon as the event behind its copy has fired: the
@@ -1193,6 +1236,7 @@ extern "C" size_t zl3_decode_frame(zl3_state* s, const zl_frame_desc* fdp, const
         if (hipMemcpyAsync(&info, d.info, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
         stamp("resolve");
         if (info.err == ZL_E_FALLBACK) return ZL_ERR(ZL_E_FALLBACK);
+        s->link_clean = keep && !info.err;  // (every launch above has run: the stream was drained for `info`)
         if (nsink && !info.err) *hint->sunk = (u64)nsink << ZL3_SINK_LOG;  // (a frame that failed or goes to the general kernel is downloaded as a whole, whatever was copied)
         if (hint && hint->run_out && !info.err) { hint->run_out[0] = info.produced; for (int k = 0; k < 3; k++) hint->run_out[1 + k] = info.rep_end[k]; }
     }
