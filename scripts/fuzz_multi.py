@@ -40,7 +40,12 @@ for rd in range(rounds):
         # (one object of more than 16 KiB without a dictionary is searched by the deep match finder, the objects of a batch by the tables:
         # both valid, not the same bytes -- DESIGN.md 3.3)
         one = z.zstd_compress(items[k], cctx=cctx, frame_layout="frames")
-        assert comps[k] == one or len(items[k]) > 131072 or (len(items[k]) > 16384 and not use_d), "batch item differs from the one-object entry"
+        if not (comps[k] == one or len(items[k]) > 131072 or (len(items[k]) > 16384 and not use_d)):
+            import os, pickle
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(f"gpurun_out/multi_fail_{rd}.pkl", "wb") as fh:
+                pickle.dump({"item": items[k], "batch": comps[k], "one": one, "dict": d_trained if use_d else None, "items": items, "k": k}, fh)
+        assert comps[k] == one or len(items[k]) > 131072 or (len(items[k]) > 16384 and not use_d), ("batch item differs from the one-object entry", len(items), use_d, len(items[k]), len(comps[k]), len(one), comps[k][:16].hex(), one[:16].hex())
         assert z.zstd_decompress(one, **kw) == items[k] or len(items[k]) > 131072
         for i in rng.integers(0, len(items), 5):
             assert ref.decompress(comps[int(i)], max(len(items[int(i)]), 1), dict=d_trained if use_d else None) == items[int(i)], "reference decoder disagrees on a batch item"

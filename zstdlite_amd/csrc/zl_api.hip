@@ -291,6 +291,7 @@ struct zl_dctx_s {
         void* big = nullptr;  // (StreamFrame*) ONE large frame that is decoded while it arrives (zl_decompressStream, below)
         size_t skip = 0;      // ... handed back to the collecting route after this many of its bytes had been handed out
         bool no_big = false;  // ... which keeps the frame under way
+        DevBuf spare_src, spare_dst;  // the device buffers of the frame before this one, when it ended well (an unpledged stream is a frame of 64 MiB after the other: two allocations, a device-wide wait and two frees each, 0.75 of a frame's 4.8 ms); at most 256 MiB each
     } ds;
     zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
     // what is known about the large frames of the call being enqueued (either, or neither):
@@ -508,6 +509,7 @@ size_t zl_freeDCtx(zl_dctx* d) {
     if (d->pending) (void)hipStreamSynchronize(d->pending_stream);
     stream_frame_free(d->ds.big);
     d->ds.big = nullptr;
+    d->ds.spare_src.release(); d->ds.spare_dst.release();
     DevBuf* bufs[] = {&d->d_src, &d->d_dst, &d->d_frames, &d->d_results, &d->d_counter, &d->d_lit, &d->d_seq, &d->d_dict, &d->d_dict_tables, &d->d_order, &d->d_stats,
                       &d->d_plan, &d->d_frec, &d->d_brec, &d->d_lit2, &d->d_seq2, &d->d_chunk_off, &d->d_run_off, &d->d_run_results, &d->d_dict_ext, &d->d_dict_pre};
     for (DevBuf* b : bufs) b->release();
@@ -1255,6 +1257,23 @@ size_t stream_frame_fallback(zl_dctx* d) {
     return 2;
 }
 
+// The route's copies go over the process's copy pair (zl_copy_pair.h), up on one stream and down on the other, and are waited for at once.
+// (A plain hipMemcpy rides the NULL stream, which waits for every blocking stream of the process -- a caller's own kernels included.  What it
+// did not change: the 1 GiB frame's time, feed 21.6 + first calls 2.5 + second calls 10.8 + downloads 19.3 of 54 ms.  A run's 85 MiB of
+// output come down beside ONE call's upload of 8 MiB, and a call may not write into the caller's buffer after it has returned.)
+#ifndef ZL_STREAM_EARLY_HALVES
+#define ZL_STREAM_EARLY_HALVES 4  // a call's early download: at most this many HALVES of the call's input size
+#endif
+#ifndef ZL_STREAM_DOWN_LATER
+#define ZL_STREAM_DOWN_LATER 1  // what a call's own second calls have decoded waits for the next calls' uploads to come down beside (0: only when the call has handed out something already, as until round 6)
+#endif
+static bool stream_copy(void* dst, const void* src, size_t n, bool up) {
+    const ZlCopyPair* const pair = zl_copy_pair();
+    if (!pair) return hipMemcpy(dst, src, n, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess;
+    const hipStream_t st = up ? pair->up : pair->down;
+    return hipMemcpyAsync(dst, src, n, up ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+}
+
 // takes bytes that follow the frame's bytes so far: walked, uploaded.  Returns how many of [p, p + n) it took, or an error code;
 // *fell: these are not a frame's blocks -- the caller leaves the route (stream_frame_fallback: the collecting route's buffer then
 // holds the frame up to and including the bytes taken here)
@@ -1265,7 +1284,7 @@ size_t stream_frame_feed(zl_dctx* d, const u8* p, size_t n, bool* fell) {
     if (F.got < F.h.header_size) {  // the header: part of the frame on the device (block positions count from the frame's start), not walked
         pre = (size_t)std::min<u64>(n, F.h.header_size - F.got);
         if (!devbuf_grow_keep(F.d_src, (size_t)(F.got + pre + 64), (size_t)F.got)) return ZL_OOM_HERE;
-        if (hipMemcpy((u8*)F.d_src.p + F.got, p, pre, hipMemcpyHostToDevice) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (!stream_copy((u8*)F.d_src.p + F.got, p, pre, true)) return ZL_ERR(ZL_E_GENERIC);
         F.got += pre;
     }
     if (n == pre || F.got < F.h.header_size || (F.last_seen && F.got >= F.frame_end())) return pre;
@@ -1274,7 +1293,7 @@ size_t stream_frame_feed(zl_dctx* d, const u8* p, size_t n, bool* fell) {
     if (bad) { *fell = true; return pre; }  // (the caller leaves the route: stream_frame_fallback)
     if (took) {
         if (!devbuf_grow_keep(F.d_src, (size_t)(F.got + took + 64), (size_t)F.got)) return ZL_OOM_HERE;
-        if (hipMemcpy((u8*)F.d_src.p + F.got, p + pre, took, hipMemcpyHostToDevice) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (!stream_copy((u8*)F.d_src.p + F.got, p + pre, took, true)) return ZL_ERR(ZL_E_GENERIC);
         F.got += took;
     }
     return pre + took;
@@ -1295,11 +1314,14 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
     bool early_ok = true;
     if (F.handed < F.out_pos && output->pos < output->size && output->dst && F.out_pos - F.handed >= ((u64)1 << 20)) {
         early_k = (size_t)std::min<u64>(output->size - output->pos, F.out_pos - F.handed);
+        // (only what this call's upload can hide: a run leaves some 85 MiB at once, and all of it beside one call's 8 MiB of input had the
+        // call wait 1.3 of the copy's 1.6 ms while the next five calls brought nothing down -- the rest rides beside THEIR uploads)
+        if (!idle_call && !F.last_seen) early_k = std::min<size_t>(early_k, std::max<size_t>((size_t)4 << 20, (size_t)ZL_STREAM_EARLY_HALVES * (input->size - input->pos) / 2));
         early_at = (u8*)output->dst + output->pos;
         int dev = 0;
         (void)hipGetDevice(&dev);
         const u8* from = (const u8*)F.d_dst.p + F.handed;
-        try { early_th = std::thread([=, &early_ok]() { (void)hipSetDevice(dev); early_ok = hipMemcpy(early_at, from, early_k, hipMemcpyDeviceToHost) == hipSuccess; }); }
+        try { early_th = std::thread([=, &early_ok]() { (void)hipSetDevice(dev); early_ok = stream_copy(early_at, from, early_k, false); }); }
         catch (...) { early_k = 0; }
     }
     auto land_early = [&]() -> bool {  // (before anything reads the bytes or the call returns)
@@ -1377,13 +1399,13 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
     }
     // (what this call's second calls have just decoded waits for the next call, which brings it down beside its own work -- unless
     // nothing is in flight to work on, the caller brought no input, or this call has handed out nothing yet)
-    const bool later = !idle_call && !F.last_seen && F.out_pos - F.handed >= ((u64)1 << 20) && output->pos != out_at_entry;
+    const bool later = !idle_call && !F.last_seen && F.out_pos - F.handed >= ((u64)1 << 20) && (ZL_STREAM_DOWN_LATER || output->pos != out_at_entry);
     if (F.handed < F.out_pos && output->pos < output->size && !later) {
         if (!output->dst) return ZL_ERR(ZL_E_DSTBUFFER_NULL);
         const size_t k = (size_t)std::min<u64>(output->size - output->pos, F.out_pos - F.handed);
         u8* at = (u8*)output->dst + output->pos;
         SF_T0;
-        if (hipMemcpy(at, (const u8*)F.d_dst.p + F.handed, k, hipMemcpyDeviceToHost) != hipSuccess) return ZL_ERR(ZL_E_GENERIC);
+        if (!stream_copy(at, (const u8*)F.d_dst.p + F.handed, k, false)) return ZL_ERR(ZL_E_GENERIC);
         SF_ADD(t_down);
         if (F.hashing) F.hasher.update(at, k);
         F.handed += k;
@@ -1396,6 +1418,14 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
 #ifdef ZL_DEV_SWITCHES
         if (getenv("ZL_DEBUG_SLAB")) fprintf(stderr, "[zl stream frame] %zu calls, %zu runs on %d slots: feed (walk + upload) %.1f ms, first calls %.1f ms, second calls %.1f ms, downloads %.1f ms\n", F.calls, F.nruns(), F.K, F.t_feed, F.t_start, F.t_finish, F.t_down);
 #endif
+        {   // (the buffers wait for the next frame: nothing is in flight on them once every run has been finished and handed out)
+            const size_t keep_max = ((size_t)256 << 20) + ((size_t)64 << 20);
+            if (verdict == 0 && F.d_src.cap <= keep_max && F.d_dst.cap <= keep_max && (hipDeviceSynchronize() == hipSuccess)) {
+                d->ds.spare_src.release(); d->ds.spare_dst.release();
+                std::swap(d->ds.spare_src.p, F.d_src.p); std::swap(d->ds.spare_src.cap, F.d_src.cap);
+                std::swap(d->ds.spare_dst.p, F.d_dst.p); std::swap(d->ds.spare_dst.cap, F.d_dst.cap);
+            }
+        }
         stream_frame_free_impl(d->ds.big);
         d->ds.big = nullptr;
         return verdict;
@@ -1420,6 +1450,8 @@ bool stream_frame_begin(zl_dctx* d, const FrameHeader& h) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (u64)h.content_size + (h.content_size >> 7) + ((u64)256 << 20) > (u64)free_b / 2) { delete F; return false; }
     }
+    std::swap(F->d_src.p, d->ds.spare_src.p); std::swap(F->d_src.cap, d->ds.spare_src.cap);  // (what the frame before left behind, if anything: ensure() keeps a buffer that is large enough)
+    std::swap(F->d_dst.p, d->ds.spare_dst.p); std::swap(F->d_dst.cap, d->ds.spare_dst.cap);
     if (!F->d_dst.ensure((size_t)h.content_size + 64) || !F->d_src.ensure((size_t)h.content_size + (size_t)(h.content_size >> 8) + ((size_t)64 << 10))) { stream_frame_free_impl(F); return false; }
     d->ds.big = F;
     return true;

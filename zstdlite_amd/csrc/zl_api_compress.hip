@@ -430,8 +430,11 @@ size_t cctx_enqueue_group(zl_cctx* c, zl_cctx_s::EncSet& es, u8* d_dst, const u8
 #define ZL_ENT_SPLIT 0  // 1: the entropy stage as two kernels with a register allocation each (zl_encode.hip zl_entropy_kernel<1>, <2>).  Measured, round 5, same bytes: 18 and 0 vector registers spilled in the halves (64 and 114 registers) against the one kernel's 60 -- and 1.98 ms per GiB of the mix against the one kernel's 1.75 (second half at 5 / 8 workgroups per CU: 1.88 / 2.03): the spills are not what the stage waits for
 #endif
     e.handover = nullptr;
-    // small objects on a dictionary's entropy tables (zl_encode.hip zl_entropy_small_kernel): levels 3 and 4 (repeat offset 1 only), no checksum, literals Huffman-coded
-    e.small_done = (ZL_ENT_SMALL && e.cdict != nullptr && !e.exact_rep && !e.raw_lits && !e.checksum && !e.joined && e.order == nullptr && c->chunk_cap < 16384u) ? 1u : 0u;
+    // small objects on a dictionary's entropy tables (zl_encode.hip zl_entropy_small_kernel): levels 3 and 4 (repeat offset 1 only), no checksum, literals Huffman-coded.
+    // (Whatever the call's other objects are like -- until the end of round 6 only calls whose LARGEST object was below 16 KiB: the kernel takes a valid
+    // table as it is where the general kernel weighs it against the predefined one, so an object came out of a batch of small ones with other bytes --
+    // of the same size, scripts/fuzz_multi.py seed 162 -- than out of the one-object entry or a batch that held a large object too.)
+    e.small_done = (ZL_ENT_SMALL && e.cdict != nullptr && !e.exact_rep && !e.raw_lits && !e.checksum && !e.joined && e.order == nullptr) ? 1u : 0u;
     if (ZL_ENT_SPLIT && c->profile < 2) {  // (the in-kernel phase stamps of ZL_c_profile = 2 describe the one-kernel form)
         if (!es.handover.ensure((size_t)cnt * ZL_ENT_HANDOVER + 64)) return kGpuUnavailable;
         e.handover = (u8*)es.handover.p;

@@ -3222,6 +3222,7 @@ struct SmallShared {
     u32 stage[SMALL_OBJECTS][SMALL_STAGE_WORDS];
 };
 
+#define SMALL_OWN_TABLE_FROM 64u  // literal bytes from which on an object whose literals stay raw under the dictionary's codes goes to the general kernel
 __global__ __launch_bounds__(SMALL_G * SMALL_OBJECTS) void zl_entropy_small_kernel(zl_entropy_args a, u32 nchunks) {
     __shared__ SmallShared S;
     const u32 t = threadIdx.x, lane = t & (SMALL_G - 1), slot = t / SMALL_G;  // (lane: inside the object's group)
@@ -3272,6 +3273,13 @@ __global__ __launch_bounds__(SMALL_G * SMALL_OBJECTS) void zl_entropy_small_kern
     const u32 csize = (lbits + 8) >> 3;
     const u32 lhs_r = 1 + (nlit >= 32);
     const bool huf = nlit >= 6 && 3 + csize < lhs_r + nlit;
+    // Literals the dictionary's codes do not shorten -- an object unlike the dictionary: i.i.d. symbols, numbers -- may well pay for a table of
+    // their own: the general kernel weighs one, this one cannot.  (scripts/fuzz_multi.py, seed 161: 300 bytes over ten letters, 314 bytes as a
+    // batch item -- a raw block -- against 158 through the one-object entry.)
+    if (!huf && nlit >= SMALL_OWN_TABLE_FROM) {
+        if (lane == 0) a.frame_size[c] = 0xFFFFFFFFu;
+        return;
+    }
     u32 lit_sec;
     if (huf) {
         lit_sec = 3 + csize;
