@@ -1261,8 +1261,8 @@ size_t stream_frame_fallback(zl_dctx* d) {
 // (A plain hipMemcpy rides the NULL stream, which waits for every blocking stream of the process -- a caller's own kernels included.  What it
 // did not change: the 1 GiB frame's time, feed 21.6 + first calls 2.5 + second calls 10.8 + downloads 19.3 of 54 ms.  A run's 85 MiB of
 // output come down beside ONE call's upload of 8 MiB, and a call may not write into the caller's buffer after it has returned.)
-#ifndef ZL_STREAM_EARLY_HALVES
-#define ZL_STREAM_EARLY_HALVES 4  // a call's early download: at most this many HALVES of the call's input size
+#ifndef ZL_STREAM_EARLY_PIECE
+#define ZL_STREAM_EARLY_PIECE (4u << 20)  // a call's early download comes down in pieces of this size, until the call is done
 #endif
 #ifndef ZL_STREAM_DOWN_LATER
 #define ZL_STREAM_DOWN_LATER 1  // what a call's own second calls have decoded waits for the next calls' uploads to come down beside (0: only when the call has handed out something already, as until round 6)
@@ -1312,22 +1312,40 @@ size_t stream_frame_step(zl_dctx* d, zl_outBuffer* output, zl_inBuffer* input) {
     u8* early_at = nullptr;
     std::thread early_th;
     bool early_ok = true;
+    std::atomic<bool> early_stop{false};
+    std::atomic<size_t> early_done{0};
     if (F.handed < F.out_pos && output->pos < output->size && output->dst && F.out_pos - F.handed >= ((u64)1 << 20)) {
         early_k = (size_t)std::min<u64>(output->size - output->pos, F.out_pos - F.handed);
-        // (only what this call's upload can hide: a run leaves some 85 MiB at once, and all of it beside one call's 8 MiB of input had the
-        // call wait 1.3 of the copy's 1.6 ms while the next five calls brought nothing down -- the rest rides beside THEIR uploads)
-        if (!idle_call && !F.last_seen) early_k = std::min<size_t>(early_k, std::max<size_t>((size_t)4 << 20, (size_t)ZL_STREAM_EARLY_HALVES * (input->size - input->pos) / 2));
+        // (A run leaves some 85 MiB at once.  All of it beside one call's 8 MiB of input had the call wait 1.3 of the copy's 1.6 ms while
+        // the next five calls brought nothing down; a fixed share -- twice the call's input -- hid 6 of the 19 ms.  Now the thread copies
+        // PIECE BY PIECE for as long as the call has work of its own -- its upload, its waits for the runs -- and stops behind the piece
+        // under way when the call is done: the rest rides beside the following calls.)
         early_at = (u8*)output->dst + output->pos;
         int dev = 0;
         (void)hipGetDevice(&dev);
         const u8* from = (const u8*)F.d_dst.p + F.handed;
-        try { early_th = std::thread([=, &early_ok]() { (void)hipSetDevice(dev); early_ok = stream_copy(early_at, from, early_k, false); }); }
+        const size_t want = early_k;
+        try {
+            early_th = std::thread([=, &early_ok, &early_stop, &early_done]() {
+                (void)hipSetDevice(dev);
+                size_t done = 0;
+                while (done < want) {
+                    const size_t piece = std::min<size_t>((size_t)ZL_STREAM_EARLY_PIECE, want - done);
+                    if (!stream_copy(early_at + done, from + done, piece, false)) { early_ok = false; break; }
+                    done += piece;
+                    early_done.store(done, std::memory_order_release);
+                    if (early_stop.load(std::memory_order_acquire)) break;
+                }
+            });
+        }
         catch (...) { early_k = 0; }
     }
     auto land_early = [&]() -> bool {  // (before anything reads the bytes or the call returns)
         if (!early_k) return true;
+        early_stop.store(true, std::memory_order_release);
         early_th.join();
         if (!early_ok) return false;
+        early_k = early_done.load(std::memory_order_acquire);
         if (F.hashing) F.hasher.update(early_at, early_k);
         F.handed += early_k;
         output->pos += early_k;
