@@ -10,7 +10,7 @@ import pytest
 
 import zstdlite_amd as z
 from zstdlite_amd import _lib
-from zl_testlib import GENERATORS, have_ref
+from zl_testlib import GENERATORS, have_ref, is_error
 
 pytestmark = pytest.mark.gpu
 needs_ref = pytest.mark.skipif(not have_ref(), reason="needs the reference build (oracle/_ref)")
@@ -626,3 +626,33 @@ def test_one_frame_from_host_memory_moves_slab_by_slab(ref, oracle):
         assert errs >= 10
     assert z.zstd_decompress(frames[0][0], dctx=dctx) == frames[0][1]  # the context is fine after the failures
     assert L.zl_DCtx_setParameter(dctx._ptr, 9010, -1) != 0 and L.zl_DCtx_setParameter(dctx._ptr, 9010, 0) == 0
+
+
+@needs_ref
+def test_an_input_taken_for_one_large_frame_that_is_not(ref, oracle):
+    """zl_decompressDCtx takes an input that OPENS with a frame large by its own word for that one frame, without a walk, and lets the
+    runs find the frame's end (zl_api.hip: spec_one); where the end is not the input's -- more frames behind it, a skippable frame, stray
+    bytes, a frame cut short -- the call starts over with the walk and must say what the reference says."""
+    import struct
+    L = _lib.lib()
+    text = GENERATORS["text"](3 << 20, seed=41)
+    ints = GENERATORS["int20"](1 << 20, seed=42)
+    big_ref, big_own = ref.compress(text, level=3, checksum=True), z.zstd_compress(text)
+    small = ref.compress(ints[:5000], level=3)
+    skip = struct.pack("<II", 0x184D2A53, 7) + b"skipped"
+    dctx = z.zstd_dctx()
+    assert L.zl_DCtx_setParameter(dctx._ptr, 9010, 1) == 0  # ZL_d_slabMiB: frames of a MiB and more move slab by slab
+    cases = []
+    for big in (big_ref, big_own):
+        cases += [(big, text), (big + small, text + ints[:5000]), (big + skip, text), (big + skip + big, text + text), (big + big_own, text + text), (skip + big, text)]
+    for buf, want in cases:
+        code, out = ref.decompress_code(buf, len(want))
+        assert code == len(want) and out == want
+        assert z.zstd_decompress(buf, dctx=dctx) == want
+    for buf in (big_ref + b"\x00\x01\x02", big_ref[:-1], big_own[:len(big_own) // 2], big_ref + small[:-3], big_own + b"\x28\xb5\x2f\xfd"):
+        cap = 2 * len(text) + 5000
+        code, _ = ref.decompress_code(buf, cap)
+        assert is_error(code)  # the reference refuses it
+        back = np.zeros(cap, dtype=np.uint8)
+        assert is_error(L.zl_decompressDCtx(dctx._ptr, back.ctypes.data, cap, buf, len(buf)))  # (the C entry: the mirror above reads frame by frame, as the R glue does)
+    assert z.zstd_decompress(big_own, dctx=dctx) == text

@@ -22,6 +22,8 @@
 #include "zl_decode3.h"
 #include "zl_xxh64.h"
 #include "zl_copy_pair.h"
+#include <deque>
+#include <memory>
 #include <mutex>
 
 static_assert(sizeof(zl_frame_t) == sizeof(zl_frame_desc), "frame table layouts must match");
@@ -294,6 +296,8 @@ struct zl_dctx_s {
         DevBuf spare_src, spare_dst;  // the device buffers of the frame before this one, when it ended well (an unpledged stream is a frame of 64 MiB after the other: two allocations, a device-wide wait and two frees each, 0.75 of a frame's 4.8 ms); at most 256 MiB each
     } ds;
     zl3_state* big = nullptr;  // large-frame pipeline (zl_decode3.hip), created on first use
+    bool spec_one = false;     // zl_decompressDCtx has taken its input for ONE large frame on the word of the frame's header, without a walk (decode_walked_frame_in_runs walks it run by run) ...
+    bool spec_failed = false;  // ... and it was not, or the runs could not take it: the call starts over with the walk
     // what is known about the large frames of the call being enqueued (either, or neither):
     struct HostWalk { std::vector<zl3_hblk> blocks; u32 end_pos = 0; const u8* host_src = nullptr; };  // (host_src: the frame's bytes in host memory, for decode_walked_frame_in_runs)
     std::vector<HostWalk> host_walk;   // host entries: per frame of the current launch group, the blocks the host walked (empty: none)
@@ -791,48 +795,108 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     const size_t n = (size_t)fd.src_size;
     FrameHeader h;
     if (ZL_IS_ERR(parse_frame_header(h, host_src, n)) || h.skippable || h.dict_id) return ZL_ERR(ZL_E_FALLBACK);
-    std::vector<Block> blk;
-    u64 pos = h.header_size;
+    SlabIO* const io = d->slab;  // (a host entry that moves the frame slab by slab: every frame it sends here is decoded in runs)
+    const size_t per = d->run_blocks ? (size_t)d->run_blocks : 8192;
+    // ---- the walk (find_frame_size's, with 64-bit positions and a look into every compressed block), cut into runs as it goes: `per`
+    // blocks each -- slab by slab, also no more compressed bytes than a slab holds.  Round 6, end: a host entry that took its input for ONE
+    // large frame on the word of its header (zl_dctx_s::spec_one) walks LAZILY, a run's blocks when the run is about to start: the two
+    // walks of this library's 1 GiB frame -- 65 536 blocks, a cache miss or two each: 5.4 ms for the frame table and 1.2 here -- used to
+    // stand in front of the first run, and with it in front of a download that is the call's longest pole (20 of its 27.6 ms).
+    const bool lazy = io != nullptr && d->spec_one;
+    // (the blocks live in chunks that never move and the cuts behind a lock: walking lazily, a thread of its own writes them AHEAD of the
+    // runs -- on the thread that starts the runs the walk of a run's 8192 blocks, a millisecond, stood in front of every start, and the call
+    // was slower than with the whole walk up front: 30.5 against 27.6 ms)
+    struct Walk {
+        enum : size_t { CH = 65536 };
+        std::unique_ptr<Block*[]> chunk;  // chunk[i]: blocks [i * CH, (i + 1) * CH)
+        size_t nchunk = 0, max_chunk = 0;
+        std::atomic<size_t> nblk{0};      // blocks written (a reader takes indices below what it has read here)
+        std::mutex m;
+        std::vector<size_t> cut{0};       // (under m) cut[r] .. cut[r + 1]: the blocks of run r ...
+        std::vector<u64> cut_pos;         // (under m) ... which begin at this frame position (the header of block cut[r]); one more entry than closed runs when the frame is over: its end
+        std::atomic<int> state{0};        // 1: the last block has been seen, 2: the bytes are not a frame's blocks (or not this frame alone), 3: told to stop
+        std::thread th;
+        ~Walk() { if (th.joinable()) { int z = 0; state.compare_exchange_strong(z, 3); th.join(); } for (size_t i = 0; i < nchunk; i++) delete[] chunk[i]; }
+        Block& at(size_t i) { return chunk[i / CH][i % CH]; }
+    } W;
+    W.max_chunk = n / (3 * Walk::CH) + 2;  // (a block takes three bytes at least)
+    W.chunk.reset(new (std::nothrow) Block*[W.max_chunk]);
+    if (!W.chunk) return kGpuUnavailable;
+    W.cut_pos.push_back(h.header_size);
+    const u64 run_bytes = io ? io->run_bytes : ~0ull;
+    const bool has_ck = h.has_checksum;
+    auto walk_all = [&W, host_src, n, per, run_bytes, has_ck, lazy, hs = (u64)h.header_size]() {
+        u64 pos = hs, open_bytes = 0;
+        size_t nb = 0, open_first = 0;
+        for (;;) {
+            if (W.state.load(std::memory_order_relaxed) == 3) return;
+            if (n - pos < 3) { W.state.store(2, std::memory_order_release); return; }
+            Block b;
+            b.hdr = rd_le(host_src + pos, 3);
+            const u32 type = (b.hdr >> 1) & 3, bsize = b.hdr >> 3;
+            const u64 csize = type == 1 ? 1 : bsize;
+            if (type == 3 || n - (pos + 3) < csize || (type == 2 && bsize > ZL_BLOCK_MAX)) { W.state.store(2, std::memory_order_release); return; }
+            // (the run so far is closed in front of a block that would make it too long)
+            if (nb - open_first >= per || open_bytes >= run_bytes) {
+                std::lock_guard<std::mutex> g(W.m);
+                W.cut.push_back(nb); W.cut_pos.push_back(pos);
+                open_first = nb; open_bytes = 0;
+            }
+            pos += 3;
+            b.at = pos;
+            b.use.uses = b.use.defs = 0;
+            if (type == 2 && !block_use(host_src + pos, bsize, b.use)) { W.state.store(2, std::memory_order_release); return; }
+            if (nb % Walk::CH == 0) {
+                if (W.nchunk >= W.max_chunk || !(W.chunk[W.nchunk] = new (std::nothrow) Block[Walk::CH])) { W.state.store(2, std::memory_order_release); return; }
+                W.nchunk++;
+            }
+            W.at(nb) = b;
+            nb++;
+            W.nblk.store(nb, std::memory_order_release);
+            pos += csize;
+            open_bytes += 3 + csize;
+            if (nb > 0x7FFFFFFFu) { W.state.store(2, std::memory_order_release); return; }
+            if (b.hdr & 1) {
+                // (the frame ends where the input does: a host entry's guess that its input is one frame is checked here)
+                const bool bad = (has_ck && n - pos < 4) || (lazy && pos + (has_ck ? 4u : 0u) != n);
+                { std::lock_guard<std::mutex> g(W.m); W.cut.push_back(nb); W.cut_pos.push_back(pos); }
+                W.state.store(bad ? 2 : 1, std::memory_order_release);
+                return;
+            }
+        }
+    };
+    // is run r cut (its last block walked, the block behind it in sight or the frame over)?  Waits for the walk as far as that takes.
+    size_t walk_err = 0;
+    auto have_run = [&](size_t r) -> bool {
+        for (;;) {
+            const int st8 = W.state.load(std::memory_order_acquire);
+            bool have;
+            { std::lock_guard<std::mutex> g(W.m); have = W.cut.size() > r + 1; }
+            if (st8 == 2) { walk_err = ZL_ERR(ZL_E_FALLBACK); return false; }
+            if (have) return true;
+            if (st8 == 1) return false;  // (the frame has no run r)
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    };
+    auto cut_of = [&](size_t r, u64* pos_out) -> size_t { std::lock_guard<std::mutex> g(W.m); if (pos_out) *pos_out = W.cut_pos[r]; return W.cut[r]; };
+    auto ncuts = [&]() -> size_t { std::lock_guard<std::mutex> g(W.m); return W.cut.size(); };
 #ifdef ZL_DEV_SWITCHES
     timespec w0; clock_gettime(CLOCK_MONOTONIC, &w0);
 #endif
-    for (;;) {  // (the walk of find_frame_size, with 64-bit positions and a look into every compressed block)
-        if (n - pos < 3) return ZL_ERR(ZL_E_FALLBACK);
-        Block b;
-        b.hdr = rd_le(host_src + pos, 3);
-        const u32 type = (b.hdr >> 1) & 3, bsize = b.hdr >> 3;
-        const u64 csize = type == 1 ? 1 : bsize;
-        pos += 3;
-        if (type == 3 || n - pos < csize || (type == 2 && bsize > ZL_BLOCK_MAX)) return ZL_ERR(ZL_E_FALLBACK);
-        b.at = pos;
-        b.use.uses = b.use.defs = 0;
-        if (type == 2 && !block_use(host_src + pos, bsize, b.use)) return ZL_ERR(ZL_E_FALLBACK);
-        blk.push_back(b);
-        pos += csize;
-        if (b.hdr & 1) break;
-        if (blk.size() > 0x7FFFFFFFu) return ZL_ERR(ZL_E_FALLBACK);
+    if (!lazy) walk_all();
+    else {
+        try { W.th = std::thread(walk_all); } catch (...) { walk_all(); }
     }
-    const u64 end_pos = pos;
+    if (!have_run(0)) return walk_err ? walk_err : ZL_ERR(ZL_E_FALLBACK);
 #ifdef ZL_DEV_SWITCHES
-    if (getenv("ZL_DEBUG_SLAB")) { timespec w1; clock_gettime(CLOCK_MONOTONIC, &w1); fprintf(stderr, "[zl slab] the runs' walk over %zu blocks: %.2f ms\n", blk.size(), (w1.tv_sec - w0.tv_sec) * 1e3 + (w1.tv_nsec - w0.tv_nsec) * 1e-6); }
+    if (getenv("ZL_DEBUG_SLAB")) { timespec w1; clock_gettime(CLOCK_MONOTONIC, &w1); fprintf(stderr, "[zl slab] the runs' walk over %zu blocks%s: %.2f ms\n", W.nblk.load(), lazy ? " so far (on a thread of its own, ahead of the runs)" : "", (w1.tv_sec - w0.tv_sec) * 1e3 + (w1.tv_nsec - w0.tv_nsec) * 1e-6); }
 #endif
-    if (h.has_checksum && n - pos < 4) return ZL_ERR(ZL_E_FALLBACK);
-    const size_t nb = blk.size();
-    const u64 bound = std::min<u64>(fd.dst_cap, (u64)nb * ZL_BLOCK_MAX);
-    const size_t per = d->run_blocks ? (size_t)d->run_blocks : 8192;
-    SlabIO* const io = d->slab;  // (a host entry that moves the frame slab by slab: every frame it sends here is decoded in runs)
-    if (!io && (d->run_blocks ? nb <= per : (bound < 0xFFFFD000ull && fd.src_size < 0xFFFFFF00ull))) return ZL_ERR(ZL_E_FALLBACK);  // (the pipeline takes it as a whole)
-    if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && h.content_size > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
-    // ---- run by run: `per` blocks each -- slab by slab, also no more compressed bytes than a slab holds
-    std::vector<size_t> cuts{0};
-    for (size_t b = 0; b < nb;) {
-        size_t e = b;
-        u64 bytes = 0;
-        while (e < nb && e - b < per && (!io || bytes < io->run_bytes)) { bytes += (e + 1 < nb ? blk[e + 1].at : end_pos + 3) - blk[e].at; e++; }
-        cuts.push_back(e);
-        b = e;
+    if (!lazy) {
+        const size_t nb = W.nblk.load();
+        const u64 bound = std::min<u64>(fd.dst_cap, (u64)nb * ZL_BLOCK_MAX);
+        if (!io && (d->run_blocks ? nb <= per : (bound < 0xFFFFD000ull && fd.src_size < 0xFFFFFF00ull))) return ZL_ERR(ZL_E_FALLBACK);  // (the pipeline takes it as a whole)
     }
-    const size_t nruns = cuts.size() - 1;
+    if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && h.content_size > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
     // ---- several runs in flight (round 4).  A run's entropy stage needs its bytes and the tables in force where it starts -- not
     // the output in front of it -- and lasts as long as its longest block's chains whatever the number of blocks (6 - 10 ms for the
     // 128 KiB blocks of a frame the reference wrote): one run after the other paid that once per run, 73 ms for the 1 GiB frame that
@@ -842,7 +906,9 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     // (four slots where blocks are large -- the reference's 128 KiB, whose entropy stage lasts 6 - 10 ms --, two where they are this
     // library's 16 KiB, whose stage is over in a millisecond or two: every slot costs its buffers, 5 GiB and 30 ms of allocation
     // in a context's first call)
-    const int K = std::min(max_slots, (end_pos / nb >= ((u64)24 << 10)) ? (int)zl_dctx_s::kRunSlots : 2);
+    u64 first_end = 0;
+    const size_t first_blocks = cut_of(1, &first_end);
+    const int K = std::min(max_slots, (first_end / first_blocks >= ((u64)24 << 10)) ? (int)zl_dctx_s::kRunSlots : 2);  // (the first run's blocks say how large the frame's are; until round 6: all of them)
     for (int k_ = 0; k_ < K; k_++) {
         auto& rs = d->run_slot[k_];
         if (!rs.big && !(rs.big = zl3_create())) return kGpuUnavailable;
@@ -868,20 +934,29 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     base_hint.host_blocks = nullptr; base_hint.d_chunk_off = nullptr; base_hint.nchunks = 0; base_hint.sink_host = nullptr; base_hint.sink_hash = nullptr;
     base_hint.headerless = 1; base_hint.not_last = 0; base_hint.tail = 0; base_hint.size_unknown = 1; base_hint.run_out = nullptr;
     base_hint.dict_id = 0;
-    std::vector<RunPlan> plan(nruns);
-    for (size_t r = 0; r < nruns; r++) {  // what the largest run needs: every slot's buffers are sized for it at once
-        const u64 blocks = cuts[r + 1] - cuts[r];
-        base_hint.reserve_blocks = std::max<u32>(base_hint.reserve_blocks, (u32)blocks + 4);
-        base_hint.reserve_span = std::max<u64>(base_hint.reserve_span, std::min<u64>(fd.dst_cap, blocks * ZL_BLOCK_MAX));
-    }
+    std::deque<RunPlan> plan;  // (grows with the runs: references stay good)
+    size_t reserved = 0;       // runs whose size is in the reserve
+    auto reserve_runs = [&]() {  // what the largest run needs: every slot's buffers are sized for it at once (walking lazily: the largest so far)
+        const size_t nc = ncuts();
+        for (; reserved + 1 < nc; reserved++) {
+            const u64 blocks = cut_of(reserved + 1, nullptr) - cut_of(reserved, nullptr);
+            base_hint.reserve_blocks = std::max<u32>(base_hint.reserve_blocks, (u32)blocks + 4);
+            base_hint.reserve_span = std::max<u64>(base_hint.reserve_span, std::min<u64>(fd.dst_cap, blocks * ZL_BLOCK_MAX));
+        }
+        if (plan.size() + 1 < nc) plan.resize(nc - 1);
+    };
+    reserve_runs();
     size_t started = 0;  // runs whose first call has been made
     // the first call of run r; wait: block until its bytes have arrived (else: only if they have).  1: started, 0: not yet, else an error code
     auto start_run = [&](size_t r, bool wait) -> size_t {
-        const size_t b0 = cuts[r], b1 = cuts[r + 1];
+        reserve_runs();
+        u64 run_s0 = 0, run_s1 = 0;
+        const size_t b0 = cut_of(r, &run_s0), b1 = cut_of(r + 1, &run_s1);
+        auto blk = [&](size_t i) -> const Block& { return W.at(i); };  // (indices below a cut: written, and published by the cut's lock)
         RunPlan& P = plan[r];
         // which tables does the run take over from the blocks in front of it?
         u32 need = 0, have = 0;
-        for (size_t b = b0; b < b1 && have != 15u; b++) { need |= blk[b].use.uses & ~have; have |= blk[b].use.defs; }
+        for (size_t b = b0; b < b1 && have != 15u; b++) { need |= blk(b).use.uses & ~have; have |= blk(b).use.defs; }
         u32 nd = 0;  // the donors: distinct, in frame order
         for (int q = 0; q < 4; q++) {
             if (!((need >> q) & 1)) continue;
@@ -892,17 +967,17 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         }
         std::sort(P.dn, P.dn + nd);
         P.need = need; P.nd = nd;
-        P.s0 = blk[b0].at - 3;
-        P.s1 = b1 < nb ? blk[b1].at - 3 : end_pos;
-        P.base = nd ? std::min<u64>(P.s0, blk[P.dn[0]].at - 3) : P.s0;
+        P.s0 = run_s0;  // (the header of the run's first block ...
+        P.s1 = run_s1;  // ... and of the block behind its last, or the frame's end)
+        P.base = nd ? std::min<u64>(P.s0, blk(P.dn[0]).at - 3) : P.s0;
         if (P.s1 - P.base >= 0xFFFFFF00ull) return ZL_ERR(ZL_E_FALLBACK);
         if (io) {  // (donors lie in front of the run: uploaded before it)
             if (!wait && io->uploaded.load(std::memory_order_acquire) < std::min<u64>(fd.src_off + P.s1, io->total)) return 0;
             if (!io->wait_uploaded(fd.src_off + P.s1)) return ZL_ERR(ZL_E_GENERIC);
         }
         hb.resize(b1 - b0 + nd);
-        for (size_t b = b0; b < b1; b++) { hb[b - b0].src_off = (u32)(blk[b].at - P.base); hb[b - b0].hdr = blk[b].hdr; }
-        for (u32 k = 0; k < nd; k++) { hb[b1 - b0 + k].src_off = (u32)(blk[P.dn[k]].at - P.base); hb[b1 - b0 + k].hdr = blk[P.dn[k]].hdr; }
+        for (size_t b = b0; b < b1; b++) { hb[b - b0].src_off = (u32)(blk(b).at - P.base); hb[b - b0].hdr = blk(b).hdr; }
+        for (u32 k = 0; k < nd; k++) { hb[b1 - b0 + k].src_off = (u32)(blk(P.dn[k]).at - P.base); hb[b1 - b0 + k].hdr = blk(P.dn[k]).hdr; }
         zl3_hint hx = base_hint;
         hx.ndonors = nd;
         for (int q = 0; q < 4; q++) {
@@ -923,24 +998,24 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         zl_dctx_s::RunSlot& rs = d->run_slot[r % K];
         const size_t e = zl3_decode_frame(rs.big, &P.run, d_src, d_dst, (u64*)d->d_run_results.p, 1, rs.st, &rs.side, &hx);
         if (e != 0) return e == kGpuUnavailable ? e : ZL_ERR(ZL_E_FALLBACK);
-        for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk[b].use.defs >> q) & 1) cur[q] = (u32)b;
+        for (size_t b = b0; b < b1; b++) for (int q = 0; q < 4; q++) if ((blk(b).use.defs >> q) & 1) cur[q] = (u32)b;
         return 1;
     };
-    for (size_t r = 0; r < nruns; r++) {
+    for (size_t r = 0; have_run(r); r++) {
 #ifdef ZL_DEV_SWITCHES
         static const bool dbg_slab = getenv("ZL_DEBUG_SLAB") != nullptr;
         auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
         const double t_a = now_ms();
 #endif
         // first calls: this run's (waiting for its bytes) and those of the next K - 1 whose bytes are there already
-        while (started < nruns && started < r + (size_t)K) {
+        while (started < r + (size_t)K && have_run(started)) {
             const size_t e = start_run(started, started == r);
             if (e == 0) break;
             if (e != 1) return e;
             started++;
         }
         // ... and while this run's entropy stage is under way, the first calls of the runs behind it as their bytes arrive
-        while (io && started < nruns && started < r + (size_t)K && hipStreamQuery(d->run_slot[r % K].st) == hipErrorNotReady) {
+        while (io && started < r + (size_t)K && hipStreamQuery(d->run_slot[r % K].st) == hipErrorNotReady && have_run(started)) {
             const size_t e = start_run(started, false);
             if (e == 1) { started++; continue; }
             if (e != 0) return e;
@@ -950,7 +1025,8 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         const double t_b = now_ms();
 #endif
         // the second call
-        const size_t b0 = cuts[r], b1 = cuts[r + 1];
+        if (walk_err) return walk_err;
+        const size_t b0 = cut_of(r, nullptr), b1 = cut_of(r + 1, nullptr);
         RunPlan& P = plan[r];
         if (out_pos > fd.dst_cap) return ZL_ERR(ZL_E_FALLBACK);
         zl3_hint hx = base_hint;
@@ -984,6 +1060,9 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
         if (io && h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos <= h.content_size) io->decoded.store(out_pos, std::memory_order_release);  // (the download thread follows)
         d->frame_runs++;
     }
+    if (walk_err) return walk_err;
+    u64 end_pos = 0;  // (every run has been through: the walk is over, its last cut is the frame's end)
+    (void)cut_of(ncuts() - 1, &end_pos);
     if (h.content_size != ZL_CONTENTSIZE_UNKNOWN && out_pos != h.content_size) return ZL_ERR(ZL_E_FALLBACK);
     const bool check = h.has_checksum && !d->ignore_checksum && !d->host_verify;
     if (io && !io->wait_uploaded(fd.src_off + n)) return ZL_ERR(ZL_E_GENERIC);
@@ -1261,6 +1340,9 @@ size_t stream_frame_fallback(zl_dctx* d) {
 // (A plain hipMemcpy rides the NULL stream, which waits for every blocking stream of the process -- a caller's own kernels included.  What it
 // did not change: the 1 GiB frame's time, feed 21.6 + first calls 2.5 + second calls 10.8 + downloads 19.3 of 54 ms.  A run's 85 MiB of
 // output come down beside ONE call's upload of 8 MiB, and a call may not write into the caller's buffer after it has returned.)
+#ifndef ZL_SPEC_ONE_FRAME
+#define ZL_SPEC_ONE_FRAME 1  // 0: zl_decompressDCtx walks every input's frames and blocks first, as until the end of round 6
+#endif
 #ifndef ZL_STREAM_EARLY_PIECE
 #define ZL_STREAM_EARLY_PIECE (4u << 20)  // a call's early download comes down in pieces of this size, until the call is done
 #endif
@@ -1601,6 +1683,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             }
             if (!d->d_run_results.ensure(64)) return kGpuUnavailable;
             e3 = decode_walked_frame_in_runs(d, tbl[i], host_src, d_src, d_dst, (u64*)d->d_results.p + i, st, hint);
+            if (d->spec_one && e3 != 0) { d->spec_failed = true; return ZL_ERR(ZL_E_FALLBACK); }  // (the frame table was a guess: nothing behind this line may go by it)
             if (e3 == kGpuUnavailable) {
                 // device memory ran out with several runs in flight: the extra slots go back, and the frame is decoded with what ONE
                 // state can do -- run after run, or (a frame the pipeline plans whole) by the whole-frame route below
@@ -1611,6 +1694,7 @@ size_t dctx_enqueue(zl_dctx* d, u8* d_dst, const u8* d_src, size_t n, hipStream_
             if (d->h_run_src.cap > ((size_t)64 << 20)) { free(d->h_run_src.p); d->h_run_src.p = nullptr; d->h_run_src.n = d->h_run_src.cap = 0; }  // (not kept: gigabytes)
             if (ZL_IS_ERR(e3) && e3 != ZL_ERR(ZL_E_FALLBACK)) return e3;
         }
+        if (d->spec_one && e3 != 0) { d->spec_failed = true; return ZL_ERR(ZL_E_FALLBACK); }  // (whatever kept the frame from the runs)
         if (e3 != 0 && d->slab) {  // the whole-frame routes need the whole frame, and decode it from its start again
             d->slab->voided = true;
             if (!d->slab->wait_uploaded(d->slab->total)) return ZL_ERR(ZL_E_GENERIC);
@@ -1994,7 +2078,21 @@ size_t decompress_with_seek_table(zl_dctx* d, u8* dst, size_t cap, const u8* src
 
 extern "C" {
 
+static size_t decompress_dctx_walked(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n, bool speculate);
+// (Round 6, end.)  An input that opens with a frame large by its own word is first taken for that ONE frame, without the walk over its
+// blocks that says where it ends: the walk is what the call's first run -- and with it the download, the longest pole -- used to wait for,
+// 6.6 of 27.6 ms for this library's 1 GiB frame.  The runs walk as they go and find the frame's end where the input's is; if not (frames
+// behind it, damage, anything the runs hand back), the call starts over the way it always went.
 size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n) {
+    if (!d) return ZL_ERR(ZL_E_GENERIC);
+    d->spec_one = d->spec_failed = false;
+    size_t r = decompress_dctx_walked(d, dst, cap, src_, n, ZL_SPEC_ONE_FRAME != 0);
+    const bool again = d->spec_failed;
+    d->spec_one = d->spec_failed = false;
+    if (again) r = decompress_dctx_walked(d, dst, cap, src_, n, false);
+    return r;
+}
+static size_t decompress_dctx_walked(zl_dctx* d, void* dst, size_t cap, const void* src_, size_t n, bool speculate) {
     if (!d) return ZL_ERR(ZL_E_GENERIC);
     if (!device_ok()) return kGpuUnavailable;
     if (d->pending) return ZL_ERR(ZL_E_STAGE_WRONG);
@@ -2071,6 +2169,25 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     size_t pos = 0;
     bool any = false;
     d->chunk_off.clear();
+    FrameHeader h_first;
+    if (speculate && early && dst && !ZL_IS_ERR(parse_frame_header(h_first, src, n)) && !h_first.dict_id && (size_t)h_first.header_size + 3 <= n &&
+        h_first.content_size != ZL_CONTENTSIZE_UNKNOWN && h_first.content_size > (u64)ZL2_MAXB * ZL_BLOCK_MAX && !d->run_headerless && !d->run_not_last) {  // (exactly the inputs the slabs below take)
+        // ONE frame, the whole input: a guess (the frame's blocks are not walked here; spec_one says so to whoever reads the table)
+        zl_frame_desc fd;
+        fd.src_off = 0; fd.src_size = n; fd.dst_off = 0; fd.dst_cap = h_first.content_size;
+        table.push_back(fd);
+        known.push_back(1);
+        has_ck.push_back(h_first.has_checksum ? 1 : 0);
+        zl_dctx_s::HostWalk hw;
+        hw.blocks.resize(1);  // (not empty: "the host has walked it" -- decode_walked_frame_in_runs does, from host_src)
+        hw.blocks[0].src_off = 0; hw.blocks[0].hdr = 0;
+        hw.end_pos = 0;
+        hw.host_src = src;
+        walks.push_back(std::move(hw));
+        d->spec_one = true;
+        pos = n;
+        any = true;
+    }
     while (n - pos >= 5) {
         FrameHeader h;
         zl_dctx_s::HostWalk hw;
@@ -2139,6 +2256,7 @@ size_t zl_decompressDCtx(zl_dctx* d, void* dst, size_t cap, const void* src_, si
     // ONE frame the host has walked, large enough: slab by slab.  Everything else: the whole input first (it is on its way already)
     const bool slabs = early && table.size() == 1 && known[0] && !walks[0].blocks.empty() && table[0].dst_cap >= slab_min && table[0].dst_cap <= cap && dst &&
                        table[0].dst_cap > (u64)ZL2_MAXB * ZL_BLOCK_MAX;  // (a frame the lane pipeline takes is read whole: it must have arrived)
+    if (d->spec_one && !slabs) { d->spec_failed = true; return ZL_ERR(ZL_E_FALLBACK); }  // (the guess is only good for the slabs)
     if (early && !slabs) {
         if (!io.wait_uploaded(n)) return ZL_ERR(ZL_E_GENERIC);
     } else if (!early) {
