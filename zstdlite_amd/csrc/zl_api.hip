@@ -907,8 +907,9 @@ size_t decode_walked_frame_in_runs(zl_dctx* d, const zl_frame_desc& fd, const u8
     // library's 16 KiB, whose stage is over in a millisecond or two: every slot costs its buffers, 5 GiB and 30 ms of allocation
     // in a context's first call)
     u64 first_end = 0;
-    const size_t first_blocks = cut_of(1, &first_end);
-    const int K = std::min(max_slots, (first_end / first_blocks >= ((u64)24 << 10)) ? (int)zl_dctx_s::kRunSlots : 2);  // (the first run's blocks say how large the frame's are; until round 6: all of them)
+    size_t first_blocks = cut_of(1, &first_end);
+    if (!lazy) first_blocks = cut_of(ncuts() - 1, &first_end);  // (the whole frame has been walked: its blocks' mean size, as ever)
+    const int K = std::min(max_slots, (first_end / first_blocks >= ((u64)24 << 10)) ? (int)zl_dctx_s::kRunSlots : 2);  // (walking lazily the first run's blocks say how large the frame's are)
     for (int k_ = 0; k_ < K; k_++) {
         auto& rs = d->run_slot[k_];
         if (!rs.big && !(rs.big = zl3_create())) return kGpuUnavailable;
