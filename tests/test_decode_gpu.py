@@ -415,3 +415,50 @@ def test_batch_entry_takes_frames_without_a_recorded_content_size(ref, oracle):
     assert r1 == 100 and one[:100].tobytes() == x
     with pytest.raises(z.ZstdError):              # (the R glue's mirror refuses it before any decoder runs, as src/raw-file.c does)
         z.zstd_decompress(f)
+
+
+def test_the_frame_table_walked_in_parts_is_the_serial_walk(ref):
+    """zl_decompressDCtx walks the frames of a large input (32 MiB and more) in PARTS side by side, every part but the first from the first
+    frame magic behind its start, and takes a part's list only where the list in front of it ends exactly there (zl_api.hip: ZL_WALK_PARTS).
+    Frame magics INSIDE frame data (random bytes are stored as they are), skippable frames, frames longer than a part and a cut-off
+    input: the same bytes and the same verdicts as the reference."""
+    import struct
+    L = _lib.lib()
+    rng = np.random.default_rng(77)
+    magic = bytes([0x28, 0xB5, 0x2F, 0xFD])
+    parts, want = [], []
+    total = 0
+    k = 0
+    while total < (40 << 20):
+        nbytes = int(rng.choice([300000, 1 << 20, 3 << 20, 9 << 20])) if k != 5 else (14 << 20)  # (one frame longer than a part of an eighth)
+        x = bytearray(rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes())
+        for at in range(1000, nbytes - 8, 65536):  # false frame starts all over the stored bytes
+            x[at:at + 4] = magic
+            x[at + 4] = int(rng.integers(0, 256))
+        x = bytes(x)
+        f = ref.compress(x, level=1) if k % 3 else z.zstd_compress(x, frame_layout="frames")
+        parts.append(f); want.append(x); total += len(f)
+        if k % 4 == 1:
+            pay = bytes(rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8))
+            parts.append(struct.pack("<II", 0x184D2A50 + k % 16, len(pay)) + pay); total += 8 + len(pay)
+        k += 1
+    buf, plain = b"".join(parts), b"".join(want)
+    dctx = z.zstd_dctx()
+    back = np.zeros(len(plain), dtype=np.uint8)
+    r = L.zl_decompressDCtx(dctx._ptr, back.ctypes.data, len(plain), buf, len(buf))
+    assert r == len(plain) and back.tobytes() == plain
+    for cut in (len(buf) - 1, len(buf) // 2, len(buf) // 8 + 5, 33 << 20):
+        rc, _ = ref.decompress_code(buf[:cut], len(plain))
+        r = L.zl_decompressDCtx(dctx._ptr, back.ctypes.data, len(plain), buf[:cut], cut)
+        assert _lib.is_error(r) == is_error(rc), cut
+    # (and a buffer whose every part starts inside a frame that holds no magic at all: one frame of zeros behind a small one)
+    zeros = bytes(600 << 20)
+    small = ref.compress(b"abc" * 1000, level=3)
+    f0 = ref.compress(zeros, level=3)
+    assert len(f0) < (1 << 20)  # (too small for the parts: the serial walk)
+    big_rand = rng.integers(0, 256, 34 << 20, dtype=np.uint8).tobytes()
+    f1 = ref.compress(big_rand, level=1)  # ONE frame of 34 MiB stored: every part lies inside it
+    buf2, plain2 = small + f1 + small, b"abc" * 1000 + big_rand + b"abc" * 1000
+    back2 = np.zeros(len(plain2), dtype=np.uint8)
+    r = L.zl_decompressDCtx(dctx._ptr, back2.ctypes.data, len(plain2), buf2, len(buf2))
+    assert r == len(plain2) and back2.tobytes() == plain2

@@ -1341,6 +1341,9 @@ size_t stream_frame_fallback(zl_dctx* d) {
 // (A plain hipMemcpy rides the NULL stream, which waits for every blocking stream of the process -- a caller's own kernels included.  What it
 // did not change: the 1 GiB frame's time, feed 21.6 + first calls 2.5 + second calls 10.8 + downloads 19.3 of 54 ms.  A run's 85 MiB of
 // output come down beside ONE call's upload of 8 MiB, and a call may not write into the caller's buffer after it has returned.)
+#ifndef ZL_WALK_PARTS
+#define ZL_WALK_PARTS 8u  // parts of a large input whose frames the pool walks side by side (zl_decompressDCtx); 1: one walk, as until the end of round 6
+#endif
 #ifndef ZL_SPEC_ONE_FRAME
 #define ZL_SPEC_ONE_FRAME 1  // 0: zl_decompressDCtx walks every input's frames and blocks first, as until the end of round 6
 #endif
@@ -2189,29 +2192,92 @@ static size_t decompress_dctx_walked(zl_dctx* d, void* dst, size_t cap, const vo
         pos = n;
         any = true;
     }
-    while (n - pos >= 5) {
-        FrameHeader h;
-        zl_dctx_s::HostWalk hw;
-        size_t fs = find_frame_size(src + pos, n - pos, &h, &hw.blocks, &hw.end_pos);
-        if (ZL_IS_ERR(fs)) {
-            if (any && fs == ZL_ERR(ZL_E_PREFIX_UNKNOWN)) fs = ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:41752
+    // The walk: frame after frame from `from`, until a frame starts at or behind `stop` (or the input ends, or a frame is not one).
+    struct FrameList { std::vector<zl_frame_desc> table; std::vector<u8> known, has_ck; std::vector<zl_dctx_s::HostWalk> walks; size_t err = 0; bool any = false; };
+    auto walk_frames = [src, n](size_t from, size_t stop, FrameList& fl) -> size_t {
+        size_t at = from;
+        while (n - at >= 5 && at < stop) {
+            FrameHeader h;
+            zl_dctx_s::HostWalk hw;
+            const size_t fs = find_frame_size(src + at, n - at, &h, &hw.blocks, &hw.end_pos);
+            if (ZL_IS_ERR(fs)) { fl.err = fs; return at; }
+            if (!h.skippable) {
+                zl_frame_desc fd;
+                fd.src_off = at;
+                fd.src_size = fs;
+                fd.dst_off = 0;
+                fd.dst_cap = h.content_size;
+                fl.table.push_back(fd);
+                fl.known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
+                fl.has_ck.push_back(h.has_checksum ? 1 : 0);
+                if (hw.blocks.size() <= ZL2_MAXB || hw.blocks.size() != h.nblocks) hw.blocks.clear();  // (small frames take the lane pipeline, which indexes on the device)
+                hw.host_src = src + at;
+                fl.walks.push_back(std::move(hw));
+            }
+            fl.any = true;
+            at += fs;
+        }
+        return at;
+    };
+    auto take = [&](FrameList& fl) {
+        table.insert(table.end(), fl.table.begin(), fl.table.end());
+        known.insert(known.end(), fl.known.begin(), fl.known.end());
+        has_ck.insert(has_ck.end(), fl.has_ck.begin(), fl.has_ck.end());
+        for (auto& w : fl.walks) walks.push_back(std::move(w));
+        any = any || fl.any;
+    };
+    // A large input of many frames (round 6, end): the walk is a chain of cache misses -- every frame's header and every block's, 5 ms for
+    // the 8192 frames of the 1 GiB mix, in front of everything else -- and a frame does not say where the next one starts.  The pool walks
+    // PARTS of the input side by side, every part but the first from the first frame magic at or behind its start; a part's list is taken
+    // only if the list in front of it ends EXACTLY where the part began (then it began at a true frame start, and what follows from one is
+    // what the serial walk finds); anything else -- magic bytes inside a frame's data, a frame longer than a part, an error -- is walked
+    // again from where the truth stands, one frame after the other.  Same table, same verdicts.
+    const size_t nparts = (pos == 0 && n >= ((size_t)32 << 20)) ? ZL_WALK_PARTS : 1;
+    if (nparts > 1) {
+        std::vector<FrameList> part(nparts);
+        std::vector<size_t> begin(nparts, (size_t)-1), end(nparts, 0);
+        zl_parallel_for(nparts, 1, [&](size_t p0, size_t p1) {
+            for (size_t p = p0; p < p1; p++) {
+                const size_t lo = n / nparts * p, hi = p + 1 < nparts ? n / nparts * (p + 1) : n;
+                size_t at = lo;
+                if (p) {  // the first 28 b5 2f fd at or behind the part's start (a frame starts with it, zstd.c:41050)
+                    at = (size_t)-1;
+                    for (const u8* q = src + lo; q + 4 <= src + hi;) {
+                        q = (const u8*)memchr(q, 0x28, (size_t)(src + hi - 3 - q));
+                        if (!q) break;
+                        if (q[1] == 0xB5 && q[2] == 0x2F && q[3] == 0xFD) { at = (size_t)(q - src); break; }
+                        q++;
+                    }
+                    if (at == (size_t)-1) continue;
+                }
+                begin[p] = at;
+                end[p] = walk_frames(at, hi, part[p]);
+            }
+        });
+        for (size_t p = 0; p < nparts; p++) {
+            const size_t hi = p + 1 < nparts ? n / nparts * (p + 1) : n;
+            if (begin[p] == pos && !part[p].err) { take(part[p]); pos = end[p]; continue; }
+            if (pos >= hi) continue;  // (a frame in front reaches over the whole part)
+            FrameList fl;
+            pos = walk_frames(pos, hi, fl);
+            take(fl);
+            if (fl.err) {
+                size_t fs = fl.err;
+                if (any && fs == ZL_ERR(ZL_E_PREFIX_UNKNOWN)) fs = ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:41752
+                return fs;
+            }
+        }
+    } else {
+        FrameList fl;
+        fl.any = any;
+        pos = walk_frames(pos, n, fl);
+        const bool had = any;
+        take(fl);
+        if (fl.err) {
+            size_t fs = fl.err;
+            if ((had || fl.any) && fs == ZL_ERR(ZL_E_PREFIX_UNKNOWN)) fs = ZL_ERR(ZL_E_SRCSIZE_WRONG);  // zstd.c:41752
             return fs;
         }
-        if (!h.skippable) {
-            zl_frame_desc fd;
-            fd.src_off = pos;
-            fd.src_size = fs;
-            fd.dst_off = 0;
-            fd.dst_cap = h.content_size;
-            table.push_back(fd);
-            known.push_back(h.content_size != ZL_CONTENTSIZE_UNKNOWN);
-            has_ck.push_back(h.has_checksum ? 1 : 0);
-            if (hw.blocks.size() <= ZL2_MAXB || hw.blocks.size() != h.nblocks) hw.blocks.clear();  // (small frames take the lane pipeline, which indexes on the device)
-            hw.host_src = src + pos;
-            walks.push_back(std::move(hw));
-        }
-        any = true;
-        pos += fs;
     }
     if (pos != n) return ZL_ERR(ZL_E_SRCSIZE_WRONG);
 #ifdef ZL_DEV_SWITCHES
